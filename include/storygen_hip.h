@@ -1,0 +1,212 @@
+/*
+ * storygen_hip.h — C ABI of libstorygen_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for StoryGen's
+ * denoising hot path.
+ *
+ * The reference (haoningwu3639/StoryGen) is pure Python on diffusers 0.13.1 and has NO FFI of its own
+ * (SURVEY §0 F1); its operator boundary is "whatever torch kernel an nn.Module call resolves to".  Each entry
+ * point below therefore names the reference *call site(s)* it replaces (file:line under /root/reference) —
+ * that is the interface a maintainer binds (ctypes stub in INTEGRATION.md).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes, no C++/torch types, no exceptions.
+ *   - every function returns 0 on success or a negative SG_E* code; sg_last_error() gives the thread-local
+ *     message.  Shapes/alignment are validated on the host before anything is enqueued.
+ *   - all device work is enqueued asynchronously on `stream` (a hipStream_t passed as void*); no hidden
+ *     allocation, no hidden synchronisation => every entry point is hipGraph-capturable.
+ *   - the library owns no device memory.  Callers pass scratch explicitly (see *_workspace_bytes).
+ *   - activations are fp16, channels-last: an image tensor is [B, H, W, C] with an explicit pixel stride
+ *     `ld*` (elements) so channel-slices of wider buffers can be read/written in place; token matrices are
+ *     [rows, cols] row-major with a row stride.  Statistics, softmax and all accumulators are fp32.
+ *   - weights are fp16: linear [N, K] (PyTorch layout), conv3x3 [Cout, 3, 3, Cin] (KRSC; repacked by the
+ *     host from PyTorch's [Cout, Cin, 3, 3]).
+ *   - every pointer that is loaded 16 bytes at a time (activations, weights, residuals) must be 16-byte
+ *     aligned and the matching ld/K/C a multiple of 8 elements; violations return SG_EINVAL.
+ */
+#ifndef STORYGEN_HIP_H
+#define STORYGEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SG_OK        0
+#define SG_EINVAL   (-1)   /* bad shape / alignment / null pointer */
+#define SG_EUNSUP   (-2)   /* valid request this build has no kernel for (e.g. head_dim not in {40,80,160}) */
+#define SG_ELAUNCH  (-3)   /* hipLaunchKernel / hipGetLastError failed */
+#define SG_EARCH    (-4)   /* device is not gfx950 */
+
+typedef void* sg_stream_t;   /* hipStream_t */
+typedef uint16_t sg_half;    /* IEEE binary16 storage */
+
+int          sg_version(void);                 /* ABI version, currently 1 */
+const char*  sg_last_error(void);              /* thread-local, never NULL */
+/* gcnArch number of the current device (950 for MI355X); negative SG_* on failure. */
+int          sg_device_arch(void);
+/* number of compute units of the current device (256 on MI355X) */
+int          sg_device_cus(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * GEMM with fused epilogue:  C[M, N'] = epi( A[M,K] @ W[N,K]^T )
+ * Replaces every nn.Linear / 1x1 nn.Conv2d on the path:
+ *   CrossAttention.to_q/to_k/to_v/to_out[0]   model/attention.py:175-183,192-199,215-223 (+ residual adds :262,277,291-293)
+ *   GEGLU.proj + FeedForward.net[2]           model/attention.py:381-393,342 (+ residual :300)
+ *   Transformer2DModel.proj_in / proj_out     model/attention.py:59,83,101,121-123
+ *   ResnetBlock2D.conv_shortcut (1x1)         diffusers resnet, instantiated model/unet_2d_blocks.py:331-344 etc.
+ * epilogue (fp32, then one rounding to fp16):
+ *   SG_EPI_LINEAR : v = acc + bias[n] + rowbias[(m / rows_per_batch) * rowbias_ld + n] + res1[m,n] + res2[m,n]
+ *                   (every term optional); N' = N
+ *   SG_EPI_GEGLU  : W rows (and bias) are stored interleaved in groups of 64: rows [64u, 64u+32) are "value"
+ *                   outputs 32u..32u+31 and rows [64u+32, 64u+64) the matching "gate" outputs;
+ *                   C[m, 32u+j] = (val + bias_v) * gelu_erf(gate + bias_g); N' = N/2 (exact erf GELU).
+ * split_k > 1 needs `workspace` of sg_gemm_workspace_bytes(M, N, split_k) bytes (fp32 partial tiles, reduced
+ * by a second kernel that applies the epilogue).  split_k == 0 lets the library choose (then pass a workspace
+ * of sg_gemm_workspace_bytes(M, N, 0) bytes, which covers the largest split it may pick, or NULL to forbid
+ * splitting).
+ */
+#define SG_EPI_LINEAR 0
+#define SG_EPI_GEGLU  1
+
+typedef struct sg_gemm_desc {
+    const sg_half* A;  int64_t lda;
+    const sg_half* W;  int64_t ldw;
+    sg_half*       C;  int64_t ldc;
+    int32_t M, N, K;
+    int32_t epilogue;                 /* SG_EPI_* */
+    const sg_half* bias;              /* [N] or NULL */
+    const float*   rowbias;           /* fp32 [batches, rowbias_ld] or NULL */
+    int64_t        rowbias_ld;
+    int32_t        rows_per_batch;    /* rows of A per rowbias row (>=1) */
+    int32_t        split_k;           /* 0 = auto, 1 = none, >1 = forced */
+    const sg_half* res1; int64_t ldr1;
+    const sg_half* res2; int64_t ldr2;
+    void*          workspace; size_t workspace_bytes;
+} sg_gemm_desc;
+
+int    sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream);
+size_t sg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * 3x3 convolution, padding 1, NHWC fp16, as implicit GEMM on MFMA:
+ *   y[b, oy, ox, co] = epi( sum_{ky,kx,ci} x[b, iy, ix, ci] * w[co, ky, kx, ci] )
+ *   iy = oy*stride + ky - 1 (stride in {1,2}); with upsample2x the input is first nearest-neighbour upsampled
+ *   by 2 (F.interpolate(scale_factor=2, mode="nearest")) — folded into the gather as iy>>1.
+ * Replaces ResnetBlock2D.conv1/conv2 (diffusers resnet; model/unet_2d_blocks.py:331-344,461-474,552-564,
+ * 688-700,222-234,252-264), Downsample2D.conv (stride 2; :361-368,478-485) and Upsample2D (interpolate + conv;
+ * :582,705,656-658,730-732).  Epilogue = SG_EPI_LINEAR terms of sg_gemm_desc (bias; rowbias = the
+ * time_emb_proj(silu(temb)) broadcast add of conv1; res1 = the block's residual/shortcut add of conv2),
+ * indexed by output pixel m = (b*Ho + oy)*Wo + ox with rows_per_batch = Ho*Wo.
+ * Cin must be a multiple of 64 (conv_in/conv_out have their own entry points).
+ */
+typedef struct sg_conv3x3_desc {
+    const sg_half* x;  int64_t ldx;   /* [B, H, W, Cin], pixel stride ldx */
+    const sg_half* w;                 /* [Cout, 3, 3, Cin] */
+    sg_half*       y;  int64_t ldy;   /* [B, Ho, Wo, Cout], pixel stride ldy */
+    int32_t B, H, W, Cin, Cout;
+    int32_t stride;                   /* 1 or 2 */
+    int32_t upsample2x;               /* 0 or 1 (then stride must be 1) */
+    const sg_half* bias;              /* [Cout] or NULL */
+    const float*   rowbias; int64_t rowbias_ld;   /* fp32 [B, rowbias_ld] or NULL */
+    const sg_half* res1; int64_t ldr1;            /* [B, Ho, Wo, Cout] or NULL */
+    int32_t        split_k;           /* as in sg_gemm_desc */
+    void*          workspace; size_t workspace_bytes;   /* sg_gemm_workspace_bytes(B*Ho*Wo, Cout, split_k) */
+} sg_conv3x3_desc;
+
+int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream);
+
+/* conv_in: x fp32 NCHW [B, Cin<=8, H, W] -> y fp16 NHWC [B,H,W,Cout], 3x3 pad 1 (unet_2d_condition.py:124,411).
+ * w_kn: fp16 [9*Cin, Cout] with k = (ky*3+kx)*Cin + ci (host repack); bias fp16 [Cout]; Cout % 8 == 0. */
+int sg_conv_in_f16(const float* x_nchw, const sg_half* w_kn, const sg_half* bias, sg_half* y, int64_t ldy,
+                   int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, sg_stream_t stream);
+/* conv_out: x fp16 NHWC [B,H,W,Cin] -> y fp32 NCHW [B, Cout<=4, H, W], 3x3 pad 1 (unet_2d_condition.py:268,480).
+ * w: fp16 [Cout, 3, 3, Cin]; bias fp16 [Cout]; Cin % 8 == 0. */
+int sg_conv_out_f16(const sg_half* x, int64_t ldx, const sg_half* w, const sg_half* bias, float* y_nchw,
+                    int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused attention (flash-style, online softmax in fp32, no mask, no dropout):
+ *   O[b, i, h*D + :] = softmax_j( scale * Q[b,i,h,:] . K[b,j,h,:] ) @ V[b,j,h,:]
+ * Replaces the attention core of CrossAttention for attn1 / attn2 / attn3 — the default CrossAttnProcessor
+ * (baddbmm -> softmax -> bmm) or xformers.memory_efficient_attention selected at inference.py:58-64; call
+ * sites model/attention.py:255-260,271-276,285-290.  Heads are interleaved in the channel dimension exactly
+ * as head_to_batch_dim expects (head h = channels [h*D, (h+1)*D)), so Q/K/V are read straight from the
+ * projection GEMM outputs and O is written heads-merged.  D in {40, 80, 160} (SD-1.5: C/8); any Nq, Nk >= 1.
+ * Strides in elements: token stride ld*, batch stride bs*.
+ */
+typedef struct sg_attn_desc {
+    const sg_half* q; int64_t ldq, bsq;
+    const sg_half* k; int64_t ldk, bsk;
+    const sg_half* v; int64_t ldv, bsv;
+    sg_half*       o; int64_t ldo, bso;
+    int32_t B, H, Nq, Nk, D;
+    float   scale;
+} sg_attn_desc;
+
+int sg_attn_fwd_f16(const sg_attn_desc* d, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * GroupNorm (+ optional SiLU) over NHWC fp16, fp32 statistics.
+ * Replaces nn.GroupNorm(32, C) [+ SiLU]: ResnetBlock2D.norm1/norm2 + nonlinearity, conv_norm_out + conv_act
+ * (unet_2d_condition.py:259-262,477-479; eps 1e-5) and Transformer2DModel.norm (attention.py:55,99; eps 1e-6).
+ * Two launches: per-(batch, pixel-chunk, group) shifted partial sums -> normalise+affine(+SiLU).
+ * workspace: sg_groupnorm_workspace_bytes(B, groups) bytes.
+ */
+int sg_groupnorm_nhwc_f16(const sg_half* x, int64_t ldx, sg_half* y, int64_t ldy, const sg_half* gamma,
+                          const sg_half* beta, int32_t B, int32_t HW, int32_t C, int32_t groups, float eps,
+                          int32_t silu, void* workspace, size_t workspace_bytes, sg_stream_t stream);
+size_t sg_groupnorm_workspace_bytes(int32_t B, int32_t groups);
+
+/* LayerNorm over the last dim of x[M, C] (row stride ldx), eps, affine; optionally a second affine output from
+ * the same statistics (norm2 and norm4 both normalise the post-self-attention state, attention.py:268,283).
+ * Replaces nn.LayerNorm at attention.py:188,206-212,225-229,234 (used :250,268,283,298). */
+int sg_layernorm_f16(const sg_half* x, int64_t ldx, int32_t M, int32_t C, float eps,
+                     const sg_half* gamma1, const sg_half* beta1, sg_half* y1, int64_t ldy1,
+                     const sg_half* gamma2, const sg_half* beta2, sg_half* y2, int64_t ldy2, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Time embedding pieces (unet_2d_condition.py:392-398 and ResnetBlock2D.time_emb_proj).
+ * sg_timestep_embed_f32: out[b, :] = [cos(t_b f_j) | sin(t_b f_j)] (flip_sin_to_cos) or [sin|cos]; `freqs` is the
+ *   fp32 table exp(-ln(1e4) j/(half-shift)), j < dim/2, computed by the host exactly as diffusers' Timesteps.
+ * sg_linear_rows_f32: y[b, n] = act_out( sum_k act_in(x[b,k]) * W[n,k] + bias[n] ) for a handful of rows
+ *   (B <= 16), x/y fp32, W/bias fp16 — TimestepEmbedding.linear_1/linear_2 and all 22 time_emb_proj at once
+ *   (W = row-concatenation).  act: 0 none, 1 SiLU.
+ */
+int sg_timestep_embed_f32(const float* t, const float* freqs, float* out, int32_t B, int32_t dim,
+                          int32_t flip_sin_to_cos, sg_stream_t stream);
+int sg_linear_rows_f32(const float* x, int64_t ldx, const sg_half* W, int64_t ldw, const sg_half* bias, float* y,
+                       int64_t ldy, int32_t B, int32_t N, int32_t K, int32_t act_in, int32_t act_out,
+                       sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Sampling-loop elementwise steps (model/pipeline.py:412-461), all fp32 NCHW [*,C,H,W] with `n` = elements per
+ * sample.  Per-step scalars live in DEVICE memory (`coef`) so a captured hipGraph can be replayed for every step.
+ * sg_ref_inputs_f32 (:419-429): out[3N] = cat(add_noise(zero), add_noise(img), add_noise(img)),
+ *     add_noise(x) = coef[0]*x + coef[1]*noise            (coef = {sqrt(abar_t), sqrt(1-abar_t)})
+ * sg_cfg_ddim_step_f32 (:457-461): eps = e_u + coef[0](e_i - e_u) + coef[1](e_a - e_i)   (eps3 = [e_u|e_i|e_a])
+ *     x0 = (x - coef[3]*eps)/coef[2];  x <- coef[4]*x0 + coef[5]*eps
+ *     (coef = {s_img, s_txt, sqrt(abar_t), sqrt(1-abar_t), sqrt(abar_prev), sqrt(1-abar_prev)}); updates
+ *     `latents` in place and also writes the three-fold replicated UNet input `latents3` if non-NULL.
+ */
+int sg_ref_inputs_f32(const float* zero, const float* img, const float* noise, const float* coef, float* out3,
+                      int32_t N, int64_t n, sg_stream_t stream);
+int sg_cfg_ddim_step_f32(const float* eps3, float* latents, float* latents3, const float* coef, int32_t N,
+                         int64_t n, sg_stream_t stream);
+
+/* Strided, batched 2-D copy of fp16 rows: dst[b][r][0:cols] = src[b][r][0:cols] (cols % 8 == 0).
+ * Replaces torch.cat([hidden, skip], dim=1) (unet_2d_blocks.py:609,626,716), the feature `.clone()`s
+ * (attention.py:263; unet_2d_condition.py:428-429,445,468-470) and the token-axis concat of per-frame
+ * features (pipeline.py:440-443) — each becomes a write into its slot of a preallocated buffer. */
+int sg_copy_rows_f16(sg_half* dst, int64_t ldd, int64_t bsd, const sg_half* src, int64_t lds, int64_t bss,
+                     int32_t batches, int32_t rows, int32_t cols, sg_stream_t stream);
+
+/* Diagnostic: raw per-lane MFMA register dump used by tests/test_mfma_layout.py to pin the fragment layout
+ * assumptions of the kernels above.  out: fp32 [64 lanes][16 regs] of D = A(32x16) @ B(16x32) with
+ * A[i][k] = a[i*16+k], B[k][j] = b[k*32+j] loaded with the kernels' own lane mapping. */
+int sg_debug_mfma_32x32x16(const sg_half* a, const sg_half* b, float* out, sg_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STORYGEN_HIP_H */

@@ -1,0 +1,114 @@
+"""ctypes binding of libstorygen_hip.so (include/storygen_hip.h).  Fails loudly when the library is missing:
+there is no CPU / eager-PyTorch fallback for the product path."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libstorygen_hip.so")
+
+c_half_p = C.c_void_p   # device pointers travel as integers
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [
+        ("A", C.c_void_p), ("lda", C.c_int64),
+        ("W", C.c_void_p), ("ldw", C.c_int64),
+        ("C", C.c_void_p), ("ldc", C.c_int64),
+        ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+        ("epilogue", C.c_int32),
+        ("bias", C.c_void_p),
+        ("rowbias", C.c_void_p),
+        ("rowbias_ld", C.c_int64),
+        ("rows_per_batch", C.c_int32),
+        ("split_k", C.c_int32),
+        ("res1", C.c_void_p), ("ldr1", C.c_int64),
+        ("res2", C.c_void_p), ("ldr2", C.c_int64),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64),
+        ("w", C.c_void_p),
+        ("y", C.c_void_p), ("ldy", C.c_int64),
+        ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+        ("stride", C.c_int32),
+        ("upsample2x", C.c_int32),
+        ("bias", C.c_void_p),
+        ("rowbias", C.c_void_p), ("rowbias_ld", C.c_int64),
+        ("res1", C.c_void_p), ("ldr1", C.c_int64),
+        ("split_k", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class AttnDesc(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("ldq", C.c_int64), ("bsq", C.c_int64),
+        ("k", C.c_void_p), ("ldk", C.c_int64), ("bsk", C.c_int64),
+        ("v", C.c_void_p), ("ldv", C.c_int64), ("bsv", C.c_int64),
+        ("o", C.c_void_p), ("ldo", C.c_int64), ("bso", C.c_int64),
+        ("B", C.c_int32), ("H", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("D", C.c_int32),
+        ("scale", C.c_float),
+    ]
+
+
+# name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header.
+SIGNATURES = {
+    "sg_version": (C.c_int, []),
+    "sg_last_error": (C.c_char_p, []),
+    "sg_device_arch": (C.c_int, []),
+    "sg_device_cus": (C.c_int, []),
+    "sg_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "sg_gemm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    "sg_conv3x3_nhwc_f16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
+    "sg_conv_in_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                 C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sg_conv_out_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sg_attn_fwd_f16": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p]),
+    "sg_groupnorm_nhwc_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
+                                        C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_size_t,
+                                        C.c_void_p]),
+    "sg_groupnorm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "sg_layernorm_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
+    "sg_timestep_embed_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sg_linear_rows_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                     C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sg_ref_inputs_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
+                                    C.c_void_p]),
+    "sg_cfg_ddim_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
+    "sg_copy_rows_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
+                                   C.c_int32, C.c_int32, C.c_void_p]),
+    "sg_debug_mfma_32x32x16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+}
+
+_lib = None
+
+
+def load() -> C.CDLL:
+    """dlopen the library and bind every declared symbol; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} is missing: build it with `python -m storygen_amd.build` (hipcc, gfx950). "
+            "storygen_amd has no CPU / eager fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code: int, what: str = "") -> None:
+    if code != 0:
+        msg = load().sg_last_error().decode(errors="replace")
+        raise RuntimeError(f"libstorygen_hip {what} failed ({code}): {msg}")

@@ -1,0 +1,61 @@
+// Shared device/host helpers for the gfx950 kernels of libstorygen_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+
+#include "../../include/storygen_hip.h"
+
+typedef _Float16 f16;
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------------- host side
+int sg_set_error(int code, const char* fmt, ...);
+
+#define SG_REQUIRE(cond, ...)                                   \
+    do {                                                        \
+        if (!(cond)) return sg_set_error(SG_EINVAL, __VA_ARGS__); \
+    } while (0)
+
+#define SG_CHECK_LAUNCH(name)                                                                  \
+    do {                                                                                       \
+        hipError_t e__ = hipGetLastError();                                                    \
+        if (e__ != hipSuccess) return sg_set_error(SG_ELAUNCH, "%s: %s", name, hipGetErrorString(e__)); \
+    } while (0)
+
+static inline bool sg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+static inline int sg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
+
+// ---------------------------------------------------------------------------------------------- device side
+__device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
+__device__ __forceinline__ void stg16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }
+
+union H8 {
+    uint4 u;
+    f16x8 v;
+    f16 h[8];
+};
+
+__device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
+// exact (erf) GELU, as torch.nn.functional.gelu(approximate="none") — /root/reference/model/attention.py:385-388
+__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+
+// XCD-aware, bijective remap of a 1-D block id: consecutive *logical* ids land on the same XCD (block b runs on
+// XCD b % 8 on MI355X), so tiles that share an operand panel share that XCD's private L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nblocks) {
+    const int q = nblocks >> 3, r = nblocks & 7;
+    const int xcd = bid & 7, local = bid >> 3;
+    const int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + local;
+}

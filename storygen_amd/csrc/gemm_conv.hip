@@ -1,0 +1,456 @@
+// MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (MI355X, CDNA4), fp16 in / fp32 accumulate.
+//
+// One mainloop serves both entry points (sg_gemm_f16, sg_conv3x3_nhwc_f16): C[M,N] = A[M,K] . W[N,K]^T where,
+// for the convolution, row m is an output pixel and the K axis enumerates (ky, kx, ci) — the A tile is *gathered*
+// from the NHWC input (zero outside the image, optional nearest-2x upsample and stride 2 folded into the index).
+//
+// Structure (CDNA4-first, see /opt/skills/guides/cdna_hip_programming.md §5):
+//   * 256 threads = 4 wave64 in a 2x2 grid; each wave owns a (BM/2)x(BN/2) sub-tile as TMxTN 32x32 accumulators of
+//     v_mfma_f32_32x32x16_f16 (one 16-byte fragment per lane per operand per MFMA).
+//   * K is walked in BK=64 slabs through two LDS stages.  Global->register loads of slab t+1 are issued before the
+//     MFMAs of slab t and written to the other stage afterwards: one barrier per slab.
+//   * LDS rows are 128 B (64 halves); the 16-byte chunk c of row r lives at chunk c ^ ((r>>1)&7): conflict-free for
+//     the ds_read_b128 fragment reads (a 16-lane service group touches 16 distinct 16-B slots of the 256-B bank row)
+//     and for the staging ds_write_b128 (8 lanes write one permuted row).
+//   * the fp32 tile is staged through LDS for the epilogue so that bias / residual / output accesses are 16-byte,
+//     row-contiguous; epilogue math is fp32 with a single rounding to fp16.
+//   * block ids are remapped so that consecutive tiles (same A row panel) run on the same XCD / L2.
+//   * small-M layers (16x16 / 8x8 latent levels at batch 3) are split along K over blockIdx.y into fp32 partial
+//     tiles; a second kernel reduces them and applies the epilogue (deterministic, no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 64;
+constexpr int NTHREADS = 256;
+constexpr int MAX_AUTO_SPLIT = 16;
+
+struct MmaParams {
+    const f16* A; long lda;
+    const f16* W; long ldw;
+    f16* C; long ldc;
+    int M, N, K, KT;
+    // conv geometry (CONV only): input [B,H,Wd,Cin] (pre-upsample), output [B,Ho,Wo,N]
+    int H, Wd, Ho, Wo, cpt /* Cin/64 */, stride, ups;
+    // epilogue
+    int mode;
+    const f16* bias;
+    const float* rowbias; long rowbias_ld; int rows_per_batch;
+    const f16* res1; long ldr1;
+    const f16* res2; long ldr2;
+    // decomposition
+    float* ws; int splits; int kt_per_split; int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ void epi_linear8(const MmaParams& p, int gm, int gn, float (&v)[8]) {
+    if (p.bias) {
+        H8 b; b.u = ldg16(p.bias + gn);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)b.h[j];
+    }
+    if (p.rowbias) {
+        const float* rb = p.rowbias + (long)(gm / p.rows_per_batch) * p.rowbias_ld + gn;
+        const float4 r0 = *reinterpret_cast<const float4*>(rb), r1 = *reinterpret_cast<const float4*>(rb + 4);
+        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
+        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+    }
+    if (p.res1) {
+        H8 r; r.u = ldg16(p.res1 + (long)gm * p.ldr1 + gn);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)r.h[j];
+    }
+    if (p.res2) {
+        H8 r; r.u = ldg16(p.res2 + (long)gm * p.ldr2 + gn);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)r.h[j];
+    }
+    H8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.h[j] = (f16)v[j];
+    stg16(p.C + (long)gm * p.ldc + gn, o.u);
+}
+
+// val/gate: 8 consecutive interleaved-layout columns starting at global column gv (value) and gv+32 (gate).
+__device__ __forceinline__ void epi_geglu8(const MmaParams& p, int gm, int gv, float (&val)[8], float (&gate)[8]) {
+    if (p.bias) {
+        H8 bv, bg; bv.u = ldg16(p.bias + gv); bg.u = ldg16(p.bias + gv + 32);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { val[j] += (float)bv.h[j]; gate[j] += (float)bg.h[j]; }
+    }
+    H8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.h[j] = (f16)(val[j] * gelu_erf_f(gate[j]));
+    const int oc = (gv >> 6) * 32 + (gv & 31);   // interleaved column -> output column
+    stg16(p.C + (long)gm * p.ldc + oc, o.u);
+}
+
+template <int BM, int BN, bool CONV>
+__global__ __launch_bounds__(NTHREADS) void mma_kernel(const MmaParams p) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr int A_IT = BM / 32, B_IT = BN / 32;
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int EPI_BYTES = BM * BN * 4;
+    constexpr int SMEM = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
+    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int m0 = (lid / p.tiles_n) * BM, n0 = (lid % p.tiles_n) * BN;
+    const int z = blockIdx.y;
+    const int kt0 = z * p.kt_per_split;
+    const int kt1 = min(p.KT, kt0 + p.kt_per_split);
+
+    // ---- per-thread staging coordinates: chunk c of rows r0 + 32*i
+    const int c = t & 7, r0 = t >> 3;
+    const f16* a_ptr[A_IT];
+    int a_oy[A_IT], a_ox[A_IT];
+    bool a_ok[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int gm = m0 + r0 + 32 * i;
+        a_ok[i] = gm < p.M;
+        if constexpr (CONV) {
+            const int hw = p.Ho * p.Wo;
+            const int b = gm / hw, rem = gm - b * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_oy[i] = a_ok[i] ? oy * p.stride - 1 : -(1 << 20);
+            a_ox[i] = ox * p.stride - 1;
+            a_ptr[i] = p.A + (long)b * p.H * p.Wd * p.lda + c * 8;
+        } else {
+            a_oy[i] = a_ox[i] = 0;
+            a_ptr[i] = p.A + (long)gm * p.lda + c * 8;
+        }
+    }
+    const f16* w_ptr[B_IT];
+    bool w_ok[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int gn = n0 + r0 + 32 * i;
+        w_ok[i] = gn < p.N;
+        w_ptr[i] = p.W + (long)gn * p.ldw + c * 8;
+    }
+    const int hin = p.H << p.ups, win = p.Wd << p.ups;
+
+    uint4 areg[A_IT], breg[B_IT];
+    auto load_regs = [&](int kt) {
+        const bool kok = kt * BK + c * 8 < p.K;
+        if constexpr (CONV) {
+            const int tap = kt / p.cpt, cc = kt - tap * p.cpt;
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int iy = a_oy[i] + ky, ix = a_ox[i] + kx;
+                const bool ok = (unsigned)iy < (unsigned)hin && (unsigned)ix < (unsigned)win;
+                const long pix = (long)(iy >> p.ups) * p.Wd + (ix >> p.ups);
+                areg[i] = ok ? ldg16(a_ptr[i] + pix * p.lda + cc * BK) : make_uint4(0, 0, 0, 0);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i)
+                areg[i] = (a_ok[i] && kok) ? ldg16(a_ptr[i] + kt * BK) : make_uint4(0, 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i)
+            breg[i] = (w_ok[i] && kok) ? ldg16(w_ptr[i] + kt * BK) : make_uint4(0, 0, 0, 0);
+    };
+    auto store_lds = [&](int buf) {
+        char* sA = smem + buf * STAGE;
+        char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int i = 0; i < A_IT; ++i) *reinterpret_cast<uint4*>(sA + lds_off(r0 + 32 * i, c)) = areg[i];
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) *reinterpret_cast<uint4*>(sB + lds_off(r0 + 32 * i, c)) = breg[i];
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (kt0 < kt1) {
+        load_regs(kt0);
+        store_lds(0);
+    }
+    __syncthreads();
+    for (int kt = kt0; kt < kt1; ++kt) {
+        const int buf = (kt - kt0) & 1;
+        const bool more = kt + 1 < kt1;
+        if (more) load_regs(kt + 1);
+        const char* sA = smem + buf * STAGE;
+        const char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f16x8 af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+                af[i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WM + i * 32 + l31, ks * 2 + hi));
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                bf[j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WN + j * 32 + l31, ks * 2 + hi));
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_lds(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- split-K: raw fp32 partial tile to the workspace, epilogue happens in splitk_reduce_kernel
+    if (p.splits > 1) {
+        float* wsz = p.ws + (size_t)z * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int gn = n0 + wn * WN + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (gm < p.M && gn < p.N) wsz[(size_t)gm * p.N + gn] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+
+    // ---- epilogue phase 1: accumulators -> LDS (fp32, [BM][BN])
+    float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = wn * WN + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                sC[m * BN + n] = acc[i][j][r];
+            }
+        }
+    __syncthreads();
+    // ---- phase 2: row-contiguous 8-column chunks, fused epilogue, 16-byte stores
+    if (p.mode == SG_EPI_LINEAR) {
+        constexpr int NCH = BN / 8;
+        for (int idx = t; idx < BM * NCH; idx += NTHREADS) {
+            const int r = idx / NCH, ch = idx - r * NCH;
+            const int gm = m0 + r, gn = n0 + ch * 8;
+            if (gm >= p.M || gn >= p.N) continue;
+            const float4 v0 = *reinterpret_cast<const float4*>(sC + r * BN + ch * 8);
+            const float4 v1 = *reinterpret_cast<const float4*>(sC + r * BN + ch * 8 + 4);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            epi_linear8(p, gm, gn, v);
+        }
+    } else {
+        constexpr int OCH = BN / 16;
+        for (int idx = t; idx < BM * OCH; idx += NTHREADS) {
+            const int r = idx / OCH, j = idx - r * OCH;
+            const int vcol = (j >> 2) * 64 + (j & 3) * 8;
+            const int gm = m0 + r, gv = n0 + vcol;
+            if (gm >= p.M || gv >= p.N) continue;
+            const float* s = sC + r * BN + vcol;
+            const float4 a0 = *reinterpret_cast<const float4*>(s), a1 = *reinterpret_cast<const float4*>(s + 4);
+            const float4 g0 = *reinterpret_cast<const float4*>(s + 32), g1 = *reinterpret_cast<const float4*>(s + 36);
+            float val[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            float gate[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            epi_geglu8(p, gm, gv, val, gate);
+        }
+    }
+}
+
+__global__ __launch_bounds__(NTHREADS) void splitk_reduce_kernel(const MmaParams p) {
+    const size_t MN = (size_t)p.M * p.N;
+    if (p.mode == SG_EPI_LINEAR) {
+        const int nch = p.N / 8;
+        const long total = (long)p.M * nch;
+        for (long idx = (long)blockIdx.x * NTHREADS + threadIdx.x; idx < total; idx += (long)gridDim.x * NTHREADS) {
+            const int gm = (int)(idx / nch), gn = (int)(idx - (long)gm * nch) * 8;
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const float* s = p.ws + (size_t)gm * p.N + gn;
+            for (int z = 0; z < p.splits; ++z) {
+                const float4 a = *reinterpret_cast<const float4*>(s + z * MN);
+                const float4 b = *reinterpret_cast<const float4*>(s + z * MN + 4);
+                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+            }
+            epi_linear8(p, gm, gn, v);
+        }
+    } else {
+        const int och = p.N / 16;
+        const long total = (long)p.M * och;
+        for (long idx = (long)blockIdx.x * NTHREADS + threadIdx.x; idx < total; idx += (long)gridDim.x * NTHREADS) {
+            const int gm = (int)(idx / och), j = (int)(idx - (long)gm * och);
+            const int gv = (j >> 2) * 64 + (j & 3) * 8;
+            float val[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gate[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const float* s = p.ws + (size_t)gm * p.N + gv;
+            for (int z = 0; z < p.splits; ++z) {
+                const float* q = s + z * MN;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { val[e] += q[e]; gate[e] += q[32 + e]; }
+            }
+            epi_geglu8(p, gm, gv, val, gate);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+struct Plan { int bm, bn, splits; };
+
+// Rough cost model in "slab units" (one 128x128x64 slab of MFMAs on one CU ~ 0.5 us): picks the tile shape and
+// the K split that minimise ceil(blocks / CUs) * per-block cost (+ the reduce pass for split-K).
+Plan choose_plan(int M, int N, int KT, int force_split, bool allow_split, int cus) {
+    static const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    static const double eff[3] = {1.0, 0.8, 0.55};
+    static const int split_opts[] = {1, 2, 3, 4, 6, 8, 12, 16};
+    Plan best{128, 128, 1};
+    double best_cost = 1e300;
+    for (int ci = 0; ci < 3; ++ci) {
+        const int bm = cand[ci][0], bn = cand[ci][1];
+        const long tiles = (long)sg_cdiv(M, bm) * sg_cdiv(N, bn);
+        for (int s : split_opts) {
+            if (force_split > 0 && s != force_split) continue;
+            if (force_split <= 0 && s > 1 && (!allow_split || KT / s < 4)) continue;
+            if (s > KT) continue;
+            const long blocks = tiles * s;
+            const double per_block = (double)bm * bn / 16384.0 * (sg_cdiv(KT, s) + 6.0) / eff[ci];
+            double cost = (double)sg_cdiv(blocks, cus) * per_block;
+            if (s > 1) cost += 4.0 + (double)M * N * 4.0 * (s + 1) / 2.5e6;   // extra launch + partial-tile traffic
+            if (cost < best_cost) { best_cost = cost; best = Plan{bm, bn, s}; }
+        }
+    }
+    if (force_split > 0 && best_cost == 1e300) best = Plan{64, 64, force_split > KT ? KT : force_split};
+    return best;
+}
+
+template <bool CONV>
+int launch_mma(MmaParams& p, int force_split, void* ws, size_t ws_bytes, hipStream_t st, const char* name) {
+    p.KT = sg_cdiv(p.K, BK);
+    const int cus = 256;
+    Plan pl = choose_plan(p.M, p.N, p.KT, force_split, ws != nullptr, cus);
+    if (pl.splits > 1) {
+        const size_t need = (size_t)p.M * p.N * 4 * pl.splits;
+        if (ws == nullptr || ws_bytes < need)
+            return sg_set_error(SG_EINVAL, "%s: split_k=%d needs %zu workspace bytes, got %zu", name, pl.splits, need,
+                                ws_bytes);
+    }
+    p.ws = reinterpret_cast<float*>(ws);
+    p.splits = pl.splits;
+    p.kt_per_split = sg_cdiv(p.KT, pl.splits);
+    p.tiles_m = sg_cdiv(p.M, pl.bm);
+    p.tiles_n = sg_cdiv(p.N, pl.bn);
+    dim3 grid(p.tiles_m * p.tiles_n, pl.splits), block(NTHREADS);
+    if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((mma_kernel<128, 128, CONV>), grid, block, 0, st, p);
+    else if (pl.bm == 128 && pl.bn == 64) hipLaunchKernelGGL((mma_kernel<128, 64, CONV>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((mma_kernel<64, 64, CONV>), grid, block, 0, st, p);
+    SG_CHECK_LAUNCH(name);
+    if (pl.splits > 1) {
+        const long items = (long)p.M * (p.N / (p.mode == SG_EPI_GEGLU ? 16 : 8));
+        const int blocks = (int)min((long)4096, (items + NTHREADS - 1) / NTHREADS);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), block, 0, st, p);
+        SG_CHECK_LAUNCH("splitk_reduce");
+    }
+    return SG_OK;
+}
+
+}  // namespace
+
+extern "C" size_t sg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
+    const int s = split_k > 0 ? split_k : MAX_AUTO_SPLIT;
+    return s > 1 ? (size_t)M * (size_t)N * 4u * (size_t)s : 0;
+}
+
+extern "C" int sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream) {
+    SG_REQUIRE(d != nullptr, "sg_gemm_f16: null descriptor");
+    SG_REQUIRE(d->A && d->W && d->C, "sg_gemm_f16: null A/W/C");
+    SG_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "sg_gemm_f16: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
+    SG_REQUIRE(d->K % 8 == 0 && d->N % 8 == 0, "sg_gemm_f16: K (%d) and N (%d) must be multiples of 8", d->K, d->N);
+    SG_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0 && d->ldc % 8 == 0, "sg_gemm_f16: lda/ldw/ldc must be multiples of 8");
+    SG_REQUIRE(d->lda >= d->K && d->ldw >= d->K, "sg_gemm_f16: lda/ldw smaller than K");
+    SG_REQUIRE(sg_aligned16(d->A) && sg_aligned16(d->W) && sg_aligned16(d->C), "sg_gemm_f16: A/W/C must be 16-byte aligned");
+    SG_REQUIRE(d->epilogue == SG_EPI_LINEAR || d->epilogue == SG_EPI_GEGLU, "sg_gemm_f16: unknown epilogue %d", d->epilogue);
+    if (d->epilogue == SG_EPI_GEGLU) {
+        SG_REQUIRE(d->N % 64 == 0, "sg_gemm_f16: GEGLU needs N %% 64 == 0 (got %d)", d->N);
+        SG_REQUIRE(!d->rowbias && !d->res1 && !d->res2, "sg_gemm_f16: GEGLU epilogue takes bias only");
+        SG_REQUIRE(d->ldc >= d->N / 2, "sg_gemm_f16: ldc smaller than N/2");
+    } else {
+        SG_REQUIRE(d->ldc >= d->N, "sg_gemm_f16: ldc smaller than N");
+    }
+    SG_REQUIRE(!d->bias || sg_aligned16(d->bias), "sg_gemm_f16: bias must be 16-byte aligned");
+    SG_REQUIRE(!d->res1 || (sg_aligned16(d->res1) && d->ldr1 % 8 == 0), "sg_gemm_f16: res1 alignment");
+    SG_REQUIRE(!d->res2 || (sg_aligned16(d->res2) && d->ldr2 % 8 == 0), "sg_gemm_f16: res2 alignment");
+    SG_REQUIRE(!d->rowbias || (sg_aligned16(d->rowbias) && d->rowbias_ld % 4 == 0 && d->rows_per_batch >= 1),
+               "sg_gemm_f16: rowbias alignment / rows_per_batch");
+    SG_REQUIRE(d->split_k >= 0 && d->split_k <= 64, "sg_gemm_f16: bad split_k %d", d->split_k);
+    SG_REQUIRE(!d->workspace || sg_aligned16(d->workspace), "sg_gemm_f16: workspace alignment");
+    MmaParams p{};
+    p.A = reinterpret_cast<const f16*>(d->A); p.lda = d->lda;
+    p.W = reinterpret_cast<const f16*>(d->W); p.ldw = d->ldw;
+    p.C = reinterpret_cast<f16*>(d->C); p.ldc = d->ldc;
+    p.M = d->M; p.N = d->N; p.K = d->K;
+    p.mode = d->epilogue;
+    p.bias = reinterpret_cast<const f16*>(d->bias);
+    p.rowbias = d->rowbias; p.rowbias_ld = d->rowbias_ld; p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1;
+    p.res1 = reinterpret_cast<const f16*>(d->res1); p.ldr1 = d->ldr1;
+    p.res2 = reinterpret_cast<const f16*>(d->res2); p.ldr2 = d->ldr2;
+    return launch_mma<false>(p, d->split_k, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_gemm_f16");
+}
+
+extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream) {
+    SG_REQUIRE(d != nullptr, "sg_conv3x3: null descriptor");
+    SG_REQUIRE(d->x && d->w && d->y, "sg_conv3x3: null x/w/y");
+    SG_REQUIRE(d->B > 0 && d->H > 0 && d->W > 0 && d->Cin > 0 && d->Cout > 0, "sg_conv3x3: bad shape");
+    SG_REQUIRE(d->Cin % 64 == 0, "sg_conv3x3: Cin (%d) must be a multiple of 64", d->Cin);
+    SG_REQUIRE(d->Cout % 8 == 0, "sg_conv3x3: Cout (%d) must be a multiple of 8", d->Cout);
+    SG_REQUIRE(d->stride == 1 || d->stride == 2, "sg_conv3x3: stride must be 1 or 2");
+    SG_REQUIRE(d->upsample2x == 0 || (d->upsample2x == 1 && d->stride == 1), "sg_conv3x3: upsample2x needs stride 1");
+    SG_REQUIRE(d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->ldx >= d->Cin && d->ldy >= d->Cout, "sg_conv3x3: bad ldx/ldy");
+    SG_REQUIRE(sg_aligned16(d->x) && sg_aligned16(d->w) && sg_aligned16(d->y), "sg_conv3x3: x/w/y must be 16-byte aligned");
+    SG_REQUIRE(!d->bias || sg_aligned16(d->bias), "sg_conv3x3: bias alignment");
+    SG_REQUIRE(!d->res1 || (sg_aligned16(d->res1) && d->ldr1 % 8 == 0), "sg_conv3x3: res1 alignment");
+    SG_REQUIRE(!d->rowbias || (sg_aligned16(d->rowbias) && d->rowbias_ld % 4 == 0), "sg_conv3x3: rowbias alignment");
+    SG_REQUIRE(d->split_k >= 0 && d->split_k <= 64, "sg_conv3x3: bad split_k %d", d->split_k);
+    const int hin = d->H << d->upsample2x, win = d->W << d->upsample2x;
+    const int Ho = (hin + 2 - 3) / d->stride + 1, Wo = (win + 2 - 3) / d->stride + 1;
+    MmaParams p{};
+    p.A = reinterpret_cast<const f16*>(d->x); p.lda = d->ldx;
+    p.W = reinterpret_cast<const f16*>(d->w); p.ldw = 9L * d->Cin;
+    p.C = reinterpret_cast<f16*>(d->y); p.ldc = d->ldy;
+    p.M = d->B * Ho * Wo; p.N = d->Cout; p.K = 9 * d->Cin;
+    p.H = d->H; p.Wd = d->W; p.Ho = Ho; p.Wo = Wo; p.cpt = d->Cin / 64; p.stride = d->stride; p.ups = d->upsample2x;
+    p.mode = SG_EPI_LINEAR;
+    p.bias = reinterpret_cast<const f16*>(d->bias);
+    p.rowbias = d->rowbias; p.rowbias_ld = d->rowbias_ld; p.rows_per_batch = Ho * Wo;
+    p.res1 = reinterpret_cast<const f16*>(d->res1); p.ldr1 = d->ldr1;
+    return launch_mma<true>(p, d->split_k, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_conv3x3_nhwc_f16");
+}
+
+// ------------------------------------------------------------------------------------------------ diagnostics
+namespace {
+__global__ void debug_mfma_kernel(const f16* a, const f16* b, float* out) {
+    const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;
+    f16x8 af, bf;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        af[j] = a[l31 * 16 + hi * 8 + j];          // A[i = l31][k = hi*8 + j]
+        bf[j] = b[(hi * 8 + j) * 32 + l31];        // B[k = hi*8 + j][n = l31]
+    }
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[lane * 16 + r] = acc[r];
+}
+}  // namespace
+
+extern "C" int sg_debug_mfma_32x32x16(const sg_half* a, const sg_half* b, float* out, sg_stream_t stream) {
+    SG_REQUIRE(a && b && out, "sg_debug_mfma: null pointer");
+    hipLaunchKernelGGL(debug_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const f16*>(a),
+                       reinterpret_cast<const f16*>(b), out);
+    SG_CHECK_LAUNCH("sg_debug_mfma_32x32x16");
+    return SG_OK;
+}

@@ -1,0 +1,284 @@
+// Small kernels of the hot path: library bookkeeping, time embedding, the two thin 3x3 convolutions (4->C and
+// C->4 channels, bandwidth/latency-bound so no MFMA), the sampling-loop elementwise steps and the strided row copy.
+#include "common.h"
+#include <string.h>
+
+// ------------------------------------------------------------------------------------------------ bookkeeping
+static thread_local char g_err[512] = "";
+
+int sg_set_error(int code, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+extern "C" int sg_version(void) { return 1; }
+extern "C" const char* sg_last_error(void) { return g_err; }
+
+extern "C" int sg_device_arch(void) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        return sg_set_error(SG_ELAUNCH, "sg_device_arch: no HIP device");
+    const char* name = prop.gcnArchName;   // e.g. "gfx950:sramecc+:xnack-"
+    if (strncmp(name, "gfx", 3) != 0) return sg_set_error(SG_EARCH, "sg_device_arch: unexpected arch '%s'", name);
+    return (int)strtol(name + 3, nullptr, 10);
+}
+
+extern "C" int sg_device_cus(void) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess)
+        return sg_set_error(SG_ELAUNCH, "sg_device_cus: no HIP device");
+    return prop.multiProcessorCount;
+}
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------ time embedding
+__global__ void timestep_embed_kernel(const float* t, const float* freqs, float* out, int B, int dim, int flip) {
+    const int half = dim / 2;
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= B * half) return;
+    const int b = idx / half, j = idx - b * half;
+    const float e = t[b] * freqs[j];
+    const float s = sinf(e), c = cosf(e);
+    float* o = out + (long)b * dim;
+    if (flip) { o[j] = c; o[half + j] = s; } else { o[j] = s; o[half + j] = c; }
+}
+
+// y[b][n] = act_out(sum_k act_in(x[b][k]) W[n][k] + bias[n]); one wave per output column n, all B rows at once
+// (the weight row is streamed exactly once: this is a weight-bandwidth-bound GEMV bundle).
+template <int MAXB>
+__global__ __launch_bounds__(256) void linear_rows_kernel(const float* x, long ldx, const f16* W, long ldw, const f16* bias,
+                                                          float* y, long ldy, int B, int N, int K, int act_in, int act_out) {
+    const int lane = threadIdx.x & 63, n = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (n >= N) return;
+    float acc[MAXB];
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) acc[b] = 0.f;
+    const f16* wr = W + (long)n * ldw;
+    for (int k0 = lane * 8; k0 < K; k0 += 64 * 8) {
+        H8 w; w.u = ldg16(wr + k0);
+#pragma unroll
+        for (int b = 0; b < MAXB; ++b) {
+            if (b < B) {
+                const float4 x0 = *reinterpret_cast<const float4*>(x + b * ldx + k0);
+                const float4 x1 = *reinterpret_cast<const float4*>(x + b * ldx + k0 + 4);
+                float xv[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float a = act_in ? silu_f(xv[j]) : xv[j];
+                    acc[b] += a * (float)w.h[j];
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < MAXB; ++b) {
+        if (b < B) {
+            float v = wave_sum(acc[b]);
+            if (lane == 0) {
+                if (bias) v += (float)bias[n];
+                if (act_out) v = silu_f(v);
+                y[b * ldy + n] = v;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ conv_in / conv_out
+// conv_in: thread = (pixel, 8 output channels); x fp32 NCHW, w fp16 [9*Cin][Cout].
+__global__ __launch_bounds__(256) void conv_in_kernel(const float* x, const f16* w, const f16* bias, f16* y, long ldy,
+                                                      int B, int H, int Wd, int Cin, int Cout) {
+    const int cg = Cout / 8;
+    const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    const long total = (long)B * H * Wd * cg;
+    if (idx >= total) return;
+    const int g = (int)(idx % cg);
+    const long pix = idx / cg;
+    const int ox = (int)(pix % Wd), oy = (int)((pix / Wd) % H), b = (int)(pix / ((long)Wd * H));
+    float acc[8];
+    {
+        H8 bb; bb.u = ldg16(bias + g * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = (float)bb.h[j];
+    }
+    for (int ky = 0; ky < 3; ++ky) {
+        const int iy = oy + ky - 1;
+        if ((unsigned)iy >= (unsigned)H) continue;
+        for (int kx = 0; kx < 3; ++kx) {
+            const int ix = ox + kx - 1;
+            if ((unsigned)ix >= (unsigned)Wd) continue;
+            for (int ci = 0; ci < Cin; ++ci) {
+                const float xv = x[(((long)b * Cin + ci) * H + iy) * Wd + ix];
+                H8 wv; wv.u = ldg16(w + ((long)((ky * 3 + kx) * Cin + ci)) * Cout + g * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) acc[j] += xv * (float)wv.h[j];
+            }
+        }
+    }
+    H8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.h[j] = (f16)acc[j];
+    stg16(y + pix * ldy + g * 8, o.u);
+}
+
+// conv_out: one wave per output pixel; lanes split the 9*Cin/8 input chunks; Cout <= 4 accumulators.
+__global__ __launch_bounds__(256) void conv_out_kernel(const f16* x, long ldx, const f16* w, const f16* bias, float* y,
+                                                       int B, int H, int Wd, int Cin, int Cout) {
+    const int lane = threadIdx.x & 63;
+    const long pix = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (pix >= (long)B * H * Wd) return;
+    const int ox = (int)(pix % Wd), oy = (int)((pix / Wd) % H), b = (int)(pix / ((long)Wd * H));
+    const int cpt = Cin / 8, nchunk = 9 * cpt;
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int ci = lane; ci < nchunk; ci += 64) {
+        const int tap = ci / cpt, cc = ci - tap * cpt;
+        const int ky = tap / 3, kx = tap - ky * 3;
+        const int iy = oy + ky - 1, ix = ox + kx - 1;
+        if ((unsigned)iy >= (unsigned)H || (unsigned)ix >= (unsigned)Wd) continue;
+        H8 xv; xv.u = ldg16(x + (((long)b * H + iy) * Wd + ix) * ldx + cc * 8);
+        for (int co = 0; co < Cout; ++co) {
+            H8 wv; wv.u = ldg16(w + ((long)co * 9 + tap) * Cin + cc * 8);
+            float s = 0.f;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s += (float)xv.h[j] * (float)wv.h[j];
+            acc[co] += s;
+        }
+    }
+    for (int co = 0; co < Cout; ++co) {
+        const float v = wave_sum(acc[co]);
+        if (lane == 0) y[(((long)b * Cout + co) * H + oy) * Wd + ox] = v + (float)bias[co];
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ sampling-loop steps
+__global__ void ref_inputs_kernel(const float* zero, const float* img, const float* noise, const float* coef, float* out,
+                                  int N, long n) {
+    const long total = (long)N * n;
+    const float a = coef[0], s = coef[1];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const float nz = s * noise[i];
+        const float vz = a * zero[i] + nz, vi = a * img[i] + nz;
+        out[i] = vz; out[total + i] = vi; out[2 * total + i] = vi;
+    }
+}
+
+__global__ void cfg_ddim_kernel(const float* eps3, float* lat, float* lat3, const float* coef, int N, long n) {
+    const long total = (long)N * n;
+    const float s_img = coef[0], s_txt = coef[1], sa = coef[2], sb = coef[3], sap = coef[4], sbp = coef[5];
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const float eu = eps3[i], ei = eps3[total + i], ea = eps3[2 * total + i];
+        const float eps = eu + s_img * (ei - eu) + s_txt * (ea - ei);
+        const float x = lat[i];
+        const float x0 = (x - sb * eps) / sa;
+        const float xp = sap * x0 + sbp * eps;
+        lat[i] = xp;
+        if (lat3) { lat3[i] = xp; lat3[total + i] = xp; lat3[2 * total + i] = xp; }
+    }
+}
+
+__global__ __launch_bounds__(256) void copy_rows_kernel(f16* dst, long ldd, long bsd, const f16* src, long lds, long bss,
+                                                        int batches, int rows, int cols) {
+    const int vpr = cols / 8;
+    const long total = (long)batches * rows * vpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % vpr);
+        const long rr = i / vpr;
+        const int r = (int)(rr % rows), b = (int)(rr / rows);
+        stg16(dst + b * bsd + (long)r * ldd + cv * 8, ldg16(src + b * bss + (long)r * lds + cv * 8));
+    }
+}
+
+}  // namespace
+
+extern "C" int sg_timestep_embed_f32(const float* t, const float* freqs, float* out, int32_t B, int32_t dim,
+                                     int32_t flip_sin_to_cos, sg_stream_t stream) {
+    SG_REQUIRE(t && freqs && out, "sg_timestep_embed: null pointer");
+    SG_REQUIRE(B > 0 && dim > 0 && dim % 2 == 0, "sg_timestep_embed: bad shape");
+    const int total = B * (dim / 2);
+    hipLaunchKernelGGL(timestep_embed_kernel, dim3(sg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, t, freqs, out, B,
+                       dim, flip_sin_to_cos);
+    SG_CHECK_LAUNCH("sg_timestep_embed_f32");
+    return SG_OK;
+}
+
+extern "C" int sg_linear_rows_f32(const float* x, int64_t ldx, const sg_half* W, int64_t ldw, const sg_half* bias, float* y,
+                                  int64_t ldy, int32_t B, int32_t N, int32_t K, int32_t act_in, int32_t act_out,
+                                  sg_stream_t stream) {
+    SG_REQUIRE(x && W && y, "sg_linear_rows: null pointer");
+    SG_REQUIRE(B > 0 && B <= 16 && N > 0 && K > 0 && K % 8 == 0, "sg_linear_rows: bad shape B=%d N=%d K=%d", B, N, K);
+    SG_REQUIRE(ldx % 4 == 0 && ldw % 8 == 0 && ldx >= K && ldw >= K && ldy >= N, "sg_linear_rows: bad strides");
+    SG_REQUIRE(sg_aligned16(x) && sg_aligned16(W), "sg_linear_rows: 16-byte alignment");
+    dim3 grid(sg_cdiv(N, 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const f16* w = reinterpret_cast<const f16*>(W);
+    const f16* bs = reinterpret_cast<const f16*>(bias);
+    if (B <= 4) hipLaunchKernelGGL(linear_rows_kernel<4>, grid, block, 0, st, x, (long)ldx, w, (long)ldw, bs, y, (long)ldy, B, N, K, act_in, act_out);
+    else if (B <= 8) hipLaunchKernelGGL(linear_rows_kernel<8>, grid, block, 0, st, x, (long)ldx, w, (long)ldw, bs, y, (long)ldy, B, N, K, act_in, act_out);
+    else hipLaunchKernelGGL(linear_rows_kernel<16>, grid, block, 0, st, x, (long)ldx, w, (long)ldw, bs, y, (long)ldy, B, N, K, act_in, act_out);
+    SG_CHECK_LAUNCH("sg_linear_rows_f32");
+    return SG_OK;
+}
+
+extern "C" int sg_conv_in_f16(const float* x_nchw, const sg_half* w_kn, const sg_half* bias, sg_half* y, int64_t ldy,
+                              int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, sg_stream_t stream) {
+    SG_REQUIRE(x_nchw && w_kn && bias && y, "sg_conv_in: null pointer");
+    SG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 8 && Cout > 0 && Cout % 8 == 0, "sg_conv_in: bad shape");
+    SG_REQUIRE(ldy % 8 == 0 && ldy >= Cout && sg_aligned16(w_kn) && sg_aligned16(bias) && sg_aligned16(y), "sg_conv_in: alignment");
+    const long total = (long)B * H * W * (Cout / 8);
+    hipLaunchKernelGGL(conv_in_kernel, dim3(sg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x_nchw,
+                       reinterpret_cast<const f16*>(w_kn), reinterpret_cast<const f16*>(bias), reinterpret_cast<f16*>(y),
+                       (long)ldy, B, H, W, Cin, Cout);
+    SG_CHECK_LAUNCH("sg_conv_in_f16");
+    return SG_OK;
+}
+
+extern "C" int sg_conv_out_f16(const sg_half* x, int64_t ldx, const sg_half* w, const sg_half* bias, float* y_nchw, int32_t B,
+                               int32_t H, int32_t W, int32_t Cin, int32_t Cout, sg_stream_t stream) {
+    SG_REQUIRE(x && w && bias && y_nchw, "sg_conv_out: null pointer");
+    SG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin % 8 == 0 && Cout > 0 && Cout <= 4, "sg_conv_out: bad shape");
+    SG_REQUIRE(ldx % 8 == 0 && ldx >= Cin && sg_aligned16(x) && sg_aligned16(w), "sg_conv_out: alignment");
+    const long pixels = (long)B * H * W;
+    hipLaunchKernelGGL(conv_out_kernel, dim3(sg_cdiv(pixels, 4)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const f16*>(x), (long)ldx, reinterpret_cast<const f16*>(w),
+                       reinterpret_cast<const f16*>(bias), y_nchw, B, H, W, Cin, Cout);
+    SG_CHECK_LAUNCH("sg_conv_out_f16");
+    return SG_OK;
+}
+
+extern "C" int sg_ref_inputs_f32(const float* zero, const float* img, const float* noise, const float* coef, float* out3,
+                                 int32_t N, int64_t n, sg_stream_t stream) {
+    SG_REQUIRE(zero && img && noise && coef && out3 && N > 0 && n > 0, "sg_ref_inputs: bad arguments");
+    const long total = (long)N * n;
+    hipLaunchKernelGGL(ref_inputs_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       zero, img, noise, coef, out3, N, (long)n);
+    SG_CHECK_LAUNCH("sg_ref_inputs_f32");
+    return SG_OK;
+}
+
+extern "C" int sg_cfg_ddim_step_f32(const float* eps3, float* latents, float* latents3, const float* coef, int32_t N, int64_t n,
+                                    sg_stream_t stream) {
+    SG_REQUIRE(eps3 && latents && coef && N > 0 && n > 0, "sg_cfg_ddim_step: bad arguments");
+    const long total = (long)N * n;
+    hipLaunchKernelGGL(cfg_ddim_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, eps3,
+                       latents, latents3, coef, N, (long)n);
+    SG_CHECK_LAUNCH("sg_cfg_ddim_step_f32");
+    return SG_OK;
+}
+
+extern "C" int sg_copy_rows_f16(sg_half* dst, int64_t ldd, int64_t bsd, const sg_half* src, int64_t lds, int64_t bss,
+                                int32_t batches, int32_t rows, int32_t cols, sg_stream_t stream) {
+    SG_REQUIRE(dst && src && batches > 0 && rows > 0 && cols > 0, "sg_copy_rows: bad arguments");
+    SG_REQUIRE(cols % 8 == 0 && ldd % 8 == 0 && lds % 8 == 0 && bsd % 8 == 0 && bss % 8 == 0, "sg_copy_rows: multiples of 8");
+    SG_REQUIRE(sg_aligned16(dst) && sg_aligned16(src), "sg_copy_rows: 16-byte alignment");
+    const long total = (long)batches * rows * (cols / 8);
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((int)min((long)2048, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<f16*>(dst), (long)ldd, (long)bsd, reinterpret_cast<const f16*>(src), (long)lds,
+                       (long)bss, batches, rows, cols);
+    SG_CHECK_LAUNCH("sg_copy_rows_f16");
+    return SG_OK;
+}

@@ -1,0 +1,245 @@
+// GroupNorm(+SiLU) over NHWC and LayerNorm over rows, fp16 in/out, fp32 statistics (HBM-bound kernels: every access
+// is a 16-byte, row-contiguous vector; statistics are deterministic — no atomics).
+#include "common.h"
+
+namespace {
+
+constexpr int GN_MAX_GROUPS = 64;
+constexpr int GN_MAX_CHUNKS = 64;
+
+struct GnParams {
+    const f16* x; long ldx;
+    f16* y; long ldy;
+    const f16* gamma; const f16* beta;
+    int HW, C, G, cpg, nchunks, rows_per_chunk;
+    float eps; int silu;
+    float* ws;   // [B][nchunks][G][2] shifted partial sums
+};
+
+// Thread layout shared by both passes: TW = min(C/8, 256) threads span one pixel row's channel vectors (looping
+// when C/8 > 256), 256/TW pixel rows are processed per pass.
+// Pass 1: per-(batch, chunk, group) sums of (x - pivot) and (x - pivot)^2, pivot = x[b, pixel 0, first channel of
+// the group] (a sample of the distribution, so E[(x-K)^2] - E[x-K]^2 has no catastrophic cancellation).
+__global__ __launch_bounds__(256) void gn_stats_kernel(const GnParams p) {
+    __shared__ float s_sum[2560], s_sq[2560];   // per-channel partials of one thread-row (C <= 2560)
+    const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
+    const int vpr = p.C / 8;
+    const int tw = vpr < 256 ? vpr : 256, rpp = 256 / tw;
+    const int my_row = t / tw, my_col = t - my_row * tw;
+    const f16* xb = p.x + (long)b * p.HW * p.ldx;
+    const int p0 = chunk * p.rows_per_chunk, p1 = min(p.HW, p0 + p.rows_per_chunk);
+    float gsum = 0.f, gsq = 0.f;   // accumulators of thread t < G (group t)
+    for (int cv0 = 0; cv0 < vpr; cv0 += tw) {
+        const int cv = cv0 + my_col;
+        float s[8], q[8], piv[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = q[j] = piv[j] = 0.f;
+        const bool active = my_row < rpp && cv < vpr;
+        if (active) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) piv[j] = (float)xb[((cv * 8 + j) / p.cpg) * p.cpg];
+            for (int px = p0 + my_row; px < p1; px += rpp) {
+                H8 v; v.u = ldg16(xb + (long)px * p.ldx + cv * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = (float)v.h[j] - piv[j];
+                    s[j] += d; q[j] += d * d;
+                }
+            }
+        }
+        // reduce the rpp thread-rows channel-wise, then channels -> groups (sequential, deterministic)
+        for (int r = 0; r < rpp; ++r) {
+            __syncthreads();
+            if (active && my_row == r) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ch = (cv - cv0) * 8 + j;
+                    if (r == 0) { s_sum[ch] = s[j]; s_sq[ch] = q[j]; }
+                    else { s_sum[ch] += s[j]; s_sq[ch] += q[j]; }
+                }
+            }
+        }
+        __syncthreads();
+        if (t < p.G) {
+            const int c_lo = max(t * p.cpg, cv0 * 8), c_hi = min((t + 1) * p.cpg, (cv0 + tw) * 8);
+            for (int ch = c_lo; ch < c_hi; ++ch) { gsum += s_sum[ch - cv0 * 8]; gsq += s_sq[ch - cv0 * 8]; }
+        }
+        __syncthreads();
+    }
+    if (t < p.G) {
+        float* w = p.ws + (((long)b * p.nchunks + chunk) * p.G + t) * 2;
+        w[0] = gsum; w[1] = gsq;
+    }
+}
+
+// Pass 2: reduce the chunk partials, then y = silu?((x - mean) * rstd * gamma + beta).
+__global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
+    __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
+    const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
+    const f16* xb = p.x + (long)b * p.HW * p.ldx;
+    f16* yb = p.y + (long)b * p.HW * p.ldy;
+    if (t < p.G) {
+        float s = 0.f, q = 0.f;
+        for (int c = 0; c < p.nchunks; ++c) {
+            const float* w = p.ws + (((long)b * p.nchunks + c) * p.G + t) * 2;
+            s += w[0]; q += w[1];
+        }
+        const float n = (float)p.HW * (float)p.cpg;
+        const float piv = (float)xb[t * p.cpg];
+        const float md = s / n;                       // E[x - K]
+        const float var = fmaxf(q / n - md * md, 0.f);
+        s_mean[t] = piv + md;
+        s_rstd[t] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+    const int vpr = p.C / 8;
+    const int tw = vpr < 256 ? vpr : 256, rpp = 256 / tw;
+    const int my_row = t / tw, my_col = t - my_row * tw;
+    if (my_row >= rpp) return;
+    const int p0 = chunk * p.rows_per_chunk, p1 = min(p.HW, p0 + p.rows_per_chunk);
+    for (int cv = my_col; cv < vpr; cv += tw) {
+        float sc[8], sh[8];
+        H8 g, be; g.u = ldg16(p.gamma + cv * 8); be.u = ldg16(p.beta + cv * 8);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int grp = (cv * 8 + j) / p.cpg;
+            sc[j] = s_rstd[grp] * (float)g.h[j];
+            sh[j] = (float)be.h[j] - s_mean[grp] * sc[j];
+        }
+        for (int px = p0 + my_row; px < p1; px += rpp) {
+            H8 v, o; v.u = ldg16(xb + (long)px * p.ldx + cv * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                float r = (float)v.h[j] * sc[j] + sh[j];
+                if (p.silu) r = silu_f(r);
+                o.h[j] = (f16)r;
+            }
+            stg16(yb + (long)px * p.ldy + cv * 8, o.u);
+        }
+    }
+}
+
+struct LnParams {
+    const f16* x; long ldx; int M, C; float eps;
+    const f16* g1; const f16* b1; f16* y1; long ldy1;
+    const f16* g2; const f16* b2; f16* y2; long ldy2;
+};
+
+// One wave per row; the row (C <= 64*8*NV halves) stays in registers; exact two-pass mean / variance.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
+    const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const int vpr = p.C / 8;
+    const f16* xr = p.x + (long)row * p.ldx;
+    H8 v[NV];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int cv = lane + 64 * i;
+        v[i].u = make_uint4(0, 0, 0, 0);
+        if (cv < vpr) {
+            v[i].u = ldg16(xr + cv * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += (float)v[i].h[j];
+        }
+    }
+    const float mean = wave_sum(sum) / (float)p.C;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i)
+        if (lane + 64 * i < vpr) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const float d = (float)v[i].h[j] - mean; sq += d * d; }
+        }
+    const float rstd = rsqrtf(wave_sum(sq) / (float)p.C + p.eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+        const int cv = lane + 64 * i;
+        if (cv < vpr) {
+            H8 g, be, o;
+            g.u = ldg16(p.g1 + cv * 8); be.u = ldg16(p.b1 + cv * 8);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) o.h[j] = (f16)(((float)v[i].h[j] - mean) * rstd * (float)g.h[j] + (float)be.h[j]);
+            stg16(p.y1 + (long)row * p.ldy1 + cv * 8, o.u);
+            if (p.y2) {
+                g.u = ldg16(p.g2 + cv * 8); be.u = ldg16(p.b2 + cv * 8);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) o.h[j] = (f16)(((float)v[i].h[j] - mean) * rstd * (float)g.h[j] + (float)be.h[j]);
+                stg16(p.y2 + (long)row * p.ldy2 + cv * 8, o.u);
+            }
+        }
+    }
+}
+
+void gn_geometry(int B, int HW, int C, int* nchunks, int* rows_per_chunk) {
+    const int vpr = C / 8, tw = vpr < 256 ? vpr : 256, rpp = 256 / tw;
+    // aim for ~512 workgroups in flight, at least 4 passes of rows per workgroup
+    int want = sg_cdiv(512, B);
+    int max_chunks = sg_cdiv(HW, rpp * 4);
+    int n = want < max_chunks ? want : max_chunks;
+    if (n < 1) n = 1;
+    if (n > GN_MAX_CHUNKS) n = GN_MAX_CHUNKS;
+    *rows_per_chunk = sg_cdiv(HW, n);
+    *nchunks = sg_cdiv(HW, *rows_per_chunk);
+}
+
+}  // namespace
+
+extern "C" size_t sg_groupnorm_workspace_bytes(int32_t B, int32_t groups) {
+    return (size_t)B * GN_MAX_CHUNKS * (size_t)groups * 2 * sizeof(float);
+}
+
+extern "C" int sg_groupnorm_nhwc_f16(const sg_half* x, int64_t ldx, sg_half* y, int64_t ldy, const sg_half* gamma,
+                                     const sg_half* beta, int32_t B, int32_t HW, int32_t C, int32_t groups, float eps,
+                                     int32_t silu, void* workspace, size_t workspace_bytes, sg_stream_t stream) {
+    SG_REQUIRE(x && y && gamma && beta && workspace, "sg_groupnorm: null pointer");
+    SG_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0, "sg_groupnorm: bad shape");
+    SG_REQUIRE(C % 8 == 0 && C % groups == 0 && C <= 2560, "sg_groupnorm: C=%d must be a multiple of 8 and of groups, <= 2560", C);
+    SG_REQUIRE(groups <= GN_MAX_GROUPS, "sg_groupnorm: at most %d groups", GN_MAX_GROUPS);
+    SG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C, "sg_groupnorm: bad ldx/ldy");
+    SG_REQUIRE(sg_aligned16(x) && sg_aligned16(y) && sg_aligned16(gamma) && sg_aligned16(beta), "sg_groupnorm: 16-byte alignment");
+    SG_REQUIRE(workspace_bytes >= sg_groupnorm_workspace_bytes(B, groups), "sg_groupnorm: workspace too small");
+    GnParams p{};
+    p.x = reinterpret_cast<const f16*>(x); p.ldx = ldx;
+    p.y = reinterpret_cast<f16*>(y); p.ldy = ldy;
+    p.gamma = reinterpret_cast<const f16*>(gamma); p.beta = reinterpret_cast<const f16*>(beta);
+    p.HW = HW; p.C = C; p.G = groups; p.cpg = C / groups; p.eps = eps; p.silu = silu;
+    p.ws = reinterpret_cast<float*>(workspace);
+    gn_geometry(B, HW, C, &p.nchunks, &p.rows_per_chunk);
+    dim3 grid(p.nchunks, B), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, st, p);
+    SG_CHECK_LAUNCH("gn_stats");
+    hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, p);
+    SG_CHECK_LAUNCH("gn_apply");
+    return SG_OK;
+}
+
+extern "C" int sg_layernorm_f16(const sg_half* x, int64_t ldx, int32_t M, int32_t C, float eps, const sg_half* gamma1,
+                                const sg_half* beta1, sg_half* y1, int64_t ldy1, const sg_half* gamma2,
+                                const sg_half* beta2, sg_half* y2, int64_t ldy2, sg_stream_t stream) {
+    SG_REQUIRE(x && gamma1 && beta1 && y1, "sg_layernorm: null pointer");
+    SG_REQUIRE(M > 0 && C > 0 && C % 8 == 0 && C <= 2048, "sg_layernorm: C=%d must be a multiple of 8, <= 2048", C);
+    SG_REQUIRE(ldx % 8 == 0 && ldy1 % 8 == 0 && ldx >= C && ldy1 >= C, "sg_layernorm: bad ldx/ldy1");
+    SG_REQUIRE(sg_aligned16(x) && sg_aligned16(y1) && sg_aligned16(gamma1) && sg_aligned16(beta1), "sg_layernorm: 16-byte alignment");
+    if (y2) {
+        SG_REQUIRE(gamma2 && beta2 && sg_aligned16(y2) && sg_aligned16(gamma2) && sg_aligned16(beta2) && ldy2 % 8 == 0 &&
+                       ldy2 >= C, "sg_layernorm: second output arguments");
+    }
+    LnParams p{};
+    p.x = reinterpret_cast<const f16*>(x); p.ldx = ldx; p.M = M; p.C = C; p.eps = eps;
+    p.g1 = reinterpret_cast<const f16*>(gamma1); p.b1 = reinterpret_cast<const f16*>(beta1);
+    p.y1 = reinterpret_cast<f16*>(y1); p.ldy1 = ldy1;
+    p.g2 = reinterpret_cast<const f16*>(gamma2); p.b2 = reinterpret_cast<const f16*>(beta2);
+    p.y2 = reinterpret_cast<f16*>(y2); p.ldy2 = ldy2;
+    dim3 grid(sg_cdiv(M, 4)), block(256);
+    hipStream_t st = (hipStream_t)stream;
+    const int nv = sg_cdiv(C / 8, 64);
+    if (nv == 1) hipLaunchKernelGGL(layernorm_kernel<1>, grid, block, 0, st, p);
+    else if (nv == 2) hipLaunchKernelGGL(layernorm_kernel<2>, grid, block, 0, st, p);
+    else if (nv == 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, p);
+    else hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, p);
+    SG_CHECK_LAUNCH("sg_layernorm_f16");
+    return SG_OK;
+}

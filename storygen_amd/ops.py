@@ -1,0 +1,260 @@
+"""Tensor-level wrappers over the C ABI (include/storygen_hip.h).
+
+Each wrapper borrows `data_ptr()`s of caller-owned torch tensors for the duration of the enqueue and launches on
+torch's *current* HIP stream, so PyTorch's caching allocator keeps stream ordering and `torch.cuda.graph` capture
+just works.  Nothing here computes: no op has a torch fallback, and importing this module without the built
+library raises (storygen_amd/_lib.py).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+from ._lib import AttnDesc, ConvDesc, GemmDesc, check
+
+lib = _lib.load()
+
+EPI_LINEAR = 0
+EPI_GEGLU = 1
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _f16(t: torch.Tensor, name: str):
+    if t.dtype != torch.float16 or not t.is_cuda:
+        raise TypeError(f"{name}: expected a CUDA/HIP float16 tensor, got {t.dtype} on {t.device}")
+
+
+def _f32(t: torch.Tensor, name: str):
+    if t.dtype != torch.float32 or not t.is_cuda:
+        raise TypeError(f"{name}: expected a CUDA/HIP float32 tensor, got {t.dtype} on {t.device}")
+
+
+def _row_stride(t: torch.Tensor, name: str) -> int:
+    """t is [..., rows, cols] with unit column stride; returns the row stride in elements."""
+    if t.stride(-1) != 1:
+        raise ValueError(f"{name}: innermost dimension must be contiguous")
+    return t.stride(-2)
+
+
+def device_arch() -> int:
+    return lib.sg_device_arch()
+
+
+def gemm_workspace_bytes(M: int, N: int, split_k: int = 0) -> int:
+    return lib.sg_gemm_workspace_bytes(M, N, split_k)
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
+         rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 1, res1: Optional[torch.Tensor] = None,
+         res2: Optional[torch.Tensor] = None, epilogue: int = EPI_LINEAR, split_k: int = 0,
+         workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, N'] = epi(a[M,K] @ w[N,K]^T); a/out/res* may be row-strided 2-D views."""
+    _f16(a, "a"), _f16(w, "w"), _f16(out, "out")
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise ValueError(f"gemm: a is [{M},{K}] but w is {tuple(w.shape)}")
+    n_out = N // 2 if epilogue == EPI_GEGLU else N
+    if tuple(out.shape) != (M, n_out):
+        raise ValueError(f"gemm: out must be [{M},{n_out}], got {tuple(out.shape)}")
+    d = GemmDesc()
+    d.A, d.lda = a.data_ptr(), _row_stride(a, "a")
+    d.W, d.ldw = w.data_ptr(), _row_stride(w, "w")
+    d.C, d.ldc = out.data_ptr(), _row_stride(out, "out")
+    d.M, d.N, d.K = M, N, K
+    d.epilogue = epilogue
+    d.bias = _p(bias)
+    if bias is not None:
+        _f16(bias, "bias")
+    if rowbias is not None:
+        _f32(rowbias, "rowbias")
+        d.rowbias, d.rowbias_ld = rowbias.data_ptr(), _row_stride(rowbias, "rowbias")
+    d.rows_per_batch = rows_per_batch
+    d.split_k = split_k
+    if res1 is not None:
+        _f16(res1, "res1")
+        d.res1, d.ldr1 = res1.data_ptr(), _row_stride(res1, "res1")
+    if res2 is not None:
+        _f16(res2, "res2")
+        d.res2, d.ldr2 = res2.data_ptr(), _row_stride(res2, "res2")
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    check(lib.sg_gemm_f16(C.byref(d), _stream()), "sg_gemm_f16")
+    return out
+
+
+def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stride: int = 1, upsample2x: bool = False,
+            bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
+            res1: Optional[torch.Tensor] = None, split_k: int = 0, workspace: Optional[torch.Tensor] = None
+            ) -> torch.Tensor:
+    """x [B,H,W,Cin] (channels-last, pixel-strided view allowed) -> out [B,Ho,Wo,Cout]; w_krsc [Cout,3,3,Cin]."""
+    _f16(x, "x"), _f16(w_krsc, "w"), _f16(out, "out")
+    B, H, W, Cin = x.shape
+    Cout = w_krsc.shape[0]
+    if tuple(w_krsc.shape) != (Cout, 3, 3, Cin) or not w_krsc.is_contiguous():
+        raise ValueError(f"conv3x3: w must be contiguous [Cout,3,3,{Cin}], got {tuple(w_krsc.shape)}")
+    hin, win = (H * 2, W * 2) if upsample2x else (H, W)
+    Ho, Wo = (hin - 1) // stride + 1, (win - 1) // stride + 1
+    if tuple(out.shape) != (B, Ho, Wo, Cout):
+        raise ValueError(f"conv3x3: out must be {(B, Ho, Wo, Cout)}, got {tuple(out.shape)}")
+
+    def pix_stride(t, name):
+        if t.stride(-1) != 1 or t.stride(1) != t.shape[2] * t.stride(2) or t.stride(0) != t.shape[1] * t.stride(1):
+            raise ValueError(f"{name}: must be [B,H,W,C] with a single pixel stride")
+        return t.stride(2)
+
+    d = ConvDesc()
+    d.x, d.ldx = x.data_ptr(), pix_stride(x, "x")
+    d.w = w_krsc.data_ptr()
+    d.y, d.ldy = out.data_ptr(), pix_stride(out, "out")
+    d.B, d.H, d.W, d.Cin, d.Cout = B, H, W, Cin, Cout
+    d.stride, d.upsample2x = stride, int(upsample2x)
+    if bias is not None:
+        _f16(bias, "bias")
+        d.bias = bias.data_ptr()
+    if rowbias is not None:
+        _f32(rowbias, "rowbias")
+        d.rowbias, d.rowbias_ld = rowbias.data_ptr(), _row_stride(rowbias, "rowbias")
+    if res1 is not None:
+        _f16(res1, "res1")
+        d.res1, d.ldr1 = res1.data_ptr(), pix_stride(res1, "res1")
+    d.split_k = split_k
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    check(lib.sg_conv3x3_nhwc_f16(C.byref(d), _stream()), "sg_conv3x3_nhwc_f16")
+    return out
+
+
+def conv_in(x_nchw: torch.Tensor, w_kn: torch.Tensor, bias: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    _f32(x_nchw, "x"), _f16(w_kn, "w"), _f16(bias, "bias"), _f16(out, "out")
+    B, Cin, H, W = x_nchw.shape
+    Cout = w_kn.shape[1]
+    if not x_nchw.is_contiguous() or tuple(w_kn.shape) != (9 * Cin, Cout) or tuple(out.shape) != (B, H, W, Cout):
+        raise ValueError("conv_in: bad shapes")
+    check(lib.sg_conv_in_f16(x_nchw.data_ptr(), w_kn.data_ptr(), bias.data_ptr(), out.data_ptr(), out.stride(2), B, H, W,
+                             Cin, Cout, _stream()), "sg_conv_in_f16")
+    return out
+
+
+def conv_out(x: torch.Tensor, w_krsc: torch.Tensor, bias: torch.Tensor, out_nchw: torch.Tensor) -> torch.Tensor:
+    _f16(x, "x"), _f16(w_krsc, "w"), _f16(bias, "bias"), _f32(out_nchw, "out")
+    B, H, W, Cin = x.shape
+    Cout = w_krsc.shape[0]
+    if tuple(out_nchw.shape) != (B, Cout, H, W) or not out_nchw.is_contiguous() or not w_krsc.is_contiguous():
+        raise ValueError("conv_out: bad shapes")
+    check(lib.sg_conv_out_f16(x.data_ptr(), x.stride(2), w_krsc.data_ptr(), bias.data_ptr(), out_nchw.data_ptr(), B, H, W,
+                              Cin, Cout, _stream()), "sg_conv_out_f16")
+    return out_nchw
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, heads: int, scale: float
+              ) -> torch.Tensor:
+    """q [B,Nq,H*D], k/v [B,Nk,H*D] (token- and batch-strided views allowed), out [B,Nq,H*D]."""
+    for n, t in (("q", q), ("k", k), ("v", v), ("out", out)):
+        _f16(t, n)
+        if t.dim() != 3 or t.stride(-1) != 1:
+            raise ValueError(f"attention: {n} must be [B,N,C] with contiguous channels")
+    B, Nq, Cq = q.shape
+    Nk = k.shape[1]
+    D = Cq // heads
+    d = AttnDesc()
+    d.q, d.ldq, d.bsq = q.data_ptr(), q.stride(1), q.stride(0)
+    d.k, d.ldk, d.bsk = k.data_ptr(), k.stride(1), k.stride(0)
+    d.v, d.ldv, d.bsv = v.data_ptr(), v.stride(1), v.stride(0)
+    d.o, d.ldo, d.bso = out.data_ptr(), out.stride(1), out.stride(0)
+    d.B, d.H, d.Nq, d.Nk, d.D = B, heads, Nq, Nk, D
+    d.scale = scale
+    check(lib.sg_attn_fwd_f16(C.byref(d), _stream()), "sg_attn_fwd_f16")
+    return out
+
+
+def groupnorm_workspace_bytes(B: int, groups: int) -> int:
+    return lib.sg_groupnorm_workspace_bytes(B, groups)
+
+
+def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, groups: int, eps: float,
+              silu: bool, workspace: torch.Tensor) -> torch.Tensor:
+    """x/out [B, HW, C] channels-last (row-strided views allowed)."""
+    _f16(x, "x"), _f16(gamma, "gamma"), _f16(beta, "beta"), _f16(out, "out")
+    B, HW, Cc = x.shape
+    if x.stride(0) != HW * x.stride(1) or out.stride(0) != HW * out.stride(1):
+        raise ValueError("groupnorm: batch stride must equal HW * row stride")
+    check(lib.sg_groupnorm_nhwc_f16(x.data_ptr(), x.stride(1), out.data_ptr(), out.stride(1), gamma.data_ptr(),
+                                    beta.data_ptr(), B, HW, Cc, groups, eps, int(silu), workspace.data_ptr(),
+                                    workspace.numel() * workspace.element_size(), _stream()), "sg_groupnorm_nhwc_f16")
+    return out
+
+
+def layernorm(x: torch.Tensor, g1: torch.Tensor, b1: torch.Tensor, y1: torch.Tensor, eps: float = 1e-5,
+              g2: Optional[torch.Tensor] = None, b2: Optional[torch.Tensor] = None,
+              y2: Optional[torch.Tensor] = None) -> None:
+    _f16(x, "x"), _f16(y1, "y1")
+    M, Cc = x.shape
+    check(lib.sg_layernorm_f16(x.data_ptr(), _row_stride(x, "x"), M, Cc, eps, g1.data_ptr(), b1.data_ptr(), y1.data_ptr(),
+                               _row_stride(y1, "y1"), _p(g2), _p(b2), _p(y2),
+                               0 if y2 is None else _row_stride(y2, "y2"), _stream()), "sg_layernorm_f16")
+
+
+def timestep_embed(t: torch.Tensor, freqs: torch.Tensor, out: torch.Tensor, flip_sin_to_cos: bool) -> torch.Tensor:
+    _f32(t, "t"), _f32(freqs, "freqs"), _f32(out, "out")
+    B, dim = out.shape
+    check(lib.sg_timestep_embed_f32(t.data_ptr(), freqs.data_ptr(), out.data_ptr(), B, dim, int(flip_sin_to_cos),
+                                    _stream()), "sg_timestep_embed_f32")
+    return out
+
+
+def linear_rows(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, act_in: bool = False,
+                act_out: bool = False) -> torch.Tensor:
+    _f32(x, "x"), _f16(w, "w"), _f32(out, "out")
+    B, K = x.shape
+    N = w.shape[0]
+    check(lib.sg_linear_rows_f32(x.data_ptr(), _row_stride(x, "x"), w.data_ptr(), _row_stride(w, "w"), _p(bias),
+                                 out.data_ptr(), _row_stride(out, "out"), B, N, K, int(act_in), int(act_out), _stream()),
+          "sg_linear_rows_f32")
+    return out
+
+
+def ref_inputs(zero: torch.Tensor, img: torch.Tensor, noise: torch.Tensor, coef: torch.Tensor, out3: torch.Tensor
+               ) -> torch.Tensor:
+    for n, t in (("zero", zero), ("img", img), ("noise", noise), ("coef", coef), ("out3", out3)):
+        _f32(t, n)
+    N = zero.shape[0]
+    check(lib.sg_ref_inputs_f32(zero.data_ptr(), img.data_ptr(), noise.data_ptr(), coef.data_ptr(), out3.data_ptr(), N,
+                                zero[0].numel(), _stream()), "sg_ref_inputs_f32")
+    return out3
+
+
+def cfg_ddim_step(eps3: torch.Tensor, latents: torch.Tensor, latents3: Optional[torch.Tensor], coef: torch.Tensor
+                  ) -> torch.Tensor:
+    _f32(eps3, "eps3"), _f32(latents, "latents"), _f32(coef, "coef")
+    N = latents.shape[0]
+    check(lib.sg_cfg_ddim_step_f32(eps3.data_ptr(), latents.data_ptr(), _p(latents3), coef.data_ptr(), N,
+                                   latents[0].numel(), _stream()), "sg_cfg_ddim_step_f32")
+    return latents
+
+
+def copy_rows(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    """dst[b, r, :cols] = src[b, r, :cols] for 3-D fp16 views with unit channel stride."""
+    _f16(dst, "dst"), _f16(src, "src")
+    Bn, rows, cols = src.shape
+    if tuple(dst.shape) != (Bn, rows, cols) or dst.stride(-1) != 1 or src.stride(-1) != 1:
+        raise ValueError("copy_rows: shape/stride mismatch")
+    check(lib.sg_copy_rows_f16(dst.data_ptr(), dst.stride(1), dst.stride(0), src.data_ptr(), src.stride(1), src.stride(0),
+                               Bn, rows, cols, _stream()), "sg_copy_rows_f16")
+    return dst
+
+
+def debug_mfma(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    out = torch.empty(64, 16, dtype=torch.float32, device=a.device)
+    check(lib.sg_debug_mfma_32x32x16(a.data_ptr(), b.data_ptr(), out.data_ptr(), _stream()), "sg_debug_mfma_32x32x16")
+    return out

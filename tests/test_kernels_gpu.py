@@ -1,0 +1,282 @@
+"""Per-kernel parity: every C-ABI entry point vs a plain PyTorch fp32 reference of the same op on the same
+fp16-rounded inputs (tolerance: fp16 output rounding, rel-L2 <= 1e-3, max-abs <= 3e-3 of the output range)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import max_rel, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+TOL_L2 = 1.0e-3
+TOL_MAX = 3.0e-3
+
+
+def rnd(shape, dev, scale=1.0, seed=0, dtype=torch.float16):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(shape, generator=g) * scale).to(dtype).to(dev)
+
+
+def check(out, ref, what, l2=TOL_L2, mx=TOL_MAX):
+    assert torch.isfinite(out.float()).all(), f"{what}: non-finite output"
+    e2, em = rel_l2(out.float().cpu(), ref.float().cpu()), max_rel(out.float().cpu(), ref.float().cpu())
+    assert e2 <= l2 and em <= mx, f"{what}: rel-L2 {e2:.2e} (tol {l2:.0e}), max-rel {em:.2e} (tol {mx:.0e})"
+
+
+def test_mfma_fragment_layout(gpu):
+    """Pins the v_mfma_f32_32x32x16_f16 operand/result lane maps every MFMA kernel here assumes:
+    A[i=l&31][k=8(l>>5)+j], B[k][n=l&31], D[row=(r&3)+8(r>>2)+4(l>>5)][col=l&31] (asymmetric operands)."""
+    from storygen_amd import ops
+    a = rnd((32, 16), gpu, seed=1)
+    b = rnd((16, 32), gpu, seed=2)
+    raw = ops.debug_mfma(a.contiguous(), b.contiguous()).cpu()
+    ref = (a.float() @ b.float()).cpu()
+    got = torch.empty(32, 32)
+    for lane in range(64):
+        for r in range(16):
+            got[(r & 3) + 8 * (r >> 2) + 4 * (lane >> 5), lane & 31] = raw[lane, r]
+    check(got, ref, "mfma layout", l2=1e-5, mx=1e-5)
+
+
+GEMM_SHAPES = [
+    # M, N, K            (tails in M and N, K not a multiple of 64, tiny, SD-1.5 layer shapes)
+    (128, 128, 64), (256, 320, 320), (200, 72, 136), (12, 320, 1280), (3072, 640, 640), (768, 1280, 2560),
+    (4096, 960, 320), (231, 2560, 768), (64, 1280, 11520 // 4),
+]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+def test_gemm_linear_epilogues(gpu, M, N, K):
+    from storygen_amd import ops
+    a, w = rnd((M, K), gpu, seed=3), rnd((N, K), gpu, 1 / math.sqrt(K), seed=4)
+    bias, r1, r2 = rnd((N,), gpu, seed=5), rnd((M, N), gpu, seed=6), rnd((M, N), gpu, seed=7)
+    rpb = max(1, M // 3)
+    rb = rnd((-(-M // rpb), N), gpu, seed=8, dtype=torch.float32)
+    acc = a.float() @ w.float().t()
+    out = torch.empty(M, N, dtype=torch.float16, device=gpu)
+    ops.gemm(a, w, out, split_k=1)
+    check(out, acc, "plain")
+    ops.gemm(a, w, out, bias=bias, res1=r1, res2=r2, rowbias=rb, rows_per_batch=rpb, split_k=1)
+    ref = acc + bias.float() + r1.float() + r2.float() + rb.repeat_interleave(rpb, 0)[:M]
+    check(out, ref, "bias+rowbias+res1+res2")
+
+
+@pytest.mark.parametrize("M,N,K,split", [(192, 1280, 1280, 4), (768, 1280, 11520, 6), (100, 72, 640, 3), (64, 640, 5120, 0)])
+def test_gemm_split_k(gpu, M, N, K, split):
+    from storygen_amd import ops
+    a, w = rnd((M, K), gpu, seed=3), rnd((N, K), gpu, 1 / math.sqrt(K), seed=4)
+    bias, r1 = rnd((N,), gpu, seed=5), rnd((M, N), gpu, seed=6)
+    ws = torch.empty(ops.gemm_workspace_bytes(M, N, split), dtype=torch.uint8, device=gpu)
+    out = torch.empty(M, N, dtype=torch.float16, device=gpu)
+    ops.gemm(a, w, out, bias=bias, res1=r1, split_k=split, workspace=ws)
+    check(out, a.float() @ w.float().t() + bias.float() + r1.float(), f"split_k={split}")
+
+
+def test_gemm_strided_views(gpu):
+    """lda/ldc/ldr larger than the logical widths: operands are column slices of wider buffers."""
+    from storygen_amd import ops
+    M, N, K = 300, 320, 640
+    abuf, cbuf, rbuf = rnd((M, K + 64), gpu, seed=1), torch.zeros(M, N + 128, dtype=torch.float16, device=gpu), rnd((M, 2 * N), gpu, seed=2)
+    w = rnd((N, K), gpu, 1 / math.sqrt(K), seed=3)
+    a, out, res = abuf[:, 64:], cbuf[:, 64:64 + N], rbuf[:, N:]
+    ops.gemm(a, w, out, res1=res, split_k=1)
+    check(out, a.float() @ w.float().t() + res.float(), "strided")
+    assert float(cbuf[:, :64].abs().max()) == 0 and float(cbuf[:, 64 + N:].abs().max()) == 0, "wrote outside the view"
+
+
+@pytest.mark.parametrize("M,C,split", [(256, 320, 1), (100, 64, 1), (192, 1280, 3)])
+def test_gemm_geglu(gpu, M, C, split):
+    """GEGLU.proj + gelu gate (model/attention.py:381-393) with the 32/32 value/gate row interleave."""
+    from storygen_amd import ops
+    from storygen_amd.repack import interleave_geglu
+    K, inner = C, 4 * C
+    a = rnd((M, K), gpu, seed=1)
+    w = rnd((2 * inner, K), gpu, 1 / math.sqrt(K), seed=2)
+    b = rnd((2 * inner,), gpu, seed=3)
+    proj = a.float() @ w.float().t() + b.float()
+    ref = proj[:, :inner] * F.gelu(proj[:, inner:])
+    wi, bi = interleave_geglu(w, b)
+    out = torch.empty(M, inner, dtype=torch.float16, device=gpu)
+    ws = torch.empty(ops.gemm_workspace_bytes(M, 2 * inner, split), dtype=torch.uint8, device=gpu) if split > 1 else None
+    ops.gemm(a, wi, out, bias=bi, epilogue=ops.EPI_GEGLU, split_k=split, workspace=ws)
+    check(out, ref, "geglu")
+
+
+CONV_CASES = [
+    # B, H, W, Cin, Cout, stride, ups, split
+    (2, 16, 16, 64, 64, 1, False, 1), (3, 8, 8, 128, 320, 1, False, 1), (1, 12, 20, 64, 72, 1, False, 1),
+    (2, 16, 16, 64, 128, 2, False, 1), (2, 8, 8, 128, 64, 1, True, 1), (3, 8, 8, 1280, 1280, 1, False, 0),
+    (1, 10, 6, 192, 136, 2, False, 1), (3, 16, 16, 640, 640, 1, False, 4),
+]
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups,split", CONV_CASES)
+def test_conv3x3(gpu, B, H, W, Cin, Cout, stride, ups, split):
+    """3x3 pad-1 conv (stride 1/2, fused nearest-2x upsample) with bias + per-batch channel bias + residual."""
+    from storygen_amd import ops
+    x = rnd((B, Cin, H, W), gpu, seed=1)
+    w = rnd((Cout, Cin, 3, 3), gpu, 1 / math.sqrt(9 * Cin), seed=2)
+    bias = rnd((Cout,), gpu, seed=3)
+    rb = rnd((B, Cout), gpu, seed=4, dtype=torch.float32)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, w.float(), bias.float(), stride=stride, padding=1) + rb[:, :, None, None]
+    res = rnd(tuple(ref.shape), gpu, seed=5)
+    ref = ref + res.float()
+    x_nhwc = x.permute(0, 2, 3, 1).contiguous()
+    w_krsc = w.permute(0, 2, 3, 1).contiguous()
+    res_nhwc = res.permute(0, 2, 3, 1).contiguous()
+    out = torch.empty(B, ref.shape[2], ref.shape[3], Cout, dtype=torch.float16, device=gpu)
+    M = B * ref.shape[2] * ref.shape[3]
+    ws = torch.empty(max(16, ops.gemm_workspace_bytes(M, Cout, split)), dtype=torch.uint8, device=gpu)
+    ops.conv3x3(x_nhwc, w_krsc, out, stride=stride, upsample2x=ups, bias=bias, rowbias=rb, res1=res_nhwc, split_k=split,
+                workspace=ws)
+    check(out.permute(0, 3, 1, 2), ref, "conv3x3")
+
+
+ATTN_CASES = [
+    # B, H, Nq, Nk, D
+    (2, 8, 256, 256, 40), (1, 8, 200, 77, 40), (3, 8, 64, 192, 160), (2, 8, 256, 768, 80), (1, 8, 1024, 1024, 80),
+    (1, 2, 130, 65, 160), (3, 8, 4096, 77, 40), (1, 8, 1024, 3072, 40), (1, 4, 33, 1, 80),
+]
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D", ATTN_CASES)
+def test_attention(gpu, B, H, Nq, Nk, D):
+    from storygen_amd import ops
+    C = H * D
+    # q/k/v as column slices of fused projection buffers, like the engine lays them out
+    qkv = rnd((B, Nq, 3 * C), gpu, 1.5, seed=1)
+    kv = rnd((B, Nk, 2 * C), gpu, 1.5, seed=2)
+    q, k, v = qkv[:, :, :C], kv[:, :, :C], kv[:, :, C:]
+    scale = D ** -0.5
+    out = torch.empty(B, Nq, C, dtype=torch.float16, device=gpu)
+    ops.attention(q, k, v, out, H, scale)
+
+    def heads(t):
+        return t.float().view(t.shape[0], t.shape[1], H, D).transpose(1, 2)
+    att = torch.softmax(heads(q) @ heads(k).transpose(-1, -2) * scale, dim=-1) @ heads(v)
+    ref = att.transpose(1, 2).reshape(B, Nq, C)
+    check(out, ref, "attention")
+
+
+def test_attention_online_softmax_rescale(gpu):
+    """Forces the running-max rescale: one key in a *late* tile dominates one query row (guide §5.4 rule 26)."""
+    from storygen_amd import ops
+    B, H, Nq, Nk, D = 1, 8, 128, 512, 40
+    C = H * D
+    q, k, v = rnd((B, Nq, C), gpu, seed=1), rnd((B, Nk, C), gpu, seed=2), rnd((B, Nk, C), gpu, seed=3)
+    k[0, 300] = q[0, 5] * 6.0          # spike: raw q.k is ~40 * 6 vs O(6) elsewhere
+    k[0, 450] = q[0, 77] * 8.0
+    out = torch.empty(B, Nq, C, dtype=torch.float16, device=gpu)
+    ops.attention(q, k, v, out, H, D ** -0.5)
+
+    def heads(t):
+        return t.float().view(B, -1, H, D).transpose(1, 2)
+    ref = (torch.softmax(heads(q) @ heads(k).transpose(-1, -2) * D ** -0.5, -1) @ heads(v)).transpose(1, 2).reshape(B, Nq, C)
+    check(out, ref, "attention rescale")
+
+
+@pytest.mark.parametrize("B,HW,C,silu,eps", [(3, 256, 320, True, 1e-5), (2, 64, 1920, True, 1e-5), (1, 100, 2560, False, 1e-6),
+                                            (3, 4096, 320, False, 1e-6), (2, 1024, 960, True, 1e-5), (1, 7, 64, True, 1e-5)])
+def test_groupnorm(gpu, B, HW, C, silu, eps):
+    from storygen_amd import ops
+    x = (rnd((B, HW, C), gpu, 2.0, seed=1).float() + 3.0).half()      # non-zero mean
+    g, b = rnd((C,), gpu, seed=2), rnd((C,), gpu, seed=3)
+    out = torch.empty_like(x)
+    ws = torch.empty(ops.groupnorm_workspace_bytes(B, 32), dtype=torch.uint8, device=gpu)
+    ops.groupnorm(x, g, b, out, 32, eps, silu, ws)
+    ref = F.group_norm(x.float().transpose(1, 2), 32, g.float(), b.float(), eps)
+    ref = (F.silu(ref) if silu else ref).transpose(1, 2)
+    check(out, ref, "groupnorm")
+
+
+@pytest.mark.parametrize("M,C", [(1024, 320), (300, 640), (77, 1280), (5, 64)])
+def test_layernorm_dual(gpu, M, C):
+    from storygen_amd import ops
+    x = (rnd((M, C), gpu, 2.0, seed=1).float() + 1.0).half()
+    g1, b1, g2, b2 = (rnd((C,), gpu, seed=s) for s in (2, 3, 4, 5))
+    y1, y2 = torch.empty_like(x), torch.empty_like(x)
+    ops.layernorm(x, g1, b1, y1, 1e-5, g2, b2, y2)
+    check(y1, F.layer_norm(x.float(), (C,), g1.float(), b1.float(), 1e-5), "layernorm 1")
+    check(y2, F.layer_norm(x.float(), (C,), g2.float(), b2.float(), 1e-5), "layernorm 2")
+    ops.layernorm(x, g2, b2, y1, 1e-5)
+    check(y1, F.layer_norm(x.float(), (C,), g2.float(), b2.float(), 1e-5), "layernorm single")
+
+
+def test_time_embedding_path(gpu):
+    """Timesteps -> linear_1 -> SiLU -> linear_2, then SiLU -> time_emb_proj (unet_2d_condition.py:392-398)."""
+    from storygen_amd import ops
+    B, dim, temb = 3, 320, 1280
+    t = torch.tensor([981.0, 98.0, 1.0], device=gpu)
+    half = dim // 2
+    freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32) / half).to(gpu)
+    emb = torch.empty(B, dim, device=gpu)
+    ops.timestep_embed(t, freqs, emb, True)
+    e = t[:, None] * freqs[None]
+    check(emb, torch.cat([torch.cos(e), torch.sin(e)], -1), "timestep embed", l2=1e-5, mx=1e-4)
+    w1, b1 = rnd((temb, dim), gpu, 0.05, seed=1), rnd((temb,), gpu, seed=2)
+    w2, b2 = rnd((960, temb), gpu, 0.03, seed=3), rnd((960,), gpu, seed=4)
+    h = torch.empty(B, temb, device=gpu)
+    ops.linear_rows(emb, w1, b1, h, act_out=True)
+    ref_h = F.silu(emb @ w1.float().t() + b1.float())
+    check(h, ref_h, "linear_rows silu-out", l2=1e-5, mx=1e-4)
+    y = torch.empty(B, 960, device=gpu)
+    ops.linear_rows(h, w2, b2, y, act_in=True)
+    check(y, F.silu(ref_h) @ w2.float().t() + b2.float(), "linear_rows silu-in", l2=1e-5, mx=1e-4)
+
+
+def test_conv_in_out(gpu):
+    from storygen_amd import ops
+    B, H, W, C = 3, 16, 24, 320
+    x = rnd((B, 4, H, W), gpu, seed=1, dtype=torch.float32)
+    w = rnd((C, 4, 3, 3), gpu, 1 / 6, seed=2)
+    b = rnd((C,), gpu, seed=3)
+    y = torch.empty(B, H, W, C, dtype=torch.float16, device=gpu)
+    ops.conv_in(x, w.permute(2, 3, 1, 0).reshape(36, C).contiguous(), b, y)
+    check(y.permute(0, 3, 1, 2), F.conv2d(x, w.float(), b.float(), padding=1), "conv_in")
+    wo = rnd((4, C, 3, 3), gpu, 1 / math.sqrt(9 * C), seed=4)
+    bo = rnd((4,), gpu, seed=5)
+    out = torch.empty(B, 4, H, W, device=gpu)
+    ops.conv_out(y, wo.permute(0, 2, 3, 1).contiguous(), bo, out)
+    check(out, F.conv2d(y.permute(0, 3, 1, 2).float(), wo.float(), bo.float(), padding=1), "conv_out", l2=1e-5, mx=1e-4)
+
+
+def test_sampling_elementwise(gpu):
+    from storygen_amd import ops
+    N, shape = 2, (2, 4, 16, 16)
+    zero, img, noise, lat = (rnd(shape, gpu, seed=s, dtype=torch.float32) for s in (1, 2, 3, 4))
+    coef = torch.tensor([0.9, 0.43], device=gpu)
+    out3 = torch.empty(3 * N, 4, 16, 16, device=gpu)
+    ops.ref_inputs(zero, img, noise, coef, out3)
+    ref = torch.cat([0.9 * zero + 0.43 * noise, 0.9 * img + 0.43 * noise, 0.9 * img + 0.43 * noise])
+    check(out3, ref, "ref_inputs", l2=1e-6, mx=1e-6)
+    eps3 = rnd((3 * N, 4, 16, 16), gpu, seed=5, dtype=torch.float32)
+    c = torch.tensor([3.5, 7.5, 0.8, 0.6, 0.85, 0.5267], device=gpu)
+    eu, ei, ea = eps3.chunk(3)
+    eps = eu + 3.5 * (ei - eu) + 7.5 * (ea - ei)
+    ref = 0.85 * (lat - 0.6 * eps) / 0.8 + 0.5267 * eps
+    lat3 = torch.empty(3 * N, 4, 16, 16, device=gpu)
+    ops.cfg_ddim_step(eps3, lat, lat3, c)
+    check(lat, ref, "cfg+ddim", l2=1e-6, mx=1e-5)
+    check(lat3, torch.cat([ref] * 3), "cfg+ddim replicate", l2=1e-6, mx=1e-5)
+
+
+def test_copy_rows(gpu):
+    from storygen_amd import ops
+    src = rnd((3, 50, 640), gpu, seed=1)
+    dst = torch.zeros(3, 150, 960, dtype=torch.float16, device=gpu)
+    ops.copy_rows(dst[:, 50:100, 320:], src)
+    assert torch.equal(dst[:, 50:100, 320:], src) and float(dst[:, :50].abs().max()) == 0 and float(dst[:, :, :320].abs().max()) == 0
+
+
+def test_abi_rejects_bad_arguments(gpu):
+    """Errors are reported through the return code + sg_last_error(), mirrored as RuntimeError (SURVEY §8b Errors)."""
+    from storygen_amd import ops
+    a, w = rnd((64, 60), gpu), rnd((64, 60), gpu)
+    with pytest.raises(RuntimeError, match="multiples of 8"):
+        ops.gemm(a, w, torch.empty(64, 64, dtype=torch.float16, device=gpu))
+    q = rnd((1, 64, 8 * 48), gpu)
+    with pytest.raises(RuntimeError, match="head dim"):
+        ops.attention(q, q, q, torch.empty_like(q), 8, 1.0)
