@@ -1,0 +1,187 @@
+#!/usr/bin/env python
+"""bench.py — StoryGen denoising hot loop on MI355X: denoising steps/s at 512x512, 3 prior-frame context, bs=1.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+One "step" = exactly one iteration of /root/reference/model/pipeline.py:412-461 with classifier-free guidance:
+R=3 reference UNet passes (batch 3) + 1 main pass (batch 3, attn3 over 12 288 context tokens) + CFG + DDIM
+= 11.05 TFLOP of conv/GEMM/attention contractions as written (nothing deduplicated or skipped).
+Workload = BASELINE.json configs[1] ("inference.py: 50-step DDIM, 512x512, 3 prior-frame context, fp16,
+1xMI355X"), SD-1.5-architecture UNet (909 M params) with synthetic fp16 weights and synthetic inputs
+(storygen_amd/synth.py) — there is no network for checkpoints.  N GPUs = N independent samples, one per GPU
+(weak scaling, no per-step communication; one RCCL all-gather of the final latents after the loop).
+
+Prints ONE JSON line (rank 0).  Extra objects:
+  roofline     — the kernel family with the largest share of the step, timed in situ with HIP events on the launch
+                 stream during one extra eager step after the timed region: achieved = algorithmic FLOPs of its
+                 launches / their summed duration; peak = 2500 TFLOP/s dense fp16 MFMA
+                 (/opt/skills/guides/MI355X_MICROARCH.md).  `families` lists every MFMA-class family the same way.
+  cpu_baseline — the oracle (oracle/storygen_oracle.py, kind "port") timed on the host cores on a bounded sample:
+                 one reference pass + one main pass (batch 3, R=3); step time = 3*t_ref + t_main.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_FP16_TFLOPS = 2500.0          # dense MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
+HW, R, N_PER_GPU, T = 64, 3, 1, 50
+REF_GF, MAIN_GF = 803.3, 1273.1    # per-sample algorithmic GFLOP of one ref / main pass at 64x64, R=3
+STEP_TFLOP = 3 * (R * REF_GF + MAIN_GF) / 1000.0
+
+
+def cpu_baseline(arch, sd, inputs):
+    from oracle import storygen_oracle as O
+    cfg = arch.config
+    sched = O.DDIM()
+    t_main = sched.timesteps(T)[0]
+    ref_t = t_main // 10
+    an = sched.add_noise
+    x = torch.cat([an(inputs["zero_prompt"], inputs["noise"], ref_t), an(inputs["image_prompts"][0], inputs["noise"], ref_t),
+                   an(inputs["image_prompts"][0], inputs["noise"], ref_t)])
+    e = torch.cat([inputs["prev_uncond"][0], inputs["prev_text"][0], inputs["prev_text"][0]])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        _, feats = O.unet_forward(sd, cfg, x, ref_t, e, None)
+        t_ref = time.perf_counter() - t0
+        ctx = {k: torch.cat([v] * R, dim=1) for k, v in feats.items()}
+        xm = torch.cat([inputs["latents"]] * 3)
+        em = torch.cat([inputs["uncond"], inputs["uncond"], inputs["text"]])
+        t0 = time.perf_counter()
+        O.unet_forward(sd, cfg, xm, t_main, em, ctx)
+        t_main_s = time.perf_counter() - t0
+    step_s = R * t_ref + t_main_s
+    return {"value": 1.0 / step_s, "unit": "denoising steps/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle fp32: 1 ref pass ({t_ref:.1f}s) + 1 main pass ({t_main_s:.1f}s), batch 3, R=3; "
+                      f"step = 3*t_ref + t_main = {step_s:.1f}s", "seconds_per_step": step_s}
+
+
+def in_situ_roofline(sampler):
+    """One extra eager step with every MFMA-class launch bracketed by HIP events on its launch stream."""
+    from storygen_amd import ops
+    sink = []
+    ops.PROFILE_SINK = sink
+    try:
+        sampler.params.copy_(sampler.table[min(sampler.k, sampler.table.shape[0] - 1)], non_blocking=True)
+        sampler._step_body()
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILE_SINK = None
+    fam = {}
+    for name, flops, a, b, _shape in sink:
+        f = fam.setdefault(name, {"launches": 0, "ms": 0.0, "gflop": 0.0})
+        f["launches"] += 1
+        f["ms"] += a.elapsed_time(b)
+        f["gflop"] += flops / 1e9
+    for f in fam.values():
+        f["tflops"] = f["gflop"] / f["ms"] if f["ms"] > 0 else 0.0
+        f["avg_us"] = 1e3 * f["ms"] / f["launches"]
+        f["frac_of_peak"] = f["tflops"] / PEAK_FP16_TFLOPS
+    dom = max(fam, key=lambda k: fam[k]["ms"])
+    d = fam[dom]
+    roof = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
+            "frac": round(d["frac_of_peak"], 4), "traffic": None, "launches_per_step": d["launches"],
+            "avg_launch_us": round(d["avg_us"], 1), "gflop_per_step": round(d["gflop"], 1),
+            "families": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(fam.items())}}
+    return roof
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X; no GPU visible (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from storygen_amd.arch import SD15_CONFIG, build_arch
+    from storygen_amd.sampler import StoryGenSampler, gather_latents
+    from storygen_amd.synth import synthetic_inputs, synthetic_state_dict
+
+    arch = build_arch(SD15_CONFIG)
+    sd = synthetic_state_dict(arch, 0)
+    inputs = synthetic_inputs(N_PER_GPU, R, HW, HW, seed=rank, cross_attention_dim=arch.config["cross_attention_dim"])
+    sampler = StoryGenSampler(arch, sd, dev, N_PER_GPU, HW, HW, R, use_graph=not args.no_graph)
+    n_sched = max(T, args.steps + args.warmup)
+    sampler.prepare(inputs, n_sched, "multi-image-condition", 7.5, 3.5)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        sampler.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        sampler.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    t0 = time.perf_counter()
+    final = gather_latents(sampler.latents)                     # the one collective of the DP path
+    torch.cuda.synchronize(dev)
+    gather_ms = 1e3 * (time.perf_counter() - t0)
+    finite = bool(torch.isfinite(final).all())
+
+    if rank == 0:
+        value = world * N_PER_GPU * args.steps / dt
+        out = {
+            "metric": "UNet denoising steps/sec @512x512, 3 prior-frame ctx, bs=1", "value": round(value, 4),
+            "unit": "denoising steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: StoryGen denoising loop, 512x512 (64x64x4 latent), R=3 prior "
+                                   "frames, CFG batch 3, DDIM, SD-1.5 UNet + attn3 (909M params, synthetic fp16 weights)",
+                       "samples_per_gpu": N_PER_GPU, "parallelism": f"dp{world} (one sample per GPU, final all-gather)",
+                       "hipgraph": not args.no_graph},
+            "tflop_per_step_algorithmic": round(STEP_TFLOP, 3),
+            "mfma_frac_whole_step": round(value * STEP_TFLOP / (world * PEAK_FP16_TFLOPS), 4),
+            "unet_forwards_per_s": round(value * (R + 1), 3),
+            "final_allgather_ms": round(gather_ms, 3), "latents_finite": finite,
+        }
+        out["roofline"] = in_situ_roofline(sampler)
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(arch, sd, inputs)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

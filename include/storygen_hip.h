@@ -62,9 +62,9 @@ int          sg_device_cus(void);
  *                   outputs 32u..32u+31 and rows [64u+32, 64u+64) the matching "gate" outputs;
  *                   C[m, 32u+j] = (val + bias_v) * gelu_erf(gate + bias_g); N' = N/2 (exact erf GELU).
  * split_k > 1 needs `workspace` of sg_gemm_workspace_bytes(M, N, split_k) bytes (fp32 partial tiles, reduced
- * by a second kernel that applies the epilogue).  split_k == 0 lets the library choose (then pass a workspace
- * of sg_gemm_workspace_bytes(M, N, 0) bytes, which covers the largest split it may pick, or NULL to forbid
- * splitting).
+ * by a second kernel that applies the epilogue).  split_k == 0 lets the library choose: it only considers
+ * splits whose partial tiles fit the workspace it was given (M*N*4 bytes per split), so any fixed scratch
+ * buffer — or NULL to forbid splitting — is valid; sg_gemm_workspace_bytes(M, N, 0) is the most it can use.
  */
 #define SG_EPI_LINEAR 0
 #define SG_EPI_GEGLU  1

@@ -99,6 +99,9 @@ def load() -> C.CDLL:
         raise RuntimeError(
             f"{LIB_PATH} is missing: build it with `python -m storygen_amd.build` (hipcc, gfx950). "
             "storygen_amd has no CPU / eager fallback.")
+    # libstorygen_hip.so and PyTorch-ROCm must share ONE HIP runtime (same soname libamdhip64.so.7): import torch
+    # first so that the dynamic loader resolves our dependency to the copy torch already mapped.
+    import torch  # noqa: F401
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)   # AttributeError if the symbol is not exported

@@ -302,7 +302,7 @@ struct Plan { int bm, bn, splits; };
 
 // Rough cost model in "slab units" (one 128x128x64 slab of MFMAs on one CU ~ 0.5 us): picks the tile shape and
 // the K split that minimise ceil(blocks / CUs) * per-block cost (+ the reduce pass for split-K).
-Plan choose_plan(int M, int N, int KT, int force_split, bool allow_split, int cus) {
+Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, int cus) {
     static const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
     static const double eff[3] = {1.0, 0.8, 0.55};
     static const int split_opts[] = {1, 2, 3, 4, 6, 8, 12, 16};
@@ -313,7 +313,7 @@ Plan choose_plan(int M, int N, int KT, int force_split, bool allow_split, int cu
         const long tiles = (long)sg_cdiv(M, bm) * sg_cdiv(N, bn);
         for (int s : split_opts) {
             if (force_split > 0 && s != force_split) continue;
-            if (force_split <= 0 && s > 1 && (!allow_split || KT / s < 4)) continue;
+            if (force_split <= 0 && s > 1 && (s > max_ws_split || KT / s < 4)) continue;
             if (s > KT) continue;
             const long blocks = tiles * s;
             const double per_block = (double)bm * bn / 16384.0 * (sg_cdiv(KT, s) + 6.0) / eff[ci];
@@ -330,7 +330,9 @@ template <bool CONV>
 int launch_mma(MmaParams& p, int force_split, void* ws, size_t ws_bytes, hipStream_t st, const char* name) {
     p.KT = sg_cdiv(p.K, BK);
     const int cus = 256;
-    Plan pl = choose_plan(p.M, p.N, p.KT, force_split, ws != nullptr, cus);
+    const size_t per_split = (size_t)p.M * p.N * 4;
+    const int max_ws_split = ws ? (int)(ws_bytes / per_split > 64 ? 64 : ws_bytes / per_split) : 1;
+    Plan pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, cus);
     if (pl.splits > 1) {
         const size_t need = (size_t)p.M * p.N * 4 * pl.splits;
         if (ws == nullptr || ws_bytes < need)

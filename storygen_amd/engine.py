@@ -1,0 +1,381 @@
+"""UNetEngine — StoryGen's UNet forward on the HIP kernels (fp16 channels-last activations, fp32 accumulate).
+
+Re-design of /root/reference/model/unet_2d_condition.py:338-485 (+ unet_2d_blocks.py forward paths and
+attention.py:85-128,236-302) around what the MI355X wants rather than around nn.Module calls:
+
+  * every activation is a channels-last fp16 matrix [B*H*W, C]; the transformer's token layout IS that matrix, so
+    the reference's permute/reshape pairs (attention.py:103,117) disappear;
+  * weights are repacked once (KRSC convs, fused QKV / KV projections, 32/32-interleaved GEGLU, all 22
+    time_emb_proj stacked into one GEMV bundle whose output, plus the conv1 bias, becomes conv1's per-sample
+    channel bias);
+  * residual adds, biases, the `(a2+h)+(a3+h)` combine (attention.py:277,291-293) and GEGLU live in GEMM/conv
+    epilogues; nearest-2x upsampling and stride-2 are folded into the conv gather; `torch.cat([h, skip])`
+    becomes "the producer writes its columns of the concat buffer" + one strided copy of the skip;
+  * harvested features (attention.py:263) are written straight into slot r of the preallocated context buffers
+    [B, R*HW, C] that the main pass cross-attends to (replaces the clones at unet_2d_condition.py:428-429,445,
+    468-470 and the token-axis concat at pipeline.py:440-443);
+  * all buffers are allocated up front, nothing allocates or synchronises inside `forward`, timestep values are
+    read from device memory — so a whole pass (or a whole denoising step) can be captured in one hipGraph.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+
+from . import ops
+from .arch import BlockSpec, ResnetSpec, UNetArch, XfSpec, feature_shapes
+from .repack import conv1x1_nk, conv3x3_krsc, conv_in_kn, interleave_geglu
+
+F16 = torch.float16
+
+
+class _Resnet:
+    __slots__ = ("spec", "n1g", "n1b", "w1", "n2g", "n2b", "w2", "b2", "wsc", "bsc", "temb_off")
+
+
+class _Xf:
+    __slots__ = ("spec", "ng", "nb", "w_in", "b_in", "w_out", "b_out", "ln", "w_qkv1", "w_o1", "b_o1", "w_q2", "w_kv2",
+                 "w_o2", "b_o2", "w_q3", "w_kv3", "w_o3", "b_o3", "w_ff1", "b_ff1", "w_ff2", "b_ff2")
+
+
+class UNetEngine:
+    def __init__(self, arch: UNetArch, state_dict: Dict[str, torch.Tensor], device, batch: int, height: int,
+                 width: int, n_ref: int = 0, seq_len: int = 77, splitk_workspace_mb: int = 96):
+        """batch = samples per UNet call (3N with classifier-free guidance); n_ref = R prior frames (sizes the
+        context buffers; 0 = harvest-only engine)."""
+        self.arch, self.dev = arch, torch.device(device)
+        self.B, self.H, self.W, self.R, self.S = batch, height, width, n_ref, seq_len
+        cfg = arch.config
+        self.cfg = cfg
+        nlev = len(cfg["block_out_channels"])
+        if height % (1 << (nlev - 1)) or width % (1 << (nlev - 1)):
+            raise ValueError(f"latent size {height}x{width} must be divisible by {1 << (nlev - 1)}")
+        self.groups, self.eps = cfg["norm_num_groups"], cfg["norm_eps"]
+        self.cad = cfg["cross_attention_dim"]
+        self.hw = [(height >> l) * (width >> l) for l in range(nlev)]
+        self._load_weights(state_dict)
+        self._alloc(splitk_workspace_mb)
+
+    # ------------------------------------------------------------------------------------------ weights
+    def _w(self, sd, key) -> torch.Tensor:
+        return sd[key].detach().to(device=self.dev, dtype=F16).contiguous()
+
+    def _load_weights(self, sd):
+        dev, arch = self.dev, self.arch
+        g = lambda k: self._w(sd, k)  # noqa: E731
+        self.w_conv_in = conv_in_kn(g("conv_in.weight"))
+        self.b_conv_in = g("conv_in.bias")
+        self.w_t1, self.b_t1 = g("time_embedding.linear_1.weight"), g("time_embedding.linear_1.bias")
+        self.w_t2, self.b_t2 = g("time_embedding.linear_2.weight"), g("time_embedding.linear_2.bias")
+        half = cfg_half = self.cfg["block_out_channels"][0] // 2
+        # diffusers Timesteps: exp(-ln(1e4) * j / (half - shift)) computed in fp32 by torch, as the reference does
+        self.freqs = torch.exp(-math.log(10000.0) * torch.arange(half, dtype=torch.float32)
+                               / (cfg_half - self.cfg["freq_shift"])).to(dev)
+        self.resnets: Dict[str, _Resnet] = {}
+        temb_w, temb_b, off = [], [], 0
+        for r in arch.resnets:
+            p = r.prefix
+            o = _Resnet()
+            o.spec = r
+            o.n1g, o.n1b = g(f"{p}.norm1.weight"), g(f"{p}.norm1.bias")
+            o.w1 = conv3x3_krsc(g(f"{p}.conv1.weight"))
+            o.n2g, o.n2b = g(f"{p}.norm2.weight"), g(f"{p}.norm2.bias")
+            o.w2, o.b2 = conv3x3_krsc(g(f"{p}.conv2.weight")), g(f"{p}.conv2.bias")
+            if r.has_shortcut:
+                o.wsc, o.bsc = conv1x1_nk(g(f"{p}.conv_shortcut.weight")), g(f"{p}.conv_shortcut.bias")
+            else:
+                o.wsc = o.bsc = None
+            temb_w.append(g(f"{p}.time_emb_proj.weight"))
+            # conv1 bias + time_emb_proj bias are both per-channel constants of the same add (resnet forward)
+            temb_b.append((sd[f"{p}.time_emb_proj.bias"].float() + sd[f"{p}.conv1.bias"].float()).to(dev, F16))
+            o.temb_off = off
+            off += r.cout
+            self.resnets[p] = o
+        self.w_temb = torch.cat(temb_w, 0).contiguous()
+        self.b_temb = torch.cat(temb_b, 0).contiguous()
+        self.temb_total = off
+        self.xfs: Dict[str, _Xf] = {}
+        for blk in arch.down + [arch.mid] + arch.up:
+            for a in blk.attns:
+                if a is None:
+                    continue
+                p, t = a.prefix, f"{a.prefix}.transformer_blocks.0"
+                o = _Xf()
+                o.spec = a
+                o.ng, o.nb = g(f"{p}.norm.weight"), g(f"{p}.norm.bias")
+                o.w_in, o.b_in = conv1x1_nk(g(f"{p}.proj_in.weight")), g(f"{p}.proj_in.bias")
+                o.w_out, o.b_out = conv1x1_nk(g(f"{p}.proj_out.weight")), g(f"{p}.proj_out.bias")
+                o.ln = {n: (g(f"{t}.{n}.weight"), g(f"{t}.{n}.bias")) for n in ("norm1", "norm2", "norm3", "norm4")}
+                o.w_qkv1 = torch.cat([g(f"{t}.attn1.to_q.weight"), g(f"{t}.attn1.to_k.weight"),
+                                      g(f"{t}.attn1.to_v.weight")], 0).contiguous()
+                o.w_o1, o.b_o1 = g(f"{t}.attn1.to_out.0.weight"), g(f"{t}.attn1.to_out.0.bias")
+                o.w_q2 = g(f"{t}.attn2.to_q.weight")
+                o.w_kv2 = torch.cat([g(f"{t}.attn2.to_k.weight"), g(f"{t}.attn2.to_v.weight")], 0).contiguous()
+                o.w_o2, o.b_o2 = g(f"{t}.attn2.to_out.0.weight"), g(f"{t}.attn2.to_out.0.bias")
+                o.w_q3 = g(f"{t}.attn3.to_q.weight")
+                o.w_kv3 = torch.cat([g(f"{t}.attn3.to_k.weight"), g(f"{t}.attn3.to_v.weight")], 0).contiguous()
+                o.w_o3, o.b_o3 = g(f"{t}.attn3.to_out.0.weight"), g(f"{t}.attn3.to_out.0.bias")
+                o.w_ff1, o.b_ff1 = interleave_geglu(g(f"{t}.ff.net.0.proj.weight"), g(f"{t}.ff.net.0.proj.bias"))
+                o.w_ff2, o.b_ff2 = g(f"{t}.ff.net.2.weight"), g(f"{t}.ff.net.2.bias")
+                self.xfs[p] = o
+        self.samplers = {}
+        for blk in arch.down + arch.up:
+            if blk.sampler_prefix:
+                self.samplers[blk.sampler_prefix] = (conv3x3_krsc(g(f"{blk.sampler_prefix}.weight")),
+                                                     g(f"{blk.sampler_prefix}.bias"))
+        self.gn_out = (g("conv_norm_out.weight"), g("conv_norm_out.bias"))
+        self.w_conv_out = conv3x3_krsc(g("conv_out.weight"))
+        self.b_conv_out = g("conv_out.bias")
+
+    # ------------------------------------------------------------------------------------------ buffers
+    def _buf(self, *shape, dtype=F16) -> torch.Tensor:
+        return torch.empty(*shape, dtype=dtype, device=self.dev)
+
+    def _alloc(self, splitk_mb: int):
+        B, arch = self.B, self.arch
+        boc = self.cfg["block_out_channels"]
+        nlev = len(boc)
+        self.x_in = self._buf(B, self.cfg["in_channels"], self.H, self.W, dtype=torch.float32)
+        self.t_in = self._buf(B, dtype=torch.float32)
+        self.text_in = self._buf(B, self.S, self.cad)
+        self.eps_out = self._buf(B, self.cfg["out_channels"], self.H, self.W, dtype=torch.float32)
+        self.temb0 = self._buf(B, boc[0], dtype=torch.float32)
+        self.temb1 = self._buf(B, arch.temb_dim, dtype=torch.float32)
+        self.temb2 = self._buf(B, arch.temb_dim, dtype=torch.float32)
+        self.tproj = self._buf(B, self.temb_total, dtype=torch.float32)
+        self.ws_split = self._buf(splitk_mb << 20, dtype=torch.uint8)
+        self.ws_gn = self._buf(ops.groupnorm_workspace_bytes(B, self.groups), dtype=torch.uint8)
+        # widest tensors per level
+        cmax = [0] * nlev       # widest resnet input (concat) at the level
+        cout = [0] * nlev       # widest block channel count at the level
+        lvl = 0
+        for blk in arch.down:
+            for r in blk.resnets:
+                cmax[lvl], cout[lvl] = max(cmax[lvl], r.cin), max(cout[lvl], r.cout)
+            if blk.sampler_prefix:
+                lvl += 1
+        for r in arch.mid.resnets:
+            cmax[lvl], cout[lvl] = max(cmax[lvl], r.cin), max(cout[lvl], r.cout)
+        for blk in arch.up:
+            for r in blk.resnets:
+                cmax[lvl], cout[lvl] = max(cmax[lvl], r.cin), max(cout[lvl], r.cout)
+            if blk.sampler_prefix:
+                lvl -= 1
+        self.lv = []
+        for l in range(nlev):
+            M, C, Cw = B * self.hw[l], cout[l], max(cmax[l], cout[l])
+            d = dict(
+                gn=self._buf(M * Cw), cat=[self._buf(M * Cw), self._buf(M * Cw)], r=self._buf(M, C), c1=self._buf(M, C),
+                t_out=self._buf(M, C),
+                sc=self._buf(M, C), h0=self._buf(M, C), h1=self._buf(M, C), h2=self._buf(M, C), h3=self._buf(M, C),
+                ln=self._buf(M, C), ln4=self._buf(M, C), qkv=self._buf(M, 3 * C), q=self._buf(M, C), att=self._buf(M, C),
+                ffi=self._buf(M, 4 * C), kvt=self._buf(B * self.S, 2 * C),
+                kvi=self._buf(B * self.R * self.hw[l], 2 * C) if self.R else None,
+            )
+            self.lv.append(d)
+        # skip tensors (down_block_res_samples) persist until the up path pops them
+        self.skips: List[torch.Tensor] = []
+        self.skip_meta = []
+        lvl = 0
+        self.skip_meta.append((0, boc[0]))
+        for blk in arch.down:
+            for _ in blk.resnets:
+                self.skip_meta.append((lvl, blk.channels))
+            if blk.sampler_prefix:
+                lvl += 1
+                self.skip_meta.append((lvl, blk.channels))
+        self.skips = [self._buf(B * self.hw[l], c) for l, c in self.skip_meta]
+        # context buffers: [B, R*HW, C] per feature key
+        self.ctx: Dict[str, torch.Tensor] = {}
+        if self.R:
+            for k, (n, c) in feature_shapes(arch, self.H, self.W).items():
+                self.ctx[k] = self._buf(B, self.R * n, c)
+
+    # ------------------------------------------------------------------------------------------ layers
+    def _groupnorm(self, x2d: torch.Tensor, gamma, beta, out2d: torch.Tensor, eps: float, silu: bool, hw: int):
+        ops.groupnorm(x2d.unflatten(0, (self.B, hw)), gamma, beta, out2d.unflatten(0, (self.B, hw)), self.groups, eps,
+                      silu, self.ws_gn)
+
+    def _img(self, x2d: torch.Tensor, lvl: int) -> torch.Tensor:
+        h, w = self.H >> lvl, self.W >> lvl
+        return x2d.unflatten(0, (self.B, h, w))
+
+    def _resnet(self, rn: _Resnet, x: torch.Tensor, out: torch.Tensor, lvl: int):
+        """x [M,Cin] (contiguous), out [M,Cout] (possibly a column slice of a concat buffer)."""
+        L, M, r = self.lv[lvl], x.shape[0], rn.spec
+        t0 = L["gn"][: M * r.cin].view(M, r.cin)
+        self._groupnorm(x, rn.n1g, rn.n1b, t0, self.eps, True, self.hw[lvl])
+        h1 = L["c1"]
+        assert h1.shape == (M, r.cout), (h1.shape, M, r.cout)
+        rb = self.tproj[:, rn.temb_off: rn.temb_off + r.cout]
+        ops.conv3x3(self._img(t0, lvl), rn.w1, self._img(h1, lvl), rowbias=rb, workspace=self.ws_split)
+        t1 = L["gn"][: M * r.cout].view(M, r.cout)
+        self._groupnorm(h1, rn.n2g, rn.n2b, t1, self.eps, True, self.hw[lvl])
+        if rn.wsc is not None:
+            sc = L["sc"]
+            ops.gemm(x, rn.wsc, sc, bias=rn.bsc, workspace=self.ws_split)
+            res = sc
+        else:
+            res = x
+        ops.conv3x3(self._img(t1, lvl), rn.w2, self._img(out, lvl), bias=rn.b2, res1=self._img(res, lvl),
+                    workspace=self.ws_split)
+
+    def _transformer(self, xf: _Xf, x: torch.Tensor, out: torch.Tensor, lvl: int, text: torch.Tensor,
+                     harvest_slot: Optional[int], consume: bool):
+        """Transformer2DModel.forward (attention.py:85-128) + BasicTransformerBlock.forward (:236-302)."""
+        L, B, hw, S = self.lv[lvl], self.B, self.hw[lvl], self.S
+        M, C, heads = x.shape[0], xf.spec.channels, xf.spec.heads
+        scale = xf.spec.dim_head ** -0.5
+        ws = self.ws_split
+        t = L["gn"][: M * C].view(M, C)
+        self._groupnorm(x, xf.ng, xf.nb, t, 1e-6, False, hw)                              # :99 (eps 1e-6, :55)
+        h0 = L["h0"]
+        ops.gemm(t, xf.w_in, h0, bias=xf.b_in, workspace=ws)                              # proj_in :101
+        # --- self-attention :250-262
+        ops.layernorm(h0, *xf.ln["norm1"], L["ln"])
+        qkv = L["qkv"]
+        ops.gemm(L["ln"], xf.w_qkv1, qkv, workspace=ws)
+        q3d = qkv.view(B, hw, 3 * C)
+        att = L["att"]
+        ops.attention(q3d[:, :, :C], q3d[:, :, C:2 * C], q3d[:, :, 2 * C:], att.view(B, hw, C), heads, scale)
+        h1 = L["h1"]
+        ops.gemm(att, xf.w_o1, h1, bias=xf.b_o1, res1=h0, workspace=ws)
+        if harvest_slot is not None:                                                     # feature :263
+            dst = self.ctx[xf.spec.feature_key][:, harvest_slot * hw:(harvest_slot + 1) * hw, :]
+            ops.copy_rows(dst, h1.view(B, hw, C))
+        # --- text cross-attention :266-277 (norm2) and image cross-attention :281-291 (norm4) share statistics
+        if consume:
+            ops.layernorm(h1, *xf.ln["norm2"], L["ln"], 1e-5, *xf.ln["norm4"], L["ln4"])
+        else:
+            ops.layernorm(h1, *xf.ln["norm2"], L["ln"])
+        ops.gemm(L["ln"], xf.w_q2, L["q"], workspace=ws)
+        kvt = L["kvt"]
+        ops.gemm(text.view(B * S, -1), xf.w_kv2, kvt, workspace=ws)
+        kv3d = kvt.view(B, S, 2 * C)
+        ops.attention(L["q"].view(B, hw, C), kv3d[:, :, :C], kv3d[:, :, C:], att.view(B, hw, C), heads, scale)
+        if consume:
+            ht = L["h2"]
+            ops.gemm(att, xf.w_o2, ht, bias=xf.b_o2, res1=h1, workspace=ws)               # h_t = a2 + h   :277
+            ctx = self.ctx[xf.spec.feature_key]
+            nk = ctx.shape[1]
+            ops.gemm(L["ln4"], xf.w_q3, L["q"], workspace=ws)
+            kvi = L["kvi"]
+            ops.gemm(ctx.view(B * nk, C), xf.w_kv3, kvi, workspace=ws)
+            kvi3 = kvi.view(B, nk, 2 * C)
+            ops.attention(L["q"].view(B, hw, C), kvi3[:, :, :C], kvi3[:, :, C:], att.view(B, hw, C), heads, scale)
+            h3 = L["h3"]
+            ops.gemm(att, xf.w_o3, h3, bias=xf.b_o3, res1=h1, res2=ht, workspace=ws)      # (a3 + h) + h_t :291-293
+        else:
+            h3 = L["h2"]
+            ops.gemm(att, xf.w_o2, h3, bias=xf.b_o2, res1=h1, workspace=ws)               # :277,295
+        # --- feed-forward :298-300
+        ops.layernorm(h3, *xf.ln["norm3"], L["ln"])
+        ops.gemm(L["ln"], xf.w_ff1, L["ffi"], bias=xf.b_ff1, epilogue=ops.EPI_GEGLU, workspace=ws)
+        h4 = L["h0"]
+        ops.gemm(L["ffi"], xf.w_ff2, h4, bias=xf.b_ff2, res1=h3, workspace=ws)
+        ops.gemm(h4, xf.w_out, out, bias=xf.b_out, res1=x, workspace=ws)                  # proj_out + residual :121-123
+
+    # ------------------------------------------------------------------------------------------ forward
+    def _cat_view(self, lvl: int, which: int, width: int) -> torch.Tensor:
+        M = self.B * self.hw[lvl]
+        return self.lv[lvl]["cat"][which][: M * width].view(M, width)
+
+    def forward(self, harvest_slot: Optional[int] = None, consume: bool = False) -> torch.Tensor:
+        """One UNet call on the static inputs (self.x_in fp32 NCHW, self.t_in fp32 [B], self.text_in fp16).
+
+        harvest_slot=r : reference pass — no image context, features written to slot r of self.ctx.
+        consume=True   : main pass — attn3 cross-attends to self.ctx.
+        Returns self.eps_out (fp32 NCHW)."""
+        if harvest_slot is not None and consume:
+            raise ValueError("a pass either harvests features or consumes them")
+        if (harvest_slot is not None or consume) and not self.R:
+            raise ValueError("engine was built without context buffers (n_ref=0)")
+        arch, ws, text, skips = self.arch, self.ws_split, self.text_in, self.skips
+        # --- time embedding :392-398, then all 22 time_emb_proj(silu(emb)) in one GEMV bundle
+        ops.timestep_embed(self.t_in, self.freqs, self.temb0, self.cfg["flip_sin_to_cos"])
+        ops.linear_rows(self.temb0, self.w_t1, self.b_t1, self.temb1, act_out=True)
+        ops.linear_rows(self.temb1, self.w_t2, self.b_t2, self.temb2)
+        ops.linear_rows(self.temb2, self.w_temb, self.b_temb, self.tproj, act_in=True)
+        # --- conv_in :411
+        ops.conv_in(self.x_in, self.w_conv_in, self.b_conv_in, self._img(skips[0], 0))
+        h, lvl, si = skips[0], 0, 1
+        # --- down :417-433 — every layer output is a skip tensor, so it is written straight into its skip buffer
+        for blk in arch.down:
+            for j, r in enumerate(blk.resnets):
+                xf, out = blk.attns[j], skips[si]
+                if xf is None:
+                    self._resnet(self.resnets[r.prefix], h, out, lvl)
+                else:
+                    rt = self.lv[lvl]["r"]
+                    self._resnet(self.resnets[r.prefix], h, rt, lvl)
+                    self._transformer(self.xfs[xf.prefix], rt, out, lvl, text, harvest_slot, consume)
+                h, si = out, si + 1
+            if blk.sampler_prefix:
+                w, b = self.samplers[blk.sampler_prefix]
+                out = skips[si]
+                ops.conv3x3(self._img(h, lvl), w, self._img(out, lvl + 1), stride=2, bias=b, workspace=ws)   # Downsample2D
+                h, lvl, si = out, lvl + 1, si + 1
+        assert si == len(skips)
+        # --- mid :436-445
+        L = self.lv[lvl]
+        m0, m1 = arch.mid.resnets
+        self._resnet(self.resnets[m0.prefix], h, L["r"], lvl)
+        self._transformer(self.xfs[arch.mid.attns[0].prefix], L["r"], L["t_out"], lvl, text, harvest_slot, consume)
+        blk0 = arch.up[0]
+        pp = 0
+        cat = self._cat_view(lvl, pp, blk0.resnets[0].cin)
+        self._resnet(self.resnets[m1.prefix], L["t_out"], cat[:, : blk0.resnets[0].cin - blk0.skip_channels[0]], lvl)
+        # --- up :448-475 — `cat` always holds [h | <room for the skip>] for the next resnet
+        for bi, blk in enumerate(arch.up):
+            L = self.lv[lvl]
+            nres = len(blk.resnets)
+            for j, r in enumerate(blk.resnets):
+                si -= 1
+                c_h = r.cin - blk.skip_channels[j]
+                assert skips[si].shape[1] == blk.skip_channels[j] and cat.shape[1] == r.cin
+                ops.copy_rows(cat[:, c_h:].unsqueeze(0), skips[si].unsqueeze(0))          # torch.cat([h, skip]) :609,716
+                if j + 1 < nres:
+                    nxt = self._cat_view(lvl, pp ^ 1, blk.resnets[j + 1].cin)
+                    out = nxt[:, : blk.resnets[j + 1].cin - blk.skip_channels[j + 1]]
+                else:
+                    nxt, out = None, L["t_out"]
+                xf = blk.attns[j]
+                if xf is None:
+                    self._resnet(self.resnets[r.prefix], cat, out, lvl)
+                else:
+                    self._resnet(self.resnets[r.prefix], cat, L["r"], lvl)
+                    self._transformer(self.xfs[xf.prefix], L["r"], out, lvl, text, harvest_slot, consume)
+                if nxt is not None:
+                    cat, pp = nxt, pp ^ 1
+                h = out
+            if blk.sampler_prefix:                                                        # Upsample2D :656-658,730-732
+                w, b = self.samplers[blk.sampler_prefix]
+                nblk = arch.up[bi + 1]
+                pp = 0
+                cat = self._cat_view(lvl - 1, pp, nblk.resnets[0].cin)
+                c_h = nblk.resnets[0].cin - nblk.skip_channels[0]
+                ops.conv3x3(self._img(h, lvl), w, self._img(cat[:, :c_h], lvl - 1), upsample2x=True, bias=b, workspace=ws)
+                lvl -= 1
+        assert si == 0 and lvl == 0
+        # --- out :477-480
+        L = self.lv[0]
+        t = L["gn"][: h.numel()].view_as(h)
+        self._groupnorm(h, *self.gn_out, t, self.eps, True, self.hw[0])
+        ops.conv_out(self._img(t, 0), self.w_conv_out, self.b_conv_out, self.eps_out)
+        return self.eps_out
+
+    # ------------------------------------------------------------------------------------------ convenience
+    def set_inputs(self, sample: torch.Tensor, timestep, text: torch.Tensor):
+        self.x_in.copy_(sample.to(self.dev, torch.float32))
+        t = timestep if torch.is_tensor(timestep) else torch.tensor([float(timestep)])
+        self.t_in.copy_(t.to(self.dev, torch.float32).reshape(-1).expand(self.B))
+        self.text_in.copy_(text.to(self.dev, F16))
+
+    def features(self, slot: int = 0) -> Dict[str, torch.Tensor]:
+        """The 16 harvested [B, HW, C] features of slot r, as views into the context buffers."""
+        out = {}
+        for k, (n, _) in feature_shapes(self.arch, self.H, self.W).items():
+            out[k] = self.ctx[k][:, slot * n:(slot + 1) * n, :]
+        return out

@@ -20,6 +20,30 @@ lib = _lib.load()
 EPI_LINEAR = 0
 EPI_GEGLU = 1
 
+# Optional in-situ kernel timer (bench.py): when set, every MFMA-class launch is bracketed by HIP events recorded
+# on the launch stream and reported as (family, algorithmic_flops, start_event, end_event).
+PROFILE_SINK = None
+
+
+class _timed:
+    __slots__ = ("family", "flops", "start", "shape")
+
+    def __init__(self, family: str, flops: float, shape: str = ""):
+        self.family, self.flops, self.shape = family, flops, shape
+
+    def __enter__(self):
+        if PROFILE_SINK is not None:
+            self.start = torch.cuda.Event(enable_timing=True)
+            self.start.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if PROFILE_SINK is not None and exc[0] is None:
+            end = torch.cuda.Event(enable_timing=True)
+            end.record(torch.cuda.current_stream())
+            PROFILE_SINK.append((self.family, self.flops, self.start, end, self.shape))
+        return False
+
 
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
@@ -89,7 +113,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[
         d.res2, d.ldr2 = res2.data_ptr(), _row_stride(res2, "res2")
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
-    check(lib.sg_gemm_f16(C.byref(d), _stream()), "sg_gemm_f16")
+    with _timed("gemm", 2.0 * M * N * K, f"M{M} N{N} K{K}{' geglu' if epilogue else ''}"):
+        check(lib.sg_gemm_f16(C.byref(d), _stream()), "sg_gemm_f16")
     return out
 
 
@@ -131,7 +156,9 @@ def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stride:
     d.split_k = split_k
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
-    check(lib.sg_conv3x3_nhwc_f16(C.byref(d), _stream()), "sg_conv3x3_nhwc_f16")
+    with _timed("conv3x3", 2.0 * B * Ho * Wo * Cout * 9 * Cin,
+                f"B{B} {Ho}x{Wo} {Cin}->{Cout} s{stride}{' up' if upsample2x else ''}"):
+        check(lib.sg_conv3x3_nhwc_f16(C.byref(d), _stream()), "sg_conv3x3_nhwc_f16")
     return out
 
 
@@ -174,7 +201,8 @@ def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tens
     d.o, d.ldo, d.bso = out.data_ptr(), out.stride(1), out.stride(0)
     d.B, d.H, d.Nq, d.Nk, d.D = B, heads, Nq, Nk, D
     d.scale = scale
-    check(lib.sg_attn_fwd_f16(C.byref(d), _stream()), "sg_attn_fwd_f16")
+    with _timed(f"attention_d{D}", 4.0 * B * heads * Nq * Nk * D, f"B{B} H{heads} Nq{Nq} Nk{Nk}"):
+        check(lib.sg_attn_fwd_f16(C.byref(d), _stream()), "sg_attn_fwd_f16")
     return out
 
 

@@ -6,6 +6,10 @@ tests/golden/*.pt (oracle/make_golden.py, in the build container) and the HIP ru
 same numbers.  Scales follow PyTorch's default init (U(+-1/sqrt(fan_in))) with three deliberate changes so the
 parity tests exercise what they should: norm affine parameters are perturbed away from (1, 0), and the
 attention q/k projections get a gain so that softmax rows are peaked rather than uniform.
+All values are rounded to fp16-representable numbers (and returned as fp32): the reference casts the UNet and its
+inputs to fp16 (inference.py:73-75), so "the reference on identical weights/inputs" means these fp16 values; an fp32
+evaluation of them is then the exact arithmetic of the fp16 model, and a parity error measures kernel arithmetic
+only, not checkpoint quantisation.
 Input recipe: SURVEY §8(d) "Synthetic inputs".
 """
 from __future__ import annotations
@@ -34,8 +38,12 @@ def _gen(name: str, seed: int) -> torch.Generator:
     return g
 
 
+def fp16_exact(t: torch.Tensor) -> torch.Tensor:
+    return t.to(torch.float16).to(torch.float32)
+
+
 def synthetic_tensor(name: str, shape, seed: int = 0, std: float = 1.0) -> torch.Tensor:
-    return torch.randn(tuple(shape), generator=_gen(name, seed), dtype=torch.float32) * std
+    return fp16_exact(torch.randn(tuple(shape), generator=_gen(name, seed), dtype=torch.float32) * std)
 
 
 def synthetic_state_dict(arch: UNetArch, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
@@ -63,7 +71,7 @@ def synthetic_state_dict(arch: UNetArch, seed: int = 0) -> "OrderedDict[str, tor
             t = (torch.rand(shape, generator=g) * 2.0 - 1.0) * bound
             if name.endswith("to_q.weight") or name.endswith("to_k.weight"):
                 t = t * QK_GAIN
-        sd[name] = t.to(torch.float32)
+        sd[name] = fp16_exact(t)
     return sd
 
 
@@ -95,7 +103,8 @@ def synthetic_inputs(n_samples: int, n_ref: int, height: int, width: int, seed: 
         latents=f("in.latents", (n_samples, 4, height, width), s),
         image_prompts=f("in.image_prompts", (n_ref, n_samples, 4, height, width), s, 0.8),
         zero_prompt=f("in.zero_prompt", (n_samples, 4, height, width), s, 0.1),
-        noise=f("in.noise", (n_samples, 4, height, width), s),
+        # drawn un-rounded: the reference pipeline draws it from the global generator in the latents' dtype
+        noise=torch.randn((n_samples, 4, height, width), generator=_gen("in.noise", s), dtype=torch.float32),
         text=f("in.text", (n_samples, seq_len, cross_attention_dim), s),
         uncond=f("in.uncond", (1, seq_len, cross_attention_dim), s).expand(n_samples, -1, -1).contiguous(),
         prev_text=f("in.prev_text", (n_ref, n_samples, seq_len, cross_attention_dim), s),

@@ -1,0 +1,165 @@
+"""End-to-end parity of the HIP UNet / denoising loop against the oracle (CPU fp32 restatement of the reference)
+and against the golden vectors produced by the reference itself (tests/golden/*.pt, oracle/make_golden.py).
+
+Tolerances (fp16 storage, fp32 accumulate vs an fp32 oracle): rel-L2 on epsilon / features / latents.  The
+north-star bar is 1e-3 relative on the latents; per-tensor bars for intermediate features are looser because a
+single fp16 rounding of an activation is already 2^-11 = 4.9e-4 relative."""
+import os
+
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL_EPS = 6e-3        # one UNet pass, epsilon / features (fp16 residual stream: ~100 roundings of 2^-11)
+TOL_LATENT = 1e-3     # latents after a denoising step (north-star)
+
+
+@pytest.fixture(scope="module")
+def sd15(gpu):
+    from storygen_amd.arch import SD15_CONFIG, build_arch
+    from storygen_amd.synth import synthetic_state_dict
+    arch = build_arch(SD15_CONFIG)
+    return arch, synthetic_state_dict(arch, 0)
+
+
+def _ref_and_main_inputs(inputs, sched, t_main):
+    ref_t = t_main // 10
+    an = sched.add_noise
+    x = torch.cat([an(inputs["zero_prompt"], inputs["noise"], ref_t), an(inputs["image_prompts"][0], inputs["noise"], ref_t),
+                   an(inputs["image_prompts"][0], inputs["noise"], ref_t)])
+    e = torch.cat([inputs["prev_uncond"][0], inputs["prev_text"][0], inputs["prev_text"][0]])
+    xm = torch.cat([inputs["latents"]] * 3)
+    em = torch.cat([inputs["uncond"], inputs["uncond"], inputs["text"]])
+    return ref_t, x, e, xm, em
+
+
+def test_unet_passes_vs_oracle_16x16(gpu, sd15):
+    """SD-1.5 architecture at a 16x16 latent (2 prior frames): harvest pass features + eps, then the main pass that
+    consumes them, HIP vs the oracle run live on the host (the reference itself cannot run this size)."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.engine import UNetEngine
+    from storygen_amd.synth import synthetic_inputs
+    arch, sd = sd15
+    cfg, hw, R = arch.config, 16, 2
+    inputs = synthetic_inputs(1, R, hw, hw, 1, cfg["cross_attention_dim"])
+    sched = O.DDIM()
+    t_main = sched.timesteps(5)[0]
+    ref_t, x, e, xm, em = _ref_and_main_inputs(inputs, sched, t_main)
+    with torch.no_grad():
+        o_eps, o_feats = O.unet_forward(sd, cfg, x, ref_t, e, None)
+        ctx = {k: torch.cat([v, 0.5 * v], dim=1) for k, v in o_feats.items()}      # two distinct "frames"
+        o_main, _ = O.unet_forward(sd, cfg, xm, t_main, em, ctx)
+    eng = UNetEngine(arch, sd, gpu, 3, hw, hw, R)
+    eng.set_inputs(x, ref_t, e)
+    eps = eng.forward(harvest_slot=0).clone()
+    torch.cuda.synchronize()
+    errs = {"eps(ref)": rel_l2(eps.cpu(), o_eps)}
+    for k, v in eng.features(0).items():
+        errs[k] = rel_l2(v.float().cpu(), o_feats[k])
+    # main pass on the ORACLE's features so that the two passes are judged independently
+    for k, v in ctx.items():
+        eng.ctx[k].copy_(v.to(gpu, torch.float16))
+    eng.set_inputs(xm, t_main, em)
+    eps_m = eng.forward(consume=True)
+    torch.cuda.synchronize()
+    errs["eps(main)"] = rel_l2(eps_m.cpu(), o_main)
+    print({k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) <= TOL_EPS, errs
+
+
+def _probe(t, summary):
+    return t.float().cpu().flatten()[summary["idx"]]
+
+
+@pytest.mark.parametrize("case", ["sd15_64_r1", "sd15_64_r3"])
+def test_denoise_steps_vs_reference_golden_64x64(gpu, sd15, case):
+    """BASELINE configs 1 and 2 (first steps): 512x512, R = 1 / 3 prior frames, against latents produced by the
+    reference's own pipeline loop (tests/golden, oracle/make_golden.py)."""
+    from storygen_amd.sampler import StoryGenSampler
+    from storygen_amd.synth import synthetic_inputs
+    path = os.path.join(GOLDEN, f"{case}.pt")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated")
+    gold = torch.load(path, weights_only=False)
+    arch, sd = sd15
+    R, hw = gold["n_ref"], gold["hw"]
+    inputs = synthetic_inputs(1, R, hw, hw, gold["seed"], arch.config["cross_attention_dim"])
+    smp = StoryGenSampler(arch, sd, gpu, 1, hw, hw, R, use_graph=True)
+    stage = "multi-image-condition"
+    smp.prepare(inputs, gold["n_steps"], stage, *gold["guidance"])
+    want = gold["stages"][stage]["latents"]
+    trace = []
+    smp.run(max_steps=len(want), trace=trace)
+    torch.cuda.synchronize()
+    errs = [rel_l2(a.cpu(), b) for a, b in zip(trace, want)]
+    # features of the last reference pass / eps of the main pass of step 0 are also pinned by the golden file
+    print(case, "latent rel-L2 per step:", [f"{e:.2e}" for e in errs])
+    assert max(errs) <= TOL_LATENT, errs
+
+
+def test_unet_single_pass_vs_reference_golden_64x64(gpu, sd15):
+    """One harvest pass + one main pass at 64x64 against probes of the reference UNet's own outputs."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.engine import UNetEngine
+    from storygen_amd.synth import synthetic_inputs
+    path = os.path.join(GOLDEN, "sd15_64_r1.pt")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated")
+    gold = torch.load(path, weights_only=False)
+    arch, sd = sd15
+    R, hw = gold["n_ref"], gold["hw"]
+    inputs = synthetic_inputs(1, R, hw, hw, gold["seed"], arch.config["cross_attention_dim"])
+    sched = O.DDIM()
+    u = gold["unet"]
+    ref_t, x, e, xm, em = _ref_and_main_inputs(inputs, sched, u["t_main"])
+    assert ref_t == u["t_ref"]
+    eng = UNetEngine(arch, sd, gpu, 3, hw, hw, R)
+    eng.set_inputs(x, ref_t, e)
+    eps = eng.forward(harvest_slot=0).clone()
+    errs = {"eps(ref)": rel_l2(eps.cpu(), u["ref_sample"]["full"])}
+    for k, v in eng.features(0).items():
+        errs[k] = rel_l2(_probe(v, u["feats"][k]), u["feats"][k]["values"])
+    eng.set_inputs(xm, u["t_main"], em)
+    eps_m = eng.forward(consume=True)          # R = 1: the context is exactly the harvested slot
+    errs["eps(main)"] = rel_l2(eps_m.cpu(), u["main_sample"]["full"])
+    print({k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) <= TOL_EPS, errs
+
+
+def test_graph_replay_matches_eager(gpu, sd15):
+    """The captured hipGraph step and the eager step are the same kernels: bit-identical latents."""
+    from storygen_amd.sampler import StoryGenSampler
+    from storygen_amd.synth import synthetic_inputs
+    arch, sd = sd15
+    inputs = synthetic_inputs(1, 2, 16, 16, 5, arch.config["cross_attention_dim"])
+    outs = []
+    for use_graph in (False, True):
+        smp = StoryGenSampler(arch, sd, gpu, 1, 16, 16, 2, use_graph=use_graph)
+        smp.prepare(inputs, 4, "auto-regressive", 7.5, 3.5)
+        outs.append(smp.run().clone())
+        torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+
+
+def test_loop_vs_oracle_both_stages_16x16(gpu, sd15):
+    """The whole loop (R=2, 3 steps) in both stages against the oracle loop at 16x16."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.sampler import StoryGenSampler
+    from storygen_amd.synth import synthetic_inputs
+    arch, sd = sd15
+    inputs = synthetic_inputs(1, 2, 16, 16, 7, arch.config["cross_attention_dim"])
+    smp = StoryGenSampler(arch, sd, gpu, 1, 16, 16, 2, use_graph=True)
+    for stage in ("multi-image-condition", "auto-regressive"):
+        want = []
+        O.sample_loop(sd, arch.config, inputs, 5, stage, 7.5, 3.5, max_steps=3, trace=want)
+        smp.prepare(inputs, 5, stage, 7.5, 3.5)
+        got = []
+        smp.run(max_steps=3, trace=got)
+        torch.cuda.synchronize()
+        errs = [rel_l2(a.cpu(), b) for a, b in zip(got, want)]
+        print(stage, [f"{e:.2e}" for e in errs])
+        assert max(errs) <= TOL_LATENT, (stage, errs)

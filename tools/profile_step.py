@@ -1,0 +1,54 @@
+#!/usr/bin/env python
+"""Per-(kernel family, shape) timing table of one denoising step (BASELINE config 2), measured in situ with HIP
+events around every MFMA-class launch of an eager step, plus the eager/graph step times.  Development tool."""
+import os
+import sys
+import time
+from collections import defaultdict
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from storygen_amd import ops  # noqa: E402
+from storygen_amd.arch import SD15_CONFIG, build_arch  # noqa: E402
+from storygen_amd.sampler import StoryGenSampler  # noqa: E402
+from storygen_amd.synth import synthetic_inputs, synthetic_state_dict  # noqa: E402
+
+
+def main():
+    arch = build_arch(SD15_CONFIG)
+    sd = synthetic_state_dict(arch, 0)
+    inputs = synthetic_inputs(1, 3, 64, 64, 0, 768)
+    smp = StoryGenSampler(arch, sd, "cuda:0", 1, 64, 64, 3, use_graph=True)
+    smp.prepare(inputs, 50, "multi-image-condition", 7.5, 3.5)
+    for _ in range(3):
+        smp.step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        smp.step()
+    torch.cuda.synchronize()
+    print(f"graph step: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms")
+    sink = []
+    ops.PROFILE_SINK = sink
+    smp.params.copy_(smp.table[8])
+    t0 = time.perf_counter()
+    smp._step_body()
+    torch.cuda.synchronize()
+    print(f"eager instrumented step: {(time.perf_counter() - t0) * 1e3:.2f} ms")
+    ops.PROFILE_SINK = None
+    rows = defaultdict(lambda: [0, 0.0, 0.0])
+    for fam, flops, a, b, shape in sink:
+        r = rows[(fam, shape)]
+        r[0] += 1
+        r[1] += a.elapsed_time(b)
+        r[2] += flops
+    tot = sum(r[1] for r in rows.values())
+    print(f"MFMA-class total {tot:.2f} ms")
+    print(f"{'family':14s} {'shape':34s} {'n':>4s} {'ms':>8s} {'%':>6s} {'us/launch':>10s} {'TFLOP/s':>8s}")
+    for (fam, shape), (n, ms, fl) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+        print(f"{fam:14s} {shape:34s} {n:4d} {ms:8.3f} {100 * ms / tot:6.1f} {1e3 * ms / n:10.1f} {fl / ms / 1e9:8.1f}")
+
+
+if __name__ == "__main__":
+    main()
