@@ -73,6 +73,9 @@ def in_situ_roofline(sampler):
     ops.PROFILE_SINK = sink
     try:
         sampler.params.copy_(sampler.table[min(sampler.k, sampler.table.shape[0] - 1)], non_blocking=True)
+        # a GPU-side spin first, so the slower eager host stays ahead of the device and every kernel starts right
+        # after its start event (otherwise host launch latency would be billed to short kernels)
+        torch.cuda._sleep(200_000_000)
         sampler._step_body()
         torch.cuda.synchronize()
     finally:

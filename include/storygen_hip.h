@@ -69,19 +69,27 @@ int          sg_device_cus(void);
 #define SG_EPI_LINEAR 0
 #define SG_EPI_GEGLU  1
 
+/* dtype flags of sg_gemm_desc / sg_conv3x3_desc: the UNet's residual stream is kept in fp32 while every MFMA
+ * operand is fp16, so outputs and residual inputs can each be fp32 (float*) instead of fp16. */
+#define SG_F_OUT_F32   1   /* C / y is float* (row stride still in elements) */
+#define SG_F_RES1_F32  2   /* res1 is const float* */
+#define SG_F_RES2_F32  4   /* res2 is const float* */
+
 typedef struct sg_gemm_desc {
     const sg_half* A;  int64_t lda;
     const sg_half* W;  int64_t ldw;
-    sg_half*       C;  int64_t ldc;
+    void*          C;  int64_t ldc;   /* fp16, or fp32 with SG_F_OUT_F32 */
+    sg_half*       C2; int64_t ldc2;  /* optional second, fp16 copy of the output (NULL = none) */
     int32_t M, N, K;
     int32_t epilogue;                 /* SG_EPI_* */
+    int32_t flags;                    /* SG_F_* */
     const sg_half* bias;              /* [N] or NULL */
     const float*   rowbias;           /* fp32 [batches, rowbias_ld] or NULL */
     int64_t        rowbias_ld;
     int32_t        rows_per_batch;    /* rows of A per rowbias row (>=1) */
     int32_t        split_k;           /* 0 = auto, 1 = none, >1 = forced */
-    const sg_half* res1; int64_t ldr1;
-    const sg_half* res2; int64_t ldr2;
+    const void*    res1; int64_t ldr1;   /* fp16, or fp32 with SG_F_RES1_F32 */
+    const void*    res2; int64_t ldr2;   /* fp16, or fp32 with SG_F_RES2_F32 */
     void*          workspace; size_t workspace_bytes;
 } sg_gemm_desc;
 
@@ -99,26 +107,32 @@ size_t sg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
  * time_emb_proj(silu(temb)) broadcast add of conv1; res1 = the block's residual/shortcut add of conv2),
  * indexed by output pixel m = (b*Ho + oy)*Wo + ox with rows_per_batch = Ho*Wo.
  * Cin must be a multiple of 64 (conv_in/conv_out have their own entry points).
+ * x_padded = 1: `x` is the start of a buffer [B, H+2, W+2, Cin] whose one-pixel border is zero (interior pixel
+ * (y, x) at row y+1, column x+1).  Padding then needs no predicate and the kernel streams its tiles with LDS-DMA
+ * through a multi-stage pipeline; x_padded = 0 reads an unpadded [B, H, W, Cin] tensor with bounds checks.
  */
 typedef struct sg_conv3x3_desc {
     const sg_half* x;  int64_t ldx;   /* [B, H, W, Cin], pixel stride ldx */
     const sg_half* w;                 /* [Cout, 3, 3, Cin] */
-    sg_half*       y;  int64_t ldy;   /* [B, Ho, Wo, Cout], pixel stride ldy */
+    void*          y;  int64_t ldy;   /* [B, Ho, Wo, Cout], pixel stride ldy; fp16, or fp32 with SG_F_OUT_F32 */
     int32_t B, H, W, Cin, Cout;
+    int32_t flags;                    /* SG_F_OUT_F32 | SG_F_RES1_F32 */
     int32_t stride;                   /* 1 or 2 */
     int32_t upsample2x;               /* 0 or 1 (then stride must be 1) */
+    int32_t x_padded;                 /* 0 or 1, see above */
     const sg_half* bias;              /* [Cout] or NULL */
     const float*   rowbias; int64_t rowbias_ld;   /* fp32 [B, rowbias_ld] or NULL */
-    const sg_half* res1; int64_t ldr1;            /* [B, Ho, Wo, Cout] or NULL */
+    const void*    res1; int64_t ldr1;            /* [B, Ho, Wo, Cout] or NULL; fp16, or fp32 with SG_F_RES1_F32 */
     int32_t        split_k;           /* as in sg_gemm_desc */
     void*          workspace; size_t workspace_bytes;   /* sg_gemm_workspace_bytes(B*Ho*Wo, Cout, split_k) */
 } sg_conv3x3_desc;
 
 int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream);
 
-/* conv_in: x fp32 NCHW [B, Cin<=8, H, W] -> y fp16 NHWC [B,H,W,Cout], 3x3 pad 1 (unet_2d_condition.py:124,411).
+/* conv_in: x fp32 NCHW [B, Cin<=8, H, W] -> y NHWC [B,H,W,Cout] (fp16, or fp32 when y_f32), 3x3 pad 1
+ * (unet_2d_condition.py:124,411).
  * w_kn: fp16 [9*Cin, Cout] with k = (ky*3+kx)*Cin + ci (host repack); bias fp16 [Cout]; Cout % 8 == 0. */
-int sg_conv_in_f16(const float* x_nchw, const sg_half* w_kn, const sg_half* bias, sg_half* y, int64_t ldy,
+int sg_conv_in_f16(const float* x_nchw, const sg_half* w_kn, const sg_half* bias, void* y, int64_t ldy, int32_t y_f32,
                    int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, sg_stream_t stream);
 /* conv_out: x fp16 NHWC [B,H,W,Cin] -> y fp32 NCHW [B, Cout<=4, H, W], 3x3 pad 1 (unet_2d_condition.py:268,480).
  * w: fp16 [Cout, 3, 3, Cin]; bias fp16 [Cout]; Cin % 8 == 0. */
@@ -153,15 +167,28 @@ int sg_attn_fwd_f16(const sg_attn_desc* d, sg_stream_t stream);
  * Two launches: per-(batch, pixel-chunk, group) shifted partial sums -> normalise+affine(+SiLU).
  * workspace: sg_groupnorm_workspace_bytes(B, groups) bytes.
  */
-int sg_groupnorm_nhwc_f16(const sg_half* x, int64_t ldx, sg_half* y, int64_t ldy, const sg_half* gamma,
-                          const sg_half* beta, int32_t B, int32_t HW, int32_t C, int32_t groups, float eps,
-                          int32_t silu, void* workspace, size_t workspace_bytes, sg_stream_t stream);
+typedef struct sg_groupnorm_desc {
+    const void*    x;  int64_t ldx;   /* [B, HW, C] channels-last, row stride ldx; fp16, or fp32 when x_f32 != 0 */
+    int32_t        x_f32;
+    int32_t        y_pad_w;           /* 0: y is [B, HW, C].  W > 0: y is the zero-bordered [B, H+2, W+2, C] input of
+                                         sg_conv3x3 (x_padded = 1); only its interior is written */
+    sg_half*       y;  int64_t ldy;
+    sg_half*       xcopy; int64_t ldxc;   /* optional raw fp16 copy of x (operand of the 1x1 conv_shortcut), or NULL */
+    const sg_half* gamma; const sg_half* beta;
+    int32_t B, HW, C, groups;
+    float   eps;
+    int32_t silu;
+    void*   workspace; size_t workspace_bytes;
+} sg_groupnorm_desc;
+
+int sg_groupnorm_nhwc_f16(const sg_groupnorm_desc* d, sg_stream_t stream);
 size_t sg_groupnorm_workspace_bytes(int32_t B, int32_t groups);
 
 /* LayerNorm over the last dim of x[M, C] (row stride ldx), eps, affine; optionally a second affine output from
  * the same statistics (norm2 and norm4 both normalise the post-self-attention state, attention.py:268,283).
+ * x is fp16, or fp32 when x_f32 != 0 (the residual stream).
  * Replaces nn.LayerNorm at attention.py:188,206-212,225-229,234 (used :250,268,283,298). */
-int sg_layernorm_f16(const sg_half* x, int64_t ldx, int32_t M, int32_t C, float eps,
+int sg_layernorm_f16(const void* x, int64_t ldx, int32_t x_f32, int32_t M, int32_t C, float eps,
                      const sg_half* gamma1, const sg_half* beta1, sg_half* y1, int64_t ldy1,
                      const sg_half* gamma2, const sg_half* beta2, sg_half* y2, int64_t ldy2, sg_stream_t stream);
 
@@ -194,17 +221,28 @@ int sg_ref_inputs_f32(const float* zero, const float* img, const float* noise, c
 int sg_cfg_ddim_step_f32(const float* eps3, float* latents, float* latents3, const float* coef, int32_t N,
                          int64_t n, sg_stream_t stream);
 
-/* Strided, batched 2-D copy of fp16 rows: dst[b][r][0:cols] = src[b][r][0:cols] (cols % 8 == 0).
+/* Strided, batched 2-D copy of rows: dst[b][r][0:cols] = src[b][r][0:cols] (cols % 8 == 0; strides in elements).
+ * mode 0: fp16 -> fp16, 1: fp32 -> fp32, 2: fp32 -> fp16 (cast).
  * Replaces torch.cat([hidden, skip], dim=1) (unet_2d_blocks.py:609,626,716), the feature `.clone()`s
  * (attention.py:263; unet_2d_condition.py:428-429,445,468-470) and the token-axis concat of per-frame
  * features (pipeline.py:440-443) — each becomes a write into its slot of a preallocated buffer. */
-int sg_copy_rows_f16(sg_half* dst, int64_t ldd, int64_t bsd, const sg_half* src, int64_t lds, int64_t bss,
-                     int32_t batches, int32_t rows, int32_t cols, sg_stream_t stream);
+int sg_copy_rows(void* dst, int64_t ldd, int64_t bsd, const void* src, int64_t lds, int64_t bss, int32_t batches,
+                 int32_t rows, int32_t cols, int32_t mode, sg_stream_t stream);
+
+/* x [B,H,W,C] (fp16, or fp32 when x_f32) -> interior of the zero-bordered fp16 buffer y [B,H+2,W+2,C] that
+ * sg_conv3x3 (x_padded = 1) consumes; the border is never written (allocate it zeroed once).  Feeds the
+ * Downsample2D / Upsample2D convolutions, whose input is a residual-stream tensor rather than a GroupNorm output. */
+int sg_pad_cast_f16(const void* x, int64_t ldx, int32_t x_f32, sg_half* y, int64_t ldy, int32_t B, int32_t H, int32_t W,
+                    int32_t C, sg_stream_t stream);
 
 /* Diagnostic: raw per-lane MFMA register dump used by tests/test_mfma_layout.py to pin the fragment layout
  * assumptions of the kernels above.  out: fp32 [64 lanes][16 regs] of D = A(32x16) @ B(16x32) with
  * A[i][k] = a[i*16+k], B[k][j] = b[k*32+j] loaded with the kernels' own lane mapping. */
 int sg_debug_mfma_32x32x16(const sg_half* a, const sg_half* b, float* out, sg_stream_t stream);
+/* Test hook: force the GEMM/conv tile shape (bm, bn in {256x128, 128x128, 256x64, 128x64, 64x128, 64x64}; 0,0 = automatic) and
+ * optionally disable the LDS-DMA pipelined kernel (no_pipe = 1), so the parity tests can cover every code path.
+ * Process-global; not for production use. */
+int sg_debug_set_tile(int32_t bm, int32_t bn, int32_t no_pipe);
 
 #ifdef __cplusplus
 }

@@ -16,8 +16,10 @@ class GemmDesc(C.Structure):
         ("A", C.c_void_p), ("lda", C.c_int64),
         ("W", C.c_void_p), ("ldw", C.c_int64),
         ("C", C.c_void_p), ("ldc", C.c_int64),
+        ("C2", C.c_void_p), ("ldc2", C.c_int64),
         ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
         ("epilogue", C.c_int32),
+        ("flags", C.c_int32),
         ("bias", C.c_void_p),
         ("rowbias", C.c_void_p),
         ("rowbias_ld", C.c_int64),
@@ -35,12 +37,29 @@ class ConvDesc(C.Structure):
         ("w", C.c_void_p),
         ("y", C.c_void_p), ("ldy", C.c_int64),
         ("B", C.c_int32), ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32),
+        ("flags", C.c_int32),
         ("stride", C.c_int32),
         ("upsample2x", C.c_int32),
+        ("x_padded", C.c_int32),
         ("bias", C.c_void_p),
         ("rowbias", C.c_void_p), ("rowbias_ld", C.c_int64),
         ("res1", C.c_void_p), ("ldr1", C.c_int64),
         ("split_k", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
+class GroupNormDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64),
+        ("x_f32", C.c_int32),
+        ("y_pad_w", C.c_int32),
+        ("y", C.c_void_p), ("ldy", C.c_int64),
+        ("xcopy", C.c_void_p), ("ldxc", C.c_int64),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("B", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("groups", C.c_int32),
+        ("eps", C.c_float),
+        ("silu", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 
@@ -65,16 +84,14 @@ SIGNATURES = {
     "sg_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "sg_gemm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sg_conv3x3_nhwc_f16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
-    "sg_conv_in_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+    "sg_conv_in_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                  C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sg_conv_out_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sg_attn_fwd_f16": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p]),
-    "sg_groupnorm_nhwc_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int32,
-                                        C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_int32, C.c_void_p, C.c_size_t,
-                                        C.c_void_p]),
+    "sg_groupnorm_nhwc_f16": (C.c_int, [C.POINTER(GroupNormDesc), C.c_void_p]),
     "sg_groupnorm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
-    "sg_layernorm_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
+    "sg_layernorm_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,
                                    C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "sg_timestep_embed_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sg_linear_rows_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
@@ -82,9 +99,12 @@ SIGNATURES = {
     "sg_ref_inputs_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                     C.c_void_p]),
     "sg_cfg_ddim_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
-    "sg_copy_rows_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32,
-                                   C.c_int32, C.c_int32, C.c_void_p]),
+    "sg_copy_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                               C.c_int32, C.c_int32, C.c_void_p]),
+    "sg_pad_cast_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                  C.c_int32, C.c_void_p]),
     "sg_debug_mfma_32x32x16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sg_debug_set_tile": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
 }
 
 _lib = None

@@ -41,6 +41,25 @@ union H8 {
     f16 h[8];
 };
 
+// 8 consecutive elements starting at element offset `off` of an fp16 or fp32 array, as floats
+__device__ __forceinline__ void load8f(const void* base, long off, bool f32, float (&v)[8]) {
+    if (f32) {
+        const float* q = reinterpret_cast<const float*>(base) + off;
+        const float4 a = *reinterpret_cast<const float4*>(q), b = *reinterpret_cast<const float4*>(q + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        H8 h; h.u = ldg16(reinterpret_cast<const f16*>(base) + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (float)h.h[j];
+    }
+}
+__device__ __forceinline__ void store8h(f16* p, const float (&v)[8]) {
+    H8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o.h[j] = (f16)v[j];
+    stg16(p, o.u);
+}
+
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exact (erf) GELU, as torch.nn.functional.gelu(approximate="none") — /root/reference/model/attention.py:385-388
 __device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

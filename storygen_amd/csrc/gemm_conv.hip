@@ -1,48 +1,82 @@
-// MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (MI355X, CDNA4), fp16 in / fp32 accumulate.
+// MFMA GEMM / implicit-GEMM 3x3 convolution for gfx950 (MI355X, CDNA4), fp16 operands / fp32 accumulate.
 //
-// One mainloop serves both entry points (sg_gemm_f16, sg_conv3x3_nhwc_f16): C[M,N] = A[M,K] . W[N,K]^T where,
+// One mainloop family serves both entry points (sg_gemm_f16, sg_conv3x3_nhwc_f16): C[M,N] = A[M,K] . W[N,K]^T where,
 // for the convolution, row m is an output pixel and the K axis enumerates (ky, kx, ci) — the A tile is *gathered*
-// from the NHWC input (zero outside the image, optional nearest-2x upsample and stride 2 folded into the index).
+// from the NHWC input (optional nearest-2x upsample and stride 2 folded into the index).
 //
 // Structure (CDNA4-first, see /opt/skills/guides/cdna_hip_programming.md §5):
-//   * 256 threads = 4 wave64 in a 2x2 grid; each wave owns a (BM/2)x(BN/2) sub-tile as TMxTN 32x32 accumulators of
-//     v_mfma_f32_32x32x16_f16 (one 16-byte fragment per lane per operand per MFMA).
-//   * K is walked in BK=64 slabs through two LDS stages.  Global->register loads of slab t+1 are issued before the
-//     MFMAs of slab t and written to the other stage afterwards: one barrier per slab.
-//   * LDS rows are 128 B (64 halves); the 16-byte chunk c of row r lives at chunk c ^ ((r>>1)&7): conflict-free for
-//     the ds_read_b128 fragment reads (a 16-lane service group touches 16 distinct 16-B slots of the 256-B bank row)
-//     and for the staging ds_write_b128 (8 lanes write one permuted row).
+//   * every wave owns a 64x64 output sub-tile = 2x2 accumulators of v_mfma_f32_32x32x16_f16 (one 16-byte fragment
+//     per lane per operand per MFMA, 1 KiB of LDS reads per MFMA); a workgroup is a WGM x WGN grid of such waves
+//     (256x128, 128x128, 256x64, 128x64, 64x128 or 64x64 tiles), chosen per problem so that the 1024 SIMDs of the chip stay busy.
+//   * pipelined kernel (the fast path): K is walked in 64-deep slabs through S=3 LDS stages filled by LDS-DMA
+//     (global_load_lds, 16 B per lane, no VGPR staging), counted vmcnt waits and ONE raw s_barrier per slab.
+//   * LDS rows are 128 B (64 halves); the 16-byte chunk c of row r lives at slot c ^ ((r>>1)&7): conflict-free for
+//     the ds_read_b128 fragment reads (a 16-lane service group touches 16 distinct 16-B slots of the 256-B bank row).
+//     LDS-DMA writes lane l of a wave to (wave-uniform base + 16 l), so the swizzle is applied on the SOURCE side
+//     (the lane that owns slot s of row r fetches logical chunk s ^ ((r>>1)&7)) and again on the reads.
+//   * generic kernel (fallback): register-staged double buffer with zero-fill predicates, for K % 64 != 0 or an
+//     unpadded convolution input.
 //   * the fp32 tile is staged through LDS for the epilogue so that bias / residual / output accesses are 16-byte,
-//     row-contiguous; epilogue math is fp32 with a single rounding to fp16.
+//     row-contiguous; epilogue math is fp32; outputs and residuals may be fp16 or fp32 (the UNet's residual stream
+//     is kept in fp32, MFMA operands in fp16).
 //   * block ids are remapped so that consecutive tiles (same A row panel) run on the same XCD / L2.
 //   * small-M layers (16x16 / 8x8 latent levels at batch 3) are split along K over blockIdx.y into fp32 partial
 //     tiles; a second kernel reduces them and applies the epilogue (deterministic, no atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
 constexpr int BK = 64;
-constexpr int NTHREADS = 256;
 constexpr int MAX_AUTO_SPLIT = 16;
 
 struct MmaParams {
     const f16* A; long lda;
     const f16* W; long ldw;
-    f16* C; long ldc;
+    void* C; long ldc;
+    f16* C2; long ldc2;            // optional second (fp16) copy of the output
     int M, N, K, KT;
     // conv geometry (CONV only): input [B,H,Wd,Cin] (pre-upsample), output [B,Ho,Wo,N]
-    int H, Wd, Ho, Wo, cpt /* Cin/64 */, stride, ups;
+    int H, Wd, Ho, Wo, cpt /* Cin/64 */, stride, ups, padded;
     // epilogue
-    int mode;
+    int mode, flags;
     const f16* bias;
     const float* rowbias; long rowbias_ld; int rows_per_batch;
-    const f16* res1; long ldr1;
-    const f16* res2; long ldr2;
+    const void* res1; long ldr1;
+    const void* res2; long ldr2;
     // decomposition
     float* ws; int splits; int kt_per_split; int tiles_m, tiles_n;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+__device__ __forceinline__ void add_res8(const void* res, long ld, bool f32, int gm, int gn, float (&v)[8]) {
+    if (f32) {
+        const float* r = reinterpret_cast<const float*>(res) + (long)gm * ld + gn;
+        const float4 a = *reinterpret_cast<const float4*>(r), b = *reinterpret_cast<const float4*>(r + 4);
+        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+    } else {
+        H8 r; r.u = ldg16(reinterpret_cast<const f16*>(res) + (long)gm * ld + gn);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)r.h[j];
+    }
+}
+
+__device__ __forceinline__ void store_out8(const MmaParams& p, int gm, int gn, const float (&v)[8]) {
+    const bool f32 = p.flags & SG_F_OUT_F32;
+    if (f32) {
+        float* o = reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn;
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    if (!f32 || p.C2) {
+        H8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o.h[j] = (f16)v[j];
+        if (!f32) stg16(reinterpret_cast<f16*>(p.C) + (long)gm * p.ldc + gn, o.u);
+        if (p.C2) stg16(p.C2 + (long)gm * p.ldc2 + gn, o.u);
+    }
+}
 
 __device__ __forceinline__ void epi_linear8(const MmaParams& p, int gm, int gn, float (&v)[8]) {
     if (p.bias) {
@@ -56,20 +90,9 @@ __device__ __forceinline__ void epi_linear8(const MmaParams& p, int gm, int gn, 
         v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
         v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
     }
-    if (p.res1) {
-        H8 r; r.u = ldg16(p.res1 + (long)gm * p.ldr1 + gn);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)r.h[j];
-    }
-    if (p.res2) {
-        H8 r; r.u = ldg16(p.res2 + (long)gm * p.ldr2 + gn);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)r.h[j];
-    }
-    H8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o.h[j] = (f16)v[j];
-    stg16(p.C + (long)gm * p.ldc + gn, o.u);
+    if (p.res1) add_res8(p.res1, p.ldr1, p.flags & SG_F_RES1_F32, gm, gn, v);
+    if (p.res2) add_res8(p.res2, p.ldr2, p.flags & SG_F_RES2_F32, gm, gn, v);
+    store_out8(p, gm, gn, v);
 }
 
 // val/gate: 8 consecutive interleaved-layout columns starting at global column gv (value) and gv+32 (gate).
@@ -79,15 +102,83 @@ __device__ __forceinline__ void epi_geglu8(const MmaParams& p, int gm, int gv, f
 #pragma unroll
         for (int j = 0; j < 8; ++j) { val[j] += (float)bv.h[j]; gate[j] += (float)bg.h[j]; }
     }
-    H8 o;
+    float o[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o.h[j] = (f16)(val[j] * gelu_erf_f(gate[j]));
-    const int oc = (gv >> 6) * 32 + (gv & 31);   // interleaved column -> output column
-    stg16(p.C + (long)gm * p.ldc + oc, o.u);
+    for (int j = 0; j < 8; ++j) o[j] = val[j] * gelu_erf_f(gate[j]);
+    store_out8(p, gm, (gv >> 6) * 32 + (gv & 31), o);   // interleaved column -> output column
 }
 
+// Shared tail of both mainloops: split-K partial store, or LDS-staged fused epilogue with 16-byte accesses.
+// Must be entered by all threads after a barrier that ends all LDS reads of the mainloop.  Wave (wm, wn) of the
+// WGM x WGN grid holds TM x TN 32x32 accumulators of its (BM/WGM) x (BN/WGN) sub-tile.
+template <int BM, int BN, int WGM, int WGN>
+__device__ __forceinline__ void tile_epilogue(const MmaParams& p, char* smem, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32],
+                                              int m0, int n0, int z) {
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32, NT = 64 * WGM * WGN;
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, hi = lane >> 5;
+    if (p.splits > 1) {   // raw fp32 partial tile; the epilogue happens in splitk_reduce_kernel
+        float* wsz = p.ws + (size_t)z * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int gn = n0 + wn * WN + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int gm = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    if (gm < p.M && gn < p.N) wsz[(size_t)gm * p.N + gn] = acc[i][j][r];
+                }
+            }
+        return;
+    }
+    // ---- phase 1: accumulators -> LDS (fp32, [BM][BN])
+    float* sC = reinterpret_cast<float*>(smem);
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = wn * WN + j * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                sC[m * BN + n] = acc[i][j][r];
+            }
+        }
+    __syncthreads();
+    // ---- phase 2: row-contiguous 8-column chunks, fused epilogue, 16-byte accesses
+    if (p.mode == SG_EPI_LINEAR) {
+        constexpr int NCH = BN / 8;
+        for (int idx = t; idx < BM * NCH; idx += NT) {
+            const int r = idx / NCH, ch = idx - r * NCH;
+            const int gm = m0 + r, gn = n0 + ch * 8;
+            if (gm >= p.M || gn >= p.N) continue;
+            const float4 v0 = *reinterpret_cast<const float4*>(sC + r * BN + ch * 8);
+            const float4 v1 = *reinterpret_cast<const float4*>(sC + r * BN + ch * 8 + 4);
+            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+            epi_linear8(p, gm, gn, v);
+        }
+    } else {
+        constexpr int OCH = BN / 16;
+        for (int idx = t; idx < BM * OCH; idx += NT) {
+            const int r = idx / OCH, j = idx - r * OCH;
+            const int vcol = (j >> 2) * 64 + (j & 3) * 8;
+            const int gm = m0 + r, gv = n0 + vcol;
+            if (gm >= p.M || gv >= p.N) continue;
+            const float* s = sC + r * BN + vcol;
+            const float4 a0 = *reinterpret_cast<const float4*>(s), a1 = *reinterpret_cast<const float4*>(s + 4);
+            const float4 g0 = *reinterpret_cast<const float4*>(s + 32), g1 = *reinterpret_cast<const float4*>(s + 36);
+            float val[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            float gate[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            epi_geglu8(p, gm, gv, val, gate);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Generic kernel: 256 threads (2x2 waves), register-staged double buffer, zero-fill predicates.
 template <int BM, int BN, bool CONV>
-__global__ __launch_bounds__(NTHREADS) void mma_kernel(const MmaParams p) {
+__global__ __launch_bounds__(256) void mma_kernel(const MmaParams p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -103,11 +194,13 @@ __global__ __launch_bounds__(NTHREADS) void mma_kernel(const MmaParams p) {
     const int kt0 = z * p.kt_per_split;
     const int kt1 = min(p.KT, kt0 + p.kt_per_split);
 
-    // ---- per-thread staging coordinates: chunk c of rows r0 + 32*i
+    // per-thread staging coordinates: chunk c of rows r0 + 32*i
     const int c = t & 7, r0 = t >> 3;
     const f16* a_ptr[A_IT];
     int a_oy[A_IT], a_ox[A_IT];
     bool a_ok[A_IT];
+    const int pad = p.padded ? 1 : 0;
+    const int wrow = p.Wd + 2 * pad;
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int gm = m0 + r0 + 32 * i;
@@ -118,7 +211,7 @@ __global__ __launch_bounds__(NTHREADS) void mma_kernel(const MmaParams p) {
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
             a_oy[i] = a_ok[i] ? oy * p.stride - 1 : -(1 << 20);
             a_ox[i] = ox * p.stride - 1;
-            a_ptr[i] = p.A + (long)b * p.H * p.Wd * p.lda + c * 8;
+            a_ptr[i] = p.A + (long)b * (p.H + 2 * pad) * wrow * p.lda + c * 8;
         } else {
             a_oy[i] = a_ox[i] = 0;
             a_ptr[i] = p.A + (long)gm * p.lda + c * 8;
@@ -144,7 +237,7 @@ __global__ __launch_bounds__(NTHREADS) void mma_kernel(const MmaParams p) {
             for (int i = 0; i < A_IT; ++i) {
                 const int iy = a_oy[i] + ky, ix = a_ox[i] + kx;
                 const bool ok = (unsigned)iy < (unsigned)hin && (unsigned)ix < (unsigned)win;
-                const long pix = (long)(iy >> p.ups) * p.Wd + (ix >> p.ups);
+                const long pix = (long)((iy >> p.ups) + pad) * wrow + ((ix >> p.ups) + pad);
                 areg[i] = ok ? ldg16(a_ptr[i] + pix * p.lda + cc * BK) : make_uint4(0, 0, 0, 0);
             }
         } else {
@@ -202,73 +295,147 @@ __global__ __launch_bounds__(NTHREADS) void mma_kernel(const MmaParams p) {
         if (more) store_lds(buf ^ 1);
         __syncthreads();
     }
-
-    // ---- split-K: raw fp32 partial tile to the workspace, epilogue happens in splitk_reduce_kernel
-    if (p.splits > 1) {
-        float* wsz = p.ws + (size_t)z * p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int gn = n0 + wn * WN + j * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int gm = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (gm < p.M && gn < p.N) wsz[(size_t)gm * p.N + gn] = acc[i][j][r];
-                }
-            }
-        return;
-    }
-
-    // ---- epilogue phase 1: accumulators -> LDS (fp32, [BM][BN])
-    float* sC = reinterpret_cast<float*>(smem);
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = wn * WN + j * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                sC[m * BN + n] = acc[i][j][r];
-            }
-        }
-    __syncthreads();
-    // ---- phase 2: row-contiguous 8-column chunks, fused epilogue, 16-byte stores
-    if (p.mode == SG_EPI_LINEAR) {
-        constexpr int NCH = BN / 8;
-        for (int idx = t; idx < BM * NCH; idx += NTHREADS) {
-            const int r = idx / NCH, ch = idx - r * NCH;
-            const int gm = m0 + r, gn = n0 + ch * 8;
-            if (gm >= p.M || gn >= p.N) continue;
-            const float4 v0 = *reinterpret_cast<const float4*>(sC + r * BN + ch * 8);
-            const float4 v1 = *reinterpret_cast<const float4*>(sC + r * BN + ch * 8 + 4);
-            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            epi_linear8(p, gm, gn, v);
-        }
-    } else {
-        constexpr int OCH = BN / 16;
-        for (int idx = t; idx < BM * OCH; idx += NTHREADS) {
-            const int r = idx / OCH, j = idx - r * OCH;
-            const int vcol = (j >> 2) * 64 + (j & 3) * 8;
-            const int gm = m0 + r, gv = n0 + vcol;
-            if (gm >= p.M || gv >= p.N) continue;
-            const float* s = sC + r * BN + vcol;
-            const float4 a0 = *reinterpret_cast<const float4*>(s), a1 = *reinterpret_cast<const float4*>(s + 4);
-            const float4 g0 = *reinterpret_cast<const float4*>(s + 32), g1 = *reinterpret_cast<const float4*>(s + 36);
-            float val[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            float gate[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-            epi_geglu8(p, gm, gv, val, gate);
-        }
-    }
+    tile_epilogue<BM, BN, 2, 2>(p, smem, acc, m0, n0, z);
 }
 
-__global__ __launch_bounds__(NTHREADS) void splitk_reduce_kernel(const MmaParams p) {
+// ------------------------------------------------------------------------------------------------------------
+// Pipelined kernel: WGM x WGN waves of 64x64, S LDS stages filled by LDS-DMA.  Requires loads that need no
+// predicate: rows beyond M / N are clamped to the last valid row (their results are discarded by the epilogue);
+// K % 64 == 0; for the convolution the input has a one-pixel zero border ([B, H+2, W+2, C]), so every tap of every
+// output pixel reads valid memory and padding costs nothing.
+// Slab t+S-1 is issued right after the barrier that (a) publishes slab t (every wave waited for its own DMA with a
+// counted vmcnt first) and (b) retires every wave's reads of slab t-1, whose stage it overwrites.
+__device__ __forceinline__ void glds16(const f16* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int WGM, int WGN, int S, bool CONV>
+__global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParams p) {
+    constexpr int NW = WGM * WGN, BM = 64 * WGM, BN = 64 * WGN;
+    constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW), LPT = A_IT + B_IT;   // LDS-DMA instructions / lane / slab
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int EPI_BYTES = BM * BN * 4;
+    constexpr int SMEM = (S * STAGE > EPI_BYTES) ? S * STAGE : EPI_BYTES;
+    constexpr int ISTR = NW * 1024;   // LDS bytes covered by one DMA instruction of the whole workgroup (8 rows / wave)
+    static_assert(S == 3 && (S - 2) * LPT < 64, "3 stages; vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, hi = lane >> 5;
+    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    const int m0 = (lid / p.tiles_n) * BM, n0 = (lid % p.tiles_n) * BN;
+    const int z = blockIdx.y;
+    const int kt0 = z * p.kt_per_split;
+    const int nt = min(p.KT, kt0 + p.kt_per_split) - kt0;
+
+    // staging coordinates of this lane for DMA instruction i: tile row srow + 8*NW*i, LDS slot (lane & 7)
+    const int srow = wave * 8 + (lane >> 3);
+    const f16* a_ptr[A_IT];
+    int a_oy[A_IT], a_ox[A_IT];
+    const int wp = p.Wd + 2;
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int row = srow + 8 * NW * i;
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);          // logical chunk this lane fetches
+        const int gm = min(m0 + row, p.M - 1);
+        if constexpr (CONV) {
+            const int hw = p.Ho * p.Wo;
+            const int b = gm / hw, rem = gm - b * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            a_oy[i] = oy * p.stride - 1;
+            a_ox[i] = ox * p.stride - 1;
+            a_ptr[i] = p.A + (long)b * (p.H + 2) * wp * p.lda + lc * 8;
+        } else {
+            a_oy[i] = a_ox[i] = 0;
+            a_ptr[i] = p.A + (long)gm * p.lda + lc * 8;
+        }
+    }
+    const f16* w_ptr[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int row = srow + 8 * NW * i;
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        w_ptr[i] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + lc * 8;
+    }
+
+    auto issue = [&](int kt, int stage) {
+        char* sA = smem + stage * STAGE + wave * 1024;
+        char* sB = sA + A_BYTES;
+        if constexpr (CONV) {
+            const int tap = kt / p.cpt, cc = kt - tap * p.cpt;
+            const int ky = tap / 3, kx = tap - ky * 3;
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) {
+                const int py = ((a_oy[i] + ky) >> p.ups) + 1, px = ((a_ox[i] + kx) >> p.ups) + 1;
+                glds16(a_ptr[i] + ((long)py * wp + px) * p.lda + cc * BK, sA + i * ISTR);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < A_IT; ++i) glds16(a_ptr[i] + kt * BK, sA + i * ISTR);
+        }
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) glds16(w_ptr[i] + kt * BK, sB + i * ISTR);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s)
+        if (s < nt) issue(kt0 + s, s);
+
+    int stage = 0;
+    for (int it = 0; it < nt; ++it) {
+        // one younger slab may stay in flight while we wait for slab `it`, except at the very end
+        if (it + 1 < nt) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (it + S - 1 < nt) {
+            int st = stage + S - 1;
+            if (st >= S) st -= S;
+            issue(kt0 + it + S - 1, st);
+        }
+        const char* sA = smem + stage * STAGE;
+        const char* sB = sA + A_BYTES;
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            f16x8 af[2], bf[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                af[i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * 64 + i * 32 + l31, ks * 2 + hi));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bf[j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * 64 + j * 32 + l31, ks * 2 + hi));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (++stage == S) stage = 0;
+    }
+    __syncthreads();   // every wave is done reading the stages before the epilogue reuses LDS
+    tile_epilogue<BM, BN, WGM, WGN>(p, smem, acc, m0, n0, z);
+}
+
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const MmaParams p) {
     const size_t MN = (size_t)p.M * p.N;
     if (p.mode == SG_EPI_LINEAR) {
         const int nch = p.N / 8;
         const long total = (long)p.M * nch;
-        for (long idx = (long)blockIdx.x * NTHREADS + threadIdx.x; idx < total; idx += (long)gridDim.x * NTHREADS) {
+        for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
             const int gm = (int)(idx / nch), gn = (int)(idx - (long)gm * nch) * 8;
             float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             const float* s = p.ws + (size_t)gm * p.N + gn;
@@ -282,7 +449,7 @@ __global__ __launch_bounds__(NTHREADS) void splitk_reduce_kernel(const MmaParams
     } else {
         const int och = p.N / 16;
         const long total = (long)p.M * och;
-        for (long idx = (long)blockIdx.x * NTHREADS + threadIdx.x; idx < total; idx += (long)gridDim.x * NTHREADS) {
+        for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
             const int gm = (int)(idx / och), j = (int)(idx - (long)gm * och);
             const int gv = (j >> 2) * 64 + (j & 3) * 8;
             float val[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gate[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -300,41 +467,73 @@ __global__ __launch_bounds__(NTHREADS) void splitk_reduce_kernel(const MmaParams
 // ------------------------------------------------------------------------------------------------ host side
 struct Plan { int bm, bn, splits; };
 
-// Rough cost model in "slab units" (one 128x128x64 slab of MFMAs on one CU ~ 0.5 us): picks the tile shape and
-// the K split that minimise ceil(blocks / CUs) * per-block cost (+ the reduce pass for split-K).
-Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, int cus) {
-    static const int cand[3][2] = {{128, 128}, {128, 64}, {64, 64}};
-    static const double eff[3] = {1.0, 0.8, 0.55};
-    static const int split_opts[] = {1, 2, 3, 4, 6, 8, 12, 16};
-    Plan best{128, 128, 1};
+// Development knobs (read once from the environment): SG_TILE="bm,bn" forces a tile shape, SG_NO_PIPE=1 disables
+// the LDS-DMA pipeline, SG_NO_SPLIT=1 disables automatic split-K.  Unset in production.
+struct Tune {
+    mutable int bm = 0, bn = 0, no_pipe = 0, no_split = 0;
+    Tune() {
+        if (const char* e = getenv("SG_TILE")) sscanf(e, "%d,%d", &bm, &bn);
+        if (const char* e = getenv("SG_NO_PIPE")) no_pipe = atoi(e);
+        if (const char* e = getenv("SG_NO_SPLIT")) no_split = atoi(e);
+    }
+};
+static const Tune g_tune;
+
+// Cost model (cycles at ~2.4 GHz).  Measured on MI355X (tools/bench_gemm.py): a CU pulls operand slabs from L2 into
+// LDS at ~18.5 B/cycle however many waves ask (L1 miss-level parallelism x L2 latency), so a launch is bound by
+//   t_bw   = (blocks a CU must run) x (bytes one block streams) / 18.5      — total bytes over the ACTIVE CUs, or by
+//   t_mfma = (waves per SIMD) x slabs x 512                                  — 16 MFMAs of 32 cycles per 64-deep slab,
+// plus a fixed prologue/epilogue.  Splitting K does not add operand bytes but multiplies the CUs that share them,
+// which is what small-M layers need; it costs a second launch that re-reads the fp32 partial tiles.
+Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool pipe) {
+    static const int cand_pipe[6][2] = {{256, 128}, {128, 128}, {256, 64}, {128, 64}, {64, 128}, {64, 64}};
+    static const int cand_gen[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    static const int split_opts[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
+    const int ncand = pipe ? 6 : 3;
+    const double CUS = 256.0, BW = pipe ? 18.5 : 12.0;
+    Plan best{64, 64, 1};
     double best_cost = 1e300;
-    for (int ci = 0; ci < 3; ++ci) {
-        const int bm = cand[ci][0], bn = cand[ci][1];
+    for (int ci = 0; ci < ncand; ++ci) {
+        const int bm = pipe ? cand_pipe[ci][0] : cand_gen[ci][0], bn = pipe ? cand_pipe[ci][1] : cand_gen[ci][1];
+        if (g_tune.bm && (bm != g_tune.bm || bn != g_tune.bn)) continue;
         const long tiles = (long)sg_cdiv(M, bm) * sg_cdiv(N, bn);
+        const double waves_per_block = pipe ? (bm / 64) * (bn / 64) : 4.0;
+        const double mfma_per_slab = pipe ? 512.0 : 512.0 * (bm / 64.0) * (bn / 64.0) / 4.0;
         for (int s : split_opts) {
             if (force_split > 0 && s != force_split) continue;
-            if (force_split <= 0 && s > 1 && (s > max_ws_split || KT / s < 4)) continue;
+            if (force_split <= 0 && s > 1 && (s > max_ws_split || KT / s < 2 || g_tune.no_split)) continue;
             if (s > KT) continue;
-            const long blocks = tiles * s;
-            const double per_block = (double)bm * bn / 16384.0 * (sg_cdiv(KT, s) + 6.0) / eff[ci];
-            double cost = (double)sg_cdiv(blocks, cus) * per_block;
-            if (s > 1) cost += 4.0 + (double)M * N * 4.0 * (s + 1) / 2.5e6;   // extra launch + partial-tile traffic
+            const double blocks = (double)tiles * s;
+            const double slabs = sg_cdiv(KT, s);
+            const double blocks_per_cu = sg_cdiv((long)blocks, (long)CUS);
+            const double t_bw = blocks_per_cu * slabs * (bm + bn) * 128.0 / BW;
+            const double waves_per_simd = sg_cdiv((long)(blocks * waves_per_block), (long)(CUS * 4));
+            const double t_mfma = waves_per_simd * slabs * mfma_per_slab;
+            double cost = (t_bw > t_mfma ? t_bw : t_mfma) + 2500.0 + blocks_per_cu * (bm * bn / 16.0);
+            if (s > 1) cost += 5000.0 + (double)M * N * 4.0 * (s + 1) / 1500.0;   // second launch + partial tiles
             if (cost < best_cost) { best_cost = cost; best = Plan{bm, bn, s}; }
         }
     }
-    if (force_split > 0 && best_cost == 1e300) best = Plan{64, 64, force_split > KT ? KT : force_split};
+    if (best_cost == 1e300) best = Plan{64, 64, force_split > KT ? KT : (force_split > 0 ? force_split : 1)};
     return best;
+}
+
+template <int WGM, int WGN, bool CONV>
+void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV>), grid, dim3(64 * WGM * WGN), 0, st, p);
 }
 
 template <bool CONV>
 int launch_mma(MmaParams& p, int force_split, void* ws, size_t ws_bytes, hipStream_t st, const char* name) {
     p.KT = sg_cdiv(p.K, BK);
-    const int cus = 256;
+    // LDS-DMA pipeline when no load needs a predicate (K % 64 == 0; conv input zero-bordered), else the
+    // register-staged kernel that zero-fills out-of-range chunks.
+    const bool pipe = (p.K % BK == 0) && (!CONV || p.padded) && !g_tune.no_pipe;
     const size_t per_split = (size_t)p.M * p.N * 4;
     const int max_ws_split = ws ? (int)(ws_bytes / per_split > 64 ? 64 : ws_bytes / per_split) : 1;
-    Plan pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, cus);
+    Plan pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, pipe);
     if (pl.splits > 1) {
-        const size_t need = (size_t)p.M * p.N * 4 * pl.splits;
+        const size_t need = per_split * pl.splits;
         if (ws == nullptr || ws_bytes < need)
             return sg_set_error(SG_EINVAL, "%s: split_k=%d needs %zu workspace bytes, got %zu", name, pl.splits, need,
                                 ws_bytes);
@@ -344,17 +543,37 @@ int launch_mma(MmaParams& p, int force_split, void* ws, size_t ws_bytes, hipStre
     p.kt_per_split = sg_cdiv(p.KT, pl.splits);
     p.tiles_m = sg_cdiv(p.M, pl.bm);
     p.tiles_n = sg_cdiv(p.N, pl.bn);
-    dim3 grid(p.tiles_m * p.tiles_n, pl.splits), block(NTHREADS);
-    if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((mma_kernel<128, 128, CONV>), grid, block, 0, st, p);
-    else if (pl.bm == 128 && pl.bn == 64) hipLaunchKernelGGL((mma_kernel<128, 64, CONV>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((mma_kernel<64, 64, CONV>), grid, block, 0, st, p);
+    dim3 grid(p.tiles_m * p.tiles_n, pl.splits);
+    if (pipe) {
+        if (pl.bm == 256 && pl.bn == 128) launch_pipe<4, 2, CONV>(p, grid, st);
+        else if (pl.bm == 128 && pl.bn == 128) launch_pipe<2, 2, CONV>(p, grid, st);
+        else if (pl.bm == 256 && pl.bn == 64) launch_pipe<4, 1, CONV>(p, grid, st);
+        else if (pl.bm == 128 && pl.bn == 64) launch_pipe<2, 1, CONV>(p, grid, st);
+        else if (pl.bm == 64 && pl.bn == 128) launch_pipe<1, 2, CONV>(p, grid, st);
+        else launch_pipe<1, 1, CONV>(p, grid, st);
+    } else {
+        dim3 block(256);
+        if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((mma_kernel<128, 128, CONV>), grid, block, 0, st, p);
+        else if (pl.bm == 128 && pl.bn == 64) hipLaunchKernelGGL((mma_kernel<128, 64, CONV>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((mma_kernel<64, 64, CONV>), grid, block, 0, st, p);
+    }
     SG_CHECK_LAUNCH(name);
     if (pl.splits > 1) {
         const long items = (long)p.M * (p.N / (p.mode == SG_EPI_GEGLU ? 16 : 8));
-        const int blocks = (int)min((long)4096, (items + NTHREADS - 1) / NTHREADS);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), block, 0, st, p);
+        const int blocks = (int)min((long)4096, (items + 255) / 256);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
         SG_CHECK_LAUNCH("splitk_reduce");
     }
+    return SG_OK;
+}
+
+int check_out_res(const char* who, int flags, const void* C, int64_t ldc, const void* C2, int64_t ldc2, const void* res1,
+                  int64_t ldr1, const void* res2, int64_t ldr2, int n_out) {
+    SG_REQUIRE((flags & ~(SG_F_OUT_F32 | SG_F_RES1_F32 | SG_F_RES2_F32)) == 0, "%s: unknown flag bits 0x%x", who, flags);
+    SG_REQUIRE(sg_aligned16(C) && ldc % 8 == 0 && ldc >= n_out, "%s: output alignment / ld", who);
+    SG_REQUIRE(!C2 || (sg_aligned16(C2) && ldc2 % 8 == 0 && ldc2 >= n_out), "%s: second output alignment / ld", who);
+    SG_REQUIRE(!res1 || (sg_aligned16(res1) && ldr1 % 8 == 0), "%s: res1 alignment", who);
+    SG_REQUIRE(!res2 || (sg_aligned16(res2) && ldr2 % 8 == 0), "%s: res2 alignment", who);
     return SG_OK;
 }
 
@@ -370,20 +589,19 @@ extern "C" int sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream) {
     SG_REQUIRE(d->A && d->W && d->C, "sg_gemm_f16: null A/W/C");
     SG_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "sg_gemm_f16: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
     SG_REQUIRE(d->K % 8 == 0 && d->N % 8 == 0, "sg_gemm_f16: K (%d) and N (%d) must be multiples of 8", d->K, d->N);
-    SG_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0 && d->ldc % 8 == 0, "sg_gemm_f16: lda/ldw/ldc must be multiples of 8");
+    SG_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0, "sg_gemm_f16: lda/ldw must be multiples of 8");
     SG_REQUIRE(d->lda >= d->K && d->ldw >= d->K, "sg_gemm_f16: lda/ldw smaller than K");
-    SG_REQUIRE(sg_aligned16(d->A) && sg_aligned16(d->W) && sg_aligned16(d->C), "sg_gemm_f16: A/W/C must be 16-byte aligned");
+    SG_REQUIRE(sg_aligned16(d->A) && sg_aligned16(d->W), "sg_gemm_f16: A/W must be 16-byte aligned");
     SG_REQUIRE(d->epilogue == SG_EPI_LINEAR || d->epilogue == SG_EPI_GEGLU, "sg_gemm_f16: unknown epilogue %d", d->epilogue);
+    int n_out = d->N;
     if (d->epilogue == SG_EPI_GEGLU) {
         SG_REQUIRE(d->N % 64 == 0, "sg_gemm_f16: GEGLU needs N %% 64 == 0 (got %d)", d->N);
         SG_REQUIRE(!d->rowbias && !d->res1 && !d->res2, "sg_gemm_f16: GEGLU epilogue takes bias only");
-        SG_REQUIRE(d->ldc >= d->N / 2, "sg_gemm_f16: ldc smaller than N/2");
-    } else {
-        SG_REQUIRE(d->ldc >= d->N, "sg_gemm_f16: ldc smaller than N");
+        n_out = d->N / 2;
     }
+    if (int rc = check_out_res("sg_gemm_f16", d->flags, d->C, d->ldc, d->C2, d->ldc2, d->res1, d->ldr1, d->res2, d->ldr2, n_out))
+        return rc;
     SG_REQUIRE(!d->bias || sg_aligned16(d->bias), "sg_gemm_f16: bias must be 16-byte aligned");
-    SG_REQUIRE(!d->res1 || (sg_aligned16(d->res1) && d->ldr1 % 8 == 0), "sg_gemm_f16: res1 alignment");
-    SG_REQUIRE(!d->res2 || (sg_aligned16(d->res2) && d->ldr2 % 8 == 0), "sg_gemm_f16: res2 alignment");
     SG_REQUIRE(!d->rowbias || (sg_aligned16(d->rowbias) && d->rowbias_ld % 4 == 0 && d->rows_per_batch >= 1),
                "sg_gemm_f16: rowbias alignment / rows_per_batch");
     SG_REQUIRE(d->split_k >= 0 && d->split_k <= 64, "sg_gemm_f16: bad split_k %d", d->split_k);
@@ -391,13 +609,14 @@ extern "C" int sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream) {
     MmaParams p{};
     p.A = reinterpret_cast<const f16*>(d->A); p.lda = d->lda;
     p.W = reinterpret_cast<const f16*>(d->W); p.ldw = d->ldw;
-    p.C = reinterpret_cast<f16*>(d->C); p.ldc = d->ldc;
+    p.C = d->C; p.ldc = d->ldc;
+    p.C2 = reinterpret_cast<f16*>(d->C2); p.ldc2 = d->ldc2;
     p.M = d->M; p.N = d->N; p.K = d->K;
-    p.mode = d->epilogue;
+    p.mode = d->epilogue; p.flags = d->flags;
     p.bias = reinterpret_cast<const f16*>(d->bias);
     p.rowbias = d->rowbias; p.rowbias_ld = d->rowbias_ld; p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1;
-    p.res1 = reinterpret_cast<const f16*>(d->res1); p.ldr1 = d->ldr1;
-    p.res2 = reinterpret_cast<const f16*>(d->res2); p.ldr2 = d->ldr2;
+    p.res1 = d->res1; p.ldr1 = d->ldr1;
+    p.res2 = d->res2; p.ldr2 = d->ldr2;
     return launch_mma<false>(p, d->split_k, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_gemm_f16");
 }
 
@@ -409,10 +628,11 @@ extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream)
     SG_REQUIRE(d->Cout % 8 == 0, "sg_conv3x3: Cout (%d) must be a multiple of 8", d->Cout);
     SG_REQUIRE(d->stride == 1 || d->stride == 2, "sg_conv3x3: stride must be 1 or 2");
     SG_REQUIRE(d->upsample2x == 0 || (d->upsample2x == 1 && d->stride == 1), "sg_conv3x3: upsample2x needs stride 1");
-    SG_REQUIRE(d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->ldx >= d->Cin && d->ldy >= d->Cout, "sg_conv3x3: bad ldx/ldy");
-    SG_REQUIRE(sg_aligned16(d->x) && sg_aligned16(d->w) && sg_aligned16(d->y), "sg_conv3x3: x/w/y must be 16-byte aligned");
+    SG_REQUIRE(d->x_padded == 0 || d->x_padded == 1, "sg_conv3x3: x_padded must be 0 or 1");
+    SG_REQUIRE(d->ldx % 8 == 0 && d->ldx >= d->Cin, "sg_conv3x3: bad ldx");
+    SG_REQUIRE(sg_aligned16(d->x) && sg_aligned16(d->w), "sg_conv3x3: x/w must be 16-byte aligned");
+    if (int rc = check_out_res("sg_conv3x3", d->flags, d->y, d->ldy, nullptr, 0, d->res1, d->ldr1, nullptr, 0, d->Cout)) return rc;
     SG_REQUIRE(!d->bias || sg_aligned16(d->bias), "sg_conv3x3: bias alignment");
-    SG_REQUIRE(!d->res1 || (sg_aligned16(d->res1) && d->ldr1 % 8 == 0), "sg_conv3x3: res1 alignment");
     SG_REQUIRE(!d->rowbias || (sg_aligned16(d->rowbias) && d->rowbias_ld % 4 == 0), "sg_conv3x3: rowbias alignment");
     SG_REQUIRE(d->split_k >= 0 && d->split_k <= 64, "sg_conv3x3: bad split_k %d", d->split_k);
     const int hin = d->H << d->upsample2x, win = d->W << d->upsample2x;
@@ -420,17 +640,23 @@ extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream)
     MmaParams p{};
     p.A = reinterpret_cast<const f16*>(d->x); p.lda = d->ldx;
     p.W = reinterpret_cast<const f16*>(d->w); p.ldw = 9L * d->Cin;
-    p.C = reinterpret_cast<f16*>(d->y); p.ldc = d->ldy;
+    p.C = d->y; p.ldc = d->ldy;
     p.M = d->B * Ho * Wo; p.N = d->Cout; p.K = 9 * d->Cin;
     p.H = d->H; p.Wd = d->W; p.Ho = Ho; p.Wo = Wo; p.cpt = d->Cin / 64; p.stride = d->stride; p.ups = d->upsample2x;
-    p.mode = SG_EPI_LINEAR;
+    p.padded = d->x_padded;
+    p.mode = SG_EPI_LINEAR; p.flags = d->flags;
     p.bias = reinterpret_cast<const f16*>(d->bias);
     p.rowbias = d->rowbias; p.rowbias_ld = d->rowbias_ld; p.rows_per_batch = Ho * Wo;
-    p.res1 = reinterpret_cast<const f16*>(d->res1); p.ldr1 = d->ldr1;
+    p.res1 = d->res1; p.ldr1 = d->ldr1;
     return launch_mma<true>(p, d->split_k, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_conv3x3_nhwc_f16");
 }
 
 // ------------------------------------------------------------------------------------------------ diagnostics
+extern "C" int sg_debug_set_tile(int32_t bm, int32_t bn, int32_t no_pipe) {
+    g_tune.bm = bm; g_tune.bn = bn; g_tune.no_pipe = no_pipe;
+    return SG_OK;
+}
+
 namespace {
 __global__ void debug_mfma_kernel(const f16* a, const f16* b, float* out) {
     const int lane = threadIdx.x & 63, l31 = lane & 31, hi = lane >> 5;

@@ -91,8 +91,8 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* x, long l
 
 // ------------------------------------------------------------------------------------------------ conv_in / conv_out
 // conv_in: thread = (pixel, 8 output channels); x fp32 NCHW, w fp16 [9*Cin][Cout].
-__global__ __launch_bounds__(256) void conv_in_kernel(const float* x, const f16* w, const f16* bias, f16* y, long ldy,
-                                                      int B, int H, int Wd, int Cin, int Cout) {
+__global__ __launch_bounds__(256) void conv_in_kernel(const float* x, const f16* w, const f16* bias, void* y, long ldy,
+                                                      int y_f32, int B, int H, int Wd, int Cin, int Cout) {
     const int cg = Cout / 8;
     const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
     const long total = (long)B * H * Wd * cg;
@@ -120,10 +120,13 @@ __global__ __launch_bounds__(256) void conv_in_kernel(const float* x, const f16*
             }
         }
     }
-    H8 o;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) o.h[j] = (f16)acc[j];
-    stg16(y + pix * ldy + g * 8, o.u);
+    if (y_f32) {
+        float* o = reinterpret_cast<float*>(y) + pix * ldy + g * 8;
+        *reinterpret_cast<float4*>(o) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    } else {
+        store8h(reinterpret_cast<f16*>(y) + pix * ldy + g * 8, acc);
+    }
 }
 
 // conv_out: one wave per output pixel; lanes split the 9*Cin/8 input chunks; Cout <= 4 accumulators.
@@ -181,15 +184,44 @@ __global__ void cfg_ddim_kernel(const float* eps3, float* lat, float* lat3, cons
     }
 }
 
-__global__ __launch_bounds__(256) void copy_rows_kernel(f16* dst, long ldd, long bsd, const f16* src, long lds, long bss,
-                                                        int batches, int rows, int cols) {
+// mode 0: fp16 -> fp16, 1: fp32 -> fp32, 2: fp32 -> fp16 (cast); 8 elements per thread per iteration
+__global__ __launch_bounds__(256) void copy_rows_kernel(void* dst, long ldd, long bsd, const void* src, long lds, long bss,
+                                                        int batches, int rows, int cols, int mode) {
     const int vpr = cols / 8;
     const long total = (long)batches * rows * vpr;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const int cv = (int)(i % vpr);
         const long rr = i / vpr;
         const int r = (int)(rr % rows), b = (int)(rr / rows);
-        stg16(dst + b * bsd + (long)r * ldd + cv * 8, ldg16(src + b * bss + (long)r * lds + cv * 8));
+        const long so = b * bss + (long)r * lds + cv * 8, doff = b * bsd + (long)r * ldd + cv * 8;
+        if (mode == 0) {
+            stg16(reinterpret_cast<f16*>(dst) + doff, ldg16(reinterpret_cast<const f16*>(src) + so));
+        } else {
+            float v[8];
+            load8f(src, so, true, v);
+            if (mode == 1) {
+                float* o = reinterpret_cast<float*>(dst) + doff;
+                *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+            } else {
+                store8h(reinterpret_cast<f16*>(dst) + doff, v);
+            }
+        }
+    }
+}
+
+// x [B,H,W,C] (fp16 or fp32) -> interior of the zero-bordered fp16 [B,H+2,W+2,C]
+__global__ __launch_bounds__(256) void pad_cast_kernel(const void* x, long ldx, int x_f32, f16* y, long ldy, int B, int H, int Wd,
+                                                       int C) {
+    const int vpr = C / 8;
+    const long total = (long)B * H * Wd * vpr;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % vpr);
+        const long pix = i / vpr;
+        const int xx = (int)(pix % Wd), yy = (int)((pix / Wd) % H), b = (int)(pix / ((long)Wd * H));
+        float v[8];
+        load8f(x, pix * ldx + cv * 8, x_f32, v);
+        store8h(y + (((long)b * (H + 2) + yy + 1) * (Wd + 2) + xx + 1) * ldy + cv * 8, v);
     }
 }
 
@@ -224,15 +256,16 @@ extern "C" int sg_linear_rows_f32(const float* x, int64_t ldx, const sg_half* W,
     return SG_OK;
 }
 
-extern "C" int sg_conv_in_f16(const float* x_nchw, const sg_half* w_kn, const sg_half* bias, sg_half* y, int64_t ldy,
-                              int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, sg_stream_t stream) {
+extern "C" int sg_conv_in_f16(const float* x_nchw, const sg_half* w_kn, const sg_half* bias, void* y, int64_t ldy,
+                              int32_t y_f32, int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                              sg_stream_t stream) {
     SG_REQUIRE(x_nchw && w_kn && bias && y, "sg_conv_in: null pointer");
     SG_REQUIRE(B > 0 && H > 0 && W > 0 && Cin > 0 && Cin <= 8 && Cout > 0 && Cout % 8 == 0, "sg_conv_in: bad shape");
     SG_REQUIRE(ldy % 8 == 0 && ldy >= Cout && sg_aligned16(w_kn) && sg_aligned16(bias) && sg_aligned16(y), "sg_conv_in: alignment");
     const long total = (long)B * H * W * (Cout / 8);
     hipLaunchKernelGGL(conv_in_kernel, dim3(sg_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, x_nchw,
-                       reinterpret_cast<const f16*>(w_kn), reinterpret_cast<const f16*>(bias), reinterpret_cast<f16*>(y),
-                       (long)ldy, B, H, W, Cin, Cout);
+                       reinterpret_cast<const f16*>(w_kn), reinterpret_cast<const f16*>(bias), y, (long)ldy, y_f32, B, H, W,
+                       Cin, Cout);
     SG_CHECK_LAUNCH("sg_conv_in_f16");
     return SG_OK;
 }
@@ -270,15 +303,27 @@ extern "C" int sg_cfg_ddim_step_f32(const float* eps3, float* latents, float* la
     return SG_OK;
 }
 
-extern "C" int sg_copy_rows_f16(sg_half* dst, int64_t ldd, int64_t bsd, const sg_half* src, int64_t lds, int64_t bss,
-                                int32_t batches, int32_t rows, int32_t cols, sg_stream_t stream) {
+extern "C" int sg_copy_rows(void* dst, int64_t ldd, int64_t bsd, const void* src, int64_t lds, int64_t bss, int32_t batches,
+                            int32_t rows, int32_t cols, int32_t mode, sg_stream_t stream) {
     SG_REQUIRE(dst && src && batches > 0 && rows > 0 && cols > 0, "sg_copy_rows: bad arguments");
+    SG_REQUIRE(mode >= 0 && mode <= 2, "sg_copy_rows: mode must be 0 (f16), 1 (f32) or 2 (f32->f16)");
     SG_REQUIRE(cols % 8 == 0 && ldd % 8 == 0 && lds % 8 == 0 && bsd % 8 == 0 && bss % 8 == 0, "sg_copy_rows: multiples of 8");
     SG_REQUIRE(sg_aligned16(dst) && sg_aligned16(src), "sg_copy_rows: 16-byte alignment");
     const long total = (long)batches * rows * (cols / 8);
-    hipLaunchKernelGGL(copy_rows_kernel, dim3((int)min((long)2048, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       reinterpret_cast<f16*>(dst), (long)ldd, (long)bsd, reinterpret_cast<const f16*>(src), (long)lds,
-                       (long)bss, batches, rows, cols);
-    SG_CHECK_LAUNCH("sg_copy_rows_f16");
+    hipLaunchKernelGGL(copy_rows_kernel, dim3((int)min((long)2048, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, dst,
+                       (long)ldd, (long)bsd, src, (long)lds, (long)bss, batches, rows, cols, mode);
+    SG_CHECK_LAUNCH("sg_copy_rows");
+    return SG_OK;
+}
+
+extern "C" int sg_pad_cast_f16(const void* x, int64_t ldx, int32_t x_f32, sg_half* y, int64_t ldy, int32_t B, int32_t H,
+                               int32_t W, int32_t C, sg_stream_t stream) {
+    SG_REQUIRE(x && y && B > 0 && H > 0 && W > 0 && C > 0, "sg_pad_cast: bad arguments");
+    SG_REQUIRE(C % 8 == 0 && ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C, "sg_pad_cast: multiples of 8");
+    SG_REQUIRE(sg_aligned16(x) && sg_aligned16(y), "sg_pad_cast: 16-byte alignment");
+    const long total = (long)B * H * W * (C / 8);
+    hipLaunchKernelGGL(pad_cast_kernel, dim3((int)min((long)2048, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x,
+                       (long)ldx, x_f32, reinterpret_cast<f16*>(y), (long)ldy, B, H, W, C);
+    SG_CHECK_LAUNCH("sg_pad_cast_f16");
     return SG_OK;
 }

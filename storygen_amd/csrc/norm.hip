@@ -8,13 +8,18 @@ constexpr int GN_MAX_GROUPS = 64;
 constexpr int GN_MAX_CHUNKS = 64;
 
 struct GnParams {
-    const f16* x; long ldx;
-    f16* y; long ldy;
+    const void* x; long ldx; int x_f32;
+    f16* y; long ldy; int pad_w;          // pad_w > 0: y is [B, H+2, pad_w+2, ldy] and only its interior is written
+    f16* xcopy; long ldxc;                // optional raw fp16 copy of x (MFMA operand for the 1x1 shortcut)
     const f16* gamma; const f16* beta;
     int HW, C, G, cpg, nchunks, rows_per_chunk;
     float eps; int silu;
     float* ws;   // [B][nchunks][G][2] shifted partial sums
 };
+
+__device__ __forceinline__ float load1f(const void* base, long off, bool f32) {
+    return f32 ? reinterpret_cast<const float*>(base)[off] : (float)reinterpret_cast<const f16*>(base)[off];
+}
 
 // Thread layout shared by both passes: TW = min(C/8, 256) threads span one pixel row's channel vectors (looping
 // when C/8 > 256), 256/TW pixel rows are processed per pass.
@@ -26,7 +31,8 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnParams p) {
     const int vpr = p.C / 8;
     const int tw = vpr < 256 ? vpr : 256, rpp = 256 / tw;
     const int my_row = t / tw, my_col = t - my_row * tw;
-    const f16* xb = p.x + (long)b * p.HW * p.ldx;
+    const long xb = (long)b * p.HW * p.ldx;   // element offset of this batch
+    const bool f32 = p.x_f32;
     const int p0 = chunk * p.rows_per_chunk, p1 = min(p.HW, p0 + p.rows_per_chunk);
     float gsum = 0.f, gsq = 0.f;   // accumulators of thread t < G (group t)
     for (int cv0 = 0; cv0 < vpr; cv0 += tw) {
@@ -37,12 +43,13 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnParams p) {
         const bool active = my_row < rpp && cv < vpr;
         if (active) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) piv[j] = (float)xb[((cv * 8 + j) / p.cpg) * p.cpg];
+            for (int j = 0; j < 8; ++j) piv[j] = load1f(p.x, xb + ((cv * 8 + j) / p.cpg) * p.cpg, f32);
             for (int px = p0 + my_row; px < p1; px += rpp) {
-                H8 v; v.u = ldg16(xb + (long)px * p.ldx + cv * 8);
+                float v[8];
+                load8f(p.x, xb + (long)px * p.ldx + cv * 8, f32, v);
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
-                    const float d = (float)v.h[j] - piv[j];
+                    const float d = v[j] - piv[j];
                     s[j] += d; q[j] += d * d;
                 }
             }
@@ -76,8 +83,12 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnParams p) {
 __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
     __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
     const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
-    const f16* xb = p.x + (long)b * p.HW * p.ldx;
-    f16* yb = p.y + (long)b * p.HW * p.ldy;
+    const long xb = (long)b * p.HW * p.ldx;
+    const bool f32 = p.x_f32;
+    const int pw = p.pad_w;
+    // padded output: pixel (yy, xx) of image b lives at row ((b*(H+2) + yy+1)*(pw+2) + xx+1)
+    f16* yb = pw ? p.y + ((long)b * (p.HW / pw + 2) * (pw + 2)) * p.ldy : p.y + (long)b * p.HW * p.ldy;
+    f16* cb = p.xcopy ? p.xcopy + (long)b * p.HW * p.ldxc : nullptr;
     if (t < p.G) {
         float s = 0.f, q = 0.f;
         for (int c = 0; c < p.nchunks; ++c) {
@@ -85,7 +96,7 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
             s += w[0]; q += w[1];
         }
         const float n = (float)p.HW * (float)p.cpg;
-        const float piv = (float)xb[t * p.cpg];
+        const float piv = load1f(p.x, xb + t * p.cpg, f32);
         const float md = s / n;                       // E[x - K]
         const float var = fmaxf(q / n - md * md, 0.f);
         s_mean[t] = piv + md;
@@ -107,20 +118,23 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
             sh[j] = (float)be.h[j] - s_mean[grp] * sc[j];
         }
         for (int px = p0 + my_row; px < p1; px += rpp) {
-            H8 v, o; v.u = ldg16(xb + (long)px * p.ldx + cv * 8);
+            float v[8], o[8];
+            load8f(p.x, xb + (long)px * p.ldx + cv * 8, f32, v);
+            if (cb) store8h(cb + (long)px * p.ldxc + cv * 8, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
-                float r = (float)v.h[j] * sc[j] + sh[j];
-                if (p.silu) r = silu_f(r);
-                o.h[j] = (f16)r;
+                float r = v[j] * sc[j] + sh[j];
+                o[j] = p.silu ? silu_f(r) : r;
             }
-            stg16(yb + (long)px * p.ldy + cv * 8, o.u);
+            long orow = px;
+            if (pw) { const int yy = px / pw, xx = px - yy * pw; orow = (long)(yy + 1) * (pw + 2) + xx + 1; }
+            store8h(yb + orow * p.ldy + cv * 8, o);
         }
     }
 }
 
 struct LnParams {
-    const f16* x; long ldx; int M, C; float eps;
+    const void* x; long ldx; int x_f32; int M, C; float eps;
     const f16* g1; const f16* b1; f16* y1; long ldy1;
     const f16* g2; const f16* b2; f16* y2; long ldy2;
 };
@@ -131,17 +145,18 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
     const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= p.M) return;
     const int vpr = p.C / 8;
-    const f16* xr = p.x + (long)row * p.ldx;
-    H8 v[NV];
+    const long xr = (long)row * p.ldx;
+    float v[NV][8];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < NV; ++i) {
         const int cv = lane + 64 * i;
-        v[i].u = make_uint4(0, 0, 0, 0);
-        if (cv < vpr) {
-            v[i].u = ldg16(xr + cv * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) sum += (float)v[i].h[j];
+        for (int j = 0; j < 8; ++j) v[i][j] = 0.f;
+        if (cv < vpr) {
+            load8f(p.x, xr + cv * 8, p.x_f32, v[i]);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) sum += v[i][j];
         }
     }
     const float mean = wave_sum(sum) / (float)p.C;
@@ -150,7 +165,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
     for (int i = 0; i < NV; ++i)
         if (lane + 64 * i < vpr) {
 #pragma unroll
-            for (int j = 0; j < 8; ++j) { const float d = (float)v[i].h[j] - mean; sq += d * d; }
+            for (int j = 0; j < 8; ++j) { const float d = v[i][j] - mean; sq += d * d; }
         }
     const float rstd = rsqrtf(wave_sum(sq) / (float)p.C + p.eps);
 #pragma unroll
@@ -160,12 +175,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
             H8 g, be, o;
             g.u = ldg16(p.g1 + cv * 8); be.u = ldg16(p.b1 + cv * 8);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) o.h[j] = (f16)(((float)v[i].h[j] - mean) * rstd * (float)g.h[j] + (float)be.h[j]);
+            for (int j = 0; j < 8; ++j) o.h[j] = (f16)((v[i][j] - mean) * rstd * (float)g.h[j] + (float)be.h[j]);
             stg16(p.y1 + (long)row * p.ldy1 + cv * 8, o.u);
             if (p.y2) {
                 g.u = ldg16(p.g2 + cv * 8); be.u = ldg16(p.b2 + cv * 8);
 #pragma unroll
-                for (int j = 0; j < 8; ++j) o.h[j] = (f16)(((float)v[i].h[j] - mean) * rstd * (float)g.h[j] + (float)be.h[j]);
+                for (int j = 0; j < 8; ++j) o.h[j] = (f16)((v[i][j] - mean) * rstd * (float)g.h[j] + (float)be.h[j]);
                 stg16(p.y2 + (long)row * p.ldy2 + cv * 8, o.u);
             }
         }
@@ -190,24 +205,28 @@ extern "C" size_t sg_groupnorm_workspace_bytes(int32_t B, int32_t groups) {
     return (size_t)B * GN_MAX_CHUNKS * (size_t)groups * 2 * sizeof(float);
 }
 
-extern "C" int sg_groupnorm_nhwc_f16(const sg_half* x, int64_t ldx, sg_half* y, int64_t ldy, const sg_half* gamma,
-                                     const sg_half* beta, int32_t B, int32_t HW, int32_t C, int32_t groups, float eps,
-                                     int32_t silu, void* workspace, size_t workspace_bytes, sg_stream_t stream) {
-    SG_REQUIRE(x && y && gamma && beta && workspace, "sg_groupnorm: null pointer");
-    SG_REQUIRE(B > 0 && HW > 0 && C > 0 && groups > 0, "sg_groupnorm: bad shape");
-    SG_REQUIRE(C % 8 == 0 && C % groups == 0 && C <= 2560, "sg_groupnorm: C=%d must be a multiple of 8 and of groups, <= 2560", C);
-    SG_REQUIRE(groups <= GN_MAX_GROUPS, "sg_groupnorm: at most %d groups", GN_MAX_GROUPS);
-    SG_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0 && ldx >= C && ldy >= C, "sg_groupnorm: bad ldx/ldy");
-    SG_REQUIRE(sg_aligned16(x) && sg_aligned16(y) && sg_aligned16(gamma) && sg_aligned16(beta), "sg_groupnorm: 16-byte alignment");
-    SG_REQUIRE(workspace_bytes >= sg_groupnorm_workspace_bytes(B, groups), "sg_groupnorm: workspace too small");
+extern "C" int sg_groupnorm_nhwc_f16(const sg_groupnorm_desc* d, sg_stream_t stream) {
+    SG_REQUIRE(d != nullptr, "sg_groupnorm: null descriptor");
+    SG_REQUIRE(d->x && d->y && d->gamma && d->beta && d->workspace, "sg_groupnorm: null pointer");
+    SG_REQUIRE(d->B > 0 && d->HW > 0 && d->C > 0 && d->groups > 0, "sg_groupnorm: bad shape");
+    SG_REQUIRE(d->C % 8 == 0 && d->C % d->groups == 0 && d->C <= 2560,
+               "sg_groupnorm: C=%d must be a multiple of 8 and of groups, <= 2560", d->C);
+    SG_REQUIRE(d->groups <= GN_MAX_GROUPS, "sg_groupnorm: at most %d groups", GN_MAX_GROUPS);
+    SG_REQUIRE(d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->ldx >= d->C && d->ldy >= d->C, "sg_groupnorm: bad ldx/ldy");
+    SG_REQUIRE(sg_aligned16(d->x) && sg_aligned16(d->y) && sg_aligned16(d->gamma) && sg_aligned16(d->beta),
+               "sg_groupnorm: 16-byte alignment");
+    SG_REQUIRE(d->y_pad_w >= 0 && (d->y_pad_w == 0 || d->HW % d->y_pad_w == 0), "sg_groupnorm: y_pad_w must divide HW");
+    SG_REQUIRE(!d->xcopy || (sg_aligned16(d->xcopy) && d->ldxc % 8 == 0 && d->ldxc >= d->C), "sg_groupnorm: xcopy alignment / ld");
+    SG_REQUIRE(d->workspace_bytes >= sg_groupnorm_workspace_bytes(d->B, d->groups), "sg_groupnorm: workspace too small");
     GnParams p{};
-    p.x = reinterpret_cast<const f16*>(x); p.ldx = ldx;
-    p.y = reinterpret_cast<f16*>(y); p.ldy = ldy;
-    p.gamma = reinterpret_cast<const f16*>(gamma); p.beta = reinterpret_cast<const f16*>(beta);
-    p.HW = HW; p.C = C; p.G = groups; p.cpg = C / groups; p.eps = eps; p.silu = silu;
-    p.ws = reinterpret_cast<float*>(workspace);
-    gn_geometry(B, HW, C, &p.nchunks, &p.rows_per_chunk);
-    dim3 grid(p.nchunks, B), block(256);
+    p.x = d->x; p.ldx = d->ldx; p.x_f32 = d->x_f32 ? 1 : 0;
+    p.y = reinterpret_cast<f16*>(d->y); p.ldy = d->ldy; p.pad_w = d->y_pad_w;
+    p.xcopy = reinterpret_cast<f16*>(d->xcopy); p.ldxc = d->ldxc;
+    p.gamma = reinterpret_cast<const f16*>(d->gamma); p.beta = reinterpret_cast<const f16*>(d->beta);
+    p.HW = d->HW; p.C = d->C; p.G = d->groups; p.cpg = d->C / d->groups; p.eps = d->eps; p.silu = d->silu;
+    p.ws = reinterpret_cast<float*>(d->workspace);
+    gn_geometry(d->B, d->HW, d->C, &p.nchunks, &p.rows_per_chunk);
+    dim3 grid(p.nchunks, d->B), block(256);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, st, p);
     SG_CHECK_LAUNCH("gn_stats");
@@ -216,7 +235,7 @@ extern "C" int sg_groupnorm_nhwc_f16(const sg_half* x, int64_t ldx, sg_half* y, 
     return SG_OK;
 }
 
-extern "C" int sg_layernorm_f16(const sg_half* x, int64_t ldx, int32_t M, int32_t C, float eps, const sg_half* gamma1,
+extern "C" int sg_layernorm_f16(const void* x, int64_t ldx, int32_t x_f32, int32_t M, int32_t C, float eps, const sg_half* gamma1,
                                 const sg_half* beta1, sg_half* y1, int64_t ldy1, const sg_half* gamma2,
                                 const sg_half* beta2, sg_half* y2, int64_t ldy2, sg_stream_t stream) {
     SG_REQUIRE(x && gamma1 && beta1 && y1, "sg_layernorm: null pointer");
@@ -228,7 +247,7 @@ extern "C" int sg_layernorm_f16(const sg_half* x, int64_t ldx, int32_t M, int32_
                        ldy2 >= C, "sg_layernorm: second output arguments");
     }
     LnParams p{};
-    p.x = reinterpret_cast<const f16*>(x); p.ldx = ldx; p.M = M; p.C = C; p.eps = eps;
+    p.x = x; p.ldx = ldx; p.x_f32 = x_f32 ? 1 : 0; p.M = M; p.C = C; p.eps = eps;
     p.g1 = reinterpret_cast<const f16*>(gamma1); p.b1 = reinterpret_cast<const f16*>(beta1);
     p.y1 = reinterpret_cast<f16*>(y1); p.ldy1 = ldy1;
     p.g2 = reinterpret_cast<const f16*>(gamma2); p.b2 = reinterpret_cast<const f16*>(beta2);

@@ -134,105 +134,116 @@ class UNetEngine:
         return torch.empty(*shape, dtype=dtype, device=self.dev)
 
     def _alloc(self, splitk_mb: int):
+        """Precision plan: the residual stream (block inputs/outputs, skips, concat buffers, the transformer's running
+        state h0..h3, shortcut outputs) is fp32; every MFMA operand (norm outputs, q/k/v, attention outputs, FF inner,
+        conv inputs) is fp16.  Conv inputs live in zero-bordered [B,H+2,W+2,C] buffers so padding needs no predicate."""
         B, arch = self.B, self.arch
         boc = self.cfg["block_out_channels"]
         nlev = len(boc)
-        self.x_in = self._buf(B, self.cfg["in_channels"], self.H, self.W, dtype=torch.float32)
-        self.t_in = self._buf(B, dtype=torch.float32)
+        F32 = torch.float32
+        self.x_in = self._buf(B, self.cfg["in_channels"], self.H, self.W, dtype=F32)
+        self.t_in = self._buf(B, dtype=F32)
         self.text_in = self._buf(B, self.S, self.cad)
-        self.eps_out = self._buf(B, self.cfg["out_channels"], self.H, self.W, dtype=torch.float32)
-        self.temb0 = self._buf(B, boc[0], dtype=torch.float32)
-        self.temb1 = self._buf(B, arch.temb_dim, dtype=torch.float32)
-        self.temb2 = self._buf(B, arch.temb_dim, dtype=torch.float32)
-        self.tproj = self._buf(B, self.temb_total, dtype=torch.float32)
+        self.eps_out = self._buf(B, self.cfg["out_channels"], self.H, self.W, dtype=F32)
+        self.temb0 = self._buf(B, boc[0], dtype=F32)
+        self.temb1 = self._buf(B, arch.temb_dim, dtype=F32)
+        self.temb2 = self._buf(B, arch.temb_dim, dtype=F32)
+        self.tproj = self._buf(B, self.temb_total, dtype=F32)
         self.ws_split = self._buf(splitk_mb << 20, dtype=torch.uint8)
         self.ws_gn = self._buf(ops.groupnorm_workspace_bytes(B, self.groups), dtype=torch.uint8)
-        # widest tensors per level
-        cmax = [0] * nlev       # widest resnet input (concat) at the level
-        cout = [0] * nlev       # widest block channel count at the level
+        # per level: widest resnet input (concat) and the level's channel count; every conv-input channel count
+        cmax, cout = [0] * nlev, [0] * nlev
+        conv_in_ch = [set() for _ in range(nlev)]
         lvl = 0
         for blk in arch.down:
             for r in blk.resnets:
                 cmax[lvl], cout[lvl] = max(cmax[lvl], r.cin), max(cout[lvl], r.cout)
+                conv_in_ch[lvl].update((r.cin, r.cout))
             if blk.sampler_prefix:
+                conv_in_ch[lvl].add(blk.channels)
                 lvl += 1
         for r in arch.mid.resnets:
             cmax[lvl], cout[lvl] = max(cmax[lvl], r.cin), max(cout[lvl], r.cout)
+            conv_in_ch[lvl].update((r.cin, r.cout))
         for blk in arch.up:
             for r in blk.resnets:
                 cmax[lvl], cout[lvl] = max(cmax[lvl], r.cin), max(cout[lvl], r.cout)
+                conv_in_ch[lvl].update((r.cin, r.cout))
             if blk.sampler_prefix:
+                conv_in_ch[lvl].add(blk.channels)
                 lvl -= 1
         self.lv = []
+        self.padded: Dict[tuple, torch.Tensor] = {}
         for l in range(nlev):
             M, C, Cw = B * self.hw[l], cout[l], max(cmax[l], cout[l])
+            h, w = self.H >> l, self.W >> l
+            for ch in conv_in_ch[l]:
+                self.padded[(l, ch)] = torch.zeros(B, h + 2, w + 2, ch, dtype=F16, device=self.dev)
+            f32 = lambda *sh: self._buf(*sh, dtype=F32)  # noqa: E731
             d = dict(
-                gn=self._buf(M * Cw), cat=[self._buf(M * Cw), self._buf(M * Cw)], r=self._buf(M, C), c1=self._buf(M, C),
-                t_out=self._buf(M, C),
-                sc=self._buf(M, C), h0=self._buf(M, C), h1=self._buf(M, C), h2=self._buf(M, C), h3=self._buf(M, C),
+                # fp32 residual stream
+                cat=[f32(M * Cw), f32(M * Cw)], r=f32(M, C), t_out=f32(M, C), sc=f32(M, C),
+                h0=f32(M, C), h1=f32(M, C), h2=f32(M, C), h3=f32(M, C),
+                # fp16 MFMA operands
+                gn=self._buf(M, C), x16=self._buf(M * Cw), c1=self._buf(M, C), h4=self._buf(M, C),
                 ln=self._buf(M, C), ln4=self._buf(M, C), qkv=self._buf(M, 3 * C), q=self._buf(M, C), att=self._buf(M, C),
                 ffi=self._buf(M, 4 * C), kvt=self._buf(B * self.S, 2 * C),
                 kvi=self._buf(B * self.R * self.hw[l], 2 * C) if self.R else None,
             )
             self.lv.append(d)
         # skip tensors (down_block_res_samples) persist until the up path pops them
-        self.skips: List[torch.Tensor] = []
-        self.skip_meta = []
+        self.skip_meta = [(0, boc[0])]
         lvl = 0
-        self.skip_meta.append((0, boc[0]))
         for blk in arch.down:
             for _ in blk.resnets:
                 self.skip_meta.append((lvl, blk.channels))
             if blk.sampler_prefix:
                 lvl += 1
                 self.skip_meta.append((lvl, blk.channels))
-        self.skips = [self._buf(B * self.hw[l], c) for l, c in self.skip_meta]
-        # context buffers: [B, R*HW, C] per feature key
+        self.skips: List[torch.Tensor] = [self._buf(B * self.hw[l], c, dtype=F32) for l, c in self.skip_meta]
+        # context buffers: [B, R*HW, C] fp16 per feature key (K/V projection operands of attn3)
         self.ctx: Dict[str, torch.Tensor] = {}
         if self.R:
             for k, (n, c) in feature_shapes(arch, self.H, self.W).items():
                 self.ctx[k] = self._buf(B, self.R * n, c)
 
     # ------------------------------------------------------------------------------------------ layers
-    def _groupnorm(self, x2d: torch.Tensor, gamma, beta, out2d: torch.Tensor, eps: float, silu: bool, hw: int):
-        ops.groupnorm(x2d.unflatten(0, (self.B, hw)), gamma, beta, out2d.unflatten(0, (self.B, hw)), self.groups, eps,
-                      silu, self.ws_gn)
-
     def _img(self, x2d: torch.Tensor, lvl: int) -> torch.Tensor:
         h, w = self.H >> lvl, self.W >> lvl
         return x2d.unflatten(0, (self.B, h, w))
 
     def _resnet(self, rn: _Resnet, x: torch.Tensor, out: torch.Tensor, lvl: int):
-        """x [M,Cin] (contiguous), out [M,Cout] (possibly a column slice of a concat buffer)."""
-        L, M, r = self.lv[lvl], x.shape[0], rn.spec
-        t0 = L["gn"][: M * r.cin].view(M, r.cin)
-        self._groupnorm(x, rn.n1g, rn.n1b, t0, self.eps, True, self.hw[lvl])
+        """diffusers ResnetBlock2D.  x fp32 [M,Cin] contiguous; out fp32 [M,Cout], possibly a column
+        slice of a concat buffer."""
+        L, M, r, B, hw = self.lv[lvl], x.shape[0], rn.spec, self.B, self.hw[lvl]
+        ws = self.ws_split
+        p_in, p_mid = self.padded[(lvl, r.cin)], self.padded[(lvl, r.cout)]
+        x16 = L["x16"][: M * r.cin].view(M, r.cin) if rn.wsc is not None else None
+        ops.groupnorm(x.unflatten(0, (B, hw)), rn.n1g, rn.n1b, p_in, self.groups, self.eps, True, self.ws_gn,
+                      xcopy=None if x16 is None else x16.unflatten(0, (B, hw)))
         h1 = L["c1"]
-        assert h1.shape == (M, r.cout), (h1.shape, M, r.cout)
         rb = self.tproj[:, rn.temb_off: rn.temb_off + r.cout]
-        ops.conv3x3(self._img(t0, lvl), rn.w1, self._img(h1, lvl), rowbias=rb, workspace=self.ws_split)
-        t1 = L["gn"][: M * r.cout].view(M, r.cout)
-        self._groupnorm(h1, rn.n2g, rn.n2b, t1, self.eps, True, self.hw[lvl])
+        ops.conv3x3(p_in, rn.w1, self._img(h1, lvl), rowbias=rb, workspace=ws, x_padded=True)
+        ops.groupnorm(h1.unflatten(0, (B, hw)), rn.n2g, rn.n2b, p_mid, self.groups, self.eps, True, self.ws_gn)
         if rn.wsc is not None:
-            sc = L["sc"]
-            ops.gemm(x, rn.wsc, sc, bias=rn.bsc, workspace=self.ws_split)
-            res = sc
+            ops.gemm(x16, rn.wsc, L["sc"], bias=rn.bsc, workspace=ws)
+            res = L["sc"]
         else:
             res = x
-        ops.conv3x3(self._img(t1, lvl), rn.w2, self._img(out, lvl), bias=rn.b2, res1=self._img(res, lvl),
-                    workspace=self.ws_split)
+        ops.conv3x3(p_mid, rn.w2, self._img(out, lvl), bias=rn.b2, res1=self._img(res, lvl), workspace=ws, x_padded=True)
 
     def _transformer(self, xf: _Xf, x: torch.Tensor, out: torch.Tensor, lvl: int, text: torch.Tensor,
                      harvest_slot: Optional[int], consume: bool):
-        """Transformer2DModel.forward (attention.py:85-128) + BasicTransformerBlock.forward (:236-302)."""
+        """Transformer2DModel.forward (attention.py:85-128) + BasicTransformerBlock.forward (:236-302).
+        x, out, h0..h3 fp32; everything that feeds an MFMA fp16."""
         L, B, hw, S = self.lv[lvl], self.B, self.hw[lvl], self.S
         M, C, heads = x.shape[0], xf.spec.channels, xf.spec.heads
         scale = xf.spec.dim_head ** -0.5
         ws = self.ws_split
-        t = L["gn"][: M * C].view(M, C)
-        self._groupnorm(x, xf.ng, xf.nb, t, 1e-6, False, hw)                              # :99 (eps 1e-6, :55)
+        ops.groupnorm(x.unflatten(0, (B, hw)), xf.ng, xf.nb, L["gn"].unflatten(0, (B, hw)), self.groups, 1e-6, False,
+                      self.ws_gn)                                                         # :99 (eps 1e-6, :55)
         h0 = L["h0"]
-        ops.gemm(t, xf.w_in, h0, bias=xf.b_in, workspace=ws)                              # proj_in :101
+        ops.gemm(L["gn"], xf.w_in, h0, bias=xf.b_in, workspace=ws)                        # proj_in :101
         # --- self-attention :250-262
         ops.layernorm(h0, *xf.ln["norm1"], L["ln"])
         qkv = L["qkv"]
@@ -241,10 +252,12 @@ class UNetEngine:
         att = L["att"]
         ops.attention(q3d[:, :, :C], q3d[:, :, C:2 * C], q3d[:, :, 2 * C:], att.view(B, hw, C), heads, scale)
         h1 = L["h1"]
-        ops.gemm(att, xf.w_o1, h1, bias=xf.b_o1, res1=h0, workspace=ws)
-        if harvest_slot is not None:                                                     # feature :263
+        if harvest_slot is not None:                                                     # feature :263, written in place
             dst = self.ctx[xf.spec.feature_key][:, harvest_slot * hw:(harvest_slot + 1) * hw, :]
+            ops.gemm(att, xf.w_o1, h1, bias=xf.b_o1, res1=h0, workspace=ws)
             ops.copy_rows(dst, h1.view(B, hw, C))
+        else:
+            ops.gemm(att, xf.w_o1, h1, bias=xf.b_o1, res1=h0, workspace=ws)
         # --- text cross-attention :266-277 (norm2) and image cross-attention :281-291 (norm4) share statistics
         if consume:
             ops.layernorm(h1, *xf.ln["norm2"], L["ln"], 1e-5, *xf.ln["norm4"], L["ln4"])
@@ -273,9 +286,17 @@ class UNetEngine:
         # --- feed-forward :298-300
         ops.layernorm(h3, *xf.ln["norm3"], L["ln"])
         ops.gemm(L["ln"], xf.w_ff1, L["ffi"], bias=xf.b_ff1, epilogue=ops.EPI_GEGLU, workspace=ws)
-        h4 = L["h0"]
-        ops.gemm(L["ffi"], xf.w_ff2, h4, bias=xf.b_ff2, res1=h3, workspace=ws)
-        ops.gemm(h4, xf.w_out, out, bias=xf.b_out, res1=x, workspace=ws)                  # proj_out + residual :121-123
+        ops.gemm(L["ffi"], xf.w_ff2, L["h4"], bias=xf.b_ff2, res1=h3, workspace=ws)       # fp16: only feeds proj_out
+        ops.gemm(L["h4"], xf.w_out, out, bias=xf.b_out, res1=x, workspace=ws)             # proj_out + residual :121-123
+
+    def _sampler_conv(self, prefix: str, h: torch.Tensor, out: torch.Tensor, lvl: int, out_lvl: int, down: bool):
+        """Downsample2D (3x3 stride 2) / Upsample2D (nearest 2x + 3x3): the fp32 stream tensor is cast into the
+        zero-bordered fp16 conv input first."""
+        w, b = self.samplers[prefix]
+        pbuf = self.padded[(lvl, h.shape[1])]
+        ops.pad_cast(self._img(h, lvl), pbuf)
+        ops.conv3x3(pbuf, w, self._img(out, out_lvl), stride=2 if down else 1, upsample2x=not down, bias=b,
+                    workspace=self.ws_split, x_padded=True)
 
     # ------------------------------------------------------------------------------------------ forward
     def _cat_view(self, lvl: int, which: int, width: int) -> torch.Tensor:
@@ -292,7 +313,7 @@ class UNetEngine:
             raise ValueError("a pass either harvests features or consumes them")
         if (harvest_slot is not None or consume) and not self.R:
             raise ValueError("engine was built without context buffers (n_ref=0)")
-        arch, ws, text, skips = self.arch, self.ws_split, self.text_in, self.skips
+        arch, text, skips = self.arch, self.text_in, self.skips
         # --- time embedding :392-398, then all 22 time_emb_proj(silu(emb)) in one GEMV bundle
         ops.timestep_embed(self.t_in, self.freqs, self.temb0, self.cfg["flip_sin_to_cos"])
         ops.linear_rows(self.temb0, self.w_t1, self.b_t1, self.temb1, act_out=True)
@@ -313,9 +334,8 @@ class UNetEngine:
                     self._transformer(self.xfs[xf.prefix], rt, out, lvl, text, harvest_slot, consume)
                 h, si = out, si + 1
             if blk.sampler_prefix:
-                w, b = self.samplers[blk.sampler_prefix]
                 out = skips[si]
-                ops.conv3x3(self._img(h, lvl), w, self._img(out, lvl + 1), stride=2, bias=b, workspace=ws)   # Downsample2D
+                self._sampler_conv(blk.sampler_prefix, h, out, lvl, lvl + 1, down=True)
                 h, lvl, si = out, lvl + 1, si + 1
         assert si == len(skips)
         # --- mid :436-445
@@ -351,19 +371,18 @@ class UNetEngine:
                     cat, pp = nxt, pp ^ 1
                 h = out
             if blk.sampler_prefix:                                                        # Upsample2D :656-658,730-732
-                w, b = self.samplers[blk.sampler_prefix]
                 nblk = arch.up[bi + 1]
                 pp = 0
                 cat = self._cat_view(lvl - 1, pp, nblk.resnets[0].cin)
                 c_h = nblk.resnets[0].cin - nblk.skip_channels[0]
-                ops.conv3x3(self._img(h, lvl), w, self._img(cat[:, :c_h], lvl - 1), upsample2x=True, bias=b, workspace=ws)
+                self._sampler_conv(blk.sampler_prefix, h, cat[:, :c_h], lvl, lvl - 1, down=False)
                 lvl -= 1
         assert si == 0 and lvl == 0
         # --- out :477-480
         L = self.lv[0]
-        t = L["gn"][: h.numel()].view_as(h)
-        self._groupnorm(h, *self.gn_out, t, self.eps, True, self.hw[0])
-        ops.conv_out(self._img(t, 0), self.w_conv_out, self.b_conv_out, self.eps_out)
+        ops.groupnorm(h.unflatten(0, (self.B, self.hw[0])), *self.gn_out, L["gn"].unflatten(0, (self.B, self.hw[0])),
+                      self.groups, self.eps, True, self.ws_gn)
+        ops.conv_out(self._img(L["gn"], 0), self.w_conv_out, self.b_conv_out, self.eps_out)
         return self.eps_out
 
     # ------------------------------------------------------------------------------------------ convenience
@@ -373,7 +392,7 @@ class UNetEngine:
         self.t_in.copy_(t.to(self.dev, torch.float32).reshape(-1).expand(self.B))
         self.text_in.copy_(text.to(self.dev, F16))
 
-    def features(self, slot: int = 0) -> Dict[str, torch.Tensor]:
+    def features(self, slot: int = 0) -> Dict[str, torch.Tensor]:  # fp16 views
         """The 16 harvested [B, HW, C] features of slot r, as views into the context buffers."""
         out = {}
         for k, (n, _) in feature_shapes(self.arch, self.H, self.W).items():

@@ -13,12 +13,13 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import AttnDesc, ConvDesc, GemmDesc, check
+from ._lib import AttnDesc, ConvDesc, GemmDesc, GroupNormDesc, check
 
 lib = _lib.load()
 
 EPI_LINEAR = 0
 EPI_GEGLU = 1
+F_OUT_F32, F_RES1_F32, F_RES2_F32 = 1, 2, 4
 
 # Optional in-situ kernel timer (bench.py): when set, every MFMA-class launch is bracketed by HIP events recorded
 # on the launch stream and reported as (family, algorithmic_flops, start_event, end_event).
@@ -58,6 +59,13 @@ def _f16(t: torch.Tensor, name: str):
         raise TypeError(f"{name}: expected a CUDA/HIP float16 tensor, got {t.dtype} on {t.device}")
 
 
+def _act(t: torch.Tensor, name: str) -> bool:
+    """Activation tensors may be fp16 (MFMA operands) or fp32 (residual stream); returns True for fp32."""
+    if t.dtype not in (torch.float16, torch.float32) or not t.is_cuda:
+        raise TypeError(f"{name}: expected a CUDA/HIP float16/float32 tensor, got {t.dtype} on {t.device}")
+    return t.dtype == torch.float32
+
+
 def _f32(t: torch.Tensor, name: str):
     if t.dtype != torch.float32 or not t.is_cuda:
         raise TypeError(f"{name}: expected a CUDA/HIP float32 tensor, got {t.dtype} on {t.device}")
@@ -81,9 +89,11 @@ def gemm_workspace_bytes(M: int, N: int, split_k: int = 0) -> int:
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
          rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 1, res1: Optional[torch.Tensor] = None,
          res2: Optional[torch.Tensor] = None, epilogue: int = EPI_LINEAR, split_k: int = 0,
-         workspace: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """out[M, N'] = epi(a[M,K] @ w[N,K]^T); a/out/res* may be row-strided 2-D views."""
-    _f16(a, "a"), _f16(w, "w"), _f16(out, "out")
+         workspace: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, N'] = epi(a[M,K] @ w[N,K]^T); a/out/res* may be row-strided 2-D views; out/res* fp16 or fp32;
+    out2 = optional extra fp16 copy of the result."""
+    _f16(a, "a"), _f16(w, "w")
+    flags = F_OUT_F32 if _act(out, "out") else 0
     M, K = a.shape
     N = w.shape[0]
     if w.shape[1] != K:
@@ -106,11 +116,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[
     d.rows_per_batch = rows_per_batch
     d.split_k = split_k
     if res1 is not None:
-        _f16(res1, "res1")
+        flags |= F_RES1_F32 if _act(res1, "res1") else 0
         d.res1, d.ldr1 = res1.data_ptr(), _row_stride(res1, "res1")
     if res2 is not None:
-        _f16(res2, "res2")
+        flags |= F_RES2_F32 if _act(res2, "res2") else 0
         d.res2, d.ldr2 = res2.data_ptr(), _row_stride(res2, "res2")
+    if out2 is not None:
+        _f16(out2, "out2")
+        d.C2, d.ldc2 = out2.data_ptr(), _row_stride(out2, "out2")
+    d.flags = flags
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     with _timed("gemm", 2.0 * M * N * K, f"M{M} N{N} K{K}{' geglu' if epilogue else ''}"):
@@ -120,11 +134,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[
 
 def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stride: int = 1, upsample2x: bool = False,
             bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
-            res1: Optional[torch.Tensor] = None, split_k: int = 0, workspace: Optional[torch.Tensor] = None
-            ) -> torch.Tensor:
-    """x [B,H,W,Cin] (channels-last, pixel-strided view allowed) -> out [B,Ho,Wo,Cout]; w_krsc [Cout,3,3,Cin]."""
-    _f16(x, "x"), _f16(w_krsc, "w"), _f16(out, "out")
+            res1: Optional[torch.Tensor] = None, split_k: int = 0, workspace: Optional[torch.Tensor] = None,
+            x_padded: bool = False) -> torch.Tensor:
+    """x [B,H,W,Cin] (channels-last, pixel-strided view allowed; or the zero-bordered [B,H+2,W+2,Cin] with
+    x_padded=True) -> out [B,Ho,Wo,Cout] (fp16 or fp32); w_krsc [Cout,3,3,Cin]; res1 fp16 or fp32."""
+    _f16(x, "x"), _f16(w_krsc, "w")
+    flags = F_OUT_F32 if _act(out, "out") else 0
     B, H, W, Cin = x.shape
+    if x_padded:
+        H, W = H - 2, W - 2
     Cout = w_krsc.shape[0]
     if tuple(w_krsc.shape) != (Cout, 3, 3, Cin) or not w_krsc.is_contiguous():
         raise ValueError(f"conv3x3: w must be contiguous [Cout,3,3,{Cin}], got {tuple(w_krsc.shape)}")
@@ -143,7 +161,7 @@ def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stride:
     d.w = w_krsc.data_ptr()
     d.y, d.ldy = out.data_ptr(), pix_stride(out, "out")
     d.B, d.H, d.W, d.Cin, d.Cout = B, H, W, Cin, Cout
-    d.stride, d.upsample2x = stride, int(upsample2x)
+    d.stride, d.upsample2x, d.x_padded = stride, int(upsample2x), int(x_padded)
     if bias is not None:
         _f16(bias, "bias")
         d.bias = bias.data_ptr()
@@ -151,8 +169,9 @@ def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stride:
         _f32(rowbias, "rowbias")
         d.rowbias, d.rowbias_ld = rowbias.data_ptr(), _row_stride(rowbias, "rowbias")
     if res1 is not None:
-        _f16(res1, "res1")
+        flags |= F_RES1_F32 if _act(res1, "res1") else 0
         d.res1, d.ldr1 = res1.data_ptr(), pix_stride(res1, "res1")
+    d.flags = flags
     d.split_k = split_k
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
@@ -163,13 +182,14 @@ def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stride:
 
 
 def conv_in(x_nchw: torch.Tensor, w_kn: torch.Tensor, bias: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
-    _f32(x_nchw, "x"), _f16(w_kn, "w"), _f16(bias, "bias"), _f16(out, "out")
+    _f32(x_nchw, "x"), _f16(w_kn, "w"), _f16(bias, "bias")
+    y_f32 = _act(out, "out")
     B, Cin, H, W = x_nchw.shape
     Cout = w_kn.shape[1]
     if not x_nchw.is_contiguous() or tuple(w_kn.shape) != (9 * Cin, Cout) or tuple(out.shape) != (B, H, W, Cout):
         raise ValueError("conv_in: bad shapes")
-    check(lib.sg_conv_in_f16(x_nchw.data_ptr(), w_kn.data_ptr(), bias.data_ptr(), out.data_ptr(), out.stride(2), B, H, W,
-                             Cin, Cout, _stream()), "sg_conv_in_f16")
+    check(lib.sg_conv_in_f16(x_nchw.data_ptr(), w_kn.data_ptr(), bias.data_ptr(), out.data_ptr(), out.stride(2), int(y_f32),
+                             B, H, W, Cin, Cout, _stream()), "sg_conv_in_f16")
     return out
 
 
@@ -211,24 +231,44 @@ def groupnorm_workspace_bytes(B: int, groups: int) -> int:
 
 
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, groups: int, eps: float,
-              silu: bool, workspace: torch.Tensor) -> torch.Tensor:
-    """x/out [B, HW, C] channels-last (row-strided views allowed)."""
-    _f16(x, "x"), _f16(gamma, "gamma"), _f16(beta, "beta"), _f16(out, "out")
+              silu: bool, workspace: torch.Tensor, xcopy: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [B, HW, C] channels-last fp16/fp32 (row-strided views allowed).  out is either [B, HW, C] fp16 or the
+    zero-bordered image [B, H+2, W+2, C] (then only the interior is written); xcopy = optional fp16 [B, HW, C] raw copy."""
+    x_f32 = _act(x, "x")
+    _f16(gamma, "gamma"), _f16(beta, "beta"), _f16(out, "out")
     B, HW, Cc = x.shape
-    if x.stride(0) != HW * x.stride(1) or out.stride(0) != HW * out.stride(1):
-        raise ValueError("groupnorm: batch stride must equal HW * row stride")
-    check(lib.sg_groupnorm_nhwc_f16(x.data_ptr(), x.stride(1), out.data_ptr(), out.stride(1), gamma.data_ptr(),
-                                    beta.data_ptr(), B, HW, Cc, groups, eps, int(silu), workspace.data_ptr(),
-                                    workspace.numel() * workspace.element_size(), _stream()), "sg_groupnorm_nhwc_f16")
+    if x.stride(0) != HW * x.stride(1):
+        raise ValueError("groupnorm: batch stride of x must equal HW * row stride")
+    d = GroupNormDesc()
+    d.x, d.ldx, d.x_f32 = x.data_ptr(), x.stride(1), int(x_f32)
+    if out.dim() == 4:
+        Hp, Wp = out.shape[1], out.shape[2]
+        if (Hp - 2) * (Wp - 2) != HW or out.stride(1) != Wp * out.stride(2) or out.stride(0) != Hp * out.stride(1):
+            raise ValueError("groupnorm: padded output must be a dense [B, H+2, W+2, C] image")
+        d.y, d.ldy, d.y_pad_w = out.data_ptr(), out.stride(2), Wp - 2
+    else:
+        if out.stride(0) != HW * out.stride(1):
+            raise ValueError("groupnorm: batch stride of out must equal HW * row stride")
+        d.y, d.ldy, d.y_pad_w = out.data_ptr(), out.stride(1), 0
+    if xcopy is not None:
+        _f16(xcopy, "xcopy")
+        if xcopy.stride(0) != HW * xcopy.stride(1):
+            raise ValueError("groupnorm: batch stride of xcopy must equal HW * row stride")
+        d.xcopy, d.ldxc = xcopy.data_ptr(), xcopy.stride(1)
+    d.gamma, d.beta = gamma.data_ptr(), beta.data_ptr()
+    d.B, d.HW, d.C, d.groups, d.eps, d.silu = B, HW, Cc, groups, eps, int(silu)
+    d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    check(lib.sg_groupnorm_nhwc_f16(C.byref(d), _stream()), "sg_groupnorm_nhwc_f16")
     return out
 
 
 def layernorm(x: torch.Tensor, g1: torch.Tensor, b1: torch.Tensor, y1: torch.Tensor, eps: float = 1e-5,
               g2: Optional[torch.Tensor] = None, b2: Optional[torch.Tensor] = None,
               y2: Optional[torch.Tensor] = None) -> None:
-    _f16(x, "x"), _f16(y1, "y1")
+    x_f32 = _act(x, "x")
+    _f16(y1, "y1")
     M, Cc = x.shape
-    check(lib.sg_layernorm_f16(x.data_ptr(), _row_stride(x, "x"), M, Cc, eps, g1.data_ptr(), b1.data_ptr(), y1.data_ptr(),
+    check(lib.sg_layernorm_f16(x.data_ptr(), _row_stride(x, "x"), int(x_f32), M, Cc, eps, g1.data_ptr(), b1.data_ptr(), y1.data_ptr(),
                                _row_stride(y1, "y1"), _p(g2), _p(b2), _p(y2),
                                0 if y2 is None else _row_stride(y2, "y2"), _stream()), "sg_layernorm_f16")
 
@@ -272,14 +312,37 @@ def cfg_ddim_step(eps3: torch.Tensor, latents: torch.Tensor, latents3: Optional[
 
 
 def copy_rows(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
-    """dst[b, r, :cols] = src[b, r, :cols] for 3-D fp16 views with unit channel stride."""
-    _f16(dst, "dst"), _f16(src, "src")
+    """dst[b, r, :cols] = src[b, r, :cols] for 3-D views with unit channel stride; fp16->fp16, fp32->fp32 or
+    fp32->fp16 (cast)."""
+    s32, d32 = _act(src, "src"), _act(dst, "dst")
+    if d32 and not s32:
+        raise TypeError("copy_rows: fp16 -> fp32 is not supported")
+    mode = 0 if not s32 else (1 if d32 else 2)
     Bn, rows, cols = src.shape
     if tuple(dst.shape) != (Bn, rows, cols) or dst.stride(-1) != 1 or src.stride(-1) != 1:
         raise ValueError("copy_rows: shape/stride mismatch")
-    check(lib.sg_copy_rows_f16(dst.data_ptr(), dst.stride(1), dst.stride(0), src.data_ptr(), src.stride(1), src.stride(0),
-                               Bn, rows, cols, _stream()), "sg_copy_rows_f16")
+    check(lib.sg_copy_rows(dst.data_ptr(), dst.stride(1), dst.stride(0), src.data_ptr(), src.stride(1), src.stride(0),
+                           Bn, rows, cols, mode, _stream()), "sg_copy_rows")
     return dst
+
+
+def pad_cast(x: torch.Tensor, out_padded: torch.Tensor) -> torch.Tensor:
+    """x [B,H,W,C] fp16/fp32 (single pixel stride) -> interior of the zero-bordered fp16 [B,H+2,W+2,C]."""
+    x_f32 = _act(x, "x")
+    _f16(out_padded, "out")
+    B, H, W, Cc = x.shape
+    if tuple(out_padded.shape) != (B, H + 2, W + 2, Cc) or not out_padded.is_contiguous():
+        raise ValueError("pad_cast: out must be a contiguous [B,H+2,W+2,C]")
+    if x.stride(-1) != 1 or x.stride(1) != W * x.stride(2) or x.stride(0) != H * x.stride(1):
+        raise ValueError("pad_cast: x must be [B,H,W,C] with a single pixel stride")
+    check(lib.sg_pad_cast_f16(x.data_ptr(), x.stride(2), int(x_f32), out_padded.data_ptr(), Cc, B, H, W, Cc, _stream()),
+          "sg_pad_cast_f16")
+    return out_padded
+
+
+def debug_set_tile(bm: int = 0, bn: int = 0, no_pipe: bool = False) -> None:
+    """Test hook: force the GEMM/conv tile shape / kernel family (0, 0 = automatic)."""
+    check(lib.sg_debug_set_tile(bm, bn, int(no_pipe)), "sg_debug_set_tile")
 
 
 def debug_mfma(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:

@@ -40,11 +40,41 @@ def test_mfma_fragment_layout(gpu):
     check(got, ref, "mfma layout", l2=1e-5, mx=1e-5)
 
 
+TILES = [(0, 0, False), (256, 128, False), (128, 128, False), (256, 64, False), (128, 64, False), (64, 128, False), (64, 64, False),
+         (128, 128, True), (128, 64, True), (64, 64, True)]
+
+
+@pytest.fixture(params=TILES, ids=lambda t: f"tile{t[0]}x{t[1]}{'-generic' if t[2] else ''}")
+def tile(request, gpu):
+    """Runs the test once per GEMM/conv tile shape and kernel family (LDS-DMA pipeline vs generic)."""
+    from storygen_amd import ops
+    ops.debug_set_tile(*request.param)
+    yield request.param
+    ops.debug_set_tile(0, 0, False)
+
+
 GEMM_SHAPES = [
     # M, N, K            (tails in M and N, K not a multiple of 64, tiny, SD-1.5 layer shapes)
     (128, 128, 64), (256, 320, 320), (200, 72, 136), (12, 320, 1280), (3072, 640, 640), (768, 1280, 2560),
     (4096, 960, 320), (231, 2560, 768), (64, 1280, 11520 // 4),
 ]
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 320, 320), (200, 72, 128), (3072, 640, 640), (300, 1280, 1920)])
+def test_gemm_all_tiles_fp32_stream(gpu, tile, M, N, K):
+    """Every tile shape / kernel family; fp32 output, fp32 + fp16 residuals, second fp16 copy of the output."""
+    from storygen_amd import ops
+    a, w = rnd((M, K), gpu, seed=3), rnd((N, K), gpu, 1 / math.sqrt(K), seed=4)
+    bias, r1 = rnd((N,), gpu, seed=5), rnd((M, N), gpu, seed=6, dtype=torch.float32)
+    r2 = rnd((M, N), gpu, seed=7)
+    ref = a.float() @ w.float().t() + bias.float() + r1 + r2.float()
+    out = torch.empty(M, N, dtype=torch.float32, device=gpu)
+    out16 = torch.empty(M, N, dtype=torch.float16, device=gpu)
+    ops.gemm(a, w, out, bias=bias, res1=r1, res2=r2, split_k=1, out2=out16)
+    check(out, ref, "fp32 out", l2=2e-6, mx=2e-5)
+    check(out16, ref, "fp16 copy")
+    ops.gemm(a, w, out16, bias=bias, res1=r2, res2=r1, split_k=1)
+    check(out16, ref, "fp16 out, swapped residual dtypes")
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
@@ -135,6 +165,29 @@ def test_conv3x3(gpu, B, H, W, Cin, Cout, stride, ups, split):
     check(out.permute(0, 3, 1, 2), ref, "conv3x3")
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,stride,ups,split", CONV_CASES)
+def test_conv3x3_padded_input_all_tiles(gpu, tile, B, H, W, Cin, Cout, stride, ups, split):
+    """Zero-bordered input (LDS-DMA pipelined kernel when the tile is not '-generic'), fp32 output + fp32 residual."""
+    from storygen_amd import ops
+    x = rnd((B, Cin, H, W), gpu, seed=1)
+    w = rnd((Cout, Cin, 3, 3), gpu, 1 / math.sqrt(9 * Cin), seed=2)
+    bias = rnd((Cout,), gpu, seed=3)
+    rb = rnd((B, Cout), gpu, seed=4, dtype=torch.float32)
+    xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+    ref = F.conv2d(xin, w.float(), bias.float(), stride=stride, padding=1) + rb[:, :, None, None]
+    res = rnd(tuple(ref.shape), gpu, seed=5, dtype=torch.float32)
+    ref = ref + res
+    xp = torch.zeros(B, H + 2, W + 2, Cin, dtype=torch.float16, device=gpu)
+    ops.pad_cast(x.permute(0, 2, 3, 1).contiguous(), xp)
+    assert float(xp[:, 0].abs().max()) == 0 and float(xp[:, :, -1].abs().max()) == 0
+    out = torch.empty(B, ref.shape[2], ref.shape[3], Cout, dtype=torch.float32, device=gpu)
+    M = B * ref.shape[2] * ref.shape[3]
+    ws = torch.empty(max(16, ops.gemm_workspace_bytes(M, Cout, split)), dtype=torch.uint8, device=gpu)
+    ops.conv3x3(xp, w.permute(0, 2, 3, 1).contiguous(), out, stride=stride, upsample2x=ups, bias=bias, rowbias=rb,
+                res1=res.permute(0, 2, 3, 1).contiguous(), split_k=split, workspace=ws, x_padded=True)
+    check(out.permute(0, 3, 1, 2), ref, "conv3x3 padded", l2=2e-6, mx=2e-5)
+
+
 ATTN_CASES = [
     # B, H, Nq, Nk, D
     (2, 8, 256, 256, 40), (1, 8, 200, 77, 40), (3, 8, 64, 192, 160), (2, 8, 256, 768, 80), (1, 8, 1024, 1024, 80),
@@ -192,6 +245,32 @@ def test_groupnorm(gpu, B, HW, C, silu, eps):
     check(out, ref, "groupnorm")
 
 
+@pytest.mark.parametrize("B,H,W,C", [(3, 16, 16, 320), (2, 8, 12, 1920), (1, 4, 4, 2560)])
+def test_groupnorm_fp32_in_padded_out_rawcopy(gpu, B, H, W, C):
+    """The resnet flavour: fp32 residual-stream input, SiLU, output into the zero-bordered conv input, raw fp16 copy."""
+    from storygen_amd import ops
+    x = rnd((B, H * W, C), gpu, 2.0, seed=1, dtype=torch.float32) + 1.5
+    g, b = rnd((C,), gpu, seed=2), rnd((C,), gpu, seed=3)
+    yp = torch.zeros(B, H + 2, W + 2, C, dtype=torch.float16, device=gpu)
+    xc = torch.empty(B, H * W, C, dtype=torch.float16, device=gpu)
+    ws = torch.empty(ops.groupnorm_workspace_bytes(B, 32), dtype=torch.uint8, device=gpu)
+    ops.groupnorm(x, g, b, yp, 32, 1e-5, True, ws, xcopy=xc)
+    ref = F.silu(F.group_norm(x.transpose(1, 2), 32, g.float(), b.float(), 1e-5)).transpose(1, 2)
+    check(yp[:, 1:-1, 1:-1].reshape(B, H * W, C), ref, "groupnorm padded")
+    assert float(yp[:, 0].abs().max()) == 0 and float(yp[:, -1].abs().max()) == 0
+    assert float(yp[:, :, 0].abs().max()) == 0 and float(yp[:, :, -1].abs().max()) == 0
+    assert torch.equal(xc, x.half())
+
+
+def test_layernorm_fp32_input(gpu):
+    from storygen_amd import ops
+    x = rnd((300, 640), gpu, 2.0, seed=1, dtype=torch.float32) + 1.0
+    g, b = rnd((640,), gpu, seed=2), rnd((640,), gpu, seed=3)
+    y = torch.empty(300, 640, dtype=torch.float16, device=gpu)
+    ops.layernorm(x, g, b, y)
+    check(y, F.layer_norm(x, (640,), g.float(), b.float(), 1e-5), "layernorm fp32 in")
+
+
 @pytest.mark.parametrize("M,C", [(1024, 320), (300, 640), (77, 1280), (5, 64)])
 def test_layernorm_dual(gpu, M, C):
     from storygen_amd import ops
@@ -236,6 +315,9 @@ def test_conv_in_out(gpu):
     y = torch.empty(B, H, W, C, dtype=torch.float16, device=gpu)
     ops.conv_in(x, w.permute(2, 3, 1, 0).reshape(36, C).contiguous(), b, y)
     check(y.permute(0, 3, 1, 2), F.conv2d(x, w.float(), b.float(), padding=1), "conv_in")
+    y32 = torch.empty(B, H, W, C, dtype=torch.float32, device=gpu)
+    ops.conv_in(x, w.permute(2, 3, 1, 0).reshape(36, C).contiguous(), b, y32)
+    check(y32.permute(0, 3, 1, 2), F.conv2d(x, w.float(), b.float(), padding=1), "conv_in fp32", l2=1e-5, mx=1e-4)
     wo = rnd((4, C, 3, 3), gpu, 1 / math.sqrt(9 * C), seed=4)
     bo = rnd((4,), gpu, seed=5)
     out = torch.empty(B, 4, H, W, device=gpu)
@@ -269,6 +351,13 @@ def test_copy_rows(gpu):
     dst = torch.zeros(3, 150, 960, dtype=torch.float16, device=gpu)
     ops.copy_rows(dst[:, 50:100, 320:], src)
     assert torch.equal(dst[:, 50:100, 320:], src) and float(dst[:, :50].abs().max()) == 0 and float(dst[:, :, :320].abs().max()) == 0
+    src32 = rnd((2, 33, 64), gpu, seed=2, dtype=torch.float32)
+    d32 = torch.zeros(2, 40, 128, device=gpu)
+    ops.copy_rows(d32[:, 3:36, 64:], src32)
+    assert torch.equal(d32[:, 3:36, 64:], src32)
+    d16 = torch.zeros(2, 33, 64, dtype=torch.float16, device=gpu)
+    ops.copy_rows(d16, src32)
+    assert torch.equal(d16, src32.half())
 
 
 def test_abi_rejects_bad_arguments(gpu):

@@ -32,6 +32,7 @@ def main():
     sink = []
     ops.PROFILE_SINK = sink
     smp.params.copy_(smp.table[8])
+    torch.cuda._sleep(200_000_000)   # ~100 ms GPU spin so the (slower) eager host stays ahead of the GPU: no launch gaps
     t0 = time.perf_counter()
     smp._step_body()
     torch.cuda.synchronize()
