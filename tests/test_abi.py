@@ -1,0 +1,137 @@
+"""C-ABI checks that need no GPU: the shared library loads, exports every entry point include/storygen_hip.h declares,
+the ctypes table in storygen_amd/_lib.py covers exactly those names with matching arity, the descriptor structs have
+the C layout, and host-side validation rejects bad descriptors before anything would be enqueued."""
+import ctypes as C
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "storygen_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from storygen_amd import _lib
+    from storygen_amd.build import build
+    build(force=False, verbose=False)      # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def _header_text():
+    src = open(HEADER).read()
+    return re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+
+
+def _declared_functions():
+    """name -> number of parameters, parsed from the header."""
+    out = {}
+    for m in re.finditer(r"\b(?:int|size_t|const\s+char\s*\*)\s+(sg_\w+)\s*\(([^;{]*?)\)\s*;", _header_text(), flags=re.S):
+        name, args = m.group(1), m.group(2).strip()
+        out[name] = 0 if args in ("", "void") else args.count(",") + 1
+    return out
+
+
+def test_header_declares_the_expected_surface():
+    fns = _declared_functions()
+    for need in ("sg_gemm_f16", "sg_conv3x3_nhwc_f16", "sg_attn_fwd_f16", "sg_groupnorm_nhwc_f16", "sg_layernorm_f16",
+                 "sg_timestep_embed_f32", "sg_cfg_ddim_step_f32", "sg_version", "sg_last_error", "sg_device_arch"):
+        assert need in fns, need
+    assert len(fns) >= 20
+
+
+def test_library_exports_every_declared_symbol(lib):
+    from storygen_amd._lib import LIB_PATH
+    nm = subprocess.run(["nm", "-D", "--defined-only", LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = {ln.split()[-1] for ln in nm.splitlines() if " T " in ln}
+    missing = sorted(set(_declared_functions()) - exported)
+    assert not missing, f"declared in the header but not exported: {missing}"
+    stray = sorted(s for s in exported if s.startswith("sg_") and s not in _declared_functions())
+    assert not stray, f"exported sg_* symbols missing from the header: {stray}"
+
+
+def test_ctypes_table_matches_header(lib):
+    from storygen_amd._lib import SIGNATURES
+    fns = _declared_functions()
+    assert set(SIGNATURES) == set(fns)
+    for name, (_, args) in SIGNATURES.items():
+        assert len(args) == fns[name], (name, len(args), fns[name])
+        assert getattr(lib, name) is not None
+
+
+def test_descriptor_layouts_match_a_c_compiler(tmp_path):
+    """sizeof / offsetof of every descriptor as gcc sees the header vs the ctypes Structures."""
+    from storygen_amd import _lib
+    structs = {"sg_gemm_desc": _lib.GemmDesc, "sg_conv3x3_desc": _lib.ConvDesc, "sg_attn_desc": _lib.AttnDesc,
+               "sg_groupnorm_desc": _lib.GroupNormDesc}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
+    for cname, st in structs.items():
+        lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
+        for f, _ in st._fields_:
+            lines.append(f'printf("{cname}.{f} %zu\\n", offsetof({cname}, {f}));')
+    lines.append("return 0;}")
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", str(src), "-o", str(exe)], check=True)   # header is plain C
+    got = dict(ln.split() for ln in subprocess.run([str(exe)], capture_output=True, text=True, check=True).stdout.splitlines())
+    for cname, st in structs.items():
+        assert int(got[cname]) == C.sizeof(st), cname
+        for f, _ in st._fields_:
+            assert int(got[f"{cname}.{f}"]) == getattr(st, f).offset, (cname, f)
+
+
+def test_version_and_error_string(lib):
+    assert lib.sg_version() == 1
+    assert isinstance(lib.sg_last_error(), bytes)
+
+
+def test_host_validation_rejects_before_launch(lib):
+    """Every entry point validates on the host first: these calls return SG_EINVAL / SG_EUNSUP without touching a
+    device (so they work on a GPU-less box) and leave a message in sg_last_error()."""
+    from storygen_amd._lib import AttnDesc, ConvDesc, GemmDesc, GroupNormDesc
+    assert lib.sg_gemm_f16(None, None) == -1
+    assert b"null" in lib.sg_last_error()
+    d = GemmDesc()
+    d.A, d.W, d.C = 0x1000, 0x2000, 0x3000
+    d.M, d.N, d.K, d.lda, d.ldw, d.ldc = 64, 64, 60, 64, 64, 64          # K not a multiple of 8
+    assert lib.sg_gemm_f16(C.byref(d), None) == -1
+    assert b"multiples of 8" in lib.sg_last_error()
+    d.K = 64
+    d.A = 0x1004                                                          # misaligned
+    assert lib.sg_gemm_f16(C.byref(d), None) == -1
+    d.A, d.epilogue = 0x1000, 7
+    assert lib.sg_gemm_f16(C.byref(d), None) == -1
+    c = ConvDesc()
+    c.x, c.w, c.y = 0x1000, 0x2000, 0x3000
+    c.B, c.H, c.W, c.Cin, c.Cout, c.ldx, c.ldy, c.stride = 1, 8, 8, 60, 64, 64, 64, 1
+    assert lib.sg_conv3x3_nhwc_f16(C.byref(c), None) == -1               # Cin % 64
+    c.Cin, c.stride = 64, 3
+    assert lib.sg_conv3x3_nhwc_f16(C.byref(c), None) == -1
+    a = AttnDesc()
+    a.q = a.k = a.v = a.o = 0x1000
+    a.B, a.H, a.Nq, a.Nk, a.D = 1, 8, 64, 64, 64
+    a.ldq = a.ldk = a.ldv = a.ldo = 512
+    assert lib.sg_attn_fwd_f16(C.byref(a), None) == -2                   # SG_EUNSUP: head dim
+    assert b"head dim" in lib.sg_last_error()
+    g = GroupNormDesc()
+    assert lib.sg_groupnorm_nhwc_f16(C.byref(g), None) == -1
+    assert lib.sg_gemm_workspace_bytes(128, 256, 4) == 128 * 256 * 4 * 4
+    assert lib.sg_gemm_workspace_bytes(128, 256, 1) == 0
+
+
+def test_product_path_has_no_cpu_fallback():
+    """The package's compute modules never import the oracle, and ops refuse CPU tensors."""
+    import torch
+    pkg = os.path.join(ROOT, "storygen_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith(".py"):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "import oracle" not in src and "from oracle" not in src, fn
+    from storygen_amd import ops
+    x = torch.zeros(8, 64, dtype=torch.float16)
+    with pytest.raises(TypeError):
+        ops.gemm(x, x, torch.zeros(8, 8, dtype=torch.float16))

@@ -1,0 +1,159 @@
+"""Host-side logic that needs no GPU: the DDIM tables the sampler uploads, the static architecture description
+(state-dict contract of SURVEY §8b), the weight repacks the kernels consume, the per-step parameter table, and the
+data-parallel sharding + the single all-gather (gloo, world_size 2)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------------------------------------ scheduler
+def test_ddim_schedule_matches_oracle_and_config():
+    from oracle import storygen_oracle as O
+    from storygen_amd.scheduler import DDIMSchedule
+    s, o = DDIMSchedule(), O.DDIM()
+    assert torch.equal(s.alphas_cumprod, o.alphas_cumprod)
+    for n in (1, 4, 40, 50):
+        assert s.timesteps(n) == o.timesteps(n)
+    x, eps = torch.randn(1, 4, 8, 8), torch.randn(1, 4, 8, 8)
+    for t in (981, 501, 21, 1):
+        ca, cb = s.add_noise_coef(t // 10)
+        assert torch.allclose(ca * x + cb * eps, o.add_noise(x, eps, t // 10), atol=1e-6)
+        sa, sb, pa, pb = s.step_coef(t, 50)
+        mine = pa * ((x - sb * eps) / sa) + pb * eps
+        assert torch.allclose(mine, o.step(eps, t, x, 50), atol=1e-5, rtol=1e-5)
+    # last step uses final_alpha_cumprod = alphas_cumprod[0] (set_alpha_to_one = false in scheduler_config.json)
+    assert s.step_coef(1, 50)[2] == pytest.approx(float(s.alphas_cumprod[0] ** 0.5))
+
+
+def test_ddim_schedule_from_shipped_json(tmp_path):
+    import json
+    from storygen_amd.scheduler import DDIMSchedule
+    cfg = {"_class_name": "PNDMScheduler", "beta_end": 0.012, "beta_schedule": "scaled_linear", "beta_start": 0.00085,
+           "num_train_timesteps": 1000, "set_alpha_to_one": False, "skip_prk_steps": True, "steps_offset": 1,
+           "trained_betas": None, "clip_sample": False}        # ckpt/stable-diffusion-v1-5/scheduler/scheduler_config.json
+    os.makedirs(tmp_path / "scheduler")
+    (tmp_path / "scheduler" / "scheduler_config.json").write_text(json.dumps(cfg))
+    s = DDIMSchedule.from_pretrained(str(tmp_path))
+    assert s.timesteps(50)[0] == 981 and torch.equal(s.alphas_cumprod, DDIMSchedule().alphas_cumprod)
+
+
+# ------------------------------------------------------------------------------------------------ architecture
+def test_arch_sd15_parameter_census():
+    from storygen_amd.arch import SD15_CONFIG, build_arch, feature_shapes, param_shapes
+    arch = build_arch(SD15_CONFIG)
+    shapes = param_shapes(arch)
+    n = sum(int(torch.Size(s).numel()) for s in shapes.values())
+    assert 905e6 < n < 912e6                                   # SD-1.5's 859.5 M + 49.6 M of attn3/norm4
+    attn3 = sum(int(torch.Size(s).numel()) for k, s in shapes.items() if ".attn3." in k or ".norm4." in k)
+    assert 49e6 < attn3 < 50.5e6
+    assert len(arch.resnets) == 22 and len(arch.feature_keys) == 16
+    assert arch.feature_keys == ["down_1_1", "down_1_2", "down_2_1", "down_2_2", "down_3_1", "down_3_2", "mid", "up_1_1",
+                                 "up_1_2", "up_1_3", "up_2_1", "up_2_2", "up_2_3", "up_3_1", "up_3_2", "up_3_3"]
+    fs = feature_shapes(arch, 64, 64)
+    assert fs["down_1_1"] == (4096, 320) and fs["mid"] == (64, 1280) and fs["up_1_1"] == (256, 1280) and fs["up_3_3"] == (4096, 320)
+    # resnet input widths of the up path (concat with the popped skips), SURVEY §2b
+    ups = [r.cin for b in arch.up for r in b.resnets]
+    assert ups == [2560, 2560, 2560, 2560, 2560, 1920, 1920, 1280, 960, 960, 640, 640]
+    assert shapes["up_blocks.1.resnets.2.conv_shortcut.weight"] == (1280, 1920, 1, 1)
+    assert shapes["down_blocks.0.attentions.0.transformer_blocks.0.attn2.to_k.weight"] == (320, 768)
+    assert shapes["down_blocks.0.attentions.0.transformer_blocks.0.attn3.to_k.weight"] == (320, 320)
+    assert "down_blocks.3.downsamplers.0.conv.weight" not in shapes and "up_blocks.3.upsamplers.0.conv.weight" not in shapes
+
+
+def test_arch_rejects_configs_off_the_storygen_path():
+    from storygen_amd.arch import SD15_CONFIG, build_arch
+    for bad in (dict(use_linear_projection=True), dict(class_embed_type="timestep"), dict(time_embedding_type="fourier"),
+                dict(down_block_types=("AttnDownBlock2D",) * 4), dict(mid_block_type="UNetMidBlock2DSimpleCrossAttn")):
+        with pytest.raises(ValueError):
+            build_arch(dict(SD15_CONFIG, **bad))
+
+
+def test_synthetic_tensors_are_order_and_device_independent():
+    from storygen_amd.arch import build_arch
+    from storygen_amd.synth import synthetic_inputs, synthetic_state_dict
+    cfg = dict(block_out_channels=(32, 64), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+               up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), cross_attention_dim=48)
+    a = synthetic_state_dict(build_arch(cfg), 3)
+    b = synthetic_state_dict(build_arch(cfg), 3)
+    assert all(torch.equal(a[k], b[k]) for k in a)
+    assert all(torch.equal(v, v.half().float()) for v in a.values())          # fp16-exact by construction
+    i1, i2 = synthetic_inputs(1, 2, 8, 8, 5, 48), synthetic_inputs(1, 2, 8, 8, 5, 48)
+    assert all(torch.equal(i1[k], i2[k]) for k in i1)
+    assert not torch.equal(synthetic_inputs(1, 2, 8, 8, 6, 48)["latents"], i1["latents"])
+
+
+# ------------------------------------------------------------------------------------------------ repacks
+def test_conv_repacks_are_the_same_linear_map():
+    from storygen_amd.repack import conv1x1_nk, conv3x3_krsc, conv_in_kn
+    w = torch.randn(16, 8, 3, 3)
+    x = torch.randn(2, 8, 6, 6)
+    want = F.conv2d(x, w, padding=1)
+    cols = F.unfold(x, 3, padding=1).view(2, 8, 9, 36).permute(0, 3, 2, 1).reshape(2, 36, 72)   # k = tap*Cin + ci
+    got = (cols @ conv3x3_krsc(w).reshape(16, 72).t()).permute(0, 2, 1).reshape(2, 16, 6, 6)
+    assert torch.allclose(got, want, atol=1e-4)
+    got_in = (cols @ conv_in_kn(w)).permute(0, 2, 1).reshape(2, 16, 6, 6)
+    assert torch.allclose(got_in, want, atol=1e-4)
+    w1 = torch.randn(16, 8, 1, 1)
+    assert torch.allclose(F.conv2d(x, w1), torch.einsum("bchw,oc->bohw", x, conv1x1_nk(w1)), atol=1e-5)
+
+
+def test_geglu_interleave_roundtrip():
+    from storygen_amd.repack import interleave_geglu
+    inner, k = 128, 16
+    w, b = torch.randn(2 * inner, k), torch.randn(2 * inner)
+    wi, bi = interleave_geglu(w, b)
+    x = torch.randn(5, k)
+    val, gate = (x @ w.t() + b).chunk(2, dim=-1)                 # attention.py:391-392
+    want = val * F.gelu(gate)
+    y = x @ wi.t() + bi
+    y = y.view(5, inner // 32, 2, 32)                            # [64u, 64u+32) value | [64u+32, 64u+64) gate
+    got = (y[:, :, 0] * F.gelu(y[:, :, 1])).reshape(5, inner)
+    assert torch.allclose(got, want, atol=1e-5)
+
+
+# ------------------------------------------------------------------------------------------------ data parallel
+def test_shard_for_rank_partitions_the_samples():
+    from storygen_amd.sampler import shard_for_rank
+    for n, world in ((8, 8), (8, 4), (10, 4), (3, 8), (1, 1)):
+        parts = [list(shard_for_rank(n, r, world)) for r in range(world)]
+        assert sorted(sum(parts, [])) == list(range(n))
+        assert max(len(p) for p in parts) - min(len(p) for p in parts) <= 1
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _dp_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from storygen_amd.sampler import gather_latents, shard_for_rank
+    mine = shard_for_rank(4, rank, world)
+    # each rank "denoises" its own samples: the payload encodes the global sample index
+    lat = torch.stack([torch.full((4, 8, 8), float(i)) for i in mine])
+    allv = gather_latents(lat)
+    torch.save(allv, os.path.join(out_dir, f"r{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_final_allgather_world2_gloo(tmp_path):
+    """The one collective of the DP path: every rank ends with all latents in global sample order."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "r0.pt"), torch.load(tmp_path / "r1.pt")
+    assert torch.equal(a, b) and a.shape == (4, 4, 8, 8)
+    assert [float(a[i, 0, 0, 0]) for i in range(4)] == [0.0, 1.0, 2.0, 3.0]
+
+
+def test_gather_is_identity_without_process_group():
+    from storygen_amd.sampler import gather_latents
+    x = torch.randn(1, 4, 8, 8)
+    assert gather_latents(x) is x

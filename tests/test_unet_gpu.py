@@ -146,7 +146,9 @@ def test_graph_replay_matches_eager(gpu, sd15):
 
 
 def test_loop_vs_oracle_both_stages_16x16(gpu, sd15):
-    """The whole loop (R=2, 3 steps) in both stages against the oracle loop at 16x16."""
+    """The whole loop (R=2, first 3 steps of the 50-step schedule BASELINE config 2 uses — the 1e-3 latent bar is
+    stated for that schedule: a coarser one multiplies the same epsilon error by a larger DDIM coefficient) in both
+    stages against the oracle loop at 16x16."""
     from oracle import storygen_oracle as O
     from storygen_amd.sampler import StoryGenSampler
     from storygen_amd.synth import synthetic_inputs
@@ -155,8 +157,8 @@ def test_loop_vs_oracle_both_stages_16x16(gpu, sd15):
     smp = StoryGenSampler(arch, sd, gpu, 1, 16, 16, 2, use_graph=True)
     for stage in ("multi-image-condition", "auto-regressive"):
         want = []
-        O.sample_loop(sd, arch.config, inputs, 5, stage, 7.5, 3.5, max_steps=3, trace=want)
-        smp.prepare(inputs, 5, stage, 7.5, 3.5)
+        O.sample_loop(sd, arch.config, inputs, 50, stage, 7.5, 3.5, max_steps=3, trace=want)
+        smp.prepare(inputs, 50, stage, 7.5, 3.5)
         got = []
         smp.run(max_steps=3, trace=got)
         torch.cuda.synchronize()
