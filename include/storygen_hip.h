@@ -209,15 +209,16 @@ int sg_linear_rows_f32(const float* x, int64_t ldx, const sg_half* W, int64_t ld
 /* ------------------------------------------------------------------------------------------------------------
  * Sampling-loop elementwise steps (model/pipeline.py:412-461), all fp32 NCHW [*,C,H,W] with `n` = elements per
  * sample.  Per-step scalars live in DEVICE memory (`coef`) so a captured hipGraph can be replayed for every step.
- * sg_ref_inputs_f32 (:419-429): out[3N] = cat(add_noise(zero), add_noise(img), add_noise(img)),
- *     add_noise(x) = coef[0]*x + coef[1]*noise            (coef = {sqrt(abar_t), sqrt(1-abar_t)})
+ * sg_add_noise_f32 (scheduler.add_noise, :419-427): out[u] = coef[2u]*src[u] + coef[2u+1]*noise[u % N] for the U
+ *     stacked reference-pass inputs (zero-image and prior-frame latents; `noise` holds the N shared noise samples,
+ *     :409), coef[2u..2u+1] = {sqrt(abar_t_u), sqrt(1-abar_t_u)} — each sample may sit at its own timestep.
  * sg_cfg_ddim_step_f32 (:457-461): eps = e_u + coef[0](e_i - e_u) + coef[1](e_a - e_i)   (eps3 = [e_u|e_i|e_a])
  *     x0 = (x - coef[3]*eps)/coef[2];  x <- coef[4]*x0 + coef[5]*eps
  *     (coef = {s_img, s_txt, sqrt(abar_t), sqrt(1-abar_t), sqrt(abar_prev), sqrt(1-abar_prev)}); updates
  *     `latents` in place and also writes the three-fold replicated UNet input `latents3` if non-NULL.
  */
-int sg_ref_inputs_f32(const float* zero, const float* img, const float* noise, const float* coef, float* out3,
-                      int32_t N, int64_t n, sg_stream_t stream);
+int sg_add_noise_f32(const float* src, const float* noise, const float* coef, float* out, int32_t U, int32_t N,
+                     int64_t n, sg_stream_t stream);
 int sg_cfg_ddim_step_f32(const float* eps3, float* latents, float* latents3, const float* coef, int32_t N,
                          int64_t n, sg_stream_t stream);
 

@@ -159,15 +159,15 @@ __global__ __launch_bounds__(256) void conv_out_kernel(const f16* x, long ldx, c
 }
 
 // ------------------------------------------------------------------------------------------------ sampling-loop steps
-__global__ void ref_inputs_kernel(const float* zero, const float* img, const float* noise, const float* coef, float* out,
-                                  int N, long n) {
-    const long total = (long)N * n;
-    const float a = coef[0], s = coef[1];
-    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const float nz = s * noise[i];
-        const float vz = a * zero[i] + nz, vi = a * img[i] + nz;
-        out[i] = vz; out[total + i] = vi; out[2 * total + i] = vi;
-    }
+// out[u] = coef[2u] * src[u] + coef[2u+1] * noise[u % N]   (blockIdx.y = u)
+__global__ void add_noise_kernel(const float* src, const float* noise, const float* coef, float* out, int N, long n) {
+    const int u = blockIdx.y;
+    const float a = coef[2 * u], s = coef[2 * u + 1];
+    const float* x = src + (long)u * n;
+    const float* z = noise + (long)(u % N) * n;
+    float* o = out + (long)u * n;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        o[i] = a * x[i] + s * z[i];
 }
 
 __global__ void cfg_ddim_kernel(const float* eps3, float* lat, float* lat3, const float* coef, int N, long n) {
@@ -283,13 +283,13 @@ extern "C" int sg_conv_out_f16(const sg_half* x, int64_t ldx, const sg_half* w, 
     return SG_OK;
 }
 
-extern "C" int sg_ref_inputs_f32(const float* zero, const float* img, const float* noise, const float* coef, float* out3,
-                                 int32_t N, int64_t n, sg_stream_t stream) {
-    SG_REQUIRE(zero && img && noise && coef && out3 && N > 0 && n > 0, "sg_ref_inputs: bad arguments");
-    const long total = (long)N * n;
-    hipLaunchKernelGGL(ref_inputs_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
-                       zero, img, noise, coef, out3, N, (long)n);
-    SG_CHECK_LAUNCH("sg_ref_inputs_f32");
+extern "C" int sg_add_noise_f32(const float* src, const float* noise, const float* coef, float* out, int32_t U, int32_t N,
+                                int64_t n, sg_stream_t stream) {
+    SG_REQUIRE(src && noise && coef && out && U > 0 && N > 0 && n > 0, "sg_add_noise: bad arguments");
+    SG_REQUIRE(U <= 65535, "sg_add_noise: at most 65535 samples");
+    hipLaunchKernelGGL(add_noise_kernel, dim3((int)min((long)256, (n + 255) / 256), U), dim3(256), 0, (hipStream_t)stream, src,
+                       noise, coef, out, N, (long)n);
+    SG_CHECK_LAUNCH("sg_add_noise_f32");
     return SG_OK;
 }
 

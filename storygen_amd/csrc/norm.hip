@@ -5,14 +5,14 @@
 namespace {
 
 constexpr int GN_MAX_GROUPS = 64;
-constexpr int GN_MAX_CHUNKS = 64;
+constexpr int GN_MAX_CHUNKS = 256;
 
 struct GnParams {
     const void* x; long ldx; int x_f32;
     f16* y; long ldy; int pad_w;          // pad_w > 0: y is [B, H+2, pad_w+2, ldy] and only its interior is written
     f16* xcopy; long ldxc;                // optional raw fp16 copy of x (MFMA operand for the 1x1 shortcut)
     const f16* gamma; const f16* beta;
-    int HW, C, G, cpg, nchunks, rows_per_chunk;
+    int HW, C, G, cpg, nchunks, rows_per_chunk, apply_rows;   // apply_rows: pixel rows per workgroup of pass 2
     float eps; int silu;
     float* ws;   // [B][nchunks][G][2] shifted partial sums
 };
@@ -44,7 +44,20 @@ __global__ __launch_bounds__(256) void gn_stats_kernel(const GnParams p) {
         if (active) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) piv[j] = load1f(p.x, xb + ((cv * 8 + j) / p.cpg) * p.cpg, f32);
-            for (int px = p0 + my_row; px < p1; px += rpp) {
+            int px = p0 + my_row;
+            for (; px + 3 * rpp < p1; px += 4 * rpp) {      // 4 independent row loads in flight per thread
+                float v[4][8];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) load8f(p.x, xb + (long)(px + u * rpp) * p.ldx + cv * 8, f32, v[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float d = v[u][j] - piv[j];
+                        s[j] += d; q[j] += d * d;
+                    }
+            }
+            for (; px < p1; px += rpp) {
                 float v[8];
                 load8f(p.x, xb + (long)px * p.ldx + cv * 8, f32, v);
 #pragma unroll
@@ -89,25 +102,35 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
     // padded output: pixel (yy, xx) of image b lives at row ((b*(H+2) + yy+1)*(pw+2) + xx+1)
     f16* yb = pw ? p.y + ((long)b * (p.HW / pw + 2) * (pw + 2)) * p.ldy : p.y + (long)b * p.HW * p.ldy;
     f16* cb = p.xcopy ? p.xcopy + (long)b * p.HW * p.ldxc : nullptr;
-    if (t < p.G) {
+    {   // reduce the chunk partials: thread (part, group) sums every `parts`-th chunk, then a fixed-order LDS tree
+        __shared__ float s_ps[256], s_pq[256];
+        const int parts = 256 / p.G;                 // G <= 64 -> parts >= 4
+        const int grp = t % p.G, part = t / p.G;
         float s = 0.f, q = 0.f;
-        for (int c = 0; c < p.nchunks; ++c) {
-            const float* w = p.ws + (((long)b * p.nchunks + c) * p.G + t) * 2;
-            s += w[0]; q += w[1];
+        if (part < parts)
+            for (int c = part; c < p.nchunks; c += parts) {
+                const float* w = p.ws + (((long)b * p.nchunks + c) * p.G + grp) * 2;
+                s += w[0]; q += w[1];
+            }
+        s_ps[t] = s; s_pq[t] = q;
+        __syncthreads();
+        if (t < p.G) {
+            s = 0.f; q = 0.f;
+            for (int k = 0; k < parts; ++k) { s += s_ps[k * p.G + t]; q += s_pq[k * p.G + t]; }
+            const float n = (float)p.HW * (float)p.cpg;
+            const float piv = load1f(p.x, xb + t * p.cpg, f32);
+            const float md = s / n;                       // E[x - K]
+            const float var = fmaxf(q / n - md * md, 0.f);
+            s_mean[t] = piv + md;
+            s_rstd[t] = rsqrtf(var + p.eps);
         }
-        const float n = (float)p.HW * (float)p.cpg;
-        const float piv = load1f(p.x, xb + t * p.cpg, f32);
-        const float md = s / n;                       // E[x - K]
-        const float var = fmaxf(q / n - md * md, 0.f);
-        s_mean[t] = piv + md;
-        s_rstd[t] = rsqrtf(var + p.eps);
     }
     __syncthreads();
     const int vpr = p.C / 8;
     const int tw = vpr < 256 ? vpr : 256, rpp = 256 / tw;
     const int my_row = t / tw, my_col = t - my_row * tw;
     if (my_row >= rpp) return;
-    const int p0 = chunk * p.rows_per_chunk, p1 = min(p.HW, p0 + p.rows_per_chunk);
+    const int p0 = chunk * p.apply_rows, p1 = min(p.HW, p0 + p.apply_rows);
     for (int cv = my_col; cv < vpr; cv += tw) {
         float sc[8], sh[8];
         H8 g, be; g.u = ldg16(p.gamma + cv * 8); be.u = ldg16(p.beta + cv * 8);
@@ -117,9 +140,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
             sc[j] = s_rstd[grp] * (float)g.h[j];
             sh[j] = (float)be.h[j] - s_mean[grp] * sc[j];
         }
-        for (int px = p0 + my_row; px < p1; px += rpp) {
-            float v[8], o[8];
-            load8f(p.x, xb + (long)px * p.ldx + cv * 8, f32, v);
+        auto emit = [&](int px, const float (&v)[8]) {
+            float o[8];
             if (cb) store8h(cb + (long)px * p.ldxc + cv * 8, v);
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
@@ -129,6 +151,19 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
             long orow = px;
             if (pw) { const int yy = px / pw, xx = px - yy * pw; orow = (long)(yy + 1) * (pw + 2) + xx + 1; }
             store8h(yb + orow * p.ldy + cv * 8, o);
+        };
+        int px = p0 + my_row;
+        for (; px + rpp < p1; px += 2 * rpp) {            // 2 independent rows in flight per thread
+            float v0[8], v1[8];
+            load8f(p.x, xb + (long)px * p.ldx + cv * 8, f32, v0);
+            load8f(p.x, xb + (long)(px + rpp) * p.ldx + cv * 8, f32, v1);
+            emit(px, v0);
+            emit(px + rpp, v1);
+        }
+        if (px < p1) {
+            float v[8];
+            load8f(p.x, xb + (long)px * p.ldx + cv * 8, f32, v);
+            emit(px, v);
         }
     }
 }
@@ -187,16 +222,23 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
     }
 }
 
-void gn_geometry(int B, int HW, int C, int* nchunks, int* rows_per_chunk) {
+// Both passes are pure streaming: they need ~8 workgroups per CU (2048 on the chip) to keep HBM busy.
+void gn_geometry(int B, int HW, int C, int* nchunks, int* rows_per_chunk, int* apply_blocks, int* apply_rows) {
     const int vpr = C / 8, tw = vpr < 256 ? vpr : 256, rpp = 256 / tw;
-    // aim for ~512 workgroups in flight, at least 4 passes of rows per workgroup
-    int want = sg_cdiv(512, B);
-    int max_chunks = sg_cdiv(HW, rpp * 4);
-    int n = want < max_chunks ? want : max_chunks;
-    if (n < 1) n = 1;
+    const int want = sg_cdiv(2048, B);
+    // pass 1: at least 4 passes of rows per workgroup (amortises the in-block reduction), at most GN_MAX_CHUNKS partials
+    int n = sg_cdiv(HW, rpp * 4);
+    if (n > want) n = want;
     if (n > GN_MAX_CHUNKS) n = GN_MAX_CHUNKS;
+    if (n < 1) n = 1;
     *rows_per_chunk = sg_cdiv(HW, n);
     *nchunks = sg_cdiv(HW, *rows_per_chunk);
+    // pass 2: at least 2 passes of rows per workgroup
+    int a = sg_cdiv(HW, rpp * 2);
+    if (a > want) a = want;
+    if (a < 1) a = 1;
+    *apply_rows = sg_cdiv(HW, a);
+    *apply_blocks = sg_cdiv(HW, *apply_rows);
 }
 
 }  // namespace
@@ -225,12 +267,13 @@ extern "C" int sg_groupnorm_nhwc_f16(const sg_groupnorm_desc* d, sg_stream_t str
     p.gamma = reinterpret_cast<const f16*>(d->gamma); p.beta = reinterpret_cast<const f16*>(d->beta);
     p.HW = d->HW; p.C = d->C; p.G = d->groups; p.cpg = d->C / d->groups; p.eps = d->eps; p.silu = d->silu;
     p.ws = reinterpret_cast<float*>(d->workspace);
-    gn_geometry(d->B, d->HW, d->C, &p.nchunks, &p.rows_per_chunk);
+    int apply_blocks = 1;
+    gn_geometry(d->B, d->HW, d->C, &p.nchunks, &p.rows_per_chunk, &apply_blocks, &p.apply_rows);
     dim3 grid(p.nchunks, d->B), block(256);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, st, p);
     SG_CHECK_LAUNCH("gn_stats");
-    hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, p);
+    hipLaunchKernelGGL(gn_apply_kernel, dim3(apply_blocks, d->B), block, 0, st, p);
     SG_CHECK_LAUNCH("gn_apply");
     return SG_OK;
 }

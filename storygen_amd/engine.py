@@ -40,25 +40,14 @@ class _Xf:
                  "w_o2", "b_o2", "w_q3", "w_kv3", "w_o3", "b_o3", "w_ff1", "b_ff1", "w_ff2", "b_ff2")
 
 
-class UNetEngine:
-    def __init__(self, arch: UNetArch, state_dict: Dict[str, torch.Tensor], device, batch: int, height: int,
-                 width: int, n_ref: int = 0, seq_len: int = 77, splitk_workspace_mb: int = 96):
-        """batch = samples per UNet call (3N with classifier-free guidance); n_ref = R prior frames (sizes the
-        context buffers; 0 = harvest-only engine)."""
-        self.arch, self.dev = arch, torch.device(device)
-        self.B, self.H, self.W, self.R, self.S = batch, height, width, n_ref, seq_len
-        cfg = arch.config
-        self.cfg = cfg
-        nlev = len(cfg["block_out_channels"])
-        if height % (1 << (nlev - 1)) or width % (1 << (nlev - 1)):
-            raise ValueError(f"latent size {height}x{width} must be divisible by {1 << (nlev - 1)}")
-        self.groups, self.eps = cfg["norm_num_groups"], cfg["norm_eps"]
-        self.cad = cfg["cross_attention_dim"]
-        self.hw = [(height >> l) * (width >> l) for l in range(nlev)]
-        self._load_weights(state_dict)
-        self._alloc(splitk_workspace_mb)
+class EngineWeights:
+    """The checkpoint repacked once into the layouts the kernels consume (fp16, on the device).  Shared by every
+    UNetEngine built on it (the reference-pass engine and the main-pass engine of the sampler use one copy)."""
 
-    # ------------------------------------------------------------------------------------------ weights
+    def __init__(self, arch: UNetArch, state_dict: Dict[str, torch.Tensor], device):
+        self.arch, self.dev, self.cfg = arch, torch.device(device), arch.config
+        self._load_weights(state_dict)
+
     def _w(self, sd, key) -> torch.Tensor:
         return sd[key].detach().to(device=self.dev, dtype=F16).contiguous()
 
@@ -129,6 +118,55 @@ class UNetEngine:
         self.w_conv_out = conv3x3_krsc(g("conv_out.weight"))
         self.b_conv_out = g("conv_out.bias")
 
+
+class HarvestPlan:
+    """Where a reference pass puts the features it harvests (attention.py:263).
+
+    `ctx` are the context buffers of the engine that will consume them ([rows, R*HW, C] fp16 per feature key) and each
+    op (src, src_step, dst_row, dst_slot, count) means: for j < count, slot dst_slot+j of ctx row dst_row <- the
+    feature of sample src + j*src_step of this pass.  One strided copy per op (src_step = 0 broadcasts one sample
+    into `count` frame slots)."""
+
+    def __init__(self, ctx: Dict[str, torch.Tensor], ops_: List[tuple]):
+        self.ctx, self.ops = ctx, list(ops_)
+
+
+class UNetEngine:
+    def __init__(self, arch: UNetArch, state_dict: Optional[Dict[str, torch.Tensor]], device, batch: int, height: int,
+                 width: int, n_ref: int = 0, seq_len: int = 77, splitk_workspace_mb: int = 96,
+                 weights: Optional[EngineWeights] = None, ctx_rows: Optional[int] = None,
+                 attn3_groups: Optional[List[tuple]] = None):
+        """batch = samples per UNet call; n_ref = R prior frames (sizes the context buffers; 0 = an engine that only
+        harvests, into another engine's buffers).  ctx_rows = number of distinct context rows (default: one per
+        sample); attn3_groups = [(q0, n, c0), ...]: samples [q0, q0+n) cross-attend to context rows [c0, c0+n) — lets
+        samples whose prior-frame features are identical (the two image-conditioned CFG branches) share
+        one copy of the context and of its K/V projection."""
+        self.arch, self.dev = arch, torch.device(device)
+        self.B, self.H, self.W, self.R, self.S = batch, height, width, n_ref, seq_len
+        cfg = arch.config
+        self.cfg = cfg
+        nlev = len(cfg["block_out_channels"])
+        if height % (1 << (nlev - 1)) or width % (1 << (nlev - 1)):
+            raise ValueError(f"latent size {height}x{width} must be divisible by {1 << (nlev - 1)}")
+        self.groups, self.eps = cfg["norm_num_groups"], cfg["norm_eps"]
+        self.cad = cfg["cross_attention_dim"]
+        self.hw = [(height >> l) * (width >> l) for l in range(nlev)]
+        self.ctx_rows = batch if ctx_rows is None else ctx_rows
+        self.attn3_groups = [(0, batch, 0)] if attn3_groups is None else list(attn3_groups)
+        covered = sorted(q for q0, n, _ in self.attn3_groups for q in range(q0, q0 + n))
+        if n_ref and (covered != list(range(batch)) or any(c0 + n > self.ctx_rows for _, n, c0 in self.attn3_groups)):
+            raise ValueError(f"attn3_groups {self.attn3_groups} must cover samples 0..{batch - 1} once, within {self.ctx_rows} context rows")
+        self.wts = weights if weights is not None else EngineWeights(arch, state_dict, device)
+        self.text_cache: Dict[str, torch.Tensor] = {}
+        self._alloc(splitk_workspace_mb)
+
+    def __getattr__(self, name):
+        # repacked weights live in the shared EngineWeights object
+        wts = self.__dict__.get("wts")
+        if wts is not None and hasattr(wts, name):
+            return getattr(wts, name)
+        raise AttributeError(name)
+
     # ------------------------------------------------------------------------------------------ buffers
     def _buf(self, *shape, dtype=F16) -> torch.Tensor:
         return torch.empty(*shape, dtype=dtype, device=self.dev)
@@ -188,7 +226,7 @@ class UNetEngine:
                 gn=self._buf(M, C), x16=self._buf(M * Cw), c1=self._buf(M, C), h4=self._buf(M, C),
                 ln=self._buf(M, C), ln4=self._buf(M, C), qkv=self._buf(M, 3 * C), q=self._buf(M, C), att=self._buf(M, C),
                 ffi=self._buf(M, 4 * C), kvt=self._buf(B * self.S, 2 * C),
-                kvi=self._buf(B * self.R * self.hw[l], 2 * C) if self.R else None,
+                kvi=self._buf(self.ctx_rows * self.R * self.hw[l], 2 * C) if self.R else None,
             )
             self.lv.append(d)
         # skip tensors (down_block_res_samples) persist until the up path pops them
@@ -201,11 +239,11 @@ class UNetEngine:
                 lvl += 1
                 self.skip_meta.append((lvl, blk.channels))
         self.skips: List[torch.Tensor] = [self._buf(B * self.hw[l], c, dtype=F32) for l, c in self.skip_meta]
-        # context buffers: [B, R*HW, C] fp16 per feature key (K/V projection operands of attn3)
+        # context buffers: [ctx_rows, R*HW, C] fp16 per feature key (K/V projection operands of attn3)
         self.ctx: Dict[str, torch.Tensor] = {}
         if self.R:
             for k, (n, c) in feature_shapes(arch, self.H, self.W).items():
-                self.ctx[k] = self._buf(B, self.R * n, c)
+                self.ctx[k] = self._buf(self.ctx_rows, self.R * n, c)
 
     # ------------------------------------------------------------------------------------------ layers
     def _img(self, x2d: torch.Tensor, lvl: int) -> torch.Tensor:
@@ -232,8 +270,30 @@ class UNetEngine:
             res = x
         ops.conv3x3(p_mid, rn.w2, self._img(out, lvl), bias=rn.b2, res1=self._img(res, lvl), workspace=ws, x_padded=True)
 
-    def _transformer(self, xf: _Xf, x: torch.Tensor, out: torch.Tensor, lvl: int, text: torch.Tensor,
-                     harvest_slot: Optional[int], consume: bool):
+    def _text_kv(self, xf: _Xf, lvl: int, text: torch.Tensor, use_cache: bool) -> torch.Tensor:
+        """K/V projection of the text embeddings for attn2 (attention.py:192-199): timestep-invariant, so the sampler
+        computes it once per prompt (cache_text_kv) instead of once per UNet call."""
+        if use_cache:
+            return self.text_cache[xf.spec.prefix]
+        kvt = self.lv[lvl]["kvt"]
+        ops.gemm(text.view(self.B * self.S, -1), xf.w_kv2, kvt, workspace=self.ws_split)
+        return kvt
+
+    def cache_text_kv(self):
+        """Run every attn2 K/V projection on the current self.text_in and keep the results (use with
+        forward(text_cache=True) while the prompts do not change)."""
+        for blk in self.arch.down + [self.arch.mid] + self.arch.up:
+            for a in blk.attns:
+                if a is None:
+                    continue
+                xf = self.xfs[a.prefix]
+                buf = self.text_cache.get(a.prefix)
+                if buf is None:
+                    buf = self.text_cache[a.prefix] = self._buf(self.B * self.S, 2 * a.channels)
+                ops.gemm(self.text_in.view(self.B * self.S, -1), xf.w_kv2, buf, workspace=self.ws_split)
+
+    def _transformer(self, xf: _Xf, x: torch.Tensor, out: Optional[torch.Tensor], lvl: int, text: torch.Tensor,
+                     harvest: Optional[HarvestPlan], consume: bool, text_cache: bool = False, stop_after_harvest: bool = False):
         """Transformer2DModel.forward (attention.py:85-128) + BasicTransformerBlock.forward (:236-302).
         x, out, h0..h3 fp32; everything that feeds an MFMA fp16."""
         L, B, hw, S = self.lv[lvl], self.B, self.hw[lvl], self.S
@@ -252,32 +312,35 @@ class UNetEngine:
         att = L["att"]
         ops.attention(q3d[:, :, :C], q3d[:, :, C:2 * C], q3d[:, :, 2 * C:], att.view(B, hw, C), heads, scale)
         h1 = L["h1"]
-        if harvest_slot is not None:                                                     # feature :263, written in place
-            dst = self.ctx[xf.spec.feature_key][:, harvest_slot * hw:(harvest_slot + 1) * hw, :]
-            ops.gemm(att, xf.w_o1, h1, bias=xf.b_o1, res1=h0, workspace=ws)
-            ops.copy_rows(dst, h1.view(B, hw, C))
-        else:
-            ops.gemm(att, xf.w_o1, h1, bias=xf.b_o1, res1=h0, workspace=ws)
+        ops.gemm(att, xf.w_o1, h1, bias=xf.b_o1, res1=h0, workspace=ws)
+        if harvest is not None:                                                           # feature :263, written in place
+            ctx = harvest.ctx[xf.spec.feature_key]
+            h1b = h1.view(B, hw, C)
+            for src, step, row, slot, cnt in harvest.ops:
+                dst = ctx[row, slot * hw:(slot + cnt) * hw, :].view(cnt, hw, C)
+                ops.copy_rows(dst, h1b[src:].as_strided((cnt, hw, C), (step * hw * C, C, 1)))
+            if stop_after_harvest:
+                return
         # --- text cross-attention :266-277 (norm2) and image cross-attention :281-291 (norm4) share statistics
         if consume:
             ops.layernorm(h1, *xf.ln["norm2"], L["ln"], 1e-5, *xf.ln["norm4"], L["ln4"])
         else:
             ops.layernorm(h1, *xf.ln["norm2"], L["ln"])
         ops.gemm(L["ln"], xf.w_q2, L["q"], workspace=ws)
-        kvt = L["kvt"]
-        ops.gemm(text.view(B * S, -1), xf.w_kv2, kvt, workspace=ws)
-        kv3d = kvt.view(B, S, 2 * C)
+        kv3d = self._text_kv(xf, lvl, text, text_cache).view(B, S, 2 * C)
         ops.attention(L["q"].view(B, hw, C), kv3d[:, :, :C], kv3d[:, :, C:], att.view(B, hw, C), heads, scale)
         if consume:
             ht = L["h2"]
             ops.gemm(att, xf.w_o2, ht, bias=xf.b_o2, res1=h1, workspace=ws)               # h_t = a2 + h   :277
             ctx = self.ctx[xf.spec.feature_key]
-            nk = ctx.shape[1]
+            rows, nk = ctx.shape[0], ctx.shape[1]
             ops.gemm(L["ln4"], xf.w_q3, L["q"], workspace=ws)
             kvi = L["kvi"]
-            ops.gemm(ctx.view(B * nk, C), xf.w_kv3, kvi, workspace=ws)
-            kvi3 = kvi.view(B, nk, 2 * C)
-            ops.attention(L["q"].view(B, hw, C), kvi3[:, :, :C], kvi3[:, :, C:], att.view(B, hw, C), heads, scale)
+            ops.gemm(ctx.view(rows * nk, C), xf.w_kv3, kvi, workspace=ws)
+            kvi3 = kvi.view(rows, nk, 2 * C)
+            q3, a3 = L["q"].view(B, hw, C), att.view(B, hw, C)
+            for q0, n, c0 in self.attn3_groups:
+                ops.attention(q3[q0:q0 + n], kvi3[c0:c0 + n, :, :C], kvi3[c0:c0 + n, :, C:], a3[q0:q0 + n], heads, scale)
             h3 = L["h3"]
             ops.gemm(att, xf.w_o3, h3, bias=xf.b_o3, res1=h1, res2=ht, workspace=ws)      # (a3 + h) + h_t :291-293
         else:
@@ -303,16 +366,32 @@ class UNetEngine:
         M = self.B * self.hw[lvl]
         return self.lv[lvl]["cat"][which][: M * width].view(M, width)
 
-    def forward(self, harvest_slot: Optional[int] = None, consume: bool = False) -> torch.Tensor:
+    def forward(self, harvest_slot: Optional[int] = None, consume: bool = False, harvest: Optional[HarvestPlan] = None,
+                harvest_only: bool = False, text_cache: bool = False) -> Optional[torch.Tensor]:
         """One UNet call on the static inputs (self.x_in fp32 NCHW, self.t_in fp32 [B], self.text_in fp16).
 
-        harvest_slot=r : reference pass — no image context, features written to slot r of self.ctx.
+        harvest_slot=r : reference pass — no image context; sample b's features go to slot r of row b of self.ctx.
+        harvest=plan   : reference pass writing into another engine's context buffers (HarvestPlan).
+        harvest_only   : stop right after the last feature is harvested (the rest of the pass — text attention and FF
+                         of the last block, conv_out — only produces an epsilon the loop discards, pipeline.py:433-435);
+                         returns None.
         consume=True   : main pass — attn3 cross-attends to self.ctx.
+        text_cache     : use the attn2 K/V projections stored by cache_text_kv().
         Returns self.eps_out (fp32 NCHW)."""
-        if harvest_slot is not None and consume:
+        if harvest_slot is not None:
+            if harvest is not None or self.ctx_rows != self.B:
+                raise ValueError("harvest_slot needs one context row per sample and no explicit plan")
+            if not self.R:
+                raise ValueError("engine was built without context buffers (n_ref=0)")
+            harvest = HarvestPlan(self.ctx, [(b, 0, b, harvest_slot, 1) for b in range(self.B)])
+        if harvest is not None and consume:
             raise ValueError("a pass either harvests features or consumes them")
-        if (harvest_slot is not None or consume) and not self.R:
+        if consume and not self.R:
             raise ValueError("engine was built without context buffers (n_ref=0)")
+        if harvest_only and harvest is None:
+            raise ValueError("harvest_only needs a harvest plan")
+        last_xf = [a for blk in self.arch.up for a in blk.attns if a is not None][-1].prefix if harvest_only else None
+        tk = dict(text_cache=text_cache)
         arch, text, skips = self.arch, self.text_in, self.skips
         # --- time embedding :392-398, then all 22 time_emb_proj(silu(emb)) in one GEMV bundle
         ops.timestep_embed(self.t_in, self.freqs, self.temb0, self.cfg["flip_sin_to_cos"])
@@ -331,7 +410,7 @@ class UNetEngine:
                 else:
                     rt = self.lv[lvl]["r"]
                     self._resnet(self.resnets[r.prefix], h, rt, lvl)
-                    self._transformer(self.xfs[xf.prefix], rt, out, lvl, text, harvest_slot, consume)
+                    self._transformer(self.xfs[xf.prefix], rt, out, lvl, text, harvest, consume, **tk)
                 h, si = out, si + 1
             if blk.sampler_prefix:
                 out = skips[si]
@@ -342,7 +421,7 @@ class UNetEngine:
         L = self.lv[lvl]
         m0, m1 = arch.mid.resnets
         self._resnet(self.resnets[m0.prefix], h, L["r"], lvl)
-        self._transformer(self.xfs[arch.mid.attns[0].prefix], L["r"], L["t_out"], lvl, text, harvest_slot, consume)
+        self._transformer(self.xfs[arch.mid.attns[0].prefix], L["r"], L["t_out"], lvl, text, harvest, consume, **tk)
         blk0 = arch.up[0]
         pp = 0
         cat = self._cat_view(lvl, pp, blk0.resnets[0].cin)
@@ -366,7 +445,10 @@ class UNetEngine:
                     self._resnet(self.resnets[r.prefix], cat, out, lvl)
                 else:
                     self._resnet(self.resnets[r.prefix], cat, L["r"], lvl)
-                    self._transformer(self.xfs[xf.prefix], L["r"], out, lvl, text, harvest_slot, consume)
+                    if xf.prefix == last_xf:
+                        self._transformer(self.xfs[xf.prefix], L["r"], None, lvl, text, harvest, consume, stop_after_harvest=True)
+                        return None
+                    self._transformer(self.xfs[xf.prefix], L["r"], out, lvl, text, harvest, consume, **tk)
                 if nxt is not None:
                     cat, pp = nxt, pp ^ 1
                 h = out

@@ -292,14 +292,18 @@ def linear_rows(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], 
     return out
 
 
-def ref_inputs(zero: torch.Tensor, img: torch.Tensor, noise: torch.Tensor, coef: torch.Tensor, out3: torch.Tensor
-               ) -> torch.Tensor:
-    for n, t in (("zero", zero), ("img", img), ("noise", noise), ("coef", coef), ("out3", out3)):
+def add_noise(src: torch.Tensor, noise: torch.Tensor, coef: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[u] = coef[u,0]*src[u] + coef[u,1]*noise[u % N]; src/out [U,...], noise [N,...], coef [U,2] (device)."""
+    for n, t in (("src", src), ("noise", noise), ("coef", coef), ("out", out)):
         _f32(t, n)
-    N = zero.shape[0]
-    check(lib.sg_ref_inputs_f32(zero.data_ptr(), img.data_ptr(), noise.data_ptr(), coef.data_ptr(), out3.data_ptr(), N,
-                                zero[0].numel(), _stream()), "sg_ref_inputs_f32")
-    return out3
+        if not t.is_contiguous():
+            raise ValueError(f"add_noise: {n} must be contiguous")
+    U, N = src.shape[0], noise.shape[0]
+    if out.shape != src.shape or src.shape[1:] != noise.shape[1:] or coef.numel() != 2 * U:
+        raise ValueError("add_noise: shape mismatch")
+    check(lib.sg_add_noise_f32(src.data_ptr(), noise.data_ptr(), coef.data_ptr(), out.data_ptr(), U, N, src[0].numel(),
+                               _stream()), "sg_add_noise_f32")
+    return out
 
 
 def cfg_ddim_step(eps3: torch.Tensor, latents: torch.Tensor, latents3: Optional[torch.Tensor], coef: torch.Tensor

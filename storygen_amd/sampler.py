@@ -1,14 +1,24 @@
 """The denoising hot loop of StoryGen on the HIP engine.
 
-One `step()` is exactly one iteration of /root/reference/model/pipeline.py:412-461 with classifier-free guidance:
-R reference UNet passes (batch 3N: [zero, img, img] latents + [uncond, prev_text_i, prev_text_i]) that harvest the 16
-diffusion features per prior frame, one main pass (batch 3N: latents x3 + [uncond, uncond, text]) whose attn3
-cross-attends to them, the 3-way guidance combine (:457-458) and the DDIM update (:461).
+One `step()` is one iteration of /root/reference/model/pipeline.py:412-461 with classifier-free guidance: the
+reference passes that harvest the 16 diffusion features of every prior frame (:418-438), one main pass (batch 3N:
+latents x3 with [uncond, uncond, text]) whose attn3 cross-attends to them (:440-453), the 3-way guidance combine
+(:457-458) and the DDIM update (:461).
 
-MI355X-first structure: the whole step is ONE hipGraph (R+1 UNet passes ~ 4000 kernel nodes) replayed per step;
-everything that changes between steps — the R+1 timestep vectors, the add_noise coefficients and the DDIM
-coefficients — lives in a small device buffer refreshed by one async H2D copy from a pinned per-run table, so
-the host does no per-kernel work at all.  Latents stay fp32 across steps (the UNet consumes them as fp16).
+MI355X-first structure
+  * The R reference passes are ONE batched UNet call.  As written, pass i runs the batch [zero_i, img_i, img_i] with
+    [uncond, text_i, text_i] (:429-430): its 2nd and 3rd samples are the same tensors, and in `multi-image-condition`
+    mode (same timestep for every frame, :425-427) the zero-image sample is the same in every pass.  With `dedup`
+    (default) each distinct sample is computed once — N(1+R) samples per step instead of 3NR (2NR in
+    `auto-regressive` mode, where each frame has its own noise level) — and its features are written to every
+    context slot the loop would have put them in; the two image-conditioned CFG branches of the main pass then share
+    one copy of the context and of its K/V projection.  The result is the same arithmetic on the same values
+    (SURVEY F7); `dedup=False` runs all 3NR samples (still as one batched call).
+  * A reference pass ends at its last harvest point (the epsilon it would go on to produce is discarded by the loop,
+    :433-435), and the text K/V projections, which do not depend on the timestep, are computed once per prompt.
+  * The whole step is ONE hipGraph replayed per step; everything that changes between steps — timesteps, add_noise
+    and DDIM coefficients — lives in a small device buffer refreshed by one async H2D copy from a pinned table.
+    Latents stay fp32 across steps.
 
 Data parallelism: one process per GPU, each running its own samples with no per-step communication;
 `gather_latents` is the single RCCL all-gather of the final [N,4,h,w] latents.
@@ -21,48 +31,106 @@ import torch
 
 from . import ops
 from .arch import UNetArch
-from .engine import UNetEngine
+from .engine import EngineWeights, HarvestPlan, UNetEngine
 from .scheduler import DDIMSchedule
 
 STAGES = ("multi-image-condition", "auto-regressive")
 
 
 class StoryGenSampler:
-    def __init__(self, arch: UNetArch, state_dict: Dict[str, torch.Tensor], device, n_samples: int = 1, height: int = 64,
-                 width: int = 64, n_ref: int = 3, seq_len: int = 77, schedule: Optional[DDIMSchedule] = None,
-                 use_graph: bool = True):
+    def __init__(self, arch: UNetArch, state_dict: Optional[Dict[str, torch.Tensor]], device, n_samples: int = 1,
+                 height: int = 64, width: int = 64, n_ref: int = 3, seq_len: int = 77,
+                 schedule: Optional[DDIMSchedule] = None, use_graph: bool = True, dedup: bool = True,
+                 weights: Optional[EngineWeights] = None):
         if n_ref < 1:
             raise ValueError("StoryGen's loop needs at least one prior frame")
         self.arch, self.dev = arch, torch.device(device)
-        self.N, self.R, self.h, self.w = n_samples, n_ref, height, width
+        self.N, self.R, self.h, self.w, self.S = n_samples, n_ref, height, width, seq_len
         self.B = 3 * n_samples
-        self.engine = UNetEngine(arch, state_dict, device, self.B, height, width, n_ref, seq_len)
+        self.weights = weights if weights is not None else EngineWeights(arch, state_dict, device)
         self.schedule = schedule or DDIMSchedule()
-        self.use_graph = use_graph
+        self.use_graph, self.dedup = use_graph, dedup
         self.graph: Optional[torch.cuda.CUDAGraph] = None
-        e = self.engine
+        self.main: Optional[UNetEngine] = None
+        self.ref: Optional[UNetEngine] = None
+        self.layout = None
         f32 = dict(dtype=torch.float32, device=self.dev)
         lat_shape = (n_samples, arch.config["in_channels"], height, width)
         self.latents = torch.zeros(lat_shape, **f32)
         self.latents3 = torch.zeros((self.B,) + lat_shape[1:], **f32)
-        self.zero = torch.zeros(lat_shape, **f32)
-        self.imgs = torch.zeros((n_ref,) + lat_shape, **f32)
         self.noise = torch.zeros(lat_shape, **f32)
-        self.text_main = torch.zeros(self.B, seq_len, e.cad, dtype=torch.float16, device=self.dev)
-        self.text_ref = torch.zeros(n_ref, self.B, seq_len, e.cad, dtype=torch.float16, device=self.dev)
-        # per-step parameters: [R+1, B] timesteps | [R, 2] add_noise coefs | [6] guidance + DDIM coefs
-        self.n_par = (n_ref + 1) * self.B + 2 * n_ref + 6
-        self.params = torch.zeros(self.n_par, **f32)
         self.table: Optional[torch.Tensor] = None
         self.num_steps = 0
         self.k = 0
 
-    # ------------------------------------------------------------------------------------------------ setup
-    def _par_views(self):
-        R, B = self.R, self.B
-        o = (R + 1) * B
-        return (self.params[:o].view(R + 1, B), self.params[o:o + 2 * R].view(R, 2), self.params[o + 2 * R:])
+    @property
+    def engine(self) -> UNetEngine:   # the main-pass engine
+        return self.main
 
+    # ------------------------------------------------------------------------------------------------ layout
+    def _plan(self, stage: str, share_zero: bool):
+        """Which reference samples are computed and where their features go.
+
+        Returns (kind, frame, sample) per reference-pass sample u, the harvest ops, the number of context rows and
+        the main pass's attn3 groups.  kind 0 = zero-image latent with the uncond embedding, 1 = prior frame `frame`
+        with its prompt.  Main-pass sample order is [uncond/zero-image x N, uncond/frames x N, text/frames x N]
+        (pipeline.py:448-450 with the context rows of :440-443)."""
+        N, R = self.N, self.R
+        units, hops = [], []
+        if self.dedup:
+            rows = 2 * N                      # context rows: [zero-image features x N | frame features x N]
+            groups = [(0, 2 * N, 0), (2 * N, N, N)]
+            if share_zero:
+                for n in range(N):
+                    units.append((0, 0, n))
+                    hops.append((n, 0, n, 0, R))                     # one sample -> all R slots of row n
+            else:
+                for i in range(R):
+                    for n in range(N):
+                        units.append((0, i, n))
+                for n in range(N):
+                    hops.append((n, N, n, 0, R))                     # samples n, n+N, ... -> slots 0..R-1 of row n
+            base = len(units)
+            for i in range(R):
+                for n in range(N):
+                    units.append((1, i, n))
+            for n in range(N):
+                hops.append((base + n, N, N + n, 0, R))
+        else:
+            rows = 3 * N
+            groups = [(0, 3 * N, 0)]
+            for i in range(R):                 # pass i = [zero_i | img_i | img_i], exactly as written
+                for kind in (0, 1, 1):
+                    for n in range(N):
+                        units.append((kind, i, n))
+            for j in range(3):
+                for n in range(N):
+                    hops.append((j * N + n, 3 * N, j * N + n, 0, R))
+        return units, hops, rows, groups
+
+    def _build(self, stage: str, share_zero: bool):
+        key = (stage if not share_zero else "shared-zero", self.dedup) if self.dedup else ("as-written", False)
+        if self.layout == key:
+            return
+        units, hops, rows, groups = self._plan(stage, share_zero)
+        self.units, self.U = units, len(units)
+        kw = dict(weights=self.weights)
+        self.main = UNetEngine(self.arch, None, self.dev, self.B, self.h, self.w, self.R, self.S, ctx_rows=rows,
+                               attn3_groups=groups, **kw)
+        self.ref = UNetEngine(self.arch, None, self.dev, self.U, self.h, self.w, 0, self.S, **kw)
+        self.plan = HarvestPlan(self.main.ctx, hops)
+        f32 = dict(dtype=torch.float32, device=self.dev)
+        self.ref_src = torch.zeros((self.U,) + tuple(self.latents.shape[1:]), **f32)
+        # per-step parameters: [U] ref timesteps | [B] main timestep | [U,2] add_noise coefs | [6] guidance + DDIM coefs
+        self.n_par = 3 * self.U + self.B + 6
+        self.params = torch.zeros(self.n_par, **f32)
+        self.layout, self.graph = key, None
+
+    def _par_views(self):
+        U, B = self.U, self.B
+        return (self.params[:U], self.params[U:U + B], self.params[U + B:3 * U + B].view(U, 2), self.params[3 * U + B:])
+
+    # ------------------------------------------------------------------------------------------------ setup
     def prepare(self, inputs: Dict[str, torch.Tensor], num_inference_steps: int = 50,
                 stage: str = "multi-image-condition", guidance_scale: float = 7.5, image_guidance_scale: float = 3.5):
         """`inputs` as produced by storygen_amd.synth.synthetic_inputs / the pipeline's CLIP+VAE plumbing
@@ -73,29 +141,32 @@ class StoryGenSampler:
         if guidance_scale <= 1.0:
             raise ValueError("only the classifier-free-guidance path of the reference loop works (SURVEY F6g)")
         dev, N, R = self.dev, self.N, self.R
+        pu = inputs["prev_uncond"]
+        share_zero = (self.dedup and stage == "multi-image-condition"
+                      and all(torch.equal(pu[i], pu[0]) for i in range(1, R)))
+        self._build(stage, share_zero)
         self.latents.copy_(inputs["latents"].to(dev, torch.float32) * self.schedule.init_noise_sigma)
-        self.zero.copy_(inputs["zero_prompt"].to(dev, torch.float32))
-        self.imgs.copy_(inputs["image_prompts"].to(dev, torch.float32))
         self.noise.copy_(inputs["noise"].to(dev, torch.float32))
         h = torch.float16
         unc, txt = inputs["uncond"].to(dev, h), inputs["text"].to(dev, h)
-        self.text_main.copy_(torch.cat([unc, unc, txt]))                                  # pipeline.py:448
-        for i in range(R):
-            pu, pt = inputs["prev_uncond"][i].to(dev, h), inputs["prev_text"][i].to(dev, h)
-            self.text_ref[i].copy_(torch.cat([pu, pt, pt]))                               # :430
+        self.main.text_in.copy_(torch.cat([unc, unc, txt]))                               # pipeline.py:448
+        zero, imgs = inputs["zero_prompt"].to(dev, torch.float32), inputs["image_prompts"].to(dev, torch.float32)
+        for u, (kind, i, n) in enumerate(self.units):                                     # :420-430
+            self.ref_src[u].copy_(zero[n] if kind == 0 else imgs[i, n])
+            self.ref.text_in[u].copy_((pu[i][n] if kind == 0 else inputs["prev_text"][i][n]).to(dev, h))
         self.latents3.copy_(torch.cat([self.latents] * 3))                                # :450
+        self.main.cache_text_kv()
+        self.ref.cache_text_kv()
         # per-step table
         ts = self.schedule.timesteps(num_inference_steps)
         rows = []
         for t in ts:
             ref_t = int(t) // 10                                                          # :414-415
-            row: List[float] = []
-            tis = [ref_t * (R - i) if stage == "auto-regressive" else ref_t for i in range(R)]   # :419-424
-            for ti in tis:
-                row += [float(ti)] * self.B
+            tis = [ref_t * (R - i) if stage == "auto-regressive" else ref_t for i in range(R)]   # :419-427
+            row: List[float] = [float(tis[i]) for _, i, _ in self.units]
             row += [float(t)] * self.B
-            for ti in tis:
-                row += list(self.schedule.add_noise_coef(ti))
+            for _, i, _ in self.units:
+                row += list(self.schedule.add_noise_coef(tis[i]))
             row += [image_guidance_scale, guidance_scale, *self.schedule.step_coef(int(t), num_inference_steps)]
             rows.append(row)
         self.table = torch.tensor(rows, dtype=torch.float32).pin_memory()
@@ -107,17 +178,14 @@ class StoryGenSampler:
 
     # ------------------------------------------------------------------------------------------------ the step
     def _step_body(self):
-        e, R = self.engine, self.R
-        t_all, an, cd = self._par_views()
-        for i in range(R):                                                                # reference passes :418-438
-            ops.ref_inputs(self.zero, self.imgs[i], self.noise, an[i], e.x_in)
-            e.t_in.copy_(t_all[i])
-            e.text_in.copy_(self.text_ref[i])
-            e.forward(harvest_slot=i)
-        e.x_in.copy_(self.latents3)                                                       # main pass :448-453
-        e.t_in.copy_(t_all[R])
-        e.text_in.copy_(self.text_main)
-        eps3 = e.forward(consume=True)
+        ref, main = self.ref, self.main
+        t_ref, t_main, an, cd = self._par_views()
+        ops.add_noise(self.ref_src, self.noise, an, ref.x_in)                             # :419-429
+        ref.t_in.copy_(t_ref)
+        ref.forward(harvest=self.plan, harvest_only=True, text_cache=True)                # reference passes :418-438
+        main.x_in.copy_(self.latents3)                                                    # main pass :448-453
+        main.t_in.copy_(t_main)
+        eps3 = main.forward(consume=True, text_cache=True)
         ops.cfg_ddim_step(eps3, self.latents, self.latents3, cd)                          # :457-461
 
     def _capture(self):
@@ -156,6 +224,10 @@ class StoryGenSampler:
             if trace is not None:
                 trace.append(self.latents.clone())
         return self.latents
+
+    def executed_sample_forwards(self):
+        """(reference-pass samples, main-pass samples) actually computed per step — for FLOP accounting."""
+        return self.U, self.B
 
 
 def gather_latents(latents: torch.Tensor) -> torch.Tensor:

@@ -329,11 +329,12 @@ def test_sampling_elementwise(gpu):
     from storygen_amd import ops
     N, shape = 2, (2, 4, 16, 16)
     zero, img, noise, lat = (rnd(shape, gpu, seed=s, dtype=torch.float32) for s in (1, 2, 3, 4))
-    coef = torch.tensor([0.9, 0.43], device=gpu)
-    out3 = torch.empty(3 * N, 4, 16, 16, device=gpu)
-    ops.ref_inputs(zero, img, noise, coef, out3)
-    ref = torch.cat([0.9 * zero + 0.43 * noise, 0.9 * img + 0.43 * noise, 0.9 * img + 0.43 * noise])
-    check(out3, ref, "ref_inputs", l2=1e-6, mx=1e-6)
+    coef = torch.tensor([[0.9, 0.43], [0.9, 0.43], [0.7, 0.71], [0.5, 0.86]], device=gpu)   # per-sample timesteps
+    src = torch.cat([zero, img])
+    out4 = torch.empty(2 * N, 4, 16, 16, device=gpu)
+    ops.add_noise(src, noise, coef, out4)
+    ref = torch.stack([coef[u, 0] * src[u] + coef[u, 1] * noise[u % N] for u in range(2 * N)])
+    check(out4, ref, "add_noise", l2=1e-6, mx=1e-6)
     eps3 = rnd((3 * N, 4, 16, 16), gpu, seed=5, dtype=torch.float32)
     c = torch.tensor([3.5, 7.5, 0.8, 0.6, 0.85, 0.5267], device=gpu)
     eu, ei, ea = eps3.chunk(3)

@@ -165,3 +165,41 @@ def test_loop_vs_oracle_both_stages_16x16(gpu, sd15):
         errs = [rel_l2(a.cpu(), b) for a, b in zip(got, want)]
         print(stage, [f"{e:.2e}" for e in errs])
         assert max(errs) <= TOL_LATENT, (stage, errs)
+
+
+@pytest.mark.parametrize("stage", ["multi-image-condition", "auto-regressive"])
+def test_dedup_of_identical_reference_samples_is_equivalent(gpu, sd15, stage):
+    """The sampler's deduplicated reference pass (each distinct sample once) against the as-written batch
+    (all 3R samples, pipeline.py:429-430): same arithmetic on the same values — only tile / split-K plans differ with
+    the batch size, which reorders fp32 sums and so decorrelates the fp16 roundings downstream — so both must sit
+    within the latent bar of the oracle and of each other."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.engine import EngineWeights
+    from storygen_amd.sampler import StoryGenSampler
+    from storygen_amd.synth import synthetic_inputs
+    arch, sd = sd15
+    inputs = synthetic_inputs(1, 2, 16, 16, 9, arch.config["cross_attention_dim"])
+    wts = EngineWeights(arch, sd, gpu)
+    outs = []
+    for dedup in (True, False):
+        smp = StoryGenSampler(arch, None, gpu, 1, 16, 16, 2, use_graph=False, dedup=dedup, weights=wts)
+        smp.prepare(inputs, 50, stage, 7.5, 3.5)
+        assert smp.U == ((3 if stage == "multi-image-condition" else 4) if dedup else 6)
+        outs.append(smp.run(max_steps=2).clone().cpu())
+    want = O.sample_loop(sd, arch.config, inputs, 50, stage, 7.5, 3.5, max_steps=2)
+    errs = [rel_l2(o, want) for o in outs]
+    print(stage, "dedup/as-written vs oracle:", [f"{e:.2e}" for e in errs], "dedup vs as-written:", f"{rel_l2(outs[0], outs[1]):.2e}")
+    assert max(errs) <= TOL_LATENT and rel_l2(outs[0], outs[1]) <= TOL_LATENT
+
+
+def test_distinct_prev_uncond_disables_zero_sharing(gpu, sd15):
+    """The zero-image sample is shared across frames only when its inputs really are identical."""
+    from storygen_amd.sampler import StoryGenSampler
+    from storygen_amd.synth import synthetic_inputs
+    arch, sd = sd15
+    inputs = synthetic_inputs(1, 2, 16, 16, 9, arch.config["cross_attention_dim"])
+    inputs["prev_uncond"] = inputs["prev_uncond"].clone()
+    inputs["prev_uncond"][1] += 0.25
+    smp = StoryGenSampler(arch, sd, gpu, 1, 16, 16, 2, use_graph=False)
+    smp.prepare(inputs, 50, "multi-image-condition", 7.5, 3.5)
+    assert smp.U == 4
