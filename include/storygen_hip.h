@@ -141,20 +141,26 @@ int sg_conv_out_f16(const sg_half* x, int64_t ldx, const sg_half* w, const sg_ha
 
 /* ------------------------------------------------------------------------------------------------------------
  * Fused attention (flash-style, online softmax in fp32, no mask, no dropout):
- *   O[b, i, h*D + :] = softmax_j( scale * Q[b,i,h,:] . K[b,j,h,:] ) @ V[b,j,h,:]
+ *   O[b, i, h*D + :] = softmax_j( scale * Q[b,i,h,:] . K[kb,j,h,:] ) @ V[kb,j,h,:]
  * Replaces the attention core of CrossAttention for attn1 / attn2 / attn3 — the default CrossAttnProcessor
  * (baddbmm -> softmax -> bmm) or xformers.memory_efficient_attention selected at inference.py:58-64; call
  * sites model/attention.py:255-260,271-276,285-290.  Heads are interleaved in the channel dimension exactly
- * as head_to_batch_dim expects (head h = channels [h*D, (h+1)*D)), so Q/K/V are read straight from the
+ * as head_to_batch_dim expects (head h = channels [h*D, (h+1)*D)), so Q/K are read straight from the
  * projection GEMM outputs and O is written heads-merged.  D in {40, 80, 160} (SD-1.5: C/8); any Nq, Nk >= 1.
- * Strides in elements: token stride ld*, batch stride bs*.
+ * V is passed TRANSPOSED: vt[kb][h*D + d][j], keys contiguous (row stride ldvt, batch stride bsvt) — the host gets it
+ * for free by running the V projection with swapped operands (VT = Wv . X^T).  Every vt row must hold finite values
+ * up to Nk rounded up to a multiple of 8 (ldvt >= that).
+ * kv_batches: 0 or B = one K/V per query batch; 0 < kv_batches < B: query batch b reads K/V batch
+ * (b < kv_batches ? b : b - (B - kv_batches)) — the image-conditioned CFG branches of the main pass share one
+ * context.  Strides in elements: token stride ld*, batch stride bs*.
  */
 typedef struct sg_attn_desc {
-    const sg_half* q; int64_t ldq, bsq;
-    const sg_half* k; int64_t ldk, bsk;
-    const sg_half* v; int64_t ldv, bsv;
-    sg_half*       o; int64_t ldo, bso;
+    const sg_half* q;  int64_t ldq, bsq;
+    const sg_half* k;  int64_t ldk, bsk;
+    const sg_half* vt; int64_t ldvt, bsvt;
+    sg_half*       o;  int64_t ldo, bso;
     int32_t B, H, Nq, Nk, D;
+    int32_t kv_batches;
     float   scale;
 } sg_attn_desc;
 

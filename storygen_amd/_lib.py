@@ -68,9 +68,10 @@ class AttnDesc(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("ldq", C.c_int64), ("bsq", C.c_int64),
         ("k", C.c_void_p), ("ldk", C.c_int64), ("bsk", C.c_int64),
-        ("v", C.c_void_p), ("ldv", C.c_int64), ("bsv", C.c_int64),
+        ("vt", C.c_void_p), ("ldvt", C.c_int64), ("bsvt", C.c_int64),
         ("o", C.c_void_p), ("ldo", C.c_int64), ("bso", C.c_int64),
         ("B", C.c_int32), ("H", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("D", C.c_int32),
+        ("kv_batches", C.c_int32),
         ("scale", C.c_float),
     ]
 

@@ -3,119 +3,141 @@
 // Serves the three attentions of StoryGen's BasicTransformerBlock (model/attention.py:255-260 self, :271-276 text,
 // :285-290 image / Visual-Language Context) — head dim D = C/8 in {40, 80, 160}, Nk = HW, 77 or R*HW.
 //
-// Work decomposition: one 256-thread workgroup = 4 wave64 = 128 query rows of one (batch, head); each wave owns 32
-// queries.  K/V are streamed in tiles of 64 keys through LDS (shared by the 4 waves).
+// Operands: Q and K token-major ([B, N, H*D], heads interleaved in the channel dimension exactly as
+// head_to_batch_dim expects) and V *transposed*: VT[b][h*D + d][key].  The V projection is a GEMM anyway, so the host
+// simply computes it with swapped operands (VT = Wv . X^T) — the attention kernel then needs no in-kernel transpose
+// and every LDS tile it consumes is a plain 16-byte-chunk copy of global memory, which is what LDS-DMA wants.
+//
+// Work decomposition: one workgroup = NW wave64, each wave owns 32 queries of one (batch, head); K / VT are streamed in
+// tiles of 64 keys through an S-stage LDS ring filled by LDS-DMA (global_load_lds, 16 B per lane, no VGPR staging),
+// counted vmcnt waits and ONE raw s_barrier per tile (same pipeline as the GEMM mainloop).
 //
 // MFMA formulation (v_mfma_f32_32x32x16_f16), chosen so that softmax never leaves registers:
-//   S^T[key, q]  = sum_d K[key, d] Q[q, d]        A-operand = K fragment (LDS, ds_read_b128), B = Q^T (registers)
-//     -> lane l holds query q = l & 31 and 16 of the 32 keys of a block: key = (r&3) + 8*(r>>2) + 4*(l>>5).
-//        Row max / row sum are in-lane reductions plus ONE exchange with lane l^32.
-//   O^T[d, q]    = sum_key V^T[d, key] P^T[key, q]   A = V^T fragment (LDS, 2x ds_read_b64), B = P^T (registers)
-//     -> the MFMA contraction index is permutation-invariant as long as A and B agree, so the k-slot (hi, j) of
-//        step ks is *defined* as key 16ks + 4hi + (j&3) + 8(j>>2): exactly the registers the lane already holds
-//        after S^T.  P never moves across lanes and never touches LDS.
-//   V is transposed on the way into LDS (each thread owns the 8-channel chunks of 4 consecutive keys and emits
-//   8-byte stores of V^T[d][4 keys]); its LDS row stride (68 halves) makes the V^T fragment reads conflict-free.
-//   K rows are padded to DK+8 halves so the ds_read_b128 of 16 consecutive keys hit 16 distinct 16-B slots.
-//   Head dim 40 is zero-padded to 48 on the contraction side (K chunk 5 / Q chunk 5) and to 64 on the O^T rows.
-// Pipelining: global loads of tile t+1 are issued into registers before the MFMAs of tile t (two barriers/tile).
+//   S^T[key, q] = sum_d K[key, d] Q[q, d]      A = K fragment (LDS, ds_read_b128), B = Q^T fragment (registers)
+//     The A rows are fed in a permuted order (row i of the MFMA reads key pi(i), pi = swap of bits 2 and 3), so that
+//     accumulator register r of lane (q = l & 31, hi = l >> 5) holds key 16 (r >> 3) + 8 hi + (r & 7): the 8 registers
+//     of a 16-key step are 8 CONSECUTIVE keys.  Row max / row sum are in-lane reductions plus ONE exchange with l^32.
+//   O^T[d, q] = sum_key VT[d, key] P^T[key, q]  A = VT fragment (LDS, one ds_read_b128 of 8 consecutive keys),
+//     B = P^T = the lane's own accumulator registers converted to fp16.  P never moves across lanes or through LDS.
+//   Head dim 40 is zero-padded to 48 on the contraction side (the Q fragment of chunk 5 is zero; the K fragment reads
+//   the first 16 bytes of the next LDS row, finite data) and to 64 on the O^T rows (rows >= D are never stored).
+// LDS images (both filled by LDS-DMA, so linear in lane order; the swizzles are applied on the SOURCE address and again
+// on the read, guide §5.4 rule 21):
+//   K tile  [64 keys][D halves], row stride 2D bytes, chunk c of row k at slot c ^ kswz(k): conflict-free ds_read_b128
+//           (kswz = 0 for D=40 whose 80-byte stride already spreads 16 rows over 16 slots, (k>>3)&1 for D=80,
+//           (k>>2)&3 for D=160).
+//   VT tile [D rows][64 keys], row stride 128 bytes, chunk c of row d at slot c ^ ((d>>1)&7).
+// Online softmax runs in the log2 domain with the scale folded into the exponent's FMA, and rescales the accumulators
+// only when some row's running max grows by more than 2^6 (wave-uniform branch; P <= 64 stays exact enough in fp16
+// and the row sums are fp32).
 #include "common.h"
 
 namespace {
 
-constexpr int QBLK = 128;   // queries per workgroup
-constexpr int KVBLK = 64;   // keys per tile
-constexpr int VSTR = 68;    // V^T LDS row stride in halves (64 keys + 4 pad)
+constexpr int KVBLK = 64;            // keys per tile
+constexpr float RESCALE_THR = 6.0f;  // log2 units
 
 struct AttnParams {
     const f16* q; long ldq, bsq;
     const f16* k; long ldk, bsk;
-    const f16* v; long ldv, bsv;
+    const f16* vt; long ldvt, bsvt;
     f16* o; long ldo, bso;
-    int H, Nq, Nk;
+    int B, H, Nq, Nk, kv_batches, nqb;
     float scale_log2;   // scale * log2(e)
 };
 
+__device__ __forceinline__ void glds16(const f16* g, char* lds_wave_base) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
+                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
 template <int D>
-__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
-    constexpr int DK = (D + 15) / 16 * 16;      // contraction length of S^T (padded)
-    constexpr int NDK = DK / 16;                // MFMA k-steps for S^T
+__device__ __forceinline__ int kswz(int row) {
+    return D == 40 ? 0 : (D == 80 ? ((row >> 3) & 1) : ((row >> 2) & 3));
+}
+
+template <int D, int NW, int S>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
+    constexpr int DC = D / 8;                   // 16-byte chunks per K row
+    constexpr int NDK = (D + 15) / 16;          // MFMA k-steps of S^T (contraction padded to 16)
     constexpr int DT = (D + 31) / 32;           // 32-row tiles of O^T
-    constexpr int KSTR = DK + 8;                // K LDS row stride (halves)
-    constexpr int DC = D / 8;                   // 16-byte chunks per K/V row
-    constexpr int KCH = KVBLK * DC;             // K chunks per tile
-    constexpr int K_IT = (KCH + 255) / 256;
-    constexpr int VGRP = (KVBLK / 4) * DC;      // V groups (4 keys x one chunk) per tile
-    constexpr int V_IT = (VGRP + 255) / 256;
-    __shared__ __attribute__((aligned(16))) f16 sK[KVBLK * KSTR];
-    __shared__ __attribute__((aligned(16))) f16 sVt[DT * 32 * VSTR];
+    constexpr int KROW = D * 2;                 // K LDS row stride in bytes
+    constexpr int K_BYTES = KVBLK * KROW;       // = D KiB / 8
+    constexpr int V_BYTES = D * 128;
+    constexpr int K_SEG = K_BYTES / 1024, V_SEG = V_BYTES / 1024, NSEG = K_SEG + V_SEG;   // 1 KiB = one wave DMA
+    constexpr int STAGE = K_BYTES + V_BYTES;
+    constexpr int MAXL = (NSEG + NW - 1) / NW;  // DMA instructions per tile of the busiest wave
+    constexpr int REM = NSEG % NW;              // waves < REM issue MAXL, the others MAXL - 1 (REM == 0: all MAXL)
+    static_assert(S == 2 || S == 3, "2 or 3 stages");
+    static_assert((S - 1) * MAXL < 64, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(16))) char smem[S * STAGE + 16];
 
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6, l31 = lane & 31, hi = lane >> 5;
-    const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * QBLK + wave * 32;
+    const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    // consecutive logical work items (q-blocks of one (batch, head)) run on the same XCD and share its L2
+    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    const int bh = work / p.nqb, qb = work - bh * p.nqb;
+    const int b = bh / p.H, h = bh - b * p.H;
+    const int kvb = b < p.kv_batches ? b : b - (p.B - p.kv_batches);
+    const int q0 = (qb * NW + wave) * 32;
     const f16* Q = p.q + (long)b * p.bsq + (long)h * D;
-    const f16* K = p.k + (long)b * p.bsk + (long)h * D;
-    const f16* V = p.v + (long)b * p.bsv + (long)h * D;
+    const f16* K = p.k + (long)kvb * p.bsk + (long)h * D;
+    const f16* VT = p.vt + (long)kvb * p.bsvt + (long)h * D * p.ldvt;
+    const int nkp8 = (p.Nk + 7) & ~7;           // VT rows hold finite data up to here (host contract)
 
-    // zero the LDS padding once (never overwritten by the tile stores)
-    for (int i = t; i < KVBLK * KSTR; i += 256) sK[i] = (f16)0.f;
-    for (int i = t; i < DT * 32 * VSTR; i += 256) sVt[i] = (f16)0.f;
+    // ---- per-lane DMA source coordinates of this wave's segments (segment g = i*NW + wave)
+    int c_row[MAXL], c_col[MAXL];               // K: key within tile, chunk*8 | VT: d*ldvt, chunk*8
+#pragma unroll
+    for (int i = 0; i < MAXL; ++i) {
+        const int g = i * NW + wave;
+        c_row[i] = c_col[i] = 0;
+        if (g < K_SEG) {
+            const int s = g * 64 + lane;        // linear 16-byte slot of the K image
+            const int kl = s / DC, cs = s - kl * DC;
+            c_row[i] = kl;
+            c_col[i] = (cs ^ kswz<D>(kl)) * 8;
+        } else if (g < NSEG) {
+            const int s = (g - K_SEG) * 64 + lane;
+            const int d = s >> 3, cs = s & 7;
+            c_row[i] = d * (int)p.ldvt;
+            c_col[i] = (cs ^ ((d >> 1) & 7)) * 8;
+        }
+    }
+    auto issue = [&](int tile, int stage) {
+        const int key0 = tile * KVBLK;
+        char* base = smem + stage * STAGE;
+#pragma unroll
+        for (int i = 0; i < MAXL; ++i) {
+            const int g = i * NW + wave;        // wave-uniform
+            if (g < K_SEG) {
+                const int key = min(key0 + c_row[i], p.Nk - 1);                 // tail rows: duplicates (finite)
+                glds16(K + (long)key * p.ldk + c_col[i], base + g * 1024);
+            } else if (g < NSEG) {
+                const int kc = min(key0 + c_col[i], nkp8 - 8);                  // tail chunks: duplicates (finite)
+                glds16(VT + c_row[i] + kc, base + g * 1024);
+            }
+        }
+    };
 
-    // Q^T fragments: lane = (query l31, d-chunk 2s+hi)
+    // ---- Q^T fragments: lane = (query l31, d-chunk 2s+hi); rows beyond Nq are clamped (never stored)
     f16x8 qf[NDK];
     {
-        const int qi = q0 + l31;
+        const int qi = min(q0 + l31, p.Nq - 1);
 #pragma unroll
         for (int s = 0; s < NDK; ++s) {
             const int d0 = s * 16 + hi * 8;
             H8 x; x.u = make_uint4(0, 0, 0, 0);
-            if (qi < p.Nq && d0 < D) x.u = ldg16(Q + (long)qi * p.ldq + d0);
+            if (d0 < D) x.u = ldg16(Q + (long)qi * p.ldq + d0);
             qf[s] = x.v;
         }
     }
-
-    uint4 kreg[K_IT];
-    uint4 vreg[V_IT][4];
-    auto load_tile = [&](int tile) {
-        const int key0 = tile * KVBLK;
-#pragma unroll
-        for (int i = 0; i < K_IT; ++i) {
-            const int ci = t + 256 * i;
-            const int key = ci / DC, dc = ci - key * DC;
-            kreg[i] = (ci < KCH && key0 + key < p.Nk) ? ldg16(K + (long)(key0 + key) * p.ldk + dc * 8) : make_uint4(0, 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < V_IT; ++i) {
-            const int gi = t + 256 * i;
-            const int kg = gi / DC, dc = gi - kg * DC;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const int key = key0 + kg * 4 + e;
-                vreg[i][e] = (gi < VGRP && key < p.Nk) ? ldg16(V + (long)key * p.ldv + dc * 8) : make_uint4(0, 0, 0, 0);
-            }
-        }
-    };
-    auto store_tile = [&]() {
-#pragma unroll
-        for (int i = 0; i < K_IT; ++i) {
-            const int ci = t + 256 * i;
-            const int key = ci / DC, dc = ci - key * DC;
-            if (ci < KCH) *reinterpret_cast<uint4*>(sK + key * KSTR + dc * 8) = kreg[i];
-        }
-#pragma unroll
-        for (int i = 0; i < V_IT; ++i) {
-            const int gi = t + 256 * i;
-            const int kg = gi / DC, dc = gi - kg * DC;
-            if (gi < VGRP) {
-                H8 r0, r1, r2, r3;
-                r0.u = vreg[i][0]; r1.u = vreg[i][1]; r2.u = vreg[i][2]; r3.u = vreg[i][3];
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    f16x4 w = {r0.h[j], r1.h[j], r2.h[j], r3.h[j]};
-                    *reinterpret_cast<f16x4*>(sVt + (dc * 8 + j) * VSTR + kg * 4) = w;
-                }
-            }
-        }
-    };
+    // settle the Q loads here: inside the tile loop the only vector-memory traffic must be the LDS-DMA ring, whose
+    // counted waits a compiler-inserted vmcnt(0) for these registers would otherwise drain every iteration
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt/lgkmcnt untouched
 
     f32x16 oacc[DT];
 #pragma unroll
@@ -126,12 +148,29 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     float l_run = 0.f;         // this lane's share of the running row sum
 
     const int ntiles = (p.Nk + KVBLK - 1) / KVBLK;
-    load_tile(0);
+#pragma unroll
+    for (int s = 0; s < S - 1; ++s)
+        if (s < ntiles) issue(s, s);
+
+    // LDS read coordinates
+    const int prow = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);          // pi(l31): swap bits 2 and 3
+    int stage = 0;
     for (int tile = 0; tile < ntiles; ++tile) {
-        __syncthreads();   // everyone is done reading the previous tile (and the zero fill is complete)
-        store_tile();
-        __syncthreads();
-        if (tile + 1 < ntiles) load_tile(tile + 1);
+        // wait for this wave's share of tile `tile` (one younger tile may stay in flight), publish, refill the ring
+        if (S == 3 && tile + 1 < ntiles) {
+            if (REM == 0 || wave < REM) wait_vmcnt<MAXL>();
+            else wait_vmcnt<(MAXL > 1 ? MAXL - 1 : 0)>();
+        } else {
+            wait_vmcnt<0>();
+        }
+        __builtin_amdgcn_s_barrier();
+        if (tile + S - 1 < ntiles) {
+            int st = stage + S - 1;
+            if (st >= S) st -= S;
+            issue(tile + S - 1, st);
+        }
+        const char* sK = smem + stage * STAGE;
+        const char* sV = sK + K_BYTES;
 
         // ---- S^T = K Q^T for the two 32-key blocks
         f32x16 s[2];
@@ -139,47 +178,53 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
         for (int kb = 0; kb < 2; ++kb) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
+            const int row = kb * 32 + prow;
+            const char* krow = sK + row * KROW;
+            const int sw = kswz<D>(row);
 #pragma unroll
             for (int st = 0; st < NDK; ++st) {
-                const f16x8 kf = *reinterpret_cast<const f16x8*>(sK + (kb * 32 + l31) * KSTR + (st * 2 + hi) * 8);
+                const f16x8 kf = *reinterpret_cast<const f16x8*>(krow + (((st * 2 + hi) ^ sw) << 4));
                 s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], s[kb], 0, 0, 0);
             }
         }
-        // ---- online softmax (log2 domain): scale, mask the key tail, row max, exponentiate
-        const bool tail = (tile + 1) * KVBLK > p.Nk;
-        float mx = -INFINITY;
+        // ---- online softmax: mask the key tail, row max (raw scores), deferred rescale, exponentiate
+        if ((tile + 1) * KVBLK > p.Nk) {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = tile * KVBLK + kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
+                    if (key >= p.Nk) s[kb][r] = -INFINITY;
+                }
+        }
+        float mx = s[0][0];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float x = s[kb][r] * p.scale_log2;
-                if (tail) {
-                    const int key = tile * KVBLK + kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (key >= p.Nk) x = -INFINITY;
-                }
-                s[kb][r] = x;
-                mx = fmaxf(mx, x);
-            }
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-        const float m_new = fmaxf(m_run, mx);          // finite: every tile holds >= 1 valid key
-        const float alpha = exp2f(m_run - m_new);      // 0 on the first tile
-        m_run = m_new;
+            for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;   // finite: every tile holds >= 1 valid key
+        if (__builtin_amdgcn_ballot_w64(mx - m_run > RESCALE_THR) != 0) {
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);            // 0 on the first tile (m_run = -inf)
+            m_run = m_new;
+            l_run *= alpha;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        }
         float psum = 0.f;
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const float e = exp2f(s[kb][r] - m_new);
+                const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2, -m_run));
                 s[kb][r] = e;
                 psum += e;
             }
-        l_run = l_run * alpha + psum;
-#pragma unroll
-        for (int i = 0; i < DT; ++i)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+        l_run += psum;
 
-        // ---- O^T += V^T P^T : 4 k-steps of 16 keys; B fragment = this lane's own P registers
+        // ---- O^T += VT P^T : 4 k-steps of 16 keys; B fragment = this lane's own P registers
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             f16x8 pf;
@@ -187,13 +232,12 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
             for (int j = 0; j < 8; ++j) pf[j] = (f16)s[ks >> 1][(ks & 1) * 8 + j];
 #pragma unroll
             for (int i = 0; i < DT; ++i) {
-                const f16* vrow = sVt + (i * 32 + l31) * VSTR + ks * 16 + hi * 4;
-                const f16x4 v0 = *reinterpret_cast<const f16x4*>(vrow);
-                const f16x4 v1 = *reinterpret_cast<const f16x4*>(vrow + 8);
-                const f16x8 vf = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+                const int d = min(i * 32 + l31, D - 1);          // rows >= D: duplicates, never stored
+                const f16x8 vf = *reinterpret_cast<const f16x8*>(sV + d * 128 + (((ks * 2 + hi) ^ ((d >> 1) & 7)) << 4));
                 oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[i], 0, 0, 0);
             }
         }
+        if (++stage == S) stage = 0;
     }
 
     // ---- normalise and store O[b, q, h*D + d]  (lane holds d = 32i + (r&3) + 8(r>>2) + 4hi for its query)
@@ -216,31 +260,44 @@ __global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
     }
 }
 
+template <int D, int NW, int S>
+void launch_attn(const AttnParams& p0, hipStream_t st) {
+    AttnParams p = p0;
+    p.nqb = sg_cdiv(p.Nq, 32 * NW);
+    hipLaunchKernelGGL((attn_fwd_kernel<D, NW, S>), dim3(p.nqb * p.H * p.B), dim3(64 * NW), 0, st, p);
+}
+
 }  // namespace
 
 extern "C" int sg_attn_fwd_f16(const sg_attn_desc* d, sg_stream_t stream) {
     SG_REQUIRE(d != nullptr, "sg_attn_fwd_f16: null descriptor");
-    SG_REQUIRE(d->q && d->k && d->v && d->o, "sg_attn_fwd_f16: null q/k/v/o");
+    SG_REQUIRE(d->q && d->k && d->vt && d->o, "sg_attn_fwd_f16: null q/k/vt/o");
     SG_REQUIRE(d->B > 0 && d->H > 0 && d->Nq > 0 && d->Nk > 0, "sg_attn_fwd_f16: bad shape");
     if (d->D != 40 && d->D != 80 && d->D != 160)
         return sg_set_error(SG_EUNSUP, "sg_attn_fwd_f16: head dim %d not in {40, 80, 160}", d->D);
-    SG_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->ldo % 4 == 0, "sg_attn_fwd_f16: token strides");
-    SG_REQUIRE(d->bsq % 8 == 0 && d->bsk % 8 == 0 && d->bsv % 8 == 0 && d->bso % 4 == 0, "sg_attn_fwd_f16: batch strides");
-    SG_REQUIRE(sg_aligned16(d->q) && sg_aligned16(d->k) && sg_aligned16(d->v) && sg_aligned16(d->o), "sg_attn_fwd_f16: 16-byte alignment");
-    SG_REQUIRE(d->ldq >= (int64_t)d->H * d->D && d->ldk >= (int64_t)d->H * d->D && d->ldv >= (int64_t)d->H * d->D &&
-                   d->ldo >= (int64_t)d->H * d->D, "sg_attn_fwd_f16: token stride smaller than H*D");
+    SG_REQUIRE(d->kv_batches >= 0 && d->kv_batches <= d->B, "sg_attn_fwd_f16: kv_batches must be in [0, B]");
+    SG_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldvt % 8 == 0 && d->ldo % 4 == 0, "sg_attn_fwd_f16: row strides");
+    SG_REQUIRE(d->bsq % 8 == 0 && d->bsk % 8 == 0 && d->bsvt % 8 == 0 && d->bso % 4 == 0, "sg_attn_fwd_f16: batch strides");
+    SG_REQUIRE(sg_aligned16(d->q) && sg_aligned16(d->k) && sg_aligned16(d->vt) && sg_aligned16(d->o), "sg_attn_fwd_f16: 16-byte alignment");
+    const int64_t hd = (int64_t)d->H * d->D;
+    SG_REQUIRE(d->ldq >= hd && d->ldk >= hd && d->ldo >= hd, "sg_attn_fwd_f16: token stride smaller than H*D");
+    SG_REQUIRE(d->ldvt >= ((d->Nk + 7) & ~7), "sg_attn_fwd_f16: ldvt must cover Nk rounded up to 8 keys");
+    SG_REQUIRE((int64_t)d->D * d->ldvt < (1ll << 31), "sg_attn_fwd_f16: VT head slab too large for 32-bit offsets");
     AttnParams p{};
     p.q = reinterpret_cast<const f16*>(d->q); p.ldq = d->ldq; p.bsq = d->bsq;
     p.k = reinterpret_cast<const f16*>(d->k); p.ldk = d->ldk; p.bsk = d->bsk;
-    p.v = reinterpret_cast<const f16*>(d->v); p.ldv = d->ldv; p.bsv = d->bsv;
+    p.vt = reinterpret_cast<const f16*>(d->vt); p.ldvt = d->ldvt; p.bsvt = d->bsvt;
     p.o = reinterpret_cast<f16*>(d->o); p.ldo = d->ldo; p.bso = d->bso;
-    p.H = d->H; p.Nq = d->Nq; p.Nk = d->Nk;
+    p.B = d->B; p.H = d->H; p.Nq = d->Nq; p.Nk = d->Nk;
+    p.kv_batches = d->kv_batches > 0 ? d->kv_batches : d->B;
     p.scale_log2 = d->scale * 1.44269504088896340736f;
-    dim3 grid((d->Nq + QBLK - 1) / QBLK, d->H, d->B), block(256);
     hipStream_t st = (hipStream_t)stream;
-    if (d->D == 40) hipLaunchKernelGGL(attn_fwd_kernel<40>, grid, block, 0, st, p);
-    else if (d->D == 80) hipLaunchKernelGGL(attn_fwd_kernel<80>, grid, block, 0, st, p);
-    else hipLaunchKernelGGL(attn_fwd_kernel<160>, grid, block, 0, st, p);
+    // 4-wave workgroups with a 3-deep ring when that still gives the chip >= 2 workgroups per CU, else 2 waves / 2 stages
+    const long wgs4 = (long)sg_cdiv(d->Nq, 128) * d->H * d->B;
+    const bool big = wgs4 >= 512;
+    if (d->D == 40) { if (big) launch_attn<40, 4, 3>(p, st); else launch_attn<40, 2, 2>(p, st); }
+    else if (d->D == 80) { if (big) launch_attn<80, 4, 3>(p, st); else launch_attn<80, 2, 2>(p, st); }
+    else launch_attn<160, 2, 2>(p, st);
     SG_CHECK_LAUNCH("sg_attn_fwd_f16");
     return SG_OK;
 }

@@ -36,8 +36,8 @@ class _Resnet:
 
 
 class _Xf:
-    __slots__ = ("spec", "ng", "nb", "w_in", "b_in", "w_out", "b_out", "ln", "w_qkv1", "w_o1", "b_o1", "w_q2", "w_kv2",
-                 "w_o2", "b_o2", "w_q3", "w_kv3", "w_o3", "b_o3", "w_ff1", "b_ff1", "w_ff2", "b_ff2")
+    __slots__ = ("spec", "ng", "nb", "w_in", "b_in", "w_out", "b_out", "ln", "w_qk1", "w_v1", "w_o1", "b_o1", "w_q2", "w_k2",
+                 "w_v2", "w_o2", "b_o2", "w_q3", "w_k3", "w_v3", "w_o3", "b_o3", "w_ff1", "b_ff1", "w_ff2", "b_ff2")
 
 
 class EngineWeights:
@@ -97,14 +97,16 @@ class EngineWeights:
                 o.w_in, o.b_in = conv1x1_nk(g(f"{p}.proj_in.weight")), g(f"{p}.proj_in.bias")
                 o.w_out, o.b_out = conv1x1_nk(g(f"{p}.proj_out.weight")), g(f"{p}.proj_out.bias")
                 o.ln = {n: (g(f"{t}.{n}.weight"), g(f"{t}.{n}.bias")) for n in ("norm1", "norm2", "norm3", "norm4")}
-                o.w_qkv1 = torch.cat([g(f"{t}.attn1.to_q.weight"), g(f"{t}.attn1.to_k.weight"),
-                                      g(f"{t}.attn1.to_v.weight")], 0).contiguous()
+                # q and k projections fused (one GEMM, token-major output); v separate: it is computed TRANSPOSED
+                # (VT = Wv . X^T, the same GEMM with its operands swapped), the layout the attention kernel streams
+                o.w_qk1 = torch.cat([g(f"{t}.attn1.to_q.weight"), g(f"{t}.attn1.to_k.weight")], 0).contiguous()
+                o.w_v1 = g(f"{t}.attn1.to_v.weight")
                 o.w_o1, o.b_o1 = g(f"{t}.attn1.to_out.0.weight"), g(f"{t}.attn1.to_out.0.bias")
                 o.w_q2 = g(f"{t}.attn2.to_q.weight")
-                o.w_kv2 = torch.cat([g(f"{t}.attn2.to_k.weight"), g(f"{t}.attn2.to_v.weight")], 0).contiguous()
+                o.w_k2, o.w_v2 = g(f"{t}.attn2.to_k.weight"), g(f"{t}.attn2.to_v.weight")
                 o.w_o2, o.b_o2 = g(f"{t}.attn2.to_out.0.weight"), g(f"{t}.attn2.to_out.0.bias")
                 o.w_q3 = g(f"{t}.attn3.to_q.weight")
-                o.w_kv3 = torch.cat([g(f"{t}.attn3.to_k.weight"), g(f"{t}.attn3.to_v.weight")], 0).contiguous()
+                o.w_k3, o.w_v3 = g(f"{t}.attn3.to_k.weight"), g(f"{t}.attn3.to_v.weight")
                 o.w_o3, o.b_o3 = g(f"{t}.attn3.to_out.0.weight"), g(f"{t}.attn3.to_out.0.bias")
                 o.w_ff1, o.b_ff1 = interleave_geglu(g(f"{t}.ff.net.0.proj.weight"), g(f"{t}.ff.net.0.proj.bias"))
                 o.w_ff2, o.b_ff2 = g(f"{t}.ff.net.2.weight"), g(f"{t}.ff.net.2.bias")
@@ -151,11 +153,20 @@ class UNetEngine:
         self.groups, self.eps = cfg["norm_num_groups"], cfg["norm_eps"]
         self.cad = cfg["cross_attention_dim"]
         self.hw = [(height >> l) * (width >> l) for l in range(nlev)]
+        self.Sp = (seq_len + 7) & ~7          # text tokens padded with zero rows to a multiple of 8 (V^T row alignment)
+        for k, lv in arch.feature_level.items():
+            if self.hw[lv] % 8:
+                raise ValueError(f"latent {height}x{width} leaves {self.hw[lv]} tokens at attention block {k}; the V^T layout "
+                                 "needs a multiple of 8 (use a latent of at least 32x32 with the 4-level SD-1.5 UNet)")
         self.ctx_rows = batch if ctx_rows is None else ctx_rows
         self.attn3_groups = [(0, batch, 0)] if attn3_groups is None else list(attn3_groups)
         covered = sorted(q for q0, n, _ in self.attn3_groups for q in range(q0, q0 + n))
         if n_ref and (covered != list(range(batch)) or any(c0 + n > self.ctx_rows for _, n, c0 in self.attn3_groups)):
             raise ValueError(f"attn3_groups {self.attn3_groups} must cover samples 0..{batch - 1} once, within {self.ctx_rows} context rows")
+        # the common sharing pattern maps onto the kernel's kv_batches argument (one launch instead of one per group)
+        rows = self.ctx_rows
+        share = sorted(self.attn3_groups) == ([(0, batch, 0)] if rows == batch else [(0, rows, 0), (rows, batch - rows, 2 * rows - batch)])
+        self.attn3_share = rows if share else None
         self.wts = weights if weights is not None else EngineWeights(arch, state_dict, device)
         self.text_cache: Dict[str, torch.Tensor] = {}
         self._alloc(splitk_workspace_mb)
@@ -181,7 +192,8 @@ class UNetEngine:
         F32 = torch.float32
         self.x_in = self._buf(B, self.cfg["in_channels"], self.H, self.W, dtype=F32)
         self.t_in = self._buf(B, dtype=F32)
-        self.text_in = self._buf(B, self.S, self.cad)
+        self.text_pad = torch.zeros(B, self.Sp, self.cad, dtype=F16, device=self.dev)    # rows >= S stay zero
+        self.text_in = self.text_pad[:, : self.S]
         self.eps_out = self._buf(B, self.cfg["out_channels"], self.H, self.W, dtype=F32)
         self.temb0 = self._buf(B, boc[0], dtype=F32)
         self.temb1 = self._buf(B, arch.temb_dim, dtype=F32)
@@ -224,9 +236,11 @@ class UNetEngine:
                 h0=f32(M, C), h1=f32(M, C), h2=f32(M, C), h3=f32(M, C),
                 # fp16 MFMA operands
                 gn=self._buf(M, C), x16=self._buf(M * Cw), c1=self._buf(M, C), h4=self._buf(M, C),
-                ln=self._buf(M, C), ln4=self._buf(M, C), qkv=self._buf(M, 3 * C), q=self._buf(M, C), att=self._buf(M, C),
-                ffi=self._buf(M, 4 * C), kvt=self._buf(B * self.S, 2 * C),
-                kvi=self._buf(self.ctx_rows * self.R * self.hw[l], 2 * C) if self.R else None,
+                ln=self._buf(M, C), ln4=self._buf(M, C), qk=self._buf(M, 2 * C), vt=self._buf(C, M), q=self._buf(M, C),
+                att=self._buf(M, C), ffi=self._buf(M, 4 * C),
+                kt=self._buf(B * self.Sp, C), vtt=self._buf(C, B * self.Sp),
+                ki=self._buf(self.ctx_rows * self.R * self.hw[l], C) if self.R else None,
+                vti=self._buf(C, self.ctx_rows * self.R * self.hw[l]) if self.R else None,
             )
             self.lv.append(d)
         # skip tensors (down_block_res_samples) persist until the up path pops them
@@ -270,27 +284,35 @@ class UNetEngine:
             res = x
         ops.conv3x3(p_mid, rn.w2, self._img(out, lvl), bias=rn.b2, res1=self._img(res, lvl), workspace=ws, x_padded=True)
 
-    def _text_kv(self, xf: _Xf, lvl: int, text: torch.Tensor, use_cache: bool) -> torch.Tensor:
-        """K/V projection of the text embeddings for attn2 (attention.py:192-199): timestep-invariant, so the sampler
-        computes it once per prompt (cache_text_kv) instead of once per UNet call."""
+    def _text_kv(self, xf: _Xf, lvl: int, use_cache: bool):
+        """K and V^T projections of the text embeddings for attn2 (attention.py:192-199): timestep-invariant, so the
+        sampler computes them once per prompt (cache_text_kv) instead of once per UNet call.  Returns (K [B,Sp,C],
+        VT [B,C,Sp]) views; rows / columns >= S come from the zero padding tokens."""
+        B, Sp, C = self.B, self.Sp, xf.spec.channels
         if use_cache:
-            return self.text_cache[xf.spec.prefix]
-        kvt = self.lv[lvl]["kvt"]
-        ops.gemm(text.view(self.B * self.S, -1), xf.w_kv2, kvt, workspace=self.ws_split)
-        return kvt
+            kt, vtt = self.text_cache[xf.spec.prefix]
+        else:
+            kt, vtt = self.lv[lvl]["kt"], self.lv[lvl]["vtt"]
+            self._project_text(xf, kt, vtt)
+        return kt.view(B, Sp, C), vtt.view(C, B, Sp).permute(1, 0, 2)
+
+    def _project_text(self, xf: _Xf, kt: torch.Tensor, vtt: torch.Tensor):
+        x = self.text_pad.view(self.B * self.Sp, self.cad)
+        ops.gemm(x, xf.w_k2, kt, workspace=self.ws_split)
+        ops.gemm(xf.w_v2, x, vtt, workspace=self.ws_split)                                 # VT = Wv . X^T
 
     def cache_text_kv(self):
-        """Run every attn2 K/V projection on the current self.text_in and keep the results (use with
+        """Run every attn2 K / V^T projection on the current self.text_in and keep the results (use with
         forward(text_cache=True) while the prompts do not change)."""
         for blk in self.arch.down + [self.arch.mid] + self.arch.up:
             for a in blk.attns:
                 if a is None:
                     continue
-                xf = self.xfs[a.prefix]
-                buf = self.text_cache.get(a.prefix)
-                if buf is None:
-                    buf = self.text_cache[a.prefix] = self._buf(self.B * self.S, 2 * a.channels)
-                ops.gemm(self.text_in.view(self.B * self.S, -1), xf.w_kv2, buf, workspace=self.ws_split)
+                bufs = self.text_cache.get(a.prefix)
+                if bufs is None:
+                    bufs = self.text_cache[a.prefix] = (self._buf(self.B * self.Sp, a.channels),
+                                                        self._buf(a.channels, self.B * self.Sp))
+                self._project_text(self.xfs[a.prefix], *bufs)
 
     def _transformer(self, xf: _Xf, x: torch.Tensor, out: Optional[torch.Tensor], lvl: int, text: torch.Tensor,
                      harvest: Optional[HarvestPlan], consume: bool, text_cache: bool = False, stop_after_harvest: bool = False):
@@ -306,11 +328,12 @@ class UNetEngine:
         ops.gemm(L["gn"], xf.w_in, h0, bias=xf.b_in, workspace=ws)                        # proj_in :101
         # --- self-attention :250-262
         ops.layernorm(h0, *xf.ln["norm1"], L["ln"])
-        qkv = L["qkv"]
-        ops.gemm(L["ln"], xf.w_qkv1, qkv, workspace=ws)
-        q3d = qkv.view(B, hw, 3 * C)
+        qk, vt = L["qk"], L["vt"]
+        ops.gemm(L["ln"], xf.w_qk1, qk, workspace=ws)
+        ops.gemm(xf.w_v1, L["ln"], vt, workspace=ws)                                      # VT[C, B*hw] = Wv . X^T
+        qk3 = qk.view(B, hw, 2 * C)
         att = L["att"]
-        ops.attention(q3d[:, :, :C], q3d[:, :, C:2 * C], q3d[:, :, 2 * C:], att.view(B, hw, C), heads, scale)
+        ops.attention(qk3[:, :, :C], qk3[:, :, C:], vt.view(C, B, hw).permute(1, 0, 2), att.view(B, hw, C), heads, scale)
         h1 = L["h1"]
         ops.gemm(att, xf.w_o1, h1, bias=xf.b_o1, res1=h0, workspace=ws)
         if harvest is not None:                                                           # feature :263, written in place
@@ -327,20 +350,24 @@ class UNetEngine:
         else:
             ops.layernorm(h1, *xf.ln["norm2"], L["ln"])
         ops.gemm(L["ln"], xf.w_q2, L["q"], workspace=ws)
-        kv3d = self._text_kv(xf, lvl, text, text_cache).view(B, S, 2 * C)
-        ops.attention(L["q"].view(B, hw, C), kv3d[:, :, :C], kv3d[:, :, C:], att.view(B, hw, C), heads, scale)
+        kt3, vtt3 = self._text_kv(xf, lvl, text_cache)
+        ops.attention(L["q"].view(B, hw, C), kt3, vtt3, att.view(B, hw, C), heads, scale, nk=S)
         if consume:
             ht = L["h2"]
             ops.gemm(att, xf.w_o2, ht, bias=xf.b_o2, res1=h1, workspace=ws)               # h_t = a2 + h   :277
             ctx = self.ctx[xf.spec.feature_key]
             rows, nk = ctx.shape[0], ctx.shape[1]
             ops.gemm(L["ln4"], xf.w_q3, L["q"], workspace=ws)
-            kvi = L["kvi"]
-            ops.gemm(ctx.view(rows * nk, C), xf.w_kv3, kvi, workspace=ws)
-            kvi3 = kvi.view(rows, nk, 2 * C)
+            ki, vti = L["ki"], L["vti"]
+            ops.gemm(ctx.view(rows * nk, C), xf.w_k3, ki, workspace=ws)
+            ops.gemm(xf.w_v3, ctx.view(rows * nk, C), vti, workspace=ws)                  # VT[C, rows*nk]
+            ki3, vti3 = ki.view(rows, nk, C), vti.view(C, rows, nk).permute(1, 0, 2)
             q3, a3 = L["q"].view(B, hw, C), att.view(B, hw, C)
-            for q0, n, c0 in self.attn3_groups:
-                ops.attention(q3[q0:q0 + n], kvi3[c0:c0 + n, :, :C], kvi3[c0:c0 + n, :, C:], a3[q0:q0 + n], heads, scale)
+            if self.attn3_share is not None:      # one launch: batch b reads context row b (b < rows) or b - (B - rows)
+                ops.attention(q3, ki3, vti3, a3, heads, scale)
+            else:
+                for q0, n, c0 in self.attn3_groups:
+                    ops.attention(q3[q0:q0 + n], ki3[c0:c0 + n], vti3[c0:c0 + n], a3[q0:q0 + n], heads, scale)
             h3 = L["h3"]
             ops.gemm(att, xf.w_o3, h3, bias=xf.b_o3, res1=h1, res2=ht, workspace=ws)      # (a3 + h) + h_t :291-293
         else:

@@ -1,0 +1,199 @@
+"""Drop-in for `model.pipeline.StableDiffusionPipeline` of the reference (/root/reference/model/pipeline.py:29-491).
+
+Same constructor (vae, text_encoder, tokenizer, unet, scheduler) and `__call__` signature (:274-294).  The plumbing
+on either side of the loop — prompt encoding (:87-196), VAE encoding of the prior frames (:387-404), latent
+preparation (:235-271), VAE decoding (:198-205) — runs on whatever stock PyTorch modules the caller passes, exactly as
+in the reference; the per-step loop body (:412-461) is the HIP sampler (storygen_amd/sampler.py): one hipGraph replay
+per step.
+
+Deliberate differences from the reference, none of which changes latents:
+  * the `callback(i, t, latents)` index is the step index (the reference passes the last prior-frame index because its
+    inner loop variable shadows `i`, pipeline.py:412,418 — SURVEY F6f);
+  * `guidance_scale <= 1` raises (the reference's non-CFG branch passes a list where a tensor is required and cannot
+    run, :430 — SURVEY F6g);
+  * only DDIM-style schedulers are supported (the reference ships a DDIM loop, inference.py:48); `scheduler` may be a
+    storygen_amd.scheduler.DDIMSchedule or any object whose `.config` carries the DDIM keys.
+"""
+from __future__ import annotations
+
+from collections import namedtuple
+from typing import Callable, List, Optional, Union
+
+import torch
+
+from ..sampler import STAGES, StoryGenSampler
+from ..scheduler import DDIMSchedule
+
+StableDiffusionPipelineOutput = namedtuple("StableDiffusionPipelineOutput", ["images", "nsfw_content_detected"])
+
+
+def _as_schedule(scheduler) -> DDIMSchedule:
+    if isinstance(scheduler, DDIMSchedule):
+        return scheduler
+    cfg = getattr(scheduler, "config", None)
+    if cfg is None:
+        raise TypeError("scheduler must be a DDIMSchedule or expose a diffusers-style .config")
+    keys = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "steps_offset", "set_alpha_to_one",
+            "clip_sample", "trained_betas")
+    return DDIMSchedule(**{k: cfg[k] for k in keys if k in cfg})
+
+
+class StableDiffusionPipeline:
+    def __init__(self, vae, text_encoder, tokenizer, unet, scheduler):
+        self.vae, self.text_encoder, self.tokenizer, self.unet, self.scheduler = vae, text_encoder, tokenizer, unet, scheduler
+        boc = getattr(getattr(vae, "config", None), "block_out_channels", (128, 256, 512, 512))
+        self.vae_scale_factor = 2 ** (len(boc) - 1)                                       # :76
+        self._sampler: Optional[StoryGenSampler] = None
+        self._sampler_key = None
+
+    # --------------------------------------------------------------------------------------------- plumbing
+    @property
+    def _execution_device(self) -> torch.device:
+        return self.unet.device
+
+    def enable_xformers_memory_efficient_attention(self, attention_op=None):   # inference.py:60
+        pass
+
+    def disable_xformers_memory_efficient_attention(self):
+        pass
+
+    def enable_vae_slicing(self):
+        if hasattr(self.vae, "enable_slicing"):
+            self.vae.enable_slicing()
+
+    def disable_vae_slicing(self):
+        if hasattr(self.vae, "disable_slicing"):
+            self.vae.disable_slicing()
+
+    def save_pretrained(self, save_directory: str, **kwargs):
+        """Only the UNet is this package's to write (diffusers folder layout, `unet/`)."""
+        import os
+        self.unet.save_pretrained(os.path.join(save_directory, "unet"), **kwargs)
+
+    def check_inputs(self, prompt, height, width, callback_steps):                        # :223-233
+        if not isinstance(prompt, str) and not isinstance(prompt, list):
+            raise ValueError(f"`prompt` has to be of type `str` or `list` but is {type(prompt)}")
+        if height % 8 != 0 or width % 8 != 0:
+            raise ValueError(f"`height` and `width` have to be divisible by 8 but are {height} and {width}.")
+        if callback_steps is None or not isinstance(callback_steps, int) or callback_steps <= 0:
+            raise ValueError(f"`callback_steps` has to be a positive integer but is {callback_steps} of type {type(callback_steps)}.")
+
+    def _embed(self, prompts: List[str], device, max_length=None) -> torch.Tensor:
+        tok = self.tokenizer(prompts, padding="max_length", max_length=max_length or self.tokenizer.model_max_length,
+                             truncation=True, return_tensors="pt")
+        cfg = getattr(self.text_encoder, "config", None)
+        mask = tok.attention_mask.to(device) if getattr(cfg, "use_attention_mask", False) else None
+        return self.text_encoder(tok.input_ids.to(device), attention_mask=mask)[0]
+
+    def _encode_prompt(self, prompt, device, num_images_per_prompt, do_classifier_free_guidance, negative_prompt):
+        """[uncond | text] embeddings, each repeated per image (:87-196)."""
+        prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+        text = self._embed(prompts, device).repeat_interleave(num_images_per_prompt, dim=0)
+        if not do_classifier_free_guidance:
+            return text
+        if negative_prompt is None:
+            neg = [""] * len(prompts)
+        elif type(prompt) is not type(negative_prompt):
+            raise TypeError(f"`negative_prompt` should be the same type to `prompt`, but got {type(negative_prompt)} != {type(prompt)}.")
+        elif isinstance(negative_prompt, str):
+            neg = [negative_prompt]
+        elif len(negative_prompt) != len(prompts):
+            raise ValueError(f"`negative_prompt`: {negative_prompt} has batch size {len(negative_prompt)}, but `prompt`: {prompt} "
+                             f"has batch size {len(prompts)}. Please make sure that passed `negative_prompt` matches the batch size of `prompt`.")
+        else:
+            neg = list(negative_prompt)
+        uncond = self._embed(neg, device, max_length=text.shape[1]).repeat_interleave(num_images_per_prompt, dim=0)
+        return torch.cat([uncond, text])
+
+    def prepare_latents(self, batch_size, num_channels_latents, height, width, dtype, device, generator, latents=None):
+        shape = (batch_size, num_channels_latents, height // self.vae_scale_factor, width // self.vae_scale_factor)   # :235-271
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective batch"
+                             f" size of {batch_size}. Make sure the batch size matches the length of the generators.")
+        if latents is None:
+            if isinstance(generator, list):
+                latents = torch.cat([torch.randn((1,) + shape[1:], generator=g, device=g.device, dtype=dtype).to(device)
+                                     for g in generator])
+            else:
+                gdev = generator.device if generator is not None else device
+                latents = torch.randn(shape, generator=generator, device=gdev, dtype=dtype).to(device)
+        else:
+            if latents.shape != shape:
+                raise ValueError(f"Unexpected latents shape, got {latents.shape}, expected {shape}")
+            latents = latents.to(device)
+        return latents
+
+    def decode_latents(self, latents):                                                   # :198-205
+        image = self.vae.decode(latents / 0.18215).sample
+        image = (image / 2 + 0.5).clamp(0, 1)
+        return image.cpu().permute(0, 2, 3, 1).float().numpy()
+
+    @staticmethod
+    def numpy_to_pil(images):
+        from PIL import Image
+        if images.ndim == 3:
+            images = images[None]
+        return [Image.fromarray((im * 255).round().astype("uint8")) for im in images]
+
+    # --------------------------------------------------------------------------------------------- the call
+    @torch.no_grad()
+    def __call__(self, stage: str, prompt: Union[str, List[str]], image_prompt: Optional[torch.Tensor] = None,
+                 prev_prompt: Optional[List[Union[str, List[str]]]] = None, height: Optional[int] = None,
+                 width: Optional[int] = None, num_inference_steps: int = 50, guidance_scale: float = 7.5,
+                 image_guidance_scale: float = 3.5, negative_prompt: Optional[Union[str, List[str]]] = None,
+                 num_images_per_prompt: Optional[int] = 1, eta: float = 0.0,
+                 generator: Optional[Union[torch.Generator, List[torch.Generator]]] = None,
+                 latents: Optional[torch.Tensor] = None, output_type: Optional[str] = "pil", return_dict: bool = True,
+                 callback: Optional[Callable[[int, int, torch.Tensor], None]] = None, callback_steps: Optional[int] = 1):
+        height = height or self.unet.config.sample_size * self.vae_scale_factor           # :347-348
+        width = width or self.unet.config.sample_size * self.vae_scale_factor
+        self.check_inputs(prompt, height, width, callback_steps)
+        if stage not in STAGES:
+            raise ValueError(f"stage must be one of {STAGES}")
+        if eta != 0.0:
+            raise NotImplementedError("eta != 0 (stochastic DDIM) is not on the StoryGen path")
+        batch_size = 1 if isinstance(prompt, str) else len(prompt)
+        device = self._execution_device
+        if not guidance_scale > 1.0:
+            raise ValueError("guidance_scale must be > 1: the reference loop only works with classifier-free guidance")
+        n = batch_size * num_images_per_prompt
+        emb = self._encode_prompt(prompt, device, num_images_per_prompt, True, negative_prompt)       # :359
+        uncond, text = emb[:n], emb[n:]
+        prev = [self._encode_prompt(p, device, num_images_per_prompt, True, negative_prompt) for p in prev_prompt]   # :361-362
+        dtype = text.dtype
+        latents = self.prepare_latents(n, self.unet.in_channels, height, width, dtype, device, generator, latents)   # :372-381
+        image_prompt = image_prompt.to(device=device, dtype=dtype)                        # [B, R, 3, H, W]  :387
+        frames = image_prompt.transpose(0, 1)
+        R = frames.shape[0]
+        if len(prev) != R:
+            raise ValueError(f"{R} prior frames but {len(prev)} previous prompts")
+        zero = self.vae.encode(frames[0] * 0).latent_dist.sample() * 0.18215              # :390-393
+        zero = zero.repeat(num_images_per_prompt, 1, 1, 1)
+        imgs = torch.stack([(self.vae.encode(f).latent_dist.sample() * 0.18215).repeat(num_images_per_prompt, 1, 1, 1)
+                            for f in frames])                                             # :397-404
+        noise = torch.randn_like(imgs[0])                                                 # :409 (global generator)
+        inputs = dict(latents=latents, image_prompts=imgs, zero_prompt=zero, noise=noise, text=text, uncond=uncond,
+                      prev_text=torch.stack([p[n:] for p in prev]), prev_uncond=torch.stack([p[:n] for p in prev]))
+        h, w = latents.shape[-2:]
+        key = (n, h, w, R, text.shape[1], id(getattr(self.unet, "_weights", None)))
+        wts = self.unet._engine_weights()
+        if self._sampler is None or self._sampler_key != key:
+            self._sampler = StoryGenSampler(self.unet._arch, None, device, n, h, w, R, text.shape[1],
+                                            schedule=_as_schedule(self.scheduler), weights=wts)
+            self._sampler_key = key
+        smp = self._sampler
+        smp.prepare(inputs, num_inference_steps, stage, guidance_scale, image_guidance_scale)
+        for i, t in enumerate(smp.timesteps):                                             # :411-469
+            smp.step(i)
+            if callback is not None and i % callback_steps == 0:
+                callback(i, t, smp.latents.to(dtype))
+        latents = smp.latents.to(dtype)
+        if output_type == "latent":
+            image = latents
+        else:
+            image = self.decode_latents(latents)                                          # :472
+            if output_type == "pil":
+                image = self.numpy_to_pil(image)
+        if not return_dict:
+            return (image, None)
+        return StableDiffusionPipelineOutput(images=image, nsfw_content_detected=None)

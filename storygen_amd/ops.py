@@ -204,22 +204,28 @@ def conv_out(x: torch.Tensor, w_krsc: torch.Tensor, bias: torch.Tensor, out_nchw
     return out_nchw
 
 
-def attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, heads: int, scale: float
-              ) -> torch.Tensor:
-    """q [B,Nq,H*D], k/v [B,Nk,H*D] (token- and batch-strided views allowed), out [B,Nq,H*D]."""
-    for n, t in (("q", q), ("k", k), ("v", v), ("out", out)):
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, heads: int, scale: float,
+              nk: Optional[int] = None) -> torch.Tensor:
+    """q [B,Nq,H*D], k [Bk,Nk',H*D] (token- and batch-strided views allowed), vt [Bk,H*D,Nk''] = V transposed (keys
+    contiguous; rows finite up to nk rounded up to 8), out [B,Nq,H*D].  nk = number of valid keys (default k.shape[1]).
+    Bk < B: query batch b uses K/V batch (b if b < Bk else b - (B - Bk))."""
+    for n, t in (("q", q), ("k", k), ("vt", vt), ("out", out)):
         _f16(t, n)
         if t.dim() != 3 or t.stride(-1) != 1:
-            raise ValueError(f"attention: {n} must be [B,N,C] with contiguous channels")
+            raise ValueError(f"attention: {n} must be 3-D with a contiguous last dimension")
     B, Nq, Cq = q.shape
-    Nk = k.shape[1]
+    Bk = k.shape[0]
+    Nk = k.shape[1] if nk is None else nk
     D = Cq // heads
+    if vt.shape[0] != Bk or vt.shape[1] != Cq or k.shape[2] != Cq or Nk > k.shape[1] or vt.shape[2] < ((Nk + 7) & ~7):
+        raise ValueError(f"attention: k {tuple(k.shape)} / vt {tuple(vt.shape)} do not match q {tuple(q.shape)}, nk={Nk}")
     d = AttnDesc()
     d.q, d.ldq, d.bsq = q.data_ptr(), q.stride(1), q.stride(0)
     d.k, d.ldk, d.bsk = k.data_ptr(), k.stride(1), k.stride(0)
-    d.v, d.ldv, d.bsv = v.data_ptr(), v.stride(1), v.stride(0)
+    d.vt, d.ldvt, d.bsvt = vt.data_ptr(), vt.stride(1), vt.stride(0)
     d.o, d.ldo, d.bso = out.data_ptr(), out.stride(1), out.stride(0)
     d.B, d.H, d.Nq, d.Nk, d.D = B, heads, Nq, Nk, D
+    d.kv_batches = Bk
     d.scale = scale
     with _timed(f"attention_d{D}", 4.0 * B * heads * Nq * Nk * D, f"B{B} H{heads} Nq{Nq} Nk{Nk}"):
         check(lib.sg_attn_fwd_f16(C.byref(d), _stream()), "sg_attn_fwd_f16")

@@ -111,9 +111,9 @@ def test_host_validation_rejects_before_launch(lib):
     c.Cin, c.stride = 64, 3
     assert lib.sg_conv3x3_nhwc_f16(C.byref(c), None) == -1
     a = AttnDesc()
-    a.q = a.k = a.v = a.o = 0x1000
+    a.q = a.k = a.vt = a.o = 0x1000
     a.B, a.H, a.Nq, a.Nk, a.D = 1, 8, 64, 64, 64
-    a.ldq = a.ldk = a.ldv = a.ldo = 512
+    a.ldq = a.ldk = a.ldvt = a.ldo = 512
     assert lib.sg_attn_fwd_f16(C.byref(a), None) == -2                   # SG_EUNSUP: head dim
     assert b"head dim" in lib.sg_last_error()
     g = GroupNormDesc()

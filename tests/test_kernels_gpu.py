@@ -188,6 +188,14 @@ def test_conv3x3_padded_input_all_tiles(gpu, tile, B, H, W, Cin, Cout, stride, u
     check(out.permute(0, 3, 1, 2), ref, "conv3x3 padded", l2=2e-6, mx=2e-5)
 
 
+def _vt(v):
+    """[B, Nk, C] -> the kernel's V^T operand [B, C, Nk rounded up to 8] (zero padding, as the engine's GEMM produces)."""
+    B, Nk, C = v.shape
+    vt = torch.zeros(B, C, (Nk + 7) & ~7, dtype=v.dtype, device=v.device)
+    vt[:, :, :Nk] = v.transpose(1, 2)
+    return vt
+
+
 ATTN_CASES = [
     # B, H, Nq, Nk, D
     (2, 8, 256, 256, 40), (1, 8, 200, 77, 40), (3, 8, 64, 192, 160), (2, 8, 256, 768, 80), (1, 8, 1024, 1024, 80),
@@ -205,7 +213,7 @@ def test_attention(gpu, B, H, Nq, Nk, D):
     q, k, v = qkv[:, :, :C], kv[:, :, :C], kv[:, :, C:]
     scale = D ** -0.5
     out = torch.empty(B, Nq, C, dtype=torch.float16, device=gpu)
-    ops.attention(q, k, v, out, H, scale)
+    ops.attention(q, k, _vt(v), out, H, scale, nk=Nk)
 
     def heads(t):
         return t.float().view(t.shape[0], t.shape[1], H, D).transpose(1, 2)
@@ -223,12 +231,48 @@ def test_attention_online_softmax_rescale(gpu):
     k[0, 300] = q[0, 5] * 6.0          # spike: raw q.k is ~40 * 6 vs O(6) elsewhere
     k[0, 450] = q[0, 77] * 8.0
     out = torch.empty(B, Nq, C, dtype=torch.float16, device=gpu)
-    ops.attention(q, k, v, out, H, D ** -0.5)
+    ops.attention(q, k, _vt(v), out, H, D ** -0.5)
 
     def heads(t):
         return t.float().view(B, -1, H, D).transpose(1, 2)
     ref = (torch.softmax(heads(q) @ heads(k).transpose(-1, -2) * D ** -0.5, -1) @ heads(v)).transpose(1, 2).reshape(B, Nq, C)
     check(out, ref, "attention rescale")
+
+
+def test_attention_deferred_rescale_threshold(gpu):
+    """Row maxima that creep up by less than the rescale threshold per tile (so the kernel keeps a stale running max
+    and P exceeds 1) and then jump far above it."""
+    from storygen_amd import ops
+    B, H, Nq, Nk, D = 1, 8, 64, 640, 40
+    C = H * D
+    q, k, v = rnd((B, Nq, C), gpu, seed=4), rnd((B, Nk, C), gpu, 0.2, seed=5), rnd((B, Nk, C), gpu, seed=6)
+    qh = q.view(B, Nq, H, D)
+    for tile in range(1, 10):                   # key tile*64 + 3 aligned with query 7: score grows ~ +2.5 log2 units per tile
+        k.view(B, Nk, H, D)[0, tile * 64 + 3] = qh[0, 7] * (0.28 * tile)
+    out = torch.empty(B, Nq, C, dtype=torch.float16, device=gpu)
+    ops.attention(q, k, _vt(v), out, H, D ** -0.5)
+
+    def heads(t):
+        return t.float().view(B, -1, H, D).transpose(1, 2)
+    ref = (torch.softmax(heads(q) @ heads(k).transpose(-1, -2) * D ** -0.5, -1) @ heads(v)).transpose(1, 2).reshape(B, Nq, C)
+    check(out, ref, "attention deferred rescale")
+
+
+@pytest.mark.parametrize("D,Nq,Nk", [(40, 4096, 640), (80, 200, 77), (160, 64, 192)])
+def test_attention_shared_kv_batches(gpu, D, Nq, Nk):
+    """Query batches [u/zero, u/img, t/img] over context rows [zero, img]: batch 2 reads K/V row 1 (kv_batches = 2)."""
+    from storygen_amd import ops
+    H = 8
+    C = H * D
+    q, k, v = rnd((3, Nq, C), gpu, 1.5, seed=1), rnd((2, Nk, C), gpu, 1.5, seed=2), rnd((2, Nk, C), gpu, seed=3)
+    out = torch.empty(3, Nq, C, dtype=torch.float16, device=gpu)
+    ops.attention(q, k, _vt(v), out, H, D ** -0.5, nk=Nk)
+    idx = [0, 1, 1]
+
+    def heads(t):
+        return t.float().view(t.shape[0], t.shape[1], H, D).transpose(1, 2)
+    att = torch.softmax(heads(q) @ heads(k[idx]).transpose(-1, -2) * D ** -0.5, dim=-1) @ heads(v[idx])
+    check(out, att.transpose(1, 2).reshape(3, Nq, C), "attention shared kv")
 
 
 @pytest.mark.parametrize("B,HW,C,silu,eps", [(3, 256, 320, True, 1e-5), (2, 64, 1920, True, 1e-5), (1, 100, 2560, False, 1e-6),
@@ -369,4 +413,4 @@ def test_abi_rejects_bad_arguments(gpu):
         ops.gemm(a, w, torch.empty(64, 64, dtype=torch.float16, device=gpu))
     q = rnd((1, 64, 8 * 48), gpu)
     with pytest.raises(RuntimeError, match="head dim"):
-        ops.attention(q, q, q, torch.empty_like(q), 8, 1.0)
+        ops.attention(q, q, q.transpose(1, 2).contiguous(), torch.empty_like(q), 8, 1.0)

@@ -37,14 +37,14 @@ def _ref_and_main_inputs(inputs, sched, t_main):
     return ref_t, x, e, xm, em
 
 
-def test_unet_passes_vs_oracle_16x16(gpu, sd15):
-    """SD-1.5 architecture at a 16x16 latent (2 prior frames): harvest pass features + eps, then the main pass that
+def test_unet_passes_vs_oracle_32x32(gpu, sd15):
+    """SD-1.5 architecture at a 32x32 latent (2 prior frames): harvest pass features + eps, then the main pass that
     consumes them, HIP vs the oracle run live on the host (the reference itself cannot run this size)."""
     from oracle import storygen_oracle as O
     from storygen_amd.engine import UNetEngine
     from storygen_amd.synth import synthetic_inputs
     arch, sd = sd15
-    cfg, hw, R = arch.config, 16, 2
+    cfg, hw, R = arch.config, 32, 2
     inputs = synthetic_inputs(1, R, hw, hw, 1, cfg["cross_attention_dim"])
     sched = O.DDIM()
     t_main = sched.timesteps(5)[0]
@@ -135,26 +135,26 @@ def test_graph_replay_matches_eager(gpu, sd15):
     from storygen_amd.sampler import StoryGenSampler
     from storygen_amd.synth import synthetic_inputs
     arch, sd = sd15
-    inputs = synthetic_inputs(1, 2, 16, 16, 5, arch.config["cross_attention_dim"])
+    inputs = synthetic_inputs(1, 2, 32, 32, 5, arch.config["cross_attention_dim"])
     outs = []
     for use_graph in (False, True):
-        smp = StoryGenSampler(arch, sd, gpu, 1, 16, 16, 2, use_graph=use_graph)
+        smp = StoryGenSampler(arch, sd, gpu, 1, 32, 32, 2, use_graph=use_graph)
         smp.prepare(inputs, 4, "auto-regressive", 7.5, 3.5)
         outs.append(smp.run().clone())
         torch.cuda.synchronize()
     assert torch.equal(outs[0], outs[1])
 
 
-def test_loop_vs_oracle_both_stages_16x16(gpu, sd15):
+def test_loop_vs_oracle_both_stages_32x32(gpu, sd15):
     """The whole loop (R=2, first 3 steps of the 50-step schedule BASELINE config 2 uses — the 1e-3 latent bar is
     stated for that schedule: a coarser one multiplies the same epsilon error by a larger DDIM coefficient) in both
-    stages against the oracle loop at 16x16."""
+    stages against the oracle loop at 32x32."""
     from oracle import storygen_oracle as O
     from storygen_amd.sampler import StoryGenSampler
     from storygen_amd.synth import synthetic_inputs
     arch, sd = sd15
-    inputs = synthetic_inputs(1, 2, 16, 16, 7, arch.config["cross_attention_dim"])
-    smp = StoryGenSampler(arch, sd, gpu, 1, 16, 16, 2, use_graph=True)
+    inputs = synthetic_inputs(1, 2, 32, 32, 7, arch.config["cross_attention_dim"])
+    smp = StoryGenSampler(arch, sd, gpu, 1, 32, 32, 2, use_graph=True)
     for stage in ("multi-image-condition", "auto-regressive"):
         want = []
         O.sample_loop(sd, arch.config, inputs, 50, stage, 7.5, 3.5, max_steps=3, trace=want)
@@ -178,11 +178,11 @@ def test_dedup_of_identical_reference_samples_is_equivalent(gpu, sd15, stage):
     from storygen_amd.sampler import StoryGenSampler
     from storygen_amd.synth import synthetic_inputs
     arch, sd = sd15
-    inputs = synthetic_inputs(1, 2, 16, 16, 9, arch.config["cross_attention_dim"])
+    inputs = synthetic_inputs(1, 2, 32, 32, 9, arch.config["cross_attention_dim"])
     wts = EngineWeights(arch, sd, gpu)
     outs = []
     for dedup in (True, False):
-        smp = StoryGenSampler(arch, None, gpu, 1, 16, 16, 2, use_graph=False, dedup=dedup, weights=wts)
+        smp = StoryGenSampler(arch, None, gpu, 1, 32, 32, 2, use_graph=False, dedup=dedup, weights=wts)
         smp.prepare(inputs, 50, stage, 7.5, 3.5)
         assert smp.U == ((3 if stage == "multi-image-condition" else 4) if dedup else 6)
         outs.append(smp.run(max_steps=2).clone().cpu())
@@ -197,9 +197,9 @@ def test_distinct_prev_uncond_disables_zero_sharing(gpu, sd15):
     from storygen_amd.sampler import StoryGenSampler
     from storygen_amd.synth import synthetic_inputs
     arch, sd = sd15
-    inputs = synthetic_inputs(1, 2, 16, 16, 9, arch.config["cross_attention_dim"])
+    inputs = synthetic_inputs(1, 2, 32, 32, 9, arch.config["cross_attention_dim"])
     inputs["prev_uncond"] = inputs["prev_uncond"].clone()
     inputs["prev_uncond"][1] += 0.25
-    smp = StoryGenSampler(arch, sd, gpu, 1, 16, 16, 2, use_graph=False)
+    smp = StoryGenSampler(arch, sd, gpu, 1, 32, 32, 2, use_graph=False)
     smp.prepare(inputs, 50, "multi-image-condition", 7.5, 3.5)
     assert smp.U == 4
