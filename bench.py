@@ -111,6 +111,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-dedup", action="store_true", help="run all 3R reference samples as written")
+    ap.add_argument("--no-overlap", action="store_true", help="one stream: reference pass, then main pass")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -136,7 +137,8 @@ def main():
     arch = build_arch(SD15_CONFIG)
     sd = synthetic_state_dict(arch, 0)
     inputs = synthetic_inputs(N_PER_GPU, R, HW, HW, seed=rank, cross_attention_dim=arch.config["cross_attention_dim"])
-    sampler = StoryGenSampler(arch, sd, dev, N_PER_GPU, HW, HW, R, use_graph=not args.no_graph, dedup=not args.no_dedup)
+    sampler = StoryGenSampler(arch, sd, dev, N_PER_GPU, HW, HW, R, use_graph=not args.no_graph, dedup=not args.no_dedup,
+                              overlap=not args.no_overlap)
     n_sched = max(T, args.steps + args.warmup)
     sampler.prepare(inputs, n_sched, "multi-image-condition", 7.5, 3.5)
 
@@ -175,7 +177,8 @@ def main():
             "config": {"workload": "BASELINE configs[1]: StoryGen denoising loop, 512x512 (64x64x4 latent), R=3 prior "
                                    "frames, CFG batch 3, DDIM, SD-1.5 UNet + attn3 (909M params, synthetic fp16 weights)",
                        "samples_per_gpu": N_PER_GPU, "parallelism": f"dp{world} (one sample per GPU, final all-gather)",
-                       "hipgraph": not args.no_graph, "dedup_identical_reference_samples": not args.no_dedup},
+                       "hipgraph": not args.no_graph, "dedup_identical_reference_samples": not args.no_dedup,
+                       "overlap_ref_pass_of_next_step": sampler.overlap},
             "tflop_per_step_as_written": round(STEP_TFLOP, 3),
             "final_allgather_ms": round(gather_ms, 3), "latents_finite": finite,
         }

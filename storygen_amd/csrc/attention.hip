@@ -89,36 +89,52 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     const f16* VT = p.vt + (long)kvb * p.bsvt + (long)h * D * p.ldvt;
     const int nkp8 = (p.Nk + 7) & ~7;           // VT rows hold finite data up to here (host contract)
 
-    // ---- per-lane DMA source coordinates of this wave's segments (segment g = i*NW + wave)
+    // ---- per-lane DMA source coordinates of this wave's segments (segment g = i*NW + wave).  off = 32-bit element
+    // offset from the (wave-uniform) tile origin, so the loads can use an SGPR base + VGPR offset.
     int c_row[MAXL], c_col[MAXL];               // K: key within tile, chunk*8 | VT: d*ldvt, chunk*8
+    unsigned off[MAXL];
 #pragma unroll
     for (int i = 0; i < MAXL; ++i) {
         const int g = i * NW + wave;
         c_row[i] = c_col[i] = 0;
+        off[i] = 0;
         if (g < K_SEG) {
             const int s = g * 64 + lane;        // linear 16-byte slot of the K image
             const int kl = s / DC, cs = s - kl * DC;
             c_row[i] = kl;
             c_col[i] = (cs ^ kswz<D>(kl)) * 8;
+            off[i] = (unsigned)(kl * (int)p.ldk + c_col[i]);
         } else if (g < NSEG) {
             const int s = (g - K_SEG) * 64 + lane;
             const int d = s >> 3, cs = s & 7;
             c_row[i] = d * (int)p.ldvt;
             c_col[i] = (cs ^ ((d >> 1) & 7)) * 8;
+            off[i] = (unsigned)(c_row[i] + c_col[i]);
         }
     }
     auto issue = [&](int tile, int stage) {
         const int key0 = tile * KVBLK;
         char* base = smem + stage * STAGE;
+        if (key0 + KVBLK <= p.Nk) {             // full tile: no clamping, uniform base + per-lane offset
+            const f16* Kt = K + (long)key0 * p.ldk;
+            const f16* Vt = VT + key0;
 #pragma unroll
-        for (int i = 0; i < MAXL; ++i) {
-            const int g = i * NW + wave;        // wave-uniform
-            if (g < K_SEG) {
-                const int key = min(key0 + c_row[i], p.Nk - 1);                 // tail rows: duplicates (finite)
-                glds16(K + (long)key * p.ldk + c_col[i], base + g * 1024);
-            } else if (g < NSEG) {
-                const int kc = min(key0 + c_col[i], nkp8 - 8);                  // tail chunks: duplicates (finite)
-                glds16(VT + c_row[i] + kc, base + g * 1024);
+            for (int i = 0; i < MAXL; ++i) {
+                const int g = i * NW + wave;    // wave-uniform
+                if (g < K_SEG) glds16(Kt + off[i], base + g * 1024);
+                else if (g < NSEG) glds16(Vt + off[i], base + g * 1024);
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < MAXL; ++i) {
+                const int g = i * NW + wave;
+                if (g < K_SEG) {
+                    const int key = min(key0 + c_row[i], p.Nk - 1);             // tail rows: duplicates (finite)
+                    glds16(K + (long)key * p.ldk + c_col[i], base + g * 1024);
+                } else if (g < NSEG) {
+                    const int kc = min(key0 + c_col[i], nkp8 - 8);              // tail chunks: duplicates (finite)
+                    glds16(VT + c_row[i] + kc, base + g * 1024);
+                }
             }
         }
     };
@@ -174,17 +190,16 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
 
         // ---- S^T = K Q^T for the two 32-key blocks
         f32x16 s[2];
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
-#pragma unroll
-            for (int r = 0; r < 16; ++r) s[kb][r] = 0.f;
             const int row = kb * 32 + prow;
             const char* krow = sK + row * KROW;
             const int sw = kswz<D>(row);
 #pragma unroll
             for (int st = 0; st < NDK; ++st) {
                 const f16x8 kf = *reinterpret_cast<const f16x8*>(krow + (((st * 2 + hi) ^ sw) << 4));
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], s[kb], 0, 0, 0);
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], st == 0 ? zero16 : s[kb], 0, 0, 0);   // C = inline 0
             }
         }
         // ---- online softmax: mask the key tail, row max (raw scores), deferred rescale, exponentiate

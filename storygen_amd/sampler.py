@@ -19,6 +19,12 @@ MI355X-first structure
   * The whole step is ONE hipGraph replayed per step; everything that changes between steps — timesteps, add_noise
     and DDIM coefficients — lives in a small device buffer refreshed by one async H2D copy from a pinned table.
     Latents stay fp32 across steps.
+  * The reference pass does not depend on the latents (its inputs are the prior frames noised to ref_t,
+    pipeline.py:414-427), only the main pass does.  With `overlap` (default, graph mode) the captured graph of step k
+    therefore has two concurrent branches on two HIP streams: the main pass of step k, reading context set k%2, and
+    the reference pass of step k+1, writing context set (k+1)%2.  Most kernels of either pass leave CUs idle at batch
+    1 (grids of 60-250 workgroups, latency-bound 5-20-slab pipelines), so the two branches fill each other's gaps;
+    the arithmetic and its order inside each pass are unchanged (the eager path runs the same kernels back to back).
 
 Data parallelism (SURVEY §8e): one process per GPU, each running its own samples with no per-step communication;
 `gather_latents` is the single RCCL all-gather of the final [N,4,h,w] latents.
@@ -41,7 +47,7 @@ class StoryGenSampler:
     def __init__(self, arch: UNetArch, state_dict: Optional[Dict[str, torch.Tensor]], device, n_samples: int = 1,
                  height: int = 64, width: int = 64, n_ref: int = 3, seq_len: int = 77,
                  schedule: Optional[DDIMSchedule] = None, use_graph: bool = True, dedup: bool = True,
-                 weights: Optional[EngineWeights] = None):
+                 weights: Optional[EngineWeights] = None, overlap: bool = True):
         if n_ref < 1:
             raise ValueError("StoryGen's loop needs at least one prior frame")
         self.arch, self.dev = arch, torch.device(device)
@@ -50,7 +56,9 @@ class StoryGenSampler:
         self.weights = weights if weights is not None else EngineWeights(arch, state_dict, device)
         self.schedule = schedule or DDIMSchedule()
         self.use_graph, self.dedup = use_graph, dedup
+        self.overlap = overlap and use_graph
         self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.graphs: List[torch.cuda.CUDAGraph] = []
         self.main: Optional[UNetEngine] = None
         self.ref: Optional[UNetEngine] = None
         self.layout = None
@@ -118,13 +126,18 @@ class StoryGenSampler:
         self.main = UNetEngine(self.arch, None, self.dev, self.B, self.h, self.w, self.R, self.S, ctx_rows=rows,
                                attn3_groups=groups, **kw)
         self.ref = UNetEngine(self.arch, None, self.dev, self.U, self.h, self.w, 0, self.S, **kw)
-        self.plan = HarvestPlan(self.main.ctx, hops)
+        # context sets: the main pass of step k reads set k%2 (only one set without overlap)
+        self.ctx_sets = [self.main.ctx]
+        if self.overlap:
+            self.ctx_sets.append({k: torch.empty_like(v) for k, v in self.main.ctx.items()})
+        self.plans = [HarvestPlan(c, hops) for c in self.ctx_sets]
+        self.plan = self.plans[0]
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.ref_src = torch.zeros((self.U,) + tuple(self.latents.shape[1:]), **f32)
         # per-step parameters: [U] ref timesteps | [B] main timestep | [U,2] add_noise coefs | [6] guidance + DDIM coefs
         self.n_par = 3 * self.U + self.B + 6
         self.params = torch.zeros(self.n_par, **f32)
-        self.layout, self.graph = key, None
+        self.layout, self.graph, self.graphs = key, None, []
 
     def _par_views(self):
         U, B = self.U, self.B
@@ -159,59 +172,105 @@ class StoryGenSampler:
         self.ref.cache_text_kv()
         # per-step table
         ts = self.schedule.timesteps(num_inference_steps)
-        rows = []
-        for t in ts:
+        def ref_part(t):
             ref_t = int(t) // 10                                                          # :414-415
             tis = [ref_t * (R - i) if stage == "auto-regressive" else ref_t for i in range(R)]   # :419-427
-            row: List[float] = [float(tis[i]) for _, i, _ in self.units]
-            row += [float(t)] * self.B
+            tt = [float(tis[i]) for _, i, _ in self.units]
+            cc: List[float] = []
             for _, i, _ in self.units:
-                row += list(self.schedule.add_noise_coef(tis[i]))
+                cc += list(self.schedule.add_noise_coef(tis[i]))
+            return tt, cc
+
+        rows = []
+        for k, t in enumerate(ts):
+            # overlap: graph k runs the main pass of step k next to the reference pass of step k+1
+            tt, cc = ref_part(ts[min(k + 1, len(ts) - 1)] if self.overlap else t)
+            row = tt + [float(t)] * self.B + cc
             row += [image_guidance_scale, guidance_scale, *self.schedule.step_coef(int(t), num_inference_steps)]
             rows.append(row)
         self.table = torch.tensor(rows, dtype=torch.float32).pin_memory()
+        tt, cc = ref_part(ts[0])
+        self.row0_ref = torch.tensor(tt + [float(ts[0])] * self.B + cc + [0.0] * 6, dtype=torch.float32).pin_memory()
         self.timesteps = ts
         self.num_steps = num_inference_steps
         self.k = 0
-        if self.use_graph and self.graph is None:
+        if self.use_graph and self.graph is None and not self.graphs:
             self._capture()
+        if self.overlap:
+            self._prime()
 
     # ------------------------------------------------------------------------------------------------ the step
     def _step_body(self):
-        ref, main = self.ref, self.main
-        t_ref, t_main, an, cd = self._par_views()
-        ops.add_noise(self.ref_src, self.noise, an, ref.x_in)                             # :419-429
-        ref.t_in.copy_(t_ref)
-        ref.forward(harvest=self.plan, harvest_only=True, text_cache=True)                # reference passes :418-438
-        main.x_in.copy_(self.latents3)                                                    # main pass :448-453
+        """One whole step, sequentially (eager mode, graph warm-up, bench instrumentation): reference passes :418-438,
+        then the main pass.  NB in overlap mode `self.params` holds the reference-pass scalars of the NEXT step."""
+        self._ref_pass(0)
+        self._main_pass(0)
+
+    def _ref_pass(self, ctx_set: int):
+        t_ref, _, an, _ = self._par_views()
+        ops.add_noise(self.ref_src, self.noise, an, self.ref.x_in)                        # :419-429
+        self.ref.t_in.copy_(t_ref)
+        self.ref.forward(harvest=self.plans[ctx_set], harvest_only=True, text_cache=True)
+
+    def _main_pass(self, ctx_set: int):
+        _, t_main, _, cd = self._par_views()
+        main = self.main
+        main.ctx = self.ctx_sets[ctx_set]
+        main.x_in.copy_(self.latents3)                                                    # :448-453
         main.t_in.copy_(t_main)
         eps3 = main.forward(consume=True, text_cache=True)
         ops.cfg_ddim_step(eps3, self.latents, self.latents3, cd)                          # :457-461
 
+    def _prime(self):
+        """Overlap mode: the reference pass of step 0 has no main pass to hide behind."""
+        self.params.copy_(self.row0_ref, non_blocking=True)
+        self._ref_pass(0)
+
     def _capture(self):
+        dev = self.dev
         self.params.copy_(self.table[0], non_blocking=True)
         saved = self.latents.clone()
-        s = torch.cuda.Stream(device=self.dev)
-        s.wait_stream(torch.cuda.current_stream(self.dev))
+        s = torch.cuda.Stream(device=dev)
+        s.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(s):
             self._step_body()                                                             # warm-up (also validates args)
-        torch.cuda.current_stream(self.dev).wait_stream(s)
-        torch.cuda.synchronize(self.dev)
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            self._step_body()
-        self.graph = g
+        torch.cuda.current_stream(dev).wait_stream(s)
+        torch.cuda.synchronize(dev)
+        if not self.overlap:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._step_body()
+            self.graph = g
+        else:
+            side = torch.cuda.Stream(device=dev)
+            self.graphs = []
+            for parity in (0, 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    cur = torch.cuda.current_stream(dev)
+                    side.wait_stream(cur)                                                 # fork
+                    with torch.cuda.stream(side):
+                        self._ref_pass(1 - parity)                                        # reference pass of step k+1
+                    self._main_pass(parity)                                               # main pass of step k
+                    cur.wait_stream(side)                                                 # join
+                self.graphs.append(g)
+        self.main.ctx = self.ctx_sets[0]
         self.latents.copy_(saved)
         self.latents3.copy_(torch.cat([saved] * 3))
-        torch.cuda.synchronize(self.dev)
+        torch.cuda.synchronize(dev)
 
     def step(self, k: Optional[int] = None):
         """Run denoising step k (default: the next one).  Asynchronous on the current stream."""
         k = self.k if k is None else k
         if self.table is None or k >= self.table.shape[0]:
             raise RuntimeError("prepare() first / no steps left")
+        if self.overlap and k != self.k:
+            raise RuntimeError("overlapped sampling runs the steps in order (the graph of step k also runs the reference "
+                               "pass of step k+1)")
         self.params.copy_(self.table[k], non_blocking=True)
-        if self.graph is not None:
+        if self.graphs:
+            self.graphs[k % 2].replay()
+        elif self.graph is not None:
             self.graph.replay()
         else:
             self._step_body()
