@@ -74,6 +74,8 @@ def in_situ_roofline(sampler):
     from storygen_amd import ops
     sink = []
     ops.PROFILE_SINK = sink
+    sides = (sampler.side_main, sampler.side_ref)
+    sampler.side_main = sampler.side_ref = None     # one stream: per-kernel durations without co-running neighbours
     try:
         sampler.params.copy_(sampler.table[min(sampler.k, sampler.table.shape[0] - 1)], non_blocking=True)
         # a GPU-side spin first, so the slower eager host stays ahead of the device and every kernel starts right
@@ -83,6 +85,7 @@ def in_situ_roofline(sampler):
         torch.cuda.synchronize()
     finally:
         ops.PROFILE_SINK = None
+        sampler.side_main, sampler.side_ref = sides
     fam = {}
     for name, flops, a, b, _shape in sink:
         f = fam.setdefault(name, {"launches": 0, "ms": 0.0, "gflop": 0.0})

@@ -188,19 +188,37 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
         const char* sK = smem + stage * STAGE;
         const char* sV = sK + K_BYTES;
 
-        // ---- S^T = K Q^T for the two 32-key blocks
+        // ---- S^T = K Q^T for the two 32-key blocks: all K fragments are requested first, so the LDS latency is paid once
         f32x16 s[2];
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        f16x8 kf[2][NDK];
 #pragma unroll
         for (int kb = 0; kb < 2; ++kb) {
             const int row = kb * 32 + prow;
             const char* krow = sK + row * KROW;
             const int sw = kswz<D>(row);
 #pragma unroll
-            for (int st = 0; st < NDK; ++st) {
-                const f16x8 kf = *reinterpret_cast<const f16x8*>(krow + (((st * 2 + hi) ^ sw) << 4));
-                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[st], st == 0 ? zero16 : s[kb], 0, 0, 0);   // C = inline 0
-            }
+            for (int st = 0; st < NDK; ++st)
+                kf[kb][st] = *reinterpret_cast<const f16x8*>(krow + (((st * 2 + hi) ^ sw) << 4));
+        }
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMAs (the scheduler would re-serialise them)
+#pragma unroll
+        for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+            for (int st = 0; st < NDK; ++st)
+                s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][st], qf[st], st == 0 ? zero16 : s[kb], 0, 0, 0);   // C = inline 0
+        // ---- V^T fragments of this tile are independent of the softmax: request them now so that their LDS latency
+        // hides behind the softmax VALU work (D <= 80: 32 / 48 VGPRs; D = 160 reads them per k-step instead)
+        constexpr bool VPRE = DT <= 3;
+        f16x8 vf[VPRE ? 4 : 1][DT];
+        if constexpr (VPRE) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int i = 0; i < DT; ++i) {
+                    const int d = min(i * 32 + l31, D - 1);      // rows >= D: duplicates, never stored
+                    vf[ks][i] = *reinterpret_cast<const f16x8*>(sV + d * 128 + (((ks * 2 + hi) ^ ((d >> 1) & 7)) << 4));
+                }
         }
         // ---- online softmax: mask the key tail, row max (raw scores), deferred rescale, exponentiate
         if ((tile + 1) * KVBLK > p.Nk) {
@@ -245,12 +263,16 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             f16x8 pf;
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[j] = (f16)s[ks >> 1][(ks & 1) * 8 + j];
+            if constexpr (!VPRE) {
 #pragma unroll
-            for (int i = 0; i < DT; ++i) {
-                const int d = min(i * 32 + l31, D - 1);          // rows >= D: duplicates, never stored
-                const f16x8 vf = *reinterpret_cast<const f16x8*>(sV + d * 128 + (((ks * 2 + hi) ^ ((d >> 1) & 7)) << 4));
-                oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf, oacc[i], 0, 0, 0);
+                for (int i = 0; i < DT; ++i) {
+                    const int d = min(i * 32 + l31, D - 1);
+                    vf[0][i] = *reinterpret_cast<const f16x8*>(sV + d * 128 + (((ks * 2 + hi) ^ ((d >> 1) & 7)) << 4));
+                }
             }
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+                oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[VPRE ? ks : 0][i], pf, oacc[i], 0, 0, 0);
         }
         if (++stage == S) stage = 0;
     }

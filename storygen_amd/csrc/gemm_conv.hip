@@ -132,45 +132,50 @@ __device__ __forceinline__ void tile_epilogue(const MmaParams& p, char* smem, f3
             }
         return;
     }
-    // ---- phase 1: accumulators -> LDS (fp32, [BM][BN])
+    // ---- fused epilogue through LDS, one 32-row band of every wave's sub-tile at a time (TM passes): the staging
+    // buffer is [WGM*32][BN] fp32 = BM*BN*4/TM bytes, so the epilogue never needs more LDS than the mainloop ring and
+    // small rings (S = 2) leave room for a second workgroup of another kernel on the same CU.
     float* sC = reinterpret_cast<float*>(smem);
+    constexpr int BR = WGM * 32;   // rows staged per pass
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int ip = 0; ip < TM; ++ip) {
+        if (ip) __syncthreads();   // previous band fully consumed
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = wn * WN + j * 32 + l31;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                sC[m * BN + n] = acc[i][j][r];
+                const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                sC[m * BN + n] = acc[ip][j][r];
             }
         }
-    __syncthreads();
-    // ---- phase 2: row-contiguous 8-column chunks, fused epilogue, 16-byte accesses
-    if (p.mode == SG_EPI_LINEAR) {
-        constexpr int NCH = BN / 8;
-        for (int idx = t; idx < BM * NCH; idx += NT) {
-            const int r = idx / NCH, ch = idx - r * NCH;
-            const int gm = m0 + r, gn = n0 + ch * 8;
-            if (gm >= p.M || gn >= p.N) continue;
-            const float4 v0 = *reinterpret_cast<const float4*>(sC + r * BN + ch * 8);
-            const float4 v1 = *reinterpret_cast<const float4*>(sC + r * BN + ch * 8 + 4);
-            float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-            epi_linear8(p, gm, gn, v);
-        }
-    } else {
-        constexpr int OCH = BN / 16;
-        for (int idx = t; idx < BM * OCH; idx += NT) {
-            const int r = idx / OCH, j = idx - r * OCH;
-            const int vcol = (j >> 2) * 64 + (j & 3) * 8;
-            const int gm = m0 + r, gv = n0 + vcol;
-            if (gm >= p.M || gv >= p.N) continue;
-            const float* s = sC + r * BN + vcol;
-            const float4 a0 = *reinterpret_cast<const float4*>(s), a1 = *reinterpret_cast<const float4*>(s + 4);
-            const float4 g0 = *reinterpret_cast<const float4*>(s + 32), g1 = *reinterpret_cast<const float4*>(s + 36);
-            float val[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            float gate[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-            epi_geglu8(p, gm, gv, val, gate);
+        __syncthreads();
+        // staged row lr belongs to wave-row lr / 32 -> tile row (lr / 32) * WM + ip * 32 + lr % 32
+        if (p.mode == SG_EPI_LINEAR) {
+            constexpr int NCH = BN / 8;
+            for (int idx = t; idx < BR * NCH; idx += NT) {
+                const int lr = idx / NCH, ch = idx - lr * NCH;
+                const int gm = m0 + (lr >> 5) * WM + ip * 32 + (lr & 31), gn = n0 + ch * 8;
+                if (gm >= p.M || gn >= p.N) continue;
+                const float4 v0 = *reinterpret_cast<const float4*>(sC + lr * BN + ch * 8);
+                const float4 v1 = *reinterpret_cast<const float4*>(sC + lr * BN + ch * 8 + 4);
+                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+                epi_linear8(p, gm, gn, v);
+            }
+        } else {
+            constexpr int OCH = BN / 16;
+            for (int idx = t; idx < BR * OCH; idx += NT) {
+                const int lr = idx / OCH, j = idx - lr * OCH;
+                const int vcol = (j >> 2) * 64 + (j & 3) * 8;
+                const int gm = m0 + (lr >> 5) * WM + ip * 32 + (lr & 31), gv = n0 + vcol;
+                if (gm >= p.M || gv >= p.N) continue;
+                const float* sp = sC + lr * BN + vcol;
+                const float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
+                const float4 g0 = *reinterpret_cast<const float4*>(sp + 32), g1 = *reinterpret_cast<const float4*>(sp + 36);
+                float val[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                float gate[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+                epi_geglu8(p, gm, gv, val, gate);
+            }
         }
     }
 }
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256) void mma_kernel(const MmaParams p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int EPI_BYTES = BM * BN * 4;
+    constexpr int EPI_BYTES = 2 * 32 * BN * 4;   // one 32-row band per wave-row (tile_epilogue)
     constexpr int SMEM = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
@@ -320,10 +325,10 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParam
     constexpr int NW = WGM * WGN, BM = 64 * WGM, BN = 64 * WGN;
     constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW), LPT = A_IT + B_IT;   // LDS-DMA instructions / lane / slab
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int EPI_BYTES = BM * BN * 4;
+    constexpr int EPI_BYTES = WGM * 32 * BN * 4;   // one 32-row band per wave-row (tile_epilogue)
     constexpr int SMEM = (S * STAGE > EPI_BYTES) ? S * STAGE : EPI_BYTES;
     constexpr int ISTR = NW * 1024;   // LDS bytes covered by one DMA instruction of the whole workgroup (8 rows / wave)
-    static_assert(S == 3 && (S - 2) * LPT < 64, "3 stages; vmcnt is a 6-bit counter");
+    static_assert((S == 2 || S == 3) && (S - 2) * LPT < 64, "2 or 3 stages; vmcnt is a 6-bit counter");
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -398,8 +403,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParam
 
     int stage = 0;
     for (int it = 0; it < nt; ++it) {
-        // one younger slab may stay in flight while we wait for slab `it`, except at the very end
-        if (it + 1 < nt) wait_vmcnt<LPT>();
+        // S = 3: one younger slab may stay in flight while we wait for slab `it`, except at the very end
+        if (S == 3 && it + 1 < nt) wait_vmcnt<LPT>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (it + S - 1 < nt) {
@@ -470,8 +475,9 @@ struct Plan { int bm, bn, splits; };
 // Development knobs (read once from the environment): SG_TILE="bm,bn" forces a tile shape, SG_NO_PIPE=1 disables
 // the LDS-DMA pipeline, SG_NO_SPLIT=1 disables automatic split-K.  Unset in production.
 struct Tune {
-    mutable int bm = 0, bn = 0, no_pipe = 0, no_split = 0;
+    mutable int bm = 0, bn = 0, no_pipe = 0, no_split = 0, stages = 0;
     Tune() {
+        if (const char* e = getenv("SG_STAGES")) stages = atoi(e);
         if (const char* e = getenv("SG_TILE")) sscanf(e, "%d,%d", &bm, &bn);
         if (const char* e = getenv("SG_NO_PIPE")) no_pipe = atoi(e);
         if (const char* e = getenv("SG_NO_SPLIT")) no_split = atoi(e);
@@ -519,8 +525,9 @@ Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool p
 }
 
 template <int WGM, int WGN, bool CONV>
-void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV>), grid, dim3(64 * WGM * WGN), 0, st, p);
+void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st, int stages) {
+    if (stages == 2) hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 2, CONV>), grid, dim3(64 * WGM * WGN), 0, st, p);
+    else hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV>), grid, dim3(64 * WGM * WGN), 0, st, p);
 }
 
 template <bool CONV>
@@ -544,13 +551,15 @@ int launch_mma(MmaParams& p, int force_split, void* ws, size_t ws_bytes, hipStre
     p.tiles_m = sg_cdiv(p.M, pl.bm);
     p.tiles_n = sg_cdiv(p.N, pl.bn);
     dim3 grid(p.tiles_m * p.tiles_n, pl.splits);
+    // ring depth: 3 stages (deeper prefetch) unless overridden; SG_STAGES=2 halves... see DESIGN.md §5.2
+    const int stages = g_tune.stages == 2 ? 2 : 3;
     if (pipe) {
-        if (pl.bm == 256 && pl.bn == 128) launch_pipe<4, 2, CONV>(p, grid, st);
-        else if (pl.bm == 128 && pl.bn == 128) launch_pipe<2, 2, CONV>(p, grid, st);
-        else if (pl.bm == 256 && pl.bn == 64) launch_pipe<4, 1, CONV>(p, grid, st);
-        else if (pl.bm == 128 && pl.bn == 64) launch_pipe<2, 1, CONV>(p, grid, st);
-        else if (pl.bm == 64 && pl.bn == 128) launch_pipe<1, 2, CONV>(p, grid, st);
-        else launch_pipe<1, 1, CONV>(p, grid, st);
+        if (pl.bm == 256 && pl.bn == 128) launch_pipe<4, 2, CONV>(p, grid, st, stages);
+        else if (pl.bm == 128 && pl.bn == 128) launch_pipe<2, 2, CONV>(p, grid, st, stages);
+        else if (pl.bm == 256 && pl.bn == 64) launch_pipe<4, 1, CONV>(p, grid, st, stages);
+        else if (pl.bm == 128 && pl.bn == 64) launch_pipe<2, 1, CONV>(p, grid, st, stages);
+        else if (pl.bm == 64 && pl.bn == 128) launch_pipe<1, 2, CONV>(p, grid, st, stages);
+        else launch_pipe<1, 1, CONV>(p, grid, st, stages);
     } else {
         dim3 block(256);
         if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((mma_kernel<128, 128, CONV>), grid, block, 0, st, p);

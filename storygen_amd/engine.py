@@ -129,8 +129,11 @@ class HarvestPlan:
     feature of sample src + j*src_step of this pass.  One strided copy per op (src_step = 0 broadcasts one sample
     into `count` frame slots)."""
 
-    def __init__(self, ctx: Dict[str, torch.Tensor], ops_: List[tuple]):
-        self.ctx, self.ops = ctx, list(ops_)
+    def __init__(self, ctx: Dict[str, torch.Tensor], ops_: List[tuple], kv: Optional[Dict[str, tuple]] = None):
+        # kv: feature key -> (K [rows*R*HW, C], VT [C, rows*R*HW]) buffers: when given, the reference pass also runs the
+        # attn3 K / V^T projections of each finished context (they depend on nothing else), taking them off the main
+        # pass's critical path.
+        self.ctx, self.ops, self.kv = ctx, list(ops_), kv
 
 
 class UNetEngine:
@@ -200,6 +203,9 @@ class UNetEngine:
         self.temb2 = self._buf(B, arch.temb_dim, dtype=F32)
         self.tproj = self._buf(B, self.temb_total, dtype=F32)
         self.ws_split = self._buf(splitk_mb << 20, dtype=torch.uint8)
+        self.ws_side = self._buf(splitk_mb << 20, dtype=torch.uint8)     # split-K scratch of the side-stream branches
+        self.side: Optional[torch.cuda.Stream] = None                   # set by forward(side=...)
+        self.kv_ext: Optional[Dict[str, tuple]] = None                  # attn3 K / V^T computed by the reference pass
         self.ws_gn = self._buf(ops.groupnorm_workspace_bytes(B, self.groups), dtype=torch.uint8)
         # per level: widest resnet input (concat) and the level's channel count; every conv-input channel count
         cmax, cout = [0] * nlev, [0] * nlev
@@ -237,7 +243,7 @@ class UNetEngine:
                 # fp16 MFMA operands
                 gn=self._buf(M, C), x16=self._buf(M * Cw), c1=self._buf(M, C), h4=self._buf(M, C),
                 ln=self._buf(M, C), ln4=self._buf(M, C), qk=self._buf(M, 2 * C), vt=self._buf(C, M), q=self._buf(M, C),
-                att=self._buf(M, C), ffi=self._buf(M, 4 * C),
+                att=self._buf(M, C), q2=self._buf(M, C), att2=self._buf(M, C), ffi=self._buf(M, 4 * C),
                 kt=self._buf(B * self.Sp, C), vtt=self._buf(C, B * self.Sp),
                 ki=self._buf(self.ctx_rows * self.R * self.hw[l], C) if self.R else None,
                 vti=self._buf(C, self.ctx_rows * self.R * self.hw[l]) if self.R else None,
@@ -264,6 +270,17 @@ class UNetEngine:
         h, w = self.H >> lvl, self.W >> lvl
         return x2d.unflatten(0, (self.B, h, w))
 
+    def _fork(self) -> bool:
+        """Start a side branch (independent kernels on the side stream) — inside a capture this becomes a parallel
+        branch of the hipGraph.  Returns False when no side stream is configured (everything stays in order)."""
+        if self.side is None:
+            return False
+        self.side.wait_stream(torch.cuda.current_stream(self.dev))
+        return True
+
+    def _join(self):
+        torch.cuda.current_stream(self.dev).wait_stream(self.side)
+
     def _resnet(self, rn: _Resnet, x: torch.Tensor, out: torch.Tensor, lvl: int):
         """diffusers ResnetBlock2D.  x fp32 [M,Cin] contiguous; out fp32 [M,Cout], possibly a column
         slice of a concat buffer."""
@@ -273,15 +290,21 @@ class UNetEngine:
         x16 = L["x16"][: M * r.cin].view(M, r.cin) if rn.wsc is not None else None
         ops.groupnorm(x.unflatten(0, (B, hw)), rn.n1g, rn.n1b, p_in, self.groups, self.eps, True, self.ws_gn,
                       xcopy=None if x16 is None else x16.unflatten(0, (B, hw)))
+        res, forked = x, False
+        if rn.wsc is not None:                     # 1x1 shortcut: independent of conv1 -> norm2, runs beside them
+            forked = self._fork()
+            if forked:
+                with torch.cuda.stream(self.side):
+                    ops.gemm(x16, rn.wsc, L["sc"], bias=rn.bsc, workspace=self.ws_side)
+            else:
+                ops.gemm(x16, rn.wsc, L["sc"], bias=rn.bsc, workspace=ws)
+            res = L["sc"]
         h1 = L["c1"]
         rb = self.tproj[:, rn.temb_off: rn.temb_off + r.cout]
         ops.conv3x3(p_in, rn.w1, self._img(h1, lvl), rowbias=rb, workspace=ws, x_padded=True)
         ops.groupnorm(h1.unflatten(0, (B, hw)), rn.n2g, rn.n2b, p_mid, self.groups, self.eps, True, self.ws_gn)
-        if rn.wsc is not None:
-            ops.gemm(x16, rn.wsc, L["sc"], bias=rn.bsc, workspace=ws)
-            res = L["sc"]
-        else:
-            res = x
+        if forked:
+            self._join()
         ops.conv3x3(p_mid, rn.w2, self._img(out, lvl), bias=rn.b2, res1=self._img(res, lvl), workspace=ws, x_padded=True)
 
     def _text_kv(self, xf: _Xf, lvl: int, use_cache: bool):
@@ -342,6 +365,11 @@ class UNetEngine:
             for src, step, row, slot, cnt in harvest.ops:
                 dst = ctx[row, slot * hw:(slot + cnt) * hw, :].view(cnt, hw, C)
                 ops.copy_rows(dst, h1b[src:].as_strided((cnt, hw, C), (step * hw * C, C, 1)))
+            if harvest.kv is not None:             # attn3 K / V^T of the finished context (attention.py:215-223)
+                ki, vti = harvest.kv[xf.spec.feature_key]
+                c2d = ctx.view(ctx.shape[0] * ctx.shape[1], C)
+                ops.gemm(c2d, xf.w_k3, ki, workspace=ws)
+                ops.gemm(xf.w_v3, c2d, vti, workspace=ws)                                  # VT[C, rows*nk]
             if stop_after_harvest:
                 return
         # --- text cross-attention :266-277 (norm2) and image cross-attention :281-291 (norm4) share statistics
@@ -349,18 +377,33 @@ class UNetEngine:
             ops.layernorm(h1, *xf.ln["norm2"], L["ln"], 1e-5, *xf.ln["norm4"], L["ln4"])
         else:
             ops.layernorm(h1, *xf.ln["norm2"], L["ln"])
-        ops.gemm(L["ln"], xf.w_q2, L["q"], workspace=ws)
         kt3, vtt3 = self._text_kv(xf, lvl, text_cache)
-        ops.attention(L["q"].view(B, hw, C), kt3, vtt3, att.view(B, hw, C), heads, scale, nk=S)
         if consume:
             ht = L["h2"]
-            ops.gemm(att, xf.w_o2, ht, bias=xf.b_o2, res1=h1, workspace=ws)               # h_t = a2 + h   :277
+            # the text branch (q2 -> attn2 -> out-proj, :266-277) and the image branch (q3 -> attn3, :281-290) only meet
+            # in the final out-projection (:291-293): run the short text branch beside the long image attention
+            forked = self._fork()
+            ws2 = self.ws_side if forked else ws
+            q2, att2 = (L["q2"], L["att2"]) if forked else (L["q"], att)
+
+            def text_branch():
+                ops.gemm(L["ln"], xf.w_q2, q2, workspace=ws2)
+                ops.attention(q2.view(B, hw, C), kt3, vtt3, att2.view(B, hw, C), heads, scale, nk=S)
+                ops.gemm(att2, xf.w_o2, ht, bias=xf.b_o2, res1=h1, workspace=ws2)         # h_t = a2 + h   :277
+            if forked:
+                with torch.cuda.stream(self.side):
+                    text_branch()
+            else:
+                text_branch()
             ctx = self.ctx[xf.spec.feature_key]
             rows, nk = ctx.shape[0], ctx.shape[1]
             ops.gemm(L["ln4"], xf.w_q3, L["q"], workspace=ws)
-            ki, vti = L["ki"], L["vti"]
-            ops.gemm(ctx.view(rows * nk, C), xf.w_k3, ki, workspace=ws)
-            ops.gemm(xf.w_v3, ctx.view(rows * nk, C), vti, workspace=ws)                  # VT[C, rows*nk]
+            if self.kv_ext is not None:
+                ki, vti = self.kv_ext[xf.spec.feature_key]
+            else:
+                ki, vti = L["ki"], L["vti"]
+                ops.gemm(ctx.view(rows * nk, C), xf.w_k3, ki, workspace=ws)
+                ops.gemm(xf.w_v3, ctx.view(rows * nk, C), vti, workspace=ws)              # VT[C, rows*nk]
             ki3, vti3 = ki.view(rows, nk, C), vti.view(C, rows, nk).permute(1, 0, 2)
             q3, a3 = L["q"].view(B, hw, C), att.view(B, hw, C)
             if self.attn3_share is not None:      # one launch: batch b reads context row b (b < rows) or b - (B - rows)
@@ -368,9 +411,13 @@ class UNetEngine:
             else:
                 for q0, n, c0 in self.attn3_groups:
                     ops.attention(q3[q0:q0 + n], ki3[c0:c0 + n], vti3[c0:c0 + n], a3[q0:q0 + n], heads, scale)
+            if forked:
+                self._join()
             h3 = L["h3"]
             ops.gemm(att, xf.w_o3, h3, bias=xf.b_o3, res1=h1, res2=ht, workspace=ws)      # (a3 + h) + h_t :291-293
         else:
+            ops.gemm(L["ln"], xf.w_q2, L["q"], workspace=ws)
+            ops.attention(L["q"].view(B, hw, C), kt3, vtt3, att.view(B, hw, C), heads, scale, nk=S)
             h3 = L["h2"]
             ops.gemm(att, xf.w_o2, h3, bias=xf.b_o2, res1=h1, workspace=ws)               # :277,295
         # --- feed-forward :298-300
@@ -394,7 +441,8 @@ class UNetEngine:
         return self.lv[lvl]["cat"][which][: M * width].view(M, width)
 
     def forward(self, harvest_slot: Optional[int] = None, consume: bool = False, harvest: Optional[HarvestPlan] = None,
-                harvest_only: bool = False, text_cache: bool = False) -> Optional[torch.Tensor]:
+                harvest_only: bool = False, text_cache: bool = False,
+                side: Optional[torch.cuda.Stream] = None) -> Optional[torch.Tensor]:
         """One UNet call on the static inputs (self.x_in fp32 NCHW, self.t_in fp32 [B], self.text_in fp16).
 
         harvest_slot=r : reference pass — no image context; sample b's features go to slot r of row b of self.ctx.
@@ -404,6 +452,8 @@ class UNetEngine:
                          returns None.
         consume=True   : main pass — attn3 cross-attends to self.ctx.
         text_cache     : use the attn2 K/V projections stored by cache_text_kv().
+        side           : a second stream for the pass's independent branches (1x1 shortcuts beside conv1/norm2, the text
+                         attention beside the image attention); in a capture they become parallel graph branches.
         Returns self.eps_out (fp32 NCHW)."""
         if harvest_slot is not None:
             if harvest is not None or self.ctx_rows != self.B:
@@ -417,6 +467,7 @@ class UNetEngine:
             raise ValueError("engine was built without context buffers (n_ref=0)")
         if harvest_only and harvest is None:
             raise ValueError("harvest_only needs a harvest plan")
+        self.side = side
         last_xf = [a for blk in self.arch.up for a in blk.attns if a is not None][-1].prefix if harvest_only else None
         tk = dict(text_cache=text_cache)
         arch, text, skips = self.arch, self.text_in, self.skips

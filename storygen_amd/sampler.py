@@ -130,8 +130,21 @@ class StoryGenSampler:
         self.ctx_sets = [self.main.ctx]
         if self.overlap:
             self.ctx_sets.append({k: torch.empty_like(v) for k, v in self.main.ctx.items()})
-        self.plans = [HarvestPlan(c, hops) for c in self.ctx_sets]
+        # attn3 K / V^T per context set: computed by the reference pass right after each feature is harvested
+        self.kv_sets = [{k: (torch.empty(v.shape[0] * v.shape[1], v.shape[2], dtype=v.dtype, device=self.dev),
+                             torch.empty(v.shape[2], v.shape[0] * v.shape[1], dtype=v.dtype, device=self.dev))
+                         for k, v in c.items()} for c in self.ctx_sets]
+        self.plans = [HarvestPlan(c, hops, kv) for c, kv in zip(self.ctx_sets, self.kv_sets)]
         self.plan = self.plans[0]
+        # side streams for the independent branches inside a pass (engine.forward(side=...)).  In overlap mode the
+        # reference pass already runs on a forked stream; a second-level fork from it crashed hipGraph capture on
+        # ROCm 7.2 (segfault in the runtime), so only the main pass, which runs on the capture stream, forks.
+        import os
+        knob = os.environ.get("SG_SIDE", "auto")          # development knob: auto | none | main | both
+        want_main = self.use_graph and knob != "none"
+        want_ref = self.use_graph and (knob == "both" or (knob == "auto" and not self.overlap))
+        self.side_main = torch.cuda.Stream(device=self.dev) if want_main else None
+        self.side_ref = torch.cuda.Stream(device=self.dev) if want_ref else None
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.ref_src = torch.zeros((self.U,) + tuple(self.latents.shape[1:]), **f32)
         # per-step parameters: [U] ref timesteps | [B] main timestep | [U,2] add_noise coefs | [6] guidance + DDIM coefs
@@ -210,15 +223,15 @@ class StoryGenSampler:
         t_ref, _, an, _ = self._par_views()
         ops.add_noise(self.ref_src, self.noise, an, self.ref.x_in)                        # :419-429
         self.ref.t_in.copy_(t_ref)
-        self.ref.forward(harvest=self.plans[ctx_set], harvest_only=True, text_cache=True)
+        self.ref.forward(harvest=self.plans[ctx_set], harvest_only=True, text_cache=True, side=self.side_ref)
 
     def _main_pass(self, ctx_set: int):
         _, t_main, _, cd = self._par_views()
         main = self.main
-        main.ctx = self.ctx_sets[ctx_set]
+        main.ctx, main.kv_ext = self.ctx_sets[ctx_set], self.kv_sets[ctx_set]
         main.x_in.copy_(self.latents3)                                                    # :448-453
         main.t_in.copy_(t_main)
-        eps3 = main.forward(consume=True, text_cache=True)
+        eps3 = main.forward(consume=True, text_cache=True, side=self.side_main)
         ops.cfg_ddim_step(eps3, self.latents, self.latents3, cd)                          # :457-461
 
     def _prime(self):
@@ -254,7 +267,7 @@ class StoryGenSampler:
                     self._main_pass(parity)                                               # main pass of step k
                     cur.wait_stream(side)                                                 # join
                 self.graphs.append(g)
-        self.main.ctx = self.ctx_sets[0]
+        self.main.ctx, self.main.kv_ext = self.ctx_sets[0], self.kv_sets[0]
         self.latents.copy_(saved)
         self.latents3.copy_(torch.cat([saved] * 3))
         torch.cuda.synchronize(dev)

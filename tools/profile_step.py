@@ -31,6 +31,7 @@ def main():
     print(f"graph step: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms")
     sink = []
     ops.PROFILE_SINK = sink
+    smp.side_main = smp.side_ref = None   # sequential: per-kernel durations without co-running neighbours
     smp.params.copy_(smp.table[8])
     torch.cuda._sleep(200_000_000)   # ~100 ms GPU spin so the (slower) eager host stays ahead of the GPU: no launch gaps
     t0 = time.perf_counter()
