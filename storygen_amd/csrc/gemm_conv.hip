@@ -137,9 +137,69 @@ __device__ __forceinline__ void tile_epilogue(const MmaParams& p, char* smem, f3
     // small rings (S = 2) leave room for a second workgroup of another kernel on the same CU.
     float* sC = reinterpret_cast<float*>(smem);
     constexpr int BR = WGM * 32;   // rows staged per pass
+    if (p.mode == SG_EPI_LINEAR) {
+        // every thread owns IT = 4 (row, 8-column chunk) items per band (BR * BN/8 / NT == 4 for every tile shape).  The
+        // additive epilogue terms (bias, temb row-bias, residuals) do not depend on the accumulators, so their global
+        // loads are issued BEFORE the band is staged: the HBM latency overlaps the LDS round trip instead of following it.
+        constexpr int NCH = BN / 8, IT = BR * NCH / NT;
+        static_assert(IT * NT == BR * NCH, "items per thread must be integral");
+#pragma unroll
+        for (int ip = 0; ip < TM; ++ip) {
+            float add[IT][8];
+            int gmv[IT], gnv[IT];
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                const int idx = t + it * NT;
+                const int lr = idx / NCH, ch = idx - lr * NCH;
+                gmv[it] = m0 + (lr >> 5) * WM + ip * 32 + (lr & 31);
+                gnv[it] = n0 + ch * 8;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) add[it][j] = 0.f;
+                if (gmv[it] < p.M && gnv[it] < p.N) {
+                    if (p.bias) {
+                        H8 b; b.u = ldg16(p.bias + gnv[it]);
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) add[it][j] += (float)b.h[j];
+                    }
+                    if (p.rowbias) {
+                        const float* rb = p.rowbias + (long)(gmv[it] / p.rows_per_batch) * p.rowbias_ld + gnv[it];
+                        const float4 r0 = *reinterpret_cast<const float4*>(rb), r1 = *reinterpret_cast<const float4*>(rb + 4);
+                        add[it][0] += r0.x; add[it][1] += r0.y; add[it][2] += r0.z; add[it][3] += r0.w;
+                        add[it][4] += r1.x; add[it][5] += r1.y; add[it][6] += r1.z; add[it][7] += r1.w;
+                    }
+                    if (p.res1) add_res8(p.res1, p.ldr1, p.flags & SG_F_RES1_F32, gmv[it], gnv[it], add[it]);
+                    if (p.res2) add_res8(p.res2, p.ldr2, p.flags & SG_F_RES2_F32, gmv[it], gnv[it], add[it]);
+                }
+            }
+            if (ip) __syncthreads();   // previous band fully consumed
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = wn * WN + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
+                    sC[m * BN + n] = acc[ip][j][r];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int it = 0; it < IT; ++it) {
+                if (gmv[it] >= p.M || gnv[it] >= p.N) continue;
+                const int idx = t + it * NT;
+                const int lr = idx / NCH, ch = idx - lr * NCH;
+                const float4 v0 = *reinterpret_cast<const float4*>(sC + lr * BN + ch * 8);
+                const float4 v1 = *reinterpret_cast<const float4*>(sC + lr * BN + ch * 8 + 4);
+                float v[8] = {v0.x + add[it][0], v0.y + add[it][1], v0.z + add[it][2], v0.w + add[it][3],
+                              v1.x + add[it][4], v1.y + add[it][5], v1.z + add[it][6], v1.w + add[it][7]};
+                store_out8(p, gmv[it], gnv[it], v);
+            }
+        }
+        return;
+    }
+    // GEGLU: bias only (tiny, cached); one band at a time
 #pragma unroll
     for (int ip = 0; ip < TM; ++ip) {
-        if (ip) __syncthreads();   // previous band fully consumed
+        if (ip) __syncthreads();
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int n = wn * WN + j * 32 + l31;
@@ -150,32 +210,18 @@ __device__ __forceinline__ void tile_epilogue(const MmaParams& p, char* smem, f3
             }
         }
         __syncthreads();
-        // staged row lr belongs to wave-row lr / 32 -> tile row (lr / 32) * WM + ip * 32 + lr % 32
-        if (p.mode == SG_EPI_LINEAR) {
-            constexpr int NCH = BN / 8;
-            for (int idx = t; idx < BR * NCH; idx += NT) {
-                const int lr = idx / NCH, ch = idx - lr * NCH;
-                const int gm = m0 + (lr >> 5) * WM + ip * 32 + (lr & 31), gn = n0 + ch * 8;
-                if (gm >= p.M || gn >= p.N) continue;
-                const float4 v0 = *reinterpret_cast<const float4*>(sC + lr * BN + ch * 8);
-                const float4 v1 = *reinterpret_cast<const float4*>(sC + lr * BN + ch * 8 + 4);
-                float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-                epi_linear8(p, gm, gn, v);
-            }
-        } else {
-            constexpr int OCH = BN / 16;
-            for (int idx = t; idx < BR * OCH; idx += NT) {
-                const int lr = idx / OCH, j = idx - lr * OCH;
-                const int vcol = (j >> 2) * 64 + (j & 3) * 8;
-                const int gm = m0 + (lr >> 5) * WM + ip * 32 + (lr & 31), gv = n0 + vcol;
-                if (gm >= p.M || gv >= p.N) continue;
-                const float* sp = sC + lr * BN + vcol;
-                const float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
-                const float4 g0 = *reinterpret_cast<const float4*>(sp + 32), g1 = *reinterpret_cast<const float4*>(sp + 36);
-                float val[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-                float gate[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-                epi_geglu8(p, gm, gv, val, gate);
-            }
+        constexpr int OCH = BN / 16;
+        for (int idx = t; idx < BR * OCH; idx += NT) {
+            const int lr = idx / OCH, j = idx - lr * OCH;
+            const int vcol = (j >> 2) * 64 + (j & 3) * 8;
+            const int gm = m0 + (lr >> 5) * WM + ip * 32 + (lr & 31), gv = n0 + vcol;
+            if (gm >= p.M || gv >= p.N) continue;
+            const float* sp = sC + lr * BN + vcol;
+            const float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
+            const float4 g0 = *reinterpret_cast<const float4*>(sp + 32), g1 = *reinterpret_cast<const float4*>(sp + 36);
+            float val[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            float gate[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+            epi_geglu8(p, gm, gv, val, gate);
         }
     }
 }
@@ -491,7 +537,7 @@ static const Tune g_tune;
 //   t_mfma = (waves per SIMD) x slabs x 512                                  — 16 MFMAs of 32 cycles per 64-deep slab,
 // plus a fixed prologue/epilogue.  Splitting K does not add operand bytes but multiplies the CUs that share them,
 // which is what small-M layers need; it costs a second launch that re-reads the fp32 partial tiles.
-Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool pipe) {
+Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool pipe, int hint_bm, int hint_bn) {
     static const int cand_pipe[6][2] = {{256, 128}, {128, 128}, {256, 64}, {128, 64}, {64, 128}, {64, 64}};
     static const int cand_gen[3][2] = {{128, 128}, {128, 64}, {64, 64}};
     static const int split_opts[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
@@ -502,6 +548,7 @@ Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool p
     for (int ci = 0; ci < ncand; ++ci) {
         const int bm = pipe ? cand_pipe[ci][0] : cand_gen[ci][0], bn = pipe ? cand_pipe[ci][1] : cand_gen[ci][1];
         if (g_tune.bm && (bm != g_tune.bm || bn != g_tune.bn)) continue;
+        if (!g_tune.bm && hint_bm && (bm != hint_bm || bn != hint_bn)) continue;
         const long tiles = (long)sg_cdiv(M, bm) * sg_cdiv(N, bn);
         const double waves_per_block = pipe ? (bm / 64) * (bn / 64) : 4.0;
         const double mfma_per_slab = pipe ? 512.0 : 512.0 * (bm / 64.0) * (bn / 64.0) / 4.0;
@@ -531,14 +578,14 @@ void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st, int stages) {
 }
 
 template <bool CONV>
-int launch_mma(MmaParams& p, int force_split, void* ws, size_t ws_bytes, hipStream_t st, const char* name) {
+int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws, size_t ws_bytes, hipStream_t st, const char* name) {
     p.KT = sg_cdiv(p.K, BK);
     // LDS-DMA pipeline when no load needs a predicate (K % 64 == 0; conv input zero-bordered), else the
     // register-staged kernel that zero-fills out-of-range chunks.
     const bool pipe = (p.K % BK == 0) && (!CONV || p.padded) && !g_tune.no_pipe;
     const size_t per_split = (size_t)p.M * p.N * 4;
     const int max_ws_split = ws ? (int)(ws_bytes / per_split > 64 ? 64 : ws_bytes / per_split) : 1;
-    Plan pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, pipe);
+    Plan pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, pipe, hint_bm, hint_bn);
     if (pl.splits > 1) {
         const size_t need = per_split * pl.splits;
         if (ws == nullptr || ws_bytes < need)
@@ -586,6 +633,14 @@ int check_out_res(const char* who, int flags, const void* C, int64_t ldc, const 
     return SG_OK;
 }
 
+int check_tile_hint(const char* who, int bm, int bn) {
+    if (bm == 0 && bn == 0) return SG_OK;
+    static const int ok[6][2] = {{256, 128}, {128, 128}, {256, 64}, {128, 64}, {64, 128}, {64, 64}};
+    for (auto& t : ok)
+        if (t[0] == bm && t[1] == bn) return SG_OK;
+    return sg_set_error(SG_EINVAL, "%s: unsupported tile hint %dx%d", who, bm, bn);
+}
+
 }  // namespace
 
 extern "C" size_t sg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
@@ -626,7 +681,8 @@ extern "C" int sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream) {
     p.rowbias = d->rowbias; p.rowbias_ld = d->rowbias_ld; p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1;
     p.res1 = d->res1; p.ldr1 = d->ldr1;
     p.res2 = d->res2; p.ldr2 = d->ldr2;
-    return launch_mma<false>(p, d->split_k, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_gemm_f16");
+    if (int rc = check_tile_hint("sg_gemm_f16", d->tile_m, d->tile_n)) return rc;
+    return launch_mma<false>(p, d->split_k, d->tile_m, d->tile_n, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_gemm_f16");
 }
 
 extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream) {
@@ -657,7 +713,8 @@ extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream)
     p.bias = reinterpret_cast<const f16*>(d->bias);
     p.rowbias = d->rowbias; p.rowbias_ld = d->rowbias_ld; p.rows_per_batch = Ho * Wo;
     p.res1 = d->res1; p.ldr1 = d->ldr1;
-    return launch_mma<true>(p, d->split_k, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_conv3x3_nhwc_f16");
+    if (int rc = check_tile_hint("sg_conv3x3", d->tile_m, d->tile_n)) return rc;
+    return launch_mma<true>(p, d->split_k, d->tile_m, d->tile_n, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_conv3x3_nhwc_f16");
 }
 
 // ------------------------------------------------------------------------------------------------ diagnostics

@@ -5,7 +5,7 @@
 namespace {
 
 constexpr int GN_MAX_GROUPS = 64;
-constexpr int GN_MAX_CHUNKS = 256;
+constexpr int GN_MAX_CHUNKS = 64;    // partial-sum rows per batch: every pass-2 workgroup re-reads all of them
 
 struct GnParams {
     const void* x; long ldx; int x_f32;
@@ -153,14 +153,14 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
             store8h(yb + orow * p.ldy + cv * 8, o);
         };
         int px = p0 + my_row;
-        for (; px + rpp < p1; px += 2 * rpp) {            // 2 independent rows in flight per thread
-            float v0[8], v1[8];
-            load8f(p.x, xb + (long)px * p.ldx + cv * 8, f32, v0);
-            load8f(p.x, xb + (long)(px + rpp) * p.ldx + cv * 8, f32, v1);
-            emit(px, v0);
-            emit(px + rpp, v1);
+        for (; px + 3 * rpp < p1; px += 4 * rpp) {        // 4 independent rows in flight per thread
+            float v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) load8f(p.x, xb + (long)(px + u * rpp) * p.ldx + cv * 8, f32, v[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) emit(px + u * rpp, v[u]);
         }
-        if (px < p1) {
+        for (; px < p1; px += rpp) {
             float v[8];
             load8f(p.x, xb + (long)px * p.ldx + cv * 8, f32, v);
             emit(px, v);
@@ -222,20 +222,24 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const LnParams p) {
     }
 }
 
-// Both passes are pure streaming: they need ~8 workgroups per CU (2048 on the chip) to keep HBM busy.
-void gn_geometry(int B, int HW, int C, int* nchunks, int* rows_per_chunk, int* apply_blocks, int* apply_rows) {
+// Both passes are pure streaming.  Pass 1 wants enough workgroups to pull HBM (>= 1 per CU) but few partial-sum rows
+// (pass 2 re-reads them all in every workgroup); pass 2 wants ~4 workgroups per CU with >= 32 KB of rows each, so that
+// the fixed prologue (partials, gamma/beta) is amortised.
+void gn_geometry(int B, int HW, int C, bool f32, int* nchunks, int* rows_per_chunk, int* apply_blocks, int* apply_rows) {
     const int vpr = C / 8, tw = vpr < 256 ? vpr : 256, rpp = 256 / tw;
-    const int want = sg_cdiv(2048, B);
-    // pass 1: at least 4 passes of rows per workgroup (amortises the in-block reduction), at most GN_MAX_CHUNKS partials
-    int n = sg_cdiv(HW, rpp * 4);
-    if (n > want) n = want;
+    int n = sg_cdiv(HW, rpp * 8);                 // >= 8 passes of rows per workgroup
+    const int want1 = sg_cdiv(512, B);
+    if (n > want1) n = want1;
     if (n > GN_MAX_CHUNKS) n = GN_MAX_CHUNKS;
     if (n < 1) n = 1;
     *rows_per_chunk = sg_cdiv(HW, n);
     *nchunks = sg_cdiv(HW, *rows_per_chunk);
-    // pass 2: at least 2 passes of rows per workgroup
-    int a = sg_cdiv(HW, rpp * 2);
-    if (a > want) a = want;
+    const long row_bytes = (long)C * (f32 ? 4 : 2);
+    int min_rows = (int)((32768 + row_bytes - 1) / row_bytes);
+    if (min_rows < 2 * rpp) min_rows = 2 * rpp;
+    int a = sg_cdiv(HW, min_rows);
+    const int want2 = sg_cdiv(1024, B);
+    if (a > want2) a = want2;
     if (a < 1) a = 1;
     *apply_rows = sg_cdiv(HW, a);
     *apply_blocks = sg_cdiv(HW, *apply_rows);
@@ -268,7 +272,7 @@ extern "C" int sg_groupnorm_nhwc_f16(const sg_groupnorm_desc* d, sg_stream_t str
     p.HW = d->HW; p.C = d->C; p.G = d->groups; p.cpg = d->C / d->groups; p.eps = d->eps; p.silu = d->silu;
     p.ws = reinterpret_cast<float*>(d->workspace);
     int apply_blocks = 1;
-    gn_geometry(d->B, d->HW, d->C, &p.nchunks, &p.rows_per_chunk, &apply_blocks, &p.apply_rows);
+    gn_geometry(d->B, d->HW, d->C, d->x_f32 != 0, &p.nchunks, &p.rows_per_chunk, &apply_blocks, &p.apply_rows);
     dim3 grid(p.nchunks, d->B), block(256);
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, st, p);

@@ -37,7 +37,7 @@ class _Resnet:
 
 class _Xf:
     __slots__ = ("spec", "ng", "nb", "w_in", "b_in", "w_out", "b_out", "ln", "w_qk1", "w_v1", "w_o1", "b_o1", "w_q2", "w_k2",
-                 "w_v2", "w_o2", "b_o2", "w_q3", "w_k3", "w_v3", "w_o3", "b_o3", "w_ff1", "b_ff1", "w_ff2", "b_ff2")
+                 "w_v2", "w_o2", "b_o2", "w_q3", "w_k3", "w_v3", "w_o3", "b_o3", "w_o23", "b_o23", "w_ff1", "b_ff1", "w_ff2", "b_ff2")
 
 
 class EngineWeights:
@@ -108,6 +108,10 @@ class EngineWeights:
                 o.w_q3 = g(f"{t}.attn3.to_q.weight")
                 o.w_k3, o.w_v3 = g(f"{t}.attn3.to_k.weight"), g(f"{t}.attn3.to_v.weight")
                 o.w_o3, o.b_o3 = g(f"{t}.attn3.to_out.0.weight"), g(f"{t}.attn3.to_out.0.bias")
+                # main pass: (attn2.to_out(a2) + h) + (attn3.to_out(a3) + h) (attention.py:277,291-293) is ONE GEMM over the
+                # concatenated heads [a2 | a3] with weights [Wo2 | Wo3] (K = 2C), bias b2 + b3 and the residual h twice
+                o.w_o23 = torch.cat([o.w_o2, o.w_o3], dim=1).contiguous()
+                o.b_o23 = (sd[f"{t}.attn2.to_out.0.bias"].float() + sd[f"{t}.attn3.to_out.0.bias"].float()).to(dev, F16)
                 o.w_ff1, o.b_ff1 = interleave_geglu(g(f"{t}.ff.net.0.proj.weight"), g(f"{t}.ff.net.0.proj.bias"))
                 o.w_ff2, o.b_ff2 = g(f"{t}.ff.net.2.weight"), g(f"{t}.ff.net.2.bias")
                 self.xfs[p] = o
@@ -243,7 +247,7 @@ class UNetEngine:
                 # fp16 MFMA operands
                 gn=self._buf(M, C), x16=self._buf(M * Cw), c1=self._buf(M, C), h4=self._buf(M, C),
                 ln=self._buf(M, C), ln4=self._buf(M, C), qk=self._buf(M, 2 * C), vt=self._buf(C, M), q=self._buf(M, C),
-                att=self._buf(M, C), q2=self._buf(M, C), att2=self._buf(M, C), ffi=self._buf(M, 4 * C),
+                att=self._buf(M, C), q2=self._buf(M, C), att23=self._buf(M, 2 * C), ffi=self._buf(M, 4 * C),
                 kt=self._buf(B * self.Sp, C), vtt=self._buf(C, B * self.Sp),
                 ki=self._buf(self.ctx_rows * self.R * self.hw[l], C) if self.R else None,
                 vti=self._buf(C, self.ctx_rows * self.R * self.hw[l]) if self.R else None,
@@ -379,17 +383,17 @@ class UNetEngine:
             ops.layernorm(h1, *xf.ln["norm2"], L["ln"])
         kt3, vtt3 = self._text_kv(xf, lvl, text_cache)
         if consume:
-            ht = L["h2"]
-            # the text branch (q2 -> attn2 -> out-proj, :266-277) and the image branch (q3 -> attn3, :281-290) only meet
-            # in the final out-projection (:291-293): run the short text branch beside the long image attention
+            # the text branch (q2 -> attn2, :266-276) and the image branch (q3 -> attn3, :281-290) write the two halves
+            # of one [M, 2C] buffer; their out-projections, biases and both residual adds (:277,291-293) are one GEMM
+            att23 = L["att23"]
+            a2v, a3v = att23[:, :C].unflatten(0, (B, hw)), att23[:, C:].unflatten(0, (B, hw))
             forked = self._fork()
             ws2 = self.ws_side if forked else ws
-            q2, att2 = (L["q2"], L["att2"]) if forked else (L["q"], att)
+            q2 = L["q2"] if forked else L["q"]
 
             def text_branch():
                 ops.gemm(L["ln"], xf.w_q2, q2, workspace=ws2)
-                ops.attention(q2.view(B, hw, C), kt3, vtt3, att2.view(B, hw, C), heads, scale, nk=S)
-                ops.gemm(att2, xf.w_o2, ht, bias=xf.b_o2, res1=h1, workspace=ws2)         # h_t = a2 + h   :277
+                ops.attention(q2.view(B, hw, C), kt3, vtt3, a2v, heads, scale, nk=S)
             if forked:
                 with torch.cuda.stream(self.side):
                     text_branch()
@@ -397,7 +401,8 @@ class UNetEngine:
                 text_branch()
             ctx = self.ctx[xf.spec.feature_key]
             rows, nk = ctx.shape[0], ctx.shape[1]
-            ops.gemm(L["ln4"], xf.w_q3, L["q"], workspace=ws)
+            q3buf = L["q"]                         # (unforked: the text attention above has consumed its q by now)
+            ops.gemm(L["ln4"], xf.w_q3, q3buf, workspace=ws)
             if self.kv_ext is not None:
                 ki, vti = self.kv_ext[xf.spec.feature_key]
             else:
@@ -405,16 +410,16 @@ class UNetEngine:
                 ops.gemm(ctx.view(rows * nk, C), xf.w_k3, ki, workspace=ws)
                 ops.gemm(xf.w_v3, ctx.view(rows * nk, C), vti, workspace=ws)              # VT[C, rows*nk]
             ki3, vti3 = ki.view(rows, nk, C), vti.view(C, rows, nk).permute(1, 0, 2)
-            q3, a3 = L["q"].view(B, hw, C), att.view(B, hw, C)
+            q3 = q3buf.view(B, hw, C)
             if self.attn3_share is not None:      # one launch: batch b reads context row b (b < rows) or b - (B - rows)
-                ops.attention(q3, ki3, vti3, a3, heads, scale)
+                ops.attention(q3, ki3, vti3, a3v, heads, scale)
             else:
                 for q0, n, c0 in self.attn3_groups:
-                    ops.attention(q3[q0:q0 + n], ki3[c0:c0 + n], vti3[c0:c0 + n], a3[q0:q0 + n], heads, scale)
+                    ops.attention(q3[q0:q0 + n], ki3[c0:c0 + n], vti3[c0:c0 + n], a3v[q0:q0 + n], heads, scale)
             if forked:
                 self._join()
             h3 = L["h3"]
-            ops.gemm(att, xf.w_o3, h3, bias=xf.b_o3, res1=h1, res2=ht, workspace=ws)      # (a3 + h) + h_t :291-293
+            ops.gemm(att23, xf.w_o23, h3, bias=xf.b_o23, res1=h1, res2=h1, workspace=ws)  # (a2 + h) + (a3 + h)
         else:
             ops.gemm(L["ln"], xf.w_q2, L["q"], workspace=ws)
             ops.attention(L["q"].view(B, hw, C), kt3, vtt3, att.view(B, hw, C), heads, scale, nk=S)

@@ -21,6 +21,24 @@ EPI_LINEAR = 0
 EPI_GEGLU = 1
 F_OUT_F32, F_RES1_F32, F_RES2_F32 = 1, 2, 4
 
+# Per-shape tile / split-K choices measured on an MI355X by tools/tune_tiles.py (storygen_amd/tuning/mi355x_tiles.json);
+# anything not listed uses the library's cost model.  TUNE_SINK: when set, every gemm/conv3x3 call appends its
+# signature and a recipe to rebuild it (the tuning tool's shape census).
+TILE_TABLE = {}
+TUNE_SINK = None
+
+
+def load_tile_table(path: Optional[str] = None) -> int:
+    import json
+    import os
+    path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "mi355x_tiles.json")
+    TILE_TABLE.clear()
+    if os.path.exists(path) and os.environ.get("SG_NO_TILE_TABLE") != "1":
+        with open(path) as f:
+            TILE_TABLE.update({k: tuple(v) for k, v in json.load(f)["tiles"].items()})
+    return len(TILE_TABLE)
+
+
 # Optional in-situ kernel timer (bench.py): when set, every MFMA-class launch is bracketed by HIP events recorded
 # on the launch stream and reported as (family, algorithmic_flops, start_event, end_event).
 PROFILE_SINK = None
@@ -44,6 +62,9 @@ class _timed:
             end.record(torch.cuda.current_stream())
             PROFILE_SINK.append((self.family, self.flops, self.start, end, self.shape))
         return False
+
+
+load_tile_table()
 
 
 def _stream() -> int:
@@ -89,7 +110,8 @@ def gemm_workspace_bytes(M: int, N: int, split_k: int = 0) -> int:
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
          rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 1, res1: Optional[torch.Tensor] = None,
          res2: Optional[torch.Tensor] = None, epilogue: int = EPI_LINEAR, split_k: int = 0,
-         workspace: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None) -> torch.Tensor:
+         workspace: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
+         tile: Optional[tuple] = None) -> torch.Tensor:
     """out[M, N'] = epi(a[M,K] @ w[N,K]^T); a/out/res* may be row-strided 2-D views; out/res* fp16 or fp32;
     out2 = optional extra fp16 copy of the result."""
     _f16(a, "a"), _f16(w, "w")
@@ -127,6 +149,15 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[
     d.flags = flags
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    sig = f"g:{M}:{N}:{K}:{epilogue}:{flags}:{int(bias is not None)}{int(rowbias is not None)}{int(res1 is not None)}{int(res2 is not None)}{int(out2 is not None)}"
+    if tile is not None:
+        d.tile_m, d.tile_n = tile
+    elif split_k == 0 and sig in TILE_TABLE:
+        d.tile_m, d.tile_n, d.split_k = TILE_TABLE[sig]
+    if TUNE_SINK is not None:
+        TUNE_SINK.append((sig, dict(kind="gemm", M=M, N=N, K=K, epilogue=epilogue, out_f32=bool(flags & F_OUT_F32), bias=bias is not None,
+                                    rowbias=rowbias is not None, rows_per_batch=rows_per_batch, out2=out2 is not None,
+                                    res1=None if res1 is None else str(res1.dtype), res2=None if res2 is None else str(res2.dtype))))
     with _timed("gemm", 2.0 * M * N * K, f"M{M} N{N} K{K}{' geglu' if epilogue else ''}"):
         check(lib.sg_gemm_f16(C.byref(d), _stream()), "sg_gemm_f16")
     return out
@@ -135,7 +166,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[
 def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stride: int = 1, upsample2x: bool = False,
             bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
             res1: Optional[torch.Tensor] = None, split_k: int = 0, workspace: Optional[torch.Tensor] = None,
-            x_padded: bool = False) -> torch.Tensor:
+            x_padded: bool = False, tile: Optional[tuple] = None) -> torch.Tensor:
     """x [B,H,W,Cin] (channels-last, pixel-strided view allowed; or the zero-bordered [B,H+2,W+2,Cin] with
     x_padded=True) -> out [B,Ho,Wo,Cout] (fp16 or fp32); w_krsc [Cout,3,3,Cin]; res1 fp16 or fp32."""
     _f16(x, "x"), _f16(w_krsc, "w")
@@ -175,6 +206,15 @@ def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stride:
     d.split_k = split_k
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    sig = f"c:{B}:{H}:{W}:{Cin}:{Cout}:{stride}:{int(upsample2x)}:{int(x_padded)}:{flags}:{int(bias is not None)}{int(rowbias is not None)}{int(res1 is not None)}"
+    if tile is not None:
+        d.tile_m, d.tile_n = tile
+    elif split_k == 0 and sig in TILE_TABLE:
+        d.tile_m, d.tile_n, d.split_k = TILE_TABLE[sig]
+    if TUNE_SINK is not None:
+        TUNE_SINK.append((sig, dict(kind="conv", B=B, H=H, W=W, Cin=Cin, Cout=Cout, stride=stride, ups=bool(upsample2x), padded=bool(x_padded),
+                                    out_f32=bool(flags & F_OUT_F32), bias=bias is not None, rowbias=rowbias is not None,
+                                    res1=None if res1 is None else str(res1.dtype))))
     with _timed("conv3x3", 2.0 * B * Ho * Wo * Cout * 9 * Cin,
                 f"B{B} {Ho}x{Wo} {Cin}->{Cout} s{stride}{' up' if upsample2x else ''}"):
         check(lib.sg_conv3x3_nhwc_f16(C.byref(d), _stream()), "sg_conv3x3_nhwc_f16")
