@@ -69,6 +69,19 @@ def cpu_baseline(arch, sd, inputs):
                       f"step = 3*t_ref + t_main = {step_s:.1f}s", "seconds_per_step": step_s}
 
 
+def measured_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the rocprofv3 PMC passes of this same command (FETCH_SIZE x2 per the gfx950
+    correction of MI355X_MICROARCH.md §HBM, + WRITE_SIZE), committed with their provenance in profiles/traffic.json;
+    None when no such measurement is on file."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        t = json.load(f)
+    e = t.get("kernels", {}).get(kernel)
+    return None if e is None else e["hbm_bytes_per_launch"]
+
+
 def in_situ_roofline(sampler):
     """One extra eager step with every MFMA-class launch bracketed by HIP events on its launch stream."""
     from storygen_amd import ops
@@ -96,12 +109,25 @@ def in_situ_roofline(sampler):
         f["tflops"] = f["gflop"] / f["ms"] if f["ms"] > 0 else 0.0
         f["avg_us"] = 1e3 * f["ms"] / f["launches"]
         f["frac_of_peak"] = f["tflops"] / PEAK_FP16_TFLOPS
-    dom = max(fam, key=lambda k: fam[k]["ms"])
-    d = fam[dom]
+    # kernels, not call sites: sg_gemm_f16 and sg_conv3x3_nhwc_f16 are the same device kernel (mma_pipe_kernel), the three
+    # attention head dims are instantiations of attn_fwd_kernel
+    kernels = {}
+    for name, f in fam.items():
+        kname = "mma_pipe_kernel (gemm + conv3x3)" if name in ("gemm", "conv3x3") else "attn_fwd_kernel"
+        k = kernels.setdefault(kname, {"launches": 0, "ms": 0.0, "gflop": 0.0})
+        for key in k:
+            k[key] += f[key]
+    for k in kernels.values():
+        k["tflops"] = k["gflop"] / k["ms"] if k["ms"] > 0 else 0.0
+        k["avg_us"] = 1e3 * k["ms"] / k["launches"]
+        k["frac_of_peak"] = k["tflops"] / PEAK_FP16_TFLOPS
+    dom = max(kernels, key=lambda k: kernels[k]["ms"])
+    d = kernels[dom]
     executed_tflop = sum(f["gflop"] for f in fam.values()) / 1e3
     roof = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(d["frac_of_peak"], 4), "traffic": None, "launches_per_step": d["launches"],
+            "frac": round(d["frac_of_peak"], 4), "traffic": measured_traffic(dom), "launches_per_step": d["launches"],
             "avg_launch_us": round(d["avg_us"], 1), "gflop_per_step": round(d["gflop"], 1),
+            "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
             "families": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(fam.items())}}
     return roof, executed_tflop
 

@@ -1,0 +1,55 @@
+#!/usr/bin/env python
+"""profiles/traffic.json from two rocprofv3 PMC passes over `python bench.py ...` (FETCH_SIZE pass, WRITE_SIZE pass).
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d out/f -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d out/w -o p -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+    python tools/traffic_from_pmc.py out/f/p_counter_collection.csv out/w/p_counter_collection.csv "<provenance note>"
+
+HBM bytes per launch = 2 * FETCH_SIZE + WRITE_SIZE (both reported in KiB): on gfx950 FETCH_SIZE counts 128-byte requests
+as 64 bytes for wide coalesced streams (MI355X_MICROARCH.md §HBM), which is what these kernels issue (16 B per lane)."""
+import collections
+import csv
+import json
+import os
+import sys
+
+GROUPS = {"mma_pipe_kernel (gemm + conv3x3)": ("mma_pipe_kernel", "mma_kernel", "splitk_reduce_kernel"),
+          "attn_fwd_kernel": ("attn_fwd_kernel",)}
+
+
+def load(path, counter):
+    tot, n = collections.Counter(), collections.Counter()
+    seen = set()
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            for g, pats in GROUPS.items():
+                if any(p in r["Kernel_Name"] for p in pats):
+                    tot[g] += float(r["Counter_Value"])
+                    key = (g, r["Dispatch_Id"])
+                    if key not in seen and "splitk_reduce" not in r["Kernel_Name"]:   # the reduce pass belongs to its GEMM launch
+                        seen.add(key)
+                        n[g] += 1
+    return tot, n
+
+
+def main():
+    fpath, wpath, note = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "")
+    ft, fn = load(fpath, "FETCH_SIZE")
+    wt, wn = load(wpath, "WRITE_SIZE")
+    out = {"note": note, "formula": "2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), averaged over every launch of the run", "kernels": {}}
+    for g in GROUPS:
+        if fn[g] == 0 or wn[g] == 0:
+            continue
+        fetch, write = ft[g] / fn[g] * 1024.0, wt[g] / wn[g] * 1024.0
+        out["kernels"][g] = {"launches_fetch_pass": fn[g], "launches_write_pass": wn[g], "fetch_size_bytes_raw": round(fetch),
+                             "write_size_bytes": round(write), "hbm_bytes_per_launch": round(2 * fetch + write)}
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "traffic.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
