@@ -46,6 +46,7 @@ struct MmaParams {
     const void* res2; long ldr2;
     // decomposition
     float* ws; int splits; int kt_per_split; int tiles_m, tiles_n;
+    int n_major;   // tile order: 1 = consecutive ids walk M first (tiles sharing a weight panel stay on one XCD / L2)
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
@@ -240,7 +241,8 @@ __global__ __launch_bounds__(256) void mma_kernel(const MmaParams p) {
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
     const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int m0 = (lid / p.tiles_n) * BM, n0 = (lid % p.tiles_n) * BN;
+    const int m0 = (p.n_major ? lid % p.tiles_m : lid / p.tiles_n) * BM;
+    const int n0 = (p.n_major ? lid / p.tiles_m : lid % p.tiles_n) * BN;
     const int z = blockIdx.y;
     const int kt0 = z * p.kt_per_split;
     const int kt1 = min(p.KT, kt0 + p.kt_per_split);
@@ -381,7 +383,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParam
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, hi = lane >> 5;
     const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-    const int m0 = (lid / p.tiles_n) * BM, n0 = (lid % p.tiles_n) * BN;
+    const int m0 = (p.n_major ? lid % p.tiles_m : lid / p.tiles_n) * BM;
+    const int n0 = (p.n_major ? lid / p.tiles_m : lid % p.tiles_n) * BN;
     const int z = blockIdx.y;
     const int kt0 = z * p.kt_per_split;
     const int nt = min(p.KT, kt0 + p.kt_per_split) - kt0;
@@ -521,9 +524,10 @@ struct Plan { int bm, bn, splits; };
 // Development knobs (read once from the environment): SG_TILE="bm,bn" forces a tile shape, SG_NO_PIPE=1 disables
 // the LDS-DMA pipeline, SG_NO_SPLIT=1 disables automatic split-K.  Unset in production.
 struct Tune {
-    mutable int bm = 0, bn = 0, no_pipe = 0, no_split = 0, stages = 0;
+    mutable int bm = 0, bn = 0, no_pipe = 0, no_split = 0, stages = 0, no_nmajor = 0;
     Tune() {
         if (const char* e = getenv("SG_STAGES")) stages = atoi(e);
+        if (const char* e = getenv("SG_NO_NMAJOR")) no_nmajor = atoi(e);
         if (const char* e = getenv("SG_TILE")) sscanf(e, "%d,%d", &bm, &bn);
         if (const char* e = getenv("SG_NO_PIPE")) no_pipe = atoi(e);
         if (const char* e = getenv("SG_NO_SPLIT")) no_split = atoi(e);
@@ -597,6 +601,14 @@ int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws
     p.kt_per_split = sg_cdiv(p.KT, pl.splits);
     p.tiles_m = sg_cdiv(p.M, pl.bm);
     p.tiles_n = sg_cdiv(p.N, pl.bn);
+    // Each XCD has a private L2 and consecutive tile ids share one (xcd_remap): let them share the LARGER operand panel, so
+    // that it is fetched from HBM / Infinity Cache by one XCD instead of by all that own a tile of it.  At the 16x16 and
+    // 8x8 latent levels the weights (up to 59 MB per layer) dwarf the activations: walk M first there.
+    {
+        const double a_bytes = CONV ? 2.0 * p.M * (p.K / 9) * (p.stride == 1 && !p.ups ? 1.0 : (p.ups ? 0.25 : 4.0)) : 2.0 * p.M * p.K;
+        const double w_bytes = 2.0 * p.N * p.K;
+        p.n_major = (w_bytes > a_bytes && !g_tune.no_nmajor) ? 1 : 0;
+    }
     dim3 grid(p.tiles_m * p.tiles_n, pl.splits);
     // ring depth: 3 stages (deeper prefetch) unless overridden; SG_STAGES=2 halves... see DESIGN.md §5.2
     const int stages = g_tune.stages == 2 ? 2 : 3;

@@ -1,6 +1,7 @@
 // GroupNorm(+SiLU) over NHWC and LayerNorm over rows, fp16 in/out, fp32 statistics (HBM-bound kernels: every access
 // is a 16-byte, row-contiguous vector; statistics are deterministic — no atomics).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -168,6 +169,80 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
     }
 }
 
+// Small feature maps (16x16 / 8x8 latent levels): one workgroup owns one (batch, group) slab, keeps it in registers,
+// computes exact two-pass statistics and writes the normalised output — one launch, one read of x.
+constexpr int GNF_MAXI = 24;   // 4-element items per thread: slabs of up to 256 * 24 * 4 = 24576 values
+
+__global__ __launch_bounds__(256) void gn_fused_kernel(const GnParams p) {
+    __shared__ float s_red[8];
+    const int t = threadIdx.x, b = blockIdx.y, g = blockIdx.x;
+    const int q = p.cpg / 4;                    // 4-channel items per pixel in this group
+    const int items = p.HW * q;
+    const long xb = (long)b * p.HW * p.ldx + (long)g * p.cpg;
+    const bool f32 = p.x_f32;
+    float v[GNF_MAXI][4];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < GNF_MAXI; ++i) {
+        const int it = t + i * 256;
+        v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+        if (it < items) {
+            const int px = it / q, c4 = it - px * q;
+            const long off = xb + (long)px * p.ldx + c4 * 4;
+            if (f32) {
+                const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.x) + off);
+                v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
+            } else {
+                const f16x4 a = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(p.x) + off);
+                v[i][0] = (float)a[0]; v[i][1] = (float)a[1]; v[i][2] = (float)a[2]; v[i][3] = (float)a[3];
+            }
+            sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+        }
+    }
+    auto block_sum = [&](float x) {
+        x = wave_sum(x);
+        __syncthreads();
+        if ((t & 63) == 0) s_red[t >> 6] = x;
+        __syncthreads();
+        return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    };
+    const float n = (float)items * 4.f;
+    const float mean = block_sum(sum) / n;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < GNF_MAXI; ++i)
+        if (t + i * 256 < items) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; sq += d * d; }
+        }
+    const float rstd = rsqrtf(block_sum(sq) / n + p.eps);
+    const int pw = p.pad_w;
+    f16* yb = pw ? p.y + ((long)b * (p.HW / pw + 2) * (pw + 2)) * p.ldy : p.y + (long)b * p.HW * p.ldy;
+    f16* cb = p.xcopy ? p.xcopy + (long)b * p.HW * p.ldxc : nullptr;
+#pragma unroll
+    for (int i = 0; i < GNF_MAXI; ++i) {
+        const int it = t + i * 256;
+        if (it < items) {
+            const int px = it / q, c4 = it - px * q;
+            const int ch = g * p.cpg + c4 * 4;
+            const f16x4 gm = *reinterpret_cast<const f16x4*>(p.gamma + ch), bt = *reinterpret_cast<const f16x4*>(p.beta + ch);
+            f16x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float r = (v[i][j] - mean) * rstd * (float)gm[j] + (float)bt[j];
+                o[j] = (f16)(p.silu ? silu_f(r) : r);
+            }
+            long orow = px;
+            if (pw) { const int yy = px / pw, xx = px - yy * pw; orow = (long)(yy + 1) * (pw + 2) + xx + 1; }
+            *reinterpret_cast<f16x4*>(yb + orow * p.ldy + ch) = o;
+            if (cb) {
+                f16x4 c = {(f16)v[i][0], (f16)v[i][1], (f16)v[i][2], (f16)v[i][3]};
+                *reinterpret_cast<f16x4*>(cb + (long)px * p.ldxc + ch) = c;
+            }
+        }
+    }
+}
+
 struct LnParams {
     const void* x; long ldx; int x_f32; int M, C; float eps;
     const f16* g1; const f16* b1; f16* y1; long ldy1;
@@ -271,6 +346,13 @@ extern "C" int sg_groupnorm_nhwc_f16(const sg_groupnorm_desc* d, sg_stream_t str
     p.gamma = reinterpret_cast<const f16*>(d->gamma); p.beta = reinterpret_cast<const f16*>(d->beta);
     p.HW = d->HW; p.C = d->C; p.G = d->groups; p.cpg = d->C / d->groups; p.eps = d->eps; p.silu = d->silu;
     p.ws = reinterpret_cast<float*>(d->workspace);
+    hipStream_t st0 = (hipStream_t)stream;
+    static const bool no_fused = [] { const char* e = getenv("SG_NO_GN_FUSED"); return e && atoi(e) != 0; }();   // development knob
+    if (p.cpg % 4 == 0 && (long)p.HW * p.cpg <= 256L * 4 * GNF_MAXI && !no_fused) {
+        hipLaunchKernelGGL(gn_fused_kernel, dim3(p.G, d->B), dim3(256), 0, st0, p);
+        SG_CHECK_LAUNCH("gn_fused");
+        return SG_OK;
+    }
     int apply_blocks = 1;
     gn_geometry(d->B, d->HW, d->C, d->x_f32 != 0, &p.nchunks, &p.rows_per_chunk, &apply_blocks, &p.apply_rows);
     dim3 grid(p.nchunks, d->B), block(256);

@@ -276,7 +276,8 @@ def test_attention_shared_kv_batches(gpu, D, Nq, Nk):
 
 
 @pytest.mark.parametrize("B,HW,C,silu,eps", [(3, 256, 320, True, 1e-5), (2, 64, 1920, True, 1e-5), (1, 100, 2560, False, 1e-6),
-                                            (3, 4096, 320, False, 1e-6), (2, 1024, 960, True, 1e-5), (1, 7, 64, True, 1e-5)])
+                                            (3, 4096, 320, False, 1e-6), (2, 1024, 960, True, 1e-5), (1, 7, 64, True, 1e-5),
+                                            (4, 256, 1280, True, 1e-5), (2, 256, 2560, False, 1e-6), (3, 64, 640, True, 1e-5)])
 def test_groupnorm(gpu, B, HW, C, silu, eps):
     from storygen_amd import ops
     x = (rnd((B, HW, C), gpu, 2.0, seed=1).float() + 3.0).half()      # non-zero mean

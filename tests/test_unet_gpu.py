@@ -203,3 +203,26 @@ def test_distinct_prev_uncond_disables_zero_sharing(gpu, sd15):
     smp = StoryGenSampler(arch, sd, gpu, 1, 32, 32, 2, use_graph=False)
     smp.prepare(inputs, 50, "multi-image-condition", 7.5, 3.5)
     assert smp.U == 4
+
+
+@pytest.mark.parametrize("stage", ["multi-image-condition", "auto-regressive"])
+def test_two_samples_per_gpu_vs_oracle_32x32(gpu, sd15, stage):
+    """N = 2 independent story frames in one sampler (num_images_per_prompt / batch of prompts): exercises the general-N
+    layout of the deduplicated reference batch, the harvest scatter and the shared-context attention groups."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.sampler import StoryGenSampler
+    from storygen_amd.synth import synthetic_inputs
+    arch, sd = sd15
+    inputs = synthetic_inputs(2, 2, 32, 32, 13, arch.config["cross_attention_dim"])
+    want = []
+    O.sample_loop(sd, arch.config, inputs, 50, stage, 7.5, 3.5, max_steps=2, trace=want)
+    smp = StoryGenSampler(arch, sd, gpu, 2, 32, 32, 2, use_graph=True)
+    smp.prepare(inputs, 50, stage, 7.5, 3.5)
+    assert smp.U == (2 * (1 + 2) if stage == "multi-image-condition" else 2 * 2 * 2)
+    got = []
+    smp.run(max_steps=2, trace=got)
+    torch.cuda.synchronize()
+    errs = [rel_l2(a.cpu(), b) for a, b in zip(got, want)]
+    per_sample = [rel_l2(got[-1][n].cpu(), want[-1][n]) for n in range(2)]
+    print(stage, [f"{e:.2e}" for e in errs], "per sample", [f"{e:.2e}" for e in per_sample])
+    assert max(errs + per_sample) <= TOL_LATENT
