@@ -78,10 +78,13 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
 
     const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    // consecutive logical work items (q-blocks of one (batch, head)) run on the same XCD and share its L2
+    // consecutive logical work items run on the same XCD and share its (private, 4 MiB) L2: order them head-major, so that
+    // an XCD works on ONE head across all batches at a time — with H = 8 heads, XCD k owns head k.  Its K/V working set
+    // is then one head's keys for the distinct K/V batches (2 x 1.9 MB for the main pass's 12 288-key context, where
+    // batches 1 and 2 share a row) instead of three different (batch, head) streams that do not fit.
     const int work = xcd_remap(blockIdx.x, gridDim.x);
     const int bh = work / p.nqb, qb = work - bh * p.nqb;
-    const int b = bh / p.H, h = bh - b * p.H;
+    const int h = bh / p.B, b = bh - h * p.B;
     const int kvb = b < p.kv_batches ? b : b - (p.B - p.kv_batches);
     const int q0 = (qb * NW + wave) * 32;
     const f16* Q = p.q + (long)b * p.bsq + (long)h * D;

@@ -368,7 +368,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WGM, int WGN, int S, bool CONV>
+template <int WGM, int WGN, int S, bool CONV, bool LATE>
 __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParams p) {
     constexpr int NW = WGM * WGN, BM = 64 * WGM, BN = 64 * WGN;
     constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW), LPT = A_IT + B_IT;   // LDS-DMA instructions / lane / slab
@@ -389,11 +389,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParam
     const int kt0 = z * p.kt_per_split;
     const int nt = min(p.KT, kt0 + p.kt_per_split) - kt0;
 
-    // staging coordinates of this lane for DMA instruction i: tile row srow + 8*NW*i, LDS slot (lane & 7)
+    // staging coordinates of this lane for DMA instruction i: tile row srow + 8*NW*i, LDS slot (lane & 7).
+    // All per-lane address arithmetic is done ONCE here as 32-bit element offsets; per slab only wave-uniform (scalar)
+    // terms change: GEMM  A + kt*64;  conv  A + ((ky*wp + kx)*lda + cc*64)  — or, with nearest-2x upsampling, where the
+    // source row (oy-1+ky)>>1 is not affine in ky, one of three precomputed row / column offsets picked by (ky, kx).
     const int srow = wave * 8 + (lane >> 3);
-    const f16* a_ptr[A_IT];
-    int a_oy[A_IT], a_ox[A_IT];
     const int wp = p.Wd + 2;
+    unsigned a_off[A_IT];                       // offset of the row (GEMM) / of tap (0, 0) (conv)
+    unsigned a_par[A_IT];                       // conv with upsampling: parity bits of (oy - 1, ox - 1)
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
         const int row = srow + 8 * NW * i;
@@ -403,20 +406,27 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParam
             const int hw = p.Ho * p.Wo;
             const int b = gm / hw, rem = gm - b * hw;
             const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            a_oy[i] = oy * p.stride - 1;
-            a_ox[i] = ox * p.stride - 1;
-            a_ptr[i] = p.A + (long)b * (p.H + 2) * wp * p.lda + lc * 8;
+            const long img = (long)b * (p.H + 2) * wp;
+            // padded input pixel of tap (ky, kx): row ((oy*stride - 1 + ky) >> ups) + 1, column likewise
+            if (!p.ups) {
+                a_off[i] = (unsigned)((img + (long)(oy * p.stride) * wp + ox * p.stride) * p.lda + lc * 8);
+                a_par[i] = 0;
+            } else {
+                // source row of tap ky: ((oy - 1 + ky) >> 1) + 1 = ((oy - 1) >> 1) + 1 + ((ky + ((oy - 1) & 1)) >> 1)
+                a_off[i] = (unsigned)((img + (long)(((oy - 1) >> 1) + 1) * wp + ((ox - 1) >> 1) + 1) * p.lda + lc * 8);
+                a_par[i] = (unsigned)(((oy - 1) & 1) | (((ox - 1) & 1) << 1));
+            }
         } else {
-            a_oy[i] = a_ox[i] = 0;
-            a_ptr[i] = p.A + (long)gm * p.lda + lc * 8;
+            a_off[i] = (unsigned)((long)gm * p.lda + lc * 8);
+            a_par[i] = 0;
         }
     }
-    const f16* w_ptr[B_IT];
+    unsigned w_off[B_IT];
 #pragma unroll
     for (int i = 0; i < B_IT; ++i) {
         const int row = srow + 8 * NW * i;
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
-        w_ptr[i] = p.W + (long)min(n0 + row, p.N - 1) * p.ldw + lc * 8;
+        w_off[i] = (unsigned)((long)min(n0 + row, p.N - 1) * p.ldw + lc * 8);
     }
 
     auto issue = [&](int kt, int stage) {
@@ -425,17 +435,27 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParam
         if constexpr (CONV) {
             const int tap = kt / p.cpt, cc = kt - tap * p.cpt;
             const int ky = tap / 3, kx = tap - ky * 3;
+            if (!p.ups) {
+                const f16* At = p.A + ((long)(ky * wp + kx) * p.lda + cc * BK);
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) {
-                const int py = ((a_oy[i] + ky) >> p.ups) + 1, px = ((a_ox[i] + kx) >> p.ups) + 1;
-                glds16(a_ptr[i] + ((long)py * wp + px) * p.lda + cc * BK, sA + i * ISTR);
+                for (int i = 0; i < A_IT; ++i) glds16(At + a_off[i], sA + i * ISTR);
+            } else {
+                const f16* At = p.A + cc * BK;
+                const unsigned rs = (unsigned)(wp * (int)p.lda), cs = (unsigned)p.lda;     // < 2^24 (validated on the host)
+#pragma unroll
+                for (int i = 0; i < A_IT; ++i) {
+                    const unsigned dy = ((unsigned)ky + (a_par[i] & 1u)) >> 1, dx = ((unsigned)kx + (a_par[i] >> 1)) >> 1;
+                    glds16(At + (a_off[i] + __umul24(dy, rs) + __umul24(dx, cs)), sA + i * ISTR);
+                }
             }
         } else {
+            const f16* At = p.A + kt * BK;
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) glds16(a_ptr[i] + kt * BK, sA + i * ISTR);
+            for (int i = 0; i < A_IT; ++i) glds16(At + a_off[i], sA + i * ISTR);
         }
+        const f16* Wt = p.W + kt * BK;
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) glds16(w_ptr[i] + kt * BK, sB + i * ISTR);
+        for (int i = 0; i < B_IT; ++i) glds16(Wt + w_off[i], sB + i * ISTR);
     };
 
     f32x16 acc[2][2];
@@ -456,7 +476,7 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParam
         if (S == 3 && it + 1 < nt) wait_vmcnt<LPT>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (it + S - 1 < nt) {
+        if (!LATE && it + S - 1 < nt) {         // refill right behind the barrier
             int st = stage + S - 1;
             if (st >= S) st -= S;
             issue(kt0 + it + S - 1, st);
@@ -465,6 +485,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParam
         const char* sB = sA + A_BYTES;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            // the refill of the ring (slab it+S-1 into the stage every wave has just left) is issued behind the first
+            // k-step's fragment reads / MFMAs rather than between the barrier and them: its address arithmetic then
+            // overlaps matrix work instead of delaying it
+            if (LATE && ks == 1 && it + S - 1 < nt) {
+                int st = stage + S - 1;
+                if (st >= S) st -= S;
+                issue(kt0 + it + S - 1, st);
+            }
             f16x8 af[2], bf[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -524,10 +552,11 @@ struct Plan { int bm, bn, splits; };
 // Development knobs (read once from the environment): SG_TILE="bm,bn" forces a tile shape, SG_NO_PIPE=1 disables
 // the LDS-DMA pipeline, SG_NO_SPLIT=1 disables automatic split-K.  Unset in production.
 struct Tune {
-    mutable int bm = 0, bn = 0, no_pipe = 0, no_split = 0, stages = 0, no_nmajor = 0;
+    mutable int bm = 0, bn = 0, no_pipe = 0, no_split = 0, stages = 0, no_nmajor = 0, late_issue = 1;
     Tune() {
         if (const char* e = getenv("SG_STAGES")) stages = atoi(e);
         if (const char* e = getenv("SG_NO_NMAJOR")) no_nmajor = atoi(e);
+        if (const char* e = getenv("SG_LATE_ISSUE")) late_issue = atoi(e);
         if (const char* e = getenv("SG_TILE")) sscanf(e, "%d,%d", &bm, &bn);
         if (const char* e = getenv("SG_NO_PIPE")) no_pipe = atoi(e);
         if (const char* e = getenv("SG_NO_SPLIT")) no_split = atoi(e);
@@ -577,8 +606,10 @@ Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool p
 
 template <int WGM, int WGN, bool CONV>
 void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st, int stages) {
-    if (stages == 2) hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 2, CONV>), grid, dim3(64 * WGM * WGN), 0, st, p);
-    else hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV>), grid, dim3(64 * WGM * WGN), 0, st, p);
+    const bool late = g_tune.late_issue != 0;
+    if (stages == 2) hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 2, CONV, false>), grid, dim3(64 * WGM * WGN), 0, st, p);
+    else if (late) hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV, true>), grid, dim3(64 * WGM * WGN), 0, st, p);
+    else hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV, false>), grid, dim3(64 * WGM * WGN), 0, st, p);
 }
 
 template <bool CONV>
@@ -682,6 +713,8 @@ extern "C" int sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream) {
                "sg_gemm_f16: rowbias alignment / rows_per_batch");
     SG_REQUIRE(d->split_k >= 0 && d->split_k <= 64, "sg_gemm_f16: bad split_k %d", d->split_k);
     SG_REQUIRE(!d->workspace || sg_aligned16(d->workspace), "sg_gemm_f16: workspace alignment");
+    SG_REQUIRE((int64_t)d->M * d->lda < (1ll << 32) && (int64_t)d->N * d->ldw < (1ll << 32),
+               "sg_gemm_f16: operands larger than 2^32 elements are not supported (32-bit DMA offsets)");
     MmaParams p{};
     p.A = reinterpret_cast<const f16*>(d->A); p.lda = d->lda;
     p.W = reinterpret_cast<const f16*>(d->W); p.ldw = d->ldw;
@@ -712,6 +745,9 @@ extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream)
     SG_REQUIRE(!d->bias || sg_aligned16(d->bias), "sg_conv3x3: bias alignment");
     SG_REQUIRE(!d->rowbias || (sg_aligned16(d->rowbias) && d->rowbias_ld % 4 == 0), "sg_conv3x3: rowbias alignment");
     SG_REQUIRE(d->split_k >= 0 && d->split_k <= 64, "sg_conv3x3: bad split_k %d", d->split_k);
+    SG_REQUIRE((int64_t)d->B * (d->H + 2) * (d->W + 2) * d->ldx < (1ll << 32) && (int64_t)d->Cout * 9 * d->Cin < (1ll << 32),
+               "sg_conv3x3: operands larger than 2^32 elements are not supported (32-bit DMA offsets)");
+    SG_REQUIRE((int64_t)(d->W + 2) * d->ldx < (1 << 24), "sg_conv3x3: input row pitch must be below 2^24 elements");
     const int hin = d->H << d->upsample2x, win = d->W << d->upsample2x;
     const int Ho = (hin + 2 - 3) / d->stride + 1, Wo = (win + 2 - 3) / d->stride + 1;
     MmaParams p{};

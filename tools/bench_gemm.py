@@ -43,7 +43,8 @@ def main():
             us = timeit(lambda: ops.gemm(a, w, out, workspace=ws))
             row += f"{us:8.1f}|{2.0 * M * N * K / us / 1e6:6.0f} "
         print(row, flush=True)
-    convs = [(3, 64, 64, 320, 320), (3, 32, 32, 640, 640), (3, 16, 16, 1280, 1280), (3, 8, 8, 1280, 1280), (3, 64, 64, 640, 320)]
+    convs = [(4, 64, 64, 320, 320), (4, 32, 32, 640, 640), (4, 16, 16, 1280, 1280), (4, 8, 8, 1280, 1280), (4, 64, 64, 640, 320),
+             (3, 64, 64, 320, 320), (3, 16, 16, 2560, 1280)]
     print("CONV3x3 padded input")
     for B, H, W, Ci, Co in convs:
         xp = torch.zeros(B, H + 2, W + 2, Ci, dtype=torch.float16, device=dev)
