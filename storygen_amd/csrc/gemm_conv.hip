@@ -368,7 +368,7 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WGM, int WGN, int S, bool CONV, bool LATE>
+template <int WGM, int WGN, int S, bool CONV, bool LATE, bool PREF>
 __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParams p) {
     constexpr int NW = WGM * WGN, BM = 64 * WGM, BN = 64 * WGN;
     constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW), LPT = A_IT + B_IT;   // LDS-DMA instructions / lane / slab
@@ -483,28 +483,35 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParam
         }
         const char* sA = smem + stage * STAGE;
         const char* sB = sA + A_BYTES;
+        // fragment reads run one k-step ahead of the MFMAs that consume them (two register sets), so that only the first
+        // read of a slab exposes LDS latency; the other three hide behind the previous k-step's four MFMAs
+        f16x8 af[2][2], bf[2][2];
+        auto load_frags = [&](int buf, int ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                af[buf][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * 64 + i * 32 + l31, ks * 2 + hi));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bf[buf][j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * 64 + j * 32 + l31, ks * 2 + hi));
+        };
+        load_frags(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
+            if (PREF) { if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1); }
+            else if (ks > 0) load_frags(ks & 1, ks);
             // the refill of the ring (slab it+S-1 into the stage every wave has just left) is issued behind the first
-            // k-step's fragment reads / MFMAs rather than between the barrier and them: its address arithmetic then
-            // overlaps matrix work instead of delaying it
+            // k-step's fragment reads rather than between the barrier and them: its address arithmetic then overlaps
+            // matrix work instead of delaying it
             if (LATE && ks == 1 && it + S - 1 < nt) {
                 int st = stage + S - 1;
                 if (st >= S) st -= S;
                 issue(kt0 + it + S - 1, st);
             }
-            f16x8 af[2], bf[2];
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                af[i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * 64 + i * 32 + l31, ks * 2 + hi));
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                bf[j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * 64 + j * 32 + l31, ks * 2 + hi));
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
         }
         if (++stage == S) stage = 0;
     }
@@ -552,11 +559,12 @@ struct Plan { int bm, bn, splits; };
 // Development knobs (read once from the environment): SG_TILE="bm,bn" forces a tile shape, SG_NO_PIPE=1 disables
 // the LDS-DMA pipeline, SG_NO_SPLIT=1 disables automatic split-K.  Unset in production.
 struct Tune {
-    mutable int bm = 0, bn = 0, no_pipe = 0, no_split = 0, stages = 0, no_nmajor = 0, late_issue = 1;
+    mutable int bm = 0, bn = 0, no_pipe = 0, no_split = 0, stages = 0, no_nmajor = 0, late_issue = 1, no_frag_prefetch = 0;
     Tune() {
         if (const char* e = getenv("SG_STAGES")) stages = atoi(e);
         if (const char* e = getenv("SG_NO_NMAJOR")) no_nmajor = atoi(e);
         if (const char* e = getenv("SG_LATE_ISSUE")) late_issue = atoi(e);
+        if (const char* e = getenv("SG_NO_FRAG_PREFETCH")) no_frag_prefetch = atoi(e);
         if (const char* e = getenv("SG_TILE")) sscanf(e, "%d,%d", &bm, &bn);
         if (const char* e = getenv("SG_NO_PIPE")) no_pipe = atoi(e);
         if (const char* e = getenv("SG_NO_SPLIT")) no_split = atoi(e);
@@ -606,10 +614,12 @@ Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool p
 
 template <int WGM, int WGN, bool CONV>
 void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st, int stages) {
-    const bool late = g_tune.late_issue != 0;
-    if (stages == 2) hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 2, CONV, false>), grid, dim3(64 * WGM * WGN), 0, st, p);
-    else if (late) hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV, true>), grid, dim3(64 * WGM * WGN), 0, st, p);
-    else hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV, false>), grid, dim3(64 * WGM * WGN), 0, st, p);
+    const bool late = g_tune.late_issue != 0, pref = g_tune.no_frag_prefetch == 0;
+    const dim3 block(64 * WGM * WGN);
+    if (stages == 2) hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 2, CONV, false, true>), grid, block, 0, st, p);
+    else if (late && pref) hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV, true, true>), grid, block, 0, st, p);
+    else if (late) hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV, true, false>), grid, block, 0, st, p);
+    else hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV, false, true>), grid, block, 0, st, p);
 }
 
 template <bool CONV>

@@ -157,3 +157,36 @@ def test_gather_is_identity_without_process_group():
     from storygen_amd.sampler import gather_latents
     x = torch.randn(1, 4, 8, 8)
     assert gather_latents(x) is x
+
+
+# ------------------------------------------------------------------------------------------------ sampler layout
+@pytest.mark.parametrize("N,R", [(1, 1), (1, 3), (2, 2), (3, 5)])
+@pytest.mark.parametrize("mode", ["shared-zero", "dedup", "as-written"])
+def test_reference_batch_layout_reproduces_the_as_written_context(N, R, mode):
+    """StoryGenSampler._plan (which reference samples are computed, where their features are scattered, which context
+    row each main-pass sample reads) against the loop as written: main sample (j, n) must see, in frame slot i, the
+    feature of sample j*N + n of reference pass i = [zero_i | img_i | img_i] (pipeline.py:429-430,440-443)."""
+    from storygen_amd.sampler import StoryGenSampler
+    smp = object.__new__(StoryGenSampler)
+    smp.N, smp.R, smp.dedup = N, R, mode != "as-written"
+    units, hops, rows, groups = smp._plan("multi-image-condition", mode == "shared-zero")
+    assert len(units) == {"shared-zero": N * (1 + R), "dedup": 2 * N * R, "as-written": 3 * N * R}[mode]
+    ctx = [[None] * R for _ in range(rows)]
+    for src, step, row, slot, cnt in hops:
+        for j in range(cnt):
+            assert ctx[row][slot + j] is None, "a context slot is written twice"
+            ctx[row][slot + j] = units[src + j * step]
+    assert all(c is not None for r in ctx for c in r), "a context slot is never written"
+    row_of = {}
+    for q0, n, c0 in groups:
+        for k in range(n):
+            assert q0 + k not in row_of
+            row_of[q0 + k] = c0 + k
+    assert sorted(row_of) == list(range(3 * N))
+    for j in range(3):
+        for n in range(N):
+            for i in range(R):
+                kind, frame, sample = ctx[row_of[j * N + n]][i]
+                assert kind == (0 if j == 0 else 1) and sample == n
+                if kind == 1 or mode != "shared-zero":
+                    assert frame == i
