@@ -154,10 +154,14 @@ def main():
         raise SystemExit("bench.py needs an MI355X; no GPU visible (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
-    if world > 1:
+    # one process per GPU under torch.distributed.run (RCCL); a torchrun launch with a single rank still goes through the
+    # same collectives, so the N > 1 code path can be exercised on a 1-GPU box
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from storygen_amd.arch import SD15_CONFIG, build_arch
     from storygen_amd.sampler import StoryGenSampler, gather_latents
@@ -172,8 +176,7 @@ def main():
     sampler.prepare(inputs, n_sched, "multi-image-condition", 7.5, 3.5)
 
     def barrier():
-        if world > 1:
-            import torch.distributed as dist
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
@@ -185,8 +188,7 @@ def main():
         sampler.step()
     barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
-        import torch.distributed as dist
+    if use_dist:
         tt = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -195,6 +197,7 @@ def main():
     torch.cuda.synchronize(dev)
     gather_ms = 1e3 * (time.perf_counter() - t0)
     finite = bool(torch.isfinite(final).all())
+    assert final.shape[0] == world * N_PER_GPU, f"all-gather returned {final.shape[0]} samples for {world} ranks"
 
     if rank == 0:
         value = world * N_PER_GPU * args.steps / dt
@@ -209,7 +212,7 @@ def main():
                        "hipgraph": not args.no_graph, "dedup_identical_reference_samples": not args.no_dedup,
                        "overlap_ref_pass_of_next_step": sampler.overlap},
             "tflop_per_step_as_written": round(STEP_TFLOP, 3),
-            "final_allgather_ms": round(gather_ms, 3), "latents_finite": finite,
+            "final_allgather_ms": round(gather_ms, 3), "latents_gathered": int(final.shape[0]), "latents_finite": finite,
         }
         out["roofline"], executed = in_situ_roofline(sampler)
         out["tflop_per_step_executed"] = round(executed, 3)
@@ -219,8 +222,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(arch, sd, inputs)
         print(json.dumps(out), flush=True)
-    if world > 1:
-        import torch.distributed as dist
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

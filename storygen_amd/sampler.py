@@ -306,7 +306,7 @@ def gather_latents(latents: torch.Tensor) -> torch.Tensor:
     """The single collective of the data-parallel loop: all-gather of the final latents (32 KiB per rank at
     512x512) over RCCL/xGMI.  Returns [world*N, 4, h, w]; identity when torch.distributed is not initialised."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return latents
     out = [torch.empty_like(latents) for _ in range(dist.get_world_size())]
     dist.all_gather(out, latents.contiguous())
