@@ -3,11 +3,14 @@
 Re-design of /root/reference/model/unet_2d_condition.py:338-485 (+ unet_2d_blocks.py forward paths and
 attention.py:85-128,236-302) around what the MI355X wants rather than around nn.Module calls:
 
-  * every activation is a channels-last fp16 matrix [B*H*W, C]; the transformer's token layout IS that matrix, so
-    the reference's permute/reshape pairs (attention.py:103,117) disappear;
-  * weights are repacked once (KRSC convs, fused QKV / KV projections, 32/32-interleaved GEGLU, all 22
+  * every activation is a channels-last matrix [B*H*W, C] — fp32 for the residual stream, fp16 for everything that
+    feeds an MFMA; the transformer's token layout IS that matrix, so the reference's permute/reshape pairs
+    (attention.py:103,117) disappear;
+  * weights are repacked once and shared by every engine (EngineWeights): KRSC convs, fused q|k projections, V
+    projections kept separate because they are computed TRANSPOSED (VT = Wv . X^T, the attention kernel's operand
+    layout), [Wo2 | Wo3] for the single out-projection of the two cross-attentions, 32/32-interleaved GEGLU, all 22
     time_emb_proj stacked into one GEMV bundle whose output, plus the conv1 bias, becomes conv1's per-sample
-    channel bias);
+    channel bias;
   * residual adds, biases, the `(a2+h)+(a3+h)` combine (attention.py:277,291-293) and GEGLU live in GEMM/conv
     epilogues; nearest-2x upsampling and stride-2 are folded into the conv gather; `torch.cat([h, skip])`
     becomes "the producer writes its columns of the concat buffer" + one strided copy of the skip;
@@ -15,7 +18,10 @@ attention.py:85-128,236-302) around what the MI355X wants rather than around nn.
     [B, R*HW, C] that the main pass cross-attends to (replaces the clones at unet_2d_condition.py:428-429,445,
     468-470 and the token-axis concat at pipeline.py:440-443);
   * all buffers are allocated up front, nothing allocates or synchronises inside `forward`, timestep values are
-    read from device memory — so a whole pass (or a whole denoising step) can be captured in one hipGraph.
+    read from device memory — so a whole pass (or a whole denoising step) can be captured in one hipGraph;
+  * independent branches inside a pass (1x1 shortcut beside conv1 -> norm2, text attention beside image attention)
+    can run on a side stream (`forward(side=...)`), and a reference pass can also run the attn3 K / V^T projections
+    of each context it completes (HarvestPlan.kv), taking them off the main pass's critical path.
 """
 from __future__ import annotations
 
@@ -341,7 +347,7 @@ class UNetEngine:
                                                         self._buf(a.channels, self.B * self.Sp))
                 self._project_text(self.xfs[a.prefix], *bufs)
 
-    def _transformer(self, xf: _Xf, x: torch.Tensor, out: Optional[torch.Tensor], lvl: int, text: torch.Tensor,
+    def _transformer(self, xf: _Xf, x: torch.Tensor, out: Optional[torch.Tensor], lvl: int, text: Optional[torch.Tensor],
                      harvest: Optional[HarvestPlan], consume: bool, text_cache: bool = False, stop_after_harvest: bool = False):
         """Transformer2DModel.forward (attention.py:85-128) + BasicTransformerBlock.forward (:236-302).
         x, out, h0..h3 fp32; everything that feeds an MFMA fp16."""
