@@ -90,6 +90,7 @@ typedef struct sg_gemm_desc {
     int32_t        split_k;           /* 0 = auto, 1 = none, >1 = forced */
     int32_t        tile_m, tile_n;    /* 0, 0 = library heuristic; else one of 256x128, 128x128, 256x64, 128x64, 64x128,
                                          64x64 (a tuning hint: results are identical up to fp32 summation order) */
+    int32_t        tile_waves;        /* 0 = default (64x64 per wave); 4 with 256x128 / 2 with 128x128 = 128x64 per wave */
     const void*    res1; int64_t ldr1;   /* fp16, or fp32 with SG_F_RES1_F32 */
     const void*    res2; int64_t ldr2;   /* fp16, or fp32 with SG_F_RES2_F32 */
     void*          workspace; size_t workspace_bytes;
@@ -126,7 +127,7 @@ typedef struct sg_conv3x3_desc {
     const float*   rowbias; int64_t rowbias_ld;   /* fp32 [B, rowbias_ld] or NULL */
     const void*    res1; int64_t ldr1;            /* [B, Ho, Wo, Cout] or NULL; fp16, or fp32 with SG_F_RES1_F32 */
     int32_t        split_k;           /* as in sg_gemm_desc */
-    int32_t        tile_m, tile_n;    /* as in sg_gemm_desc */
+    int32_t        tile_m, tile_n, tile_waves;   /* as in sg_gemm_desc */
     void*          workspace; size_t workspace_bytes;   /* sg_gemm_workspace_bytes(B*Ho*Wo, Cout, split_k) */
 } sg_conv3x3_desc;
 

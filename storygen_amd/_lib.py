@@ -25,7 +25,7 @@ class GemmDesc(C.Structure):
         ("rowbias_ld", C.c_int64),
         ("rows_per_batch", C.c_int32),
         ("split_k", C.c_int32),
-        ("tile_m", C.c_int32), ("tile_n", C.c_int32),
+        ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("tile_waves", C.c_int32),
         ("res1", C.c_void_p), ("ldr1", C.c_int64),
         ("res2", C.c_void_p), ("ldr2", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
@@ -46,7 +46,7 @@ class ConvDesc(C.Structure):
         ("rowbias", C.c_void_p), ("rowbias_ld", C.c_int64),
         ("res1", C.c_void_p), ("ldr1", C.c_int64),
         ("split_k", C.c_int32),
-        ("tile_m", C.c_int32), ("tile_n", C.c_int32),
+        ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("tile_waves", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
     ]
 

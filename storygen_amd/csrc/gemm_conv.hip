@@ -368,9 +368,12 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WGM, int WGN, int S, bool CONV, bool LATE, bool PREF>
+template <int WGM, int WGN, int S, bool CONV, bool LATE, bool PREF, int WTM = 2, int WTN = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParams p) {
-    constexpr int NW = WGM * WGN, BM = 64 * WGM, BN = 64 * WGN;
+    // every wave owns a (32 WTM) x (32 WTN) output sub-tile.  2 x 2 needs 1 KiB of LDS fragment reads per MFMA, which at
+    // full MFMA rate is the whole LDS read bandwidth of the CU (8 waves x 32 B/clk); "fat" 4 x 2 waves (128 x 64, 128
+    // accumulator registers, one wave per SIMD) need 0.75 KiB per MFMA and half as many waves for the same tile.
+    constexpr int NW = WGM * WGN, WM = 32 * WTM, WN = 32 * WTN, BM = WM * WGM, BN = WN * WGN;
     constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW), LPT = A_IT + B_IT;   // LDS-DMA instructions / lane / slab
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int EPI_BYTES = WGM * 32 * BN * 4;   // one 32-row band per wave-row (tile_epilogue)
@@ -458,11 +461,11 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParam
         for (int i = 0; i < B_IT; ++i) glds16(Wt + w_off[i], sB + i * ISTR);
     };
 
-    f32x16 acc[2][2];
+    f32x16 acc[WTM][WTN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < WTM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j)
+        for (int j = 0; j < WTN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
@@ -485,14 +488,14 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParam
         const char* sB = sA + A_BYTES;
         // fragment reads run one k-step ahead of the MFMAs that consume them (two register sets), so that only the first
         // read of a slab exposes LDS latency; the other three hide behind the previous k-step's four MFMAs
-        f16x8 af[2][2], bf[2][2];
+        f16x8 af[2][WTM], bf[2][WTN];
         auto load_frags = [&](int buf, int ks) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
-                af[buf][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * 64 + i * 32 + l31, ks * 2 + hi));
+            for (int i = 0; i < WTM; ++i)
+                af[buf][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WM + i * 32 + l31, ks * 2 + hi));
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
-                bf[buf][j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * 64 + j * 32 + l31, ks * 2 + hi));
+            for (int j = 0; j < WTN; ++j)
+                bf[buf][j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WN + j * 32 + l31, ks * 2 + hi));
         };
         load_frags(0, 0);
 #pragma unroll
@@ -508,9 +511,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParam
                 issue(kt0 + it + S - 1, st);
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < WTM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < WTN; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
         }
         if (++stage == S) stage = 0;
@@ -554,17 +557,18 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const MmaParams p) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-struct Plan { int bm, bn, splits; };
+struct Plan { int bm, bn, splits, fat; };
 
 // Development knobs (read once from the environment): SG_TILE="bm,bn" forces a tile shape, SG_NO_PIPE=1 disables
 // the LDS-DMA pipeline, SG_NO_SPLIT=1 disables automatic split-K.  Unset in production.
 struct Tune {
-    mutable int bm = 0, bn = 0, no_pipe = 0, no_split = 0, stages = 0, no_nmajor = 0, late_issue = 1, no_frag_prefetch = 0;
+    mutable int bm = 0, bn = 0, no_pipe = 0, no_split = 0, stages = 0, no_nmajor = 0, late_issue = 1, no_frag_prefetch = 0, fat = 0;
     Tune() {
         if (const char* e = getenv("SG_STAGES")) stages = atoi(e);
         if (const char* e = getenv("SG_NO_NMAJOR")) no_nmajor = atoi(e);
         if (const char* e = getenv("SG_LATE_ISSUE")) late_issue = atoi(e);
         if (const char* e = getenv("SG_NO_FRAG_PREFETCH")) no_frag_prefetch = atoi(e);
+        if (const char* e = getenv("SG_FAT")) fat = atoi(e);
         if (const char* e = getenv("SG_TILE")) sscanf(e, "%d,%d", &bm, &bn);
         if (const char* e = getenv("SG_NO_PIPE")) no_pipe = atoi(e);
         if (const char* e = getenv("SG_NO_SPLIT")) no_split = atoi(e);
@@ -578,13 +582,13 @@ static const Tune g_tune;
 //   t_mfma = (waves per SIMD) x slabs x 512                                  — 16 MFMAs of 32 cycles per 64-deep slab,
 // plus a fixed prologue/epilogue.  Splitting K does not add operand bytes but multiplies the CUs that share them,
 // which is what small-M layers need; it costs a second launch that re-reads the fp32 partial tiles.
-Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool pipe, int hint_bm, int hint_bn) {
+Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool pipe, int hint_bm, int hint_bn, int hint_waves) {
     static const int cand_pipe[6][2] = {{256, 128}, {128, 128}, {256, 64}, {128, 64}, {64, 128}, {64, 64}};
     static const int cand_gen[3][2] = {{128, 128}, {128, 64}, {64, 64}};
     static const int split_opts[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
     const int ncand = pipe ? 6 : 3;
     const double CUS = 256.0, BW = pipe ? 18.5 : 12.0;
-    Plan best{64, 64, 1};
+    Plan best{64, 64, 1, 0};
     double best_cost = 1e300;
     for (int ci = 0; ci < ncand; ++ci) {
         const int bm = pipe ? cand_pipe[ci][0] : cand_gen[ci][0], bn = pipe ? cand_pipe[ci][1] : cand_gen[ci][1];
@@ -605,11 +609,20 @@ Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool p
             const double t_mfma = waves_per_simd * slabs * mfma_per_slab;
             double cost = (t_bw > t_mfma ? t_bw : t_mfma) + 2500.0 + blocks_per_cu * (bm * bn / 16.0);
             if (s > 1) cost += 5000.0 + (double)M * N * 4.0 * (s + 1) / 1500.0;   // second launch + partial tiles
-            if (cost < best_cost) { best_cost = cost; best = Plan{bm, bn, s}; }
+            if (cost < best_cost) { best_cost = cost; best = Plan{bm, bn, s, 0}; }
         }
     }
-    if (best_cost == 1e300) best = Plan{64, 64, force_split > KT ? KT : (force_split > 0 ? force_split : 1)};
+    if (best_cost == 1e300) best = Plan{64, 64, force_split > KT ? KT : (force_split > 0 ? force_split : 1), 0};
+    // "fat" waves (128 x 64 per wave): 256x128 with 4 waves, 128x128 with 2 — on request (tile_waves hint) or SG_FAT=1
+    const bool can_fat = pipe && ((best.bm == 256 && best.bn == 128) || (best.bm == 128 && best.bn == 128));
+    const int fat_waves = best.bm == 256 ? 4 : 2;
+    if (can_fat && (hint_waves == fat_waves || (hint_waves == 0 && g_tune.fat))) best.fat = 1;
     return best;
+}
+
+template <int WGM, int WGN, bool CONV>
+void launch_pipe_fat(const MmaParams& p, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV, true, true, 4, 2>), grid, dim3(64 * WGM * WGN), 0, st, p);
 }
 
 template <int WGM, int WGN, bool CONV>
@@ -623,14 +636,14 @@ void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st, int stages) {
 }
 
 template <bool CONV>
-int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws, size_t ws_bytes, hipStream_t st, const char* name) {
+int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_waves, void* ws, size_t ws_bytes, hipStream_t st, const char* name) {
     p.KT = sg_cdiv(p.K, BK);
     // LDS-DMA pipeline when no load needs a predicate (K % 64 == 0; conv input zero-bordered), else the
     // register-staged kernel that zero-fills out-of-range chunks.
     const bool pipe = (p.K % BK == 0) && (!CONV || p.padded) && !g_tune.no_pipe;
     const size_t per_split = (size_t)p.M * p.N * 4;
     const int max_ws_split = ws ? (int)(ws_bytes / per_split > 64 ? 64 : ws_bytes / per_split) : 1;
-    Plan pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, pipe, hint_bm, hint_bn);
+    Plan pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, pipe, hint_bm, hint_bn, hint_waves);
     if (pl.splits > 1) {
         const size_t need = per_split * pl.splits;
         if (ws == nullptr || ws_bytes < need)
@@ -653,7 +666,10 @@ int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws
     dim3 grid(p.tiles_m * p.tiles_n, pl.splits);
     // ring depth: 3 stages (deeper prefetch) unless overridden; SG_STAGES=2 halves... see DESIGN.md §5.2
     const int stages = g_tune.stages == 2 ? 2 : 3;
-    if (pipe) {
+    if (pipe && pl.fat) {
+        if (pl.bm == 256) launch_pipe_fat<2, 2, CONV>(p, grid, st);
+        else launch_pipe_fat<1, 2, CONV>(p, grid, st);
+    } else if (pipe) {
         if (pl.bm == 256 && pl.bn == 128) launch_pipe<4, 2, CONV>(p, grid, st, stages);
         else if (pl.bm == 128 && pl.bn == 128) launch_pipe<2, 2, CONV>(p, grid, st, stages);
         else if (pl.bm == 256 && pl.bn == 64) launch_pipe<4, 1, CONV>(p, grid, st, stages);
@@ -686,7 +702,9 @@ int check_out_res(const char* who, int flags, const void* C, int64_t ldc, const 
     return SG_OK;
 }
 
-int check_tile_hint(const char* who, int bm, int bn) {
+int check_tile_hint(const char* who, int bm, int bn, int waves) {
+    if (waves != 0 && !((bm == 256 && bn == 128 && (waves == 4 || waves == 8)) || (bm == 128 && bn == 128 && (waves == 2 || waves == 4))))
+        return sg_set_error(SG_EINVAL, "%s: tile_waves=%d is not available for tile %dx%d", who, waves, bm, bn);
     if (bm == 0 && bn == 0) return SG_OK;
     static const int ok[6][2] = {{256, 128}, {128, 128}, {256, 64}, {128, 64}, {64, 128}, {64, 64}};
     for (auto& t : ok)
@@ -736,8 +754,8 @@ extern "C" int sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream) {
     p.rowbias = d->rowbias; p.rowbias_ld = d->rowbias_ld; p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1;
     p.res1 = d->res1; p.ldr1 = d->ldr1;
     p.res2 = d->res2; p.ldr2 = d->ldr2;
-    if (int rc = check_tile_hint("sg_gemm_f16", d->tile_m, d->tile_n)) return rc;
-    return launch_mma<false>(p, d->split_k, d->tile_m, d->tile_n, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_gemm_f16");
+    if (int rc = check_tile_hint("sg_gemm_f16", d->tile_m, d->tile_n, d->tile_waves)) return rc;
+    return launch_mma<false>(p, d->split_k, d->tile_m, d->tile_n, d->tile_waves, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_gemm_f16");
 }
 
 extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream) {
@@ -771,8 +789,8 @@ extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream)
     p.bias = reinterpret_cast<const f16*>(d->bias);
     p.rowbias = d->rowbias; p.rowbias_ld = d->rowbias_ld; p.rows_per_batch = Ho * Wo;
     p.res1 = d->res1; p.ldr1 = d->ldr1;
-    if (int rc = check_tile_hint("sg_conv3x3", d->tile_m, d->tile_n)) return rc;
-    return launch_mma<true>(p, d->split_k, d->tile_m, d->tile_n, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_conv3x3_nhwc_f16");
+    if (int rc = check_tile_hint("sg_conv3x3", d->tile_m, d->tile_n, d->tile_waves)) return rc;
+    return launch_mma<true>(p, d->split_k, d->tile_m, d->tile_n, d->tile_waves, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_conv3x3_nhwc_f16");
 }
 
 // ------------------------------------------------------------------------------------------------ diagnostics

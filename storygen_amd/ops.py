@@ -28,6 +28,19 @@ TILE_TABLE = {}
 TUNE_SINK = None
 
 
+def _apply_tile(d, tile, split_k, sig):
+    """tile = (bm, bn) or (bm, bn, waves) from the caller, else the tuned table entry (bm, bn, split[, waves])."""
+    if tile is not None:
+        d.tile_m, d.tile_n = tile[0], tile[1]
+        if len(tile) > 2:
+            d.tile_waves = tile[2]
+    elif split_k == 0 and sig in TILE_TABLE:
+        e = TILE_TABLE[sig]
+        d.tile_m, d.tile_n, d.split_k = e[0], e[1], e[2]
+        if len(e) > 3:
+            d.tile_waves = e[3]
+
+
 def load_tile_table(path: Optional[str] = None) -> int:
     import json
     import os
@@ -150,10 +163,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     sig = f"g:{M}:{N}:{K}:{epilogue}:{flags}:{int(bias is not None)}{int(rowbias is not None)}{int(res1 is not None)}{int(res2 is not None)}{int(out2 is not None)}"
-    if tile is not None:
-        d.tile_m, d.tile_n = tile
-    elif split_k == 0 and sig in TILE_TABLE:
-        d.tile_m, d.tile_n, d.split_k = TILE_TABLE[sig]
+    _apply_tile(d, tile, split_k, sig)
     if TUNE_SINK is not None:
         TUNE_SINK.append((sig, dict(kind="gemm", M=M, N=N, K=K, epilogue=epilogue, out_f32=bool(flags & F_OUT_F32), bias=bias is not None,
                                     rowbias=rowbias is not None, rows_per_batch=rows_per_batch, out2=out2 is not None,
@@ -207,10 +217,7 @@ def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stride:
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
     sig = f"c:{B}:{H}:{W}:{Cin}:{Cout}:{stride}:{int(upsample2x)}:{int(x_padded)}:{flags}:{int(bias is not None)}{int(rowbias is not None)}{int(res1 is not None)}"
-    if tile is not None:
-        d.tile_m, d.tile_n = tile
-    elif split_k == 0 and sig in TILE_TABLE:
-        d.tile_m, d.tile_n, d.split_k = TILE_TABLE[sig]
+    _apply_tile(d, tile, split_k, sig)
     if TUNE_SINK is not None:
         TUNE_SINK.append((sig, dict(kind="conv", B=B, H=H, W=W, Cin=Cin, Cout=Cout, stride=stride, ups=bool(upsample2x), padded=bool(x_padded),
                                     out_f32=bool(flags & F_OUT_F32), bias=bias is not None, rowbias=rowbias is not None,

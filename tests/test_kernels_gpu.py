@@ -104,6 +104,34 @@ def test_gemm_split_k(gpu, M, N, K, split):
     check(out, a.float() @ w.float().t() + bias.float() + r1.float(), f"split_k={split}")
 
 
+@pytest.mark.parametrize("tile", [(256, 128, 4), (128, 128, 2)])
+def test_gemm_and_conv_fat_wave_tiles(gpu, tile):
+    """The 128x64-per-wave variants (tile_waves hint): GEMM with every epilogue term, GEGLU, and a padded-input conv."""
+    from storygen_amd import ops
+    M, N, K = 600, 384, 640
+    a, w, bias = rnd((M, K), gpu, seed=1), rnd((N, K), gpu, K ** -0.5, seed=2), rnd((N,), gpu, seed=3)
+    r1, r2 = rnd((M, N), gpu, seed=4, dtype=torch.float32), rnd((M, N), gpu, seed=5)
+    out = torch.empty(M, N, dtype=torch.float32, device=gpu)
+    ops.gemm(a, w, out, bias=bias, res1=r1, res2=r2, tile=tile)
+    check(out, a.float() @ w.float().t() + bias.float() + r1 + r2.float(), "gemm fat", l2=2e-6, mx=2e-5)
+    C = 128
+    wg, bg = rnd((8 * C, C), gpu, C ** -0.5, seed=6), rnd((8 * C,), gpu, seed=7)
+    from storygen_amd.repack import interleave_geglu
+    wi, bi = interleave_geglu(wg, bg)
+    x = rnd((300, C), gpu, seed=8)
+    og = torch.empty(300, 4 * C, dtype=torch.float16, device=gpu)
+    ops.gemm(x, wi, og, bias=bi, epilogue=ops.EPI_GEGLU, tile=tile)
+    val, gate = (x.float() @ wg.float().t() + bg.float()).chunk(2, dim=-1)
+    check(og, val * F.gelu(gate), "geglu fat")
+    B, H, W, Ci, Co = 2, 24, 24, 128, 192
+    xin, wc = rnd((B, Ci, H, W), gpu, seed=9), rnd((Co, Ci, 3, 3), gpu, (9 * Ci) ** -0.5, seed=10)
+    xp = torch.zeros(B, H + 2, W + 2, Ci, dtype=torch.float16, device=gpu)
+    xp[:, 1:-1, 1:-1] = xin.permute(0, 2, 3, 1)
+    oc = torch.empty(B, H, W, Co, dtype=torch.float32, device=gpu)
+    ops.conv3x3(xp, wc.permute(0, 2, 3, 1).contiguous(), oc, x_padded=True, tile=tile)
+    check(oc.permute(0, 3, 1, 2), F.conv2d(xin.float(), wc.float(), padding=1), "conv fat", l2=2e-6, mx=2e-5)
+
+
 def test_gemm_strided_views(gpu):
     """lda/ldc/ldr larger than the logical widths: operands are column slices of wider buffers."""
     from storygen_amd import ops

@@ -13,6 +13,9 @@ TILES = [(0, 0, False), (256, 128, False), (128, 128, False), (256, 64, False), 
          (128, 64, True)]
 
 
+FAT = [(256, 128, 4), (128, 128, 2)]     # 128x64-per-wave variants
+
+
 def timeit(fn, n=20):
     for _ in range(3):
         fn()
@@ -32,7 +35,8 @@ def main():
     gemms = [(12288, 320, 320), (12288, 320, 2880), (12288, 960, 320), (12288, 2560, 320), (12288, 320, 1280), (3072, 640, 640),
              (3072, 640, 5760), (768, 1280, 1280), (768, 1280, 11520), (192, 1280, 11520), (192, 1280, 1280), (36864, 640, 320)]
     print("GEMM  (us | TFLOP/s) per tile; last columns = generic kernel")
-    print(f"{'shape':24s}" + "".join(f"{f'{t[0]}x{t[1]}' + ('g' if t[2] else ''):>16s}" for t in TILES))
+    print(f"{'shape':24s}" + "".join(f"{f'{t[0]}x{t[1]}' + ('g' if t[2] else ''):>16s}" for t in TILES)
+          + "".join(f"{f'{t[0]}x{t[1]}/{t[2]}w':>16s}" for t in FAT))
     for M, N, K in gemms:
         a = torch.randn(M, K, device=dev).half()
         w = (torch.randn(N, K, device=dev) / K ** 0.5).half()
@@ -41,6 +45,10 @@ def main():
         for t in TILES:
             ops.debug_set_tile(*t)
             us = timeit(lambda: ops.gemm(a, w, out, workspace=ws))
+            row += f"{us:8.1f}|{2.0 * M * N * K / us / 1e6:6.0f} "
+        ops.debug_set_tile(0, 0, False)
+        for t in FAT:
+            us = timeit(lambda: ops.gemm(a, w, out, workspace=ws, tile=t))
             row += f"{us:8.1f}|{2.0 * M * N * K / us / 1e6:6.0f} "
         print(row, flush=True)
     convs = [(4, 64, 64, 320, 320), (4, 32, 32, 640, 640), (4, 16, 16, 1280, 1280), (4, 8, 8, 1280, 1280), (4, 64, 64, 640, 320),
@@ -55,6 +63,10 @@ def main():
         for t in TILES:
             ops.debug_set_tile(*t)
             us = timeit(lambda: ops.conv3x3(xp, w, out, workspace=ws, x_padded=True))
+            row += f"{us:8.1f}|{2.0 * B * H * W * Co * 9 * Ci / us / 1e6:6.0f} "
+        ops.debug_set_tile(0, 0, False)
+        for t in FAT:
+            us = timeit(lambda: ops.conv3x3(xp, w, out, workspace=ws, x_padded=True, tile=t))
             row += f"{us:8.1f}|{2.0 * B * H * W * Co * 9 * Ci / us / 1e6:6.0f} "
         print(row, flush=True)
     ops.debug_set_tile(0, 0, False)
