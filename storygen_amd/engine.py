@@ -13,7 +13,8 @@ attention.py:85-128,236-302) around what the MI355X wants rather than around nn.
     channel bias;
   * residual adds, biases, the `(a2+h)+(a3+h)` combine (attention.py:277,291-293) and GEGLU live in GEMM/conv
     epilogues; nearest-2x upsampling and stride-2 are folded into the conv gather; `torch.cat([h, skip])`
-    becomes "the producer writes its columns of the concat buffer" + one strided copy of the skip;
+    costs nothing: the producer of h and the down-path producer of the skip both write their columns of the
+    consuming resnet's concat buffer;
   * harvested features (attention.py:263) are written straight into slot r of the preallocated context buffers
     [B, R*HW, C] that the main pass cross-attends to (replaces the clones at unet_2d_condition.py:428-429,445,
     468-470 and the token-axis concat at pipeline.py:440-443);
@@ -248,7 +249,7 @@ class UNetEngine:
             f32 = lambda *sh: self._buf(*sh, dtype=F32)  # noqa: E731
             d = dict(
                 # fp32 residual stream
-                cat=[f32(M * Cw), f32(M * Cw)], r=f32(M, C), t_out=f32(M, C), sc=f32(M, C),
+                r=f32(M, C), t_out=f32(M, C), sc=f32(M, C),
                 h0=f32(M, C), h1=f32(M, C), h2=f32(M, C), h3=f32(M, C),
                 # fp16 MFMA operands
                 gn=self._buf(M, C), x16=self._buf(M * Cw), c1=self._buf(M, C), h4=self._buf(M, C),
@@ -259,7 +260,20 @@ class UNetEngine:
                 vti=self._buf(C, self.ctx_rows * self.R * self.hw[l]) if self.R else None,
             )
             self.lv.append(d)
-        # skip tensors (down_block_res_samples) persist until the up path pops them
+        # torch.cat([h, skip]) (unet_2d_blocks.py:609,626,716) without a copy: every up-path resnet owns its concat input
+        # buffer [M, cin] (fp32); the producer of h writes columns [0, c_h) and the skip tensor (down_block_res_samples)
+        # IS the column slice [c_h, cin) of the buffer of the resnet that will pop it — the down path writes it there.
+        self.up_cats: List[torch.Tensor] = []
+        skip_views: List[torch.Tensor] = []
+        lvl = nlev - 1
+        for blk in arch.up:
+            for j, r in enumerate(blk.resnets):
+                buf = self._buf(B * self.hw[lvl], r.cin, dtype=F32)
+                self.up_cats.append(buf)
+                skip_views.append(buf[:, r.cin - blk.skip_channels[j]:])
+            if blk.sampler_prefix:
+                lvl -= 1
+        self.skips: List[torch.Tensor] = list(reversed(skip_views))       # skips[i] = i-th tensor the down path produces
         self.skip_meta = [(0, boc[0])]
         lvl = 0
         for blk in arch.down:
@@ -268,7 +282,9 @@ class UNetEngine:
             if blk.sampler_prefix:
                 lvl += 1
                 self.skip_meta.append((lvl, blk.channels))
-        self.skips: List[torch.Tensor] = [self._buf(B * self.hw[l], c, dtype=F32) for l, c in self.skip_meta]
+        assert len(self.skips) == len(self.skip_meta)
+        for sk, (l, c) in zip(self.skips, self.skip_meta):
+            assert tuple(sk.shape) == (B * self.hw[l], c), (tuple(sk.shape), l, c)
         # context buffers: [ctx_rows, R*HW, C] fp16 per feature key (K/V projection operands of attn3)
         self.ctx: Dict[str, torch.Tensor] = {}
         if self.R:
@@ -447,10 +463,6 @@ class UNetEngine:
                     workspace=self.ws_split, x_padded=True)
 
     # ------------------------------------------------------------------------------------------ forward
-    def _cat_view(self, lvl: int, which: int, width: int) -> torch.Tensor:
-        M = self.B * self.hw[lvl]
-        return self.lv[lvl]["cat"][which][: M * width].view(M, width)
-
     def forward(self, harvest_slot: Optional[int] = None, consume: bool = False, harvest: Optional[HarvestPlan] = None,
                 harvest_only: bool = False, text_cache: bool = False,
                 side: Optional[torch.cuda.Stream] = None) -> Optional[torch.Tensor]:
@@ -512,20 +524,18 @@ class UNetEngine:
         self._resnet(self.resnets[m0.prefix], h, L["r"], lvl)
         self._transformer(self.xfs[arch.mid.attns[0].prefix], L["r"], L["t_out"], lvl, text, harvest, consume, **tk)
         blk0 = arch.up[0]
-        pp = 0
-        cat = self._cat_view(lvl, pp, blk0.resnets[0].cin)
+        k = 0                                                                              # index of the up-path resnet
+        cat = self.up_cats[k]
         self._resnet(self.resnets[m1.prefix], L["t_out"], cat[:, : blk0.resnets[0].cin - blk0.skip_channels[0]], lvl)
-        # --- up :448-475 — `cat` always holds [h | <room for the skip>] for the next resnet
+        # --- up :448-475 — `cat` = [h | skip]: h was written by the previous layer, the skip by the down path
         for bi, blk in enumerate(arch.up):
             L = self.lv[lvl]
             nres = len(blk.resnets)
             for j, r in enumerate(blk.resnets):
                 si -= 1
-                c_h = r.cin - blk.skip_channels[j]
-                assert skips[si].shape[1] == blk.skip_channels[j] and cat.shape[1] == r.cin
-                ops.copy_rows(cat[:, c_h:].unsqueeze(0), skips[si].unsqueeze(0))          # torch.cat([h, skip]) :609,716
+                assert cat.shape[1] == r.cin and skips[si].data_ptr() == cat[:, r.cin - blk.skip_channels[j]:].data_ptr()
                 if j + 1 < nres:
-                    nxt = self._cat_view(lvl, pp ^ 1, blk.resnets[j + 1].cin)
+                    nxt = self.up_cats[k + 1]
                     out = nxt[:, : blk.resnets[j + 1].cin - blk.skip_channels[j + 1]]
                 else:
                     nxt, out = None, L["t_out"]
@@ -538,13 +548,13 @@ class UNetEngine:
                         self._transformer(self.xfs[xf.prefix], L["r"], None, lvl, text, harvest, consume, stop_after_harvest=True)
                         return None
                     self._transformer(self.xfs[xf.prefix], L["r"], out, lvl, text, harvest, consume, **tk)
+                k += 1
                 if nxt is not None:
-                    cat, pp = nxt, pp ^ 1
+                    cat = nxt
                 h = out
             if blk.sampler_prefix:                                                        # Upsample2D :656-658,730-732
                 nblk = arch.up[bi + 1]
-                pp = 0
-                cat = self._cat_view(lvl - 1, pp, nblk.resnets[0].cin)
+                cat = self.up_cats[k]
                 c_h = nblk.resnets[0].cin - nblk.skip_channels[0]
                 self._sampler_conv(blk.sampler_prefix, h, cat[:, :c_h], lvl, lvl - 1, down=False)
                 lvl -= 1
