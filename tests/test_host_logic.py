@@ -190,3 +190,17 @@ def test_reference_batch_layout_reproduces_the_as_written_context(N, R, mode):
                 assert kind == (0 if j == 0 else 1) and sample == n
                 if kind == 1 or mode != "shared-zero":
                     assert frame == i
+
+
+def test_tuned_tile_table_is_well_formed():
+    """storygen_amd/tuning/mi355x_tiles.json: every override names a tile the kernels implement."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "storygen_amd", "tuning", "mi355x_tiles.json")
+    with open(path) as f:
+        t = json.load(f)
+    tiles = {(256, 128), (128, 128), (256, 64), (128, 64), (64, 128), (64, 64)}
+    assert t["tiles"], "empty tuning table"
+    for sig, e in t["tiles"].items():
+        assert sig[0] in "gc" and (e[0], e[1]) in tiles and 0 <= e[2] <= 64, (sig, e)
+        if len(e) > 3:
+            assert (e[0], e[1], e[3]) in {(256, 128, 4), (256, 128, 8), (128, 128, 2), (128, 128, 4)}
