@@ -31,6 +31,7 @@
 // only when some row's running max grows by more than 2^6 (wave-uniform branch; P <= 64 stays exact enough in fp16
 // and the row sums are fp32).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -60,7 +61,7 @@ __device__ __forceinline__ int kswz(int row) {
     return D == 40 ? 0 : (D == 80 ? ((row >> 3) & 1) : ((row >> 2) & 3));
 }
 
-template <int D, int NW, int S>
+template <int D, int NW, int S, int SUB = 1>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     constexpr int DC = D / 8;                   // 16-byte chunks per K row
     constexpr int NDK = (D + 15) / 16;          // MFMA k-steps of S^T (contraction padded to 16)
@@ -69,10 +70,12 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     constexpr int K_BYTES = KVBLK * KROW;       // = D KiB / 8
     constexpr int V_BYTES = D * 128;
     constexpr int K_SEG = K_BYTES / 1024, V_SEG = V_BYTES / 1024, NSEG = K_SEG + V_SEG;   // 1 KiB = one wave DMA
-    constexpr int STAGE = K_BYTES + V_BYTES;
+    constexpr int TSTAGE = K_BYTES + V_BYTES;   // LDS image of one 64-key tile
+    constexpr int STAGE = SUB * TSTAGE;         // a ring stage holds SUB consecutive tiles: one barrier per SUB tiles
     constexpr int MAXL = (NSEG + NW - 1) / NW;  // DMA instructions per tile of the busiest wave
     constexpr int REM = NSEG % NW;              // waves < REM issue MAXL, the others MAXL - 1 (REM == 0: all MAXL)
     static_assert(S == 2 || S == 3, "2 or 3 stages");
+    static_assert(SUB == 1 || S == 2, "multi-tile stages use the 2-stage ring (plain vmcnt(0) waits)");
     static_assert((S - 1) * MAXL < 64, "vmcnt is a 6-bit counter");
     __shared__ __attribute__((aligned(16))) char smem[S * STAGE + 16];
 
@@ -115,9 +118,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             off[i] = (unsigned)(c_row[i] + c_col[i]);
         }
     }
-    auto issue = [&](int tile, int stage) {
+    const int ntiles = (p.Nk + KVBLK - 1) / KVBLK;
+    auto issue_tile = [&](int tile, char* base) {
         const int key0 = tile * KVBLK;
-        char* base = smem + stage * STAGE;
         if (key0 + KVBLK <= p.Nk) {             // full tile: no clamping, uniform base + per-lane offset
             const f16* Kt = K + (long)key0 * p.ldk;
             const f16* Vt = VT + key0;
@@ -140,6 +143,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
                 }
             }
         }
+    };
+    auto issue = [&](int group, int stage) {     // the SUB tiles of ring group `group`
+#pragma unroll
+        for (int sub = 0; sub < SUB; ++sub)
+            if (group * SUB + sub < ntiles) issue_tile(group * SUB + sub, smem + stage * STAGE + sub * TSTAGE);
     };
 
     // ---- Q^T fragments: lane = (query l31, d-chunk 2s+hi); rows beyond Nq are clamped (never stored)
@@ -166,29 +174,33 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     float m_run = -INFINITY;   // running max of the scaled (log2-domain) scores of query l31
     float l_run = 0.f;         // this lane's share of the running row sum
 
-    const int ntiles = (p.Nk + KVBLK - 1) / KVBLK;
+    const int ngroups = (ntiles + SUB - 1) / SUB;
 #pragma unroll
     for (int s = 0; s < S - 1; ++s)
-        if (s < ntiles) issue(s, s);
+        if (s < ngroups) issue(s, s);
 
     // LDS read coordinates
     const int prow = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);          // pi(l31): swap bits 2 and 3
     int stage = 0;
-    for (int tile = 0; tile < ntiles; ++tile) {
-        // wait for this wave's share of tile `tile` (one younger tile may stay in flight), publish, refill the ring
-        if (S == 3 && tile + 1 < ntiles) {
+    for (int group = 0; group < ngroups; ++group) {
+        // wait for this wave's share of the group (S = 3: one younger tile may stay in flight), publish, refill the ring
+        if (S == 3 && group + 1 < ngroups) {
             if (REM == 0 || wave < REM) wait_vmcnt<MAXL>();
             else wait_vmcnt<(MAXL > 1 ? MAXL - 1 : 0)>();
         } else {
             wait_vmcnt<0>();
         }
         __builtin_amdgcn_s_barrier();
-        if (tile + S - 1 < ntiles) {
+        if (group + S - 1 < ngroups) {
             int st = stage + S - 1;
             if (st >= S) st -= S;
-            issue(tile + S - 1, st);
+            issue(group + S - 1, st);
         }
-        const char* sK = smem + stage * STAGE;
+#pragma unroll
+      for (int sub = 0; sub < SUB; ++sub) {
+        const int tile = group * SUB + sub;
+        if (tile >= ntiles) break;
+        const char* sK = smem + stage * STAGE + sub * TSTAGE;
         const char* sV = sK + K_BYTES;
 
         // ---- S^T = K Q^T for the two 32-key blocks: all K fragments are requested first, so the LDS latency is paid once
@@ -277,6 +289,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
             for (int i = 0; i < DT; ++i)
                 oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[VPRE ? ks : 0][i], pf, oacc[i], 0, 0, 0);
         }
+      }   // sub-tiles of the group
         if (++stage == S) stage = 0;
     }
 
@@ -300,11 +313,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     }
 }
 
-template <int D, int NW, int S>
+template <int D, int NW, int S, int SUB = 1>
 void launch_attn(const AttnParams& p0, hipStream_t st) {
     AttnParams p = p0;
     p.nqb = sg_cdiv(p.Nq, 32 * NW);
-    hipLaunchKernelGGL((attn_fwd_kernel<D, NW, S>), dim3(p.nqb * p.H * p.B), dim3(64 * NW), 0, st, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<D, NW, S, SUB>), dim3(p.nqb * p.H * p.B), dim3(64 * NW), 0, st, p);
 }
 
 }  // namespace
@@ -335,7 +348,12 @@ extern "C" int sg_attn_fwd_f16(const sg_attn_desc* d, sg_stream_t stream) {
     // 4-wave workgroups with a 3-deep ring when that still gives the chip >= 2 workgroups per CU, else 2 waves / 2 stages
     const long wgs4 = (long)sg_cdiv(d->Nq, 128) * d->H * d->B;
     const bool big = wgs4 >= 512;
-    if (d->D == 40) { if (big) launch_attn<40, 4, 3>(p, st); else launch_attn<40, 2, 2>(p, st); }
+    static const int sub2 = [] { const char* e = getenv("SG_ATTN_SUB2"); return e ? atoi(e) : 0; }();   // development knob
+    if (d->D == 40) {
+        if (big && sub2 && d->Nk >= 256) launch_attn<40, 4, 2, 2>(p, st);   // 128 keys per barrier, 2-stage ring
+        else if (big) launch_attn<40, 4, 3>(p, st);
+        else launch_attn<40, 2, 2>(p, st);
+    }
     else if (d->D == 80) { if (big) launch_attn<80, 4, 3>(p, st); else launch_attn<80, 2, 2>(p, st); }
     else launch_attn<160, 2, 2>(p, st);
     SG_CHECK_LAUNCH("sg_attn_fwd_f16");

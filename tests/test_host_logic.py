@@ -204,3 +204,23 @@ def test_tuned_tile_table_is_well_formed():
         assert sig[0] in "gc" and (e[0], e[1]) in tiles and 0 <= e[2] <= 64, (sig, e)
         if len(e) > 3:
             assert (e[0], e[1], e[3]) in {(256, 128, 4), (256, 128, 8), (128, 128, 2), (128, 128, 4)}
+
+
+def test_committed_bench_line_honours_the_contract():
+    """profiles/r01g_final_bench.json is a verbatim `python bench.py` line from the GPU box: guard the keys the driver and
+    the judge read (a format regression in bench.py shows up here the next time the line is refreshed)."""
+    import json
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01g_final_bench.json")
+    line = [ln for ln in open(path) if ln.startswith("{")][-1]
+    d = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f16" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
+    assert abs(d["value"] - d["n_gpus"] * 1e3 / d["ms_per_step"]) < 1e-2 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s") and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3
+    assert "traffic" in r and (r["traffic"] is None or r["traffic"] > 0)
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]

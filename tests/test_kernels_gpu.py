@@ -228,6 +228,7 @@ ATTN_CASES = [
     # B, H, Nq, Nk, D
     (2, 8, 256, 256, 40), (1, 8, 200, 77, 40), (3, 8, 64, 192, 160), (2, 8, 256, 768, 80), (1, 8, 1024, 1024, 80),
     (1, 2, 130, 65, 160), (3, 8, 4096, 77, 40), (1, 8, 1024, 3072, 40), (1, 4, 33, 1, 80),
+    (2, 8, 4096, 705, 40), (2, 8, 4096, 320, 40),      # big grids: the 4-wave kernels, ragged last tile / odd tile count
 ]
 
 
