@@ -111,3 +111,19 @@ def synthetic_inputs(n_samples: int, n_ref: int, height: int, width: int, seed: 
         prev_uncond=f("in.uncond", (1, seq_len, cross_attention_dim), s)
         .expand(n_ref, n_samples, -1, -1).contiguous(),
     )
+
+
+def synthetic_train_batch(b: int, hw: int, cad: int, seed: int) -> Dict[str, torch.Tensor]:
+    """Inputs of one stage-2 training step after its CLIP / VAE plumbing (/root/reference/train_StorySalon_stage2.py:265-302):
+    latents, the 3 reference-frame latents, the two noise tensors, per-sample timesteps, text / previous-prompt embeddings and
+    the 1/8-downsampled loss mask (BASELINE config 4)."""
+    import torch.nn.functional as F
+    f = synthetic_tensor
+    g = torch.Generator().manual_seed(seed_int("train.aux", seed))
+    return dict(latents=f("train.latents", (b, 4, hw, hw), seed, 0.8), ref_latents=f("train.ref_latents", (3, b, 4, hw, hw), seed, 0.8),
+                noise=f("train.noise", (b, 4, hw, hw), seed), ref_noise=f("train.ref_noise", (b, 4, hw, hw), seed),
+                timesteps=torch.randint(0, 1000, (b,), generator=g), text=f("train.text", (b, 77, cad), seed),
+                prev_text=f("train.prev_text", (3, b, 77, cad), seed),
+                # bilinear 1/8 downsample of a binary text/face mask gives values in [0, 1] (:268-270)
+                mask=F.interpolate((torch.rand(b, 4, hw * 8, hw * 8, generator=g) > 0.7).float(), scale_factor=1 / 8.0, mode="bilinear",
+                                   align_corners=False))

@@ -129,3 +129,27 @@ def test_oracle_leaf_semantics():
     xt = s.add_noise(x, n, 981)
     ap = s.alphas_cumprod[961]
     assert torch.allclose(s.step(n, 981, xt, 50), ap.sqrt() * x + (1 - ap).sqrt() * n, atol=1e-5)
+
+
+@pytest.mark.parametrize("use_refs", [(2,), pytest.param((0, 1, 2), marks=pytest.mark.skipif(os.environ.get("SG_SLOW_TESTS") != "1",
+                                                                                               reason="~40 s of CPU; set SG_SLOW_TESTS=1"))])
+def test_oracle_train_step_vs_reference_golden(use_refs):
+    """BASELINE config 4 (stage-2 training step): loss and the 80 attn3 gradient tensors of the oracle's restatement
+    (oracle.storygen_oracle.train_step, train_StorySalon_stage2.py:291-327) against what the reference's own UNet + torch autograd
+    produced (oracle/make_golden_train.py).  This pins the oracle for the backward path before any HIP backward kernel exists."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.arch import build_arch
+    from storygen_amd.synth import synthetic_state_dict, synthetic_train_batch
+    gold = _load("tiny_train")
+    arch = build_arch(gold["config"])
+    sd = synthetic_state_dict(arch, gold["seed"])
+    batch = synthetic_train_batch(gold["batch"], gold["hw"], arch.config["cross_attention_dim"], gold["seed"])
+    g = gold["cases"]["refs_" + "".join(map(str, use_refs))]
+    loss, grads = O.train_step(sd, arch.config, batch, use_refs)
+    assert abs(float(loss) - g["loss"]) <= 1e-5 * abs(g["loss"])
+    assert set(grads) == set(g["grads"]) and len(grads) == 5 * len(arch.feature_keys)
+    errs = {}
+    for k, e in g["grads"].items():
+        assert tuple(grads[k].shape) == tuple(e["shape"])
+        errs[k] = max(rel_l2(grads[k].flatten()[e["idx"]], e["values"]), abs(float(grads[k].double().norm()) - e["l2"]) / e["l2"])
+    assert max(errs.values()) < 1e-4, max(errs.items(), key=lambda kv: kv[1])
