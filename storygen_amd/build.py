@@ -7,7 +7,9 @@ but shipped to the GPU box by gpurun) and is what storygen_amd/_lib.py dlopens.
 """
 from __future__ import annotations
 
+import json
 import os
+import re
 import shutil
 import subprocess
 import sys
@@ -17,7 +19,9 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libstorygen_hip.so")
 SOURCES = ["gemm_conv.hip", "attention.hip", "norm.hip", "misc.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+         "-Rpass-analysis=kernel-resource-usage"]          # remarks only: parsed into lib/kernel_resources.json
+RESOURCES = os.path.join(LIBDIR, "kernel_resources.json")
 # attention keeps its O^T accumulators live across the softmax VALU code of every tile: with MFMA results in AGPRs the
 # compiler shuttles them through v_accvgpr_read/write around each tile (137 of 281 VALU instructions per tile,
 # profiles/r01d_pmc_kernels.txt); the VGPR form of MFMA (gfx950's register file is unified) removes all of them.
@@ -31,8 +35,39 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC or install ROCm)")
 
 
+_REMARK = re.compile(r"remark: +(Function Name|TotalSGPRs|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]|"
+                     r"LDS Size \[bytes/block\]): +(\S+)")
+_KEYS = {"TotalSGPRs": "sgprs", "VGPRs": "vgprs", "AGPRs": "agprs", "ScratchSize [bytes/lane]": "scratch_bytes_per_lane",
+         "Occupancy [waves/SIMD]": "occupancy_waves_per_simd", "LDS Size [bytes/block]": "lds_bytes_per_block"}
+
+
+def _parse_resource_remarks(out: str, src: str, into: dict) -> str:
+    """Moves hipcc's -Rpass-analysis=kernel-resource-usage remarks of one translation unit into `into`
+    ({mangled kernel name: {...}}); returns the remaining compiler output (real warnings)."""
+    rest, cur, in_remark, pending = [], None, False, []
+    for line in out.splitlines():
+        if line.startswith("In file included from"):        # include stack: belongs to whatever diagnostic follows
+            pending.append(line)
+            continue
+        if "remark:" not in line:
+            rest.extend(pending)
+        pending = []
+        m = _REMARK.search(line)
+        if re.match(r"^\s*\d*\s*\|", line) and in_remark:     # source snippet under a remark
+            continue
+        in_remark = "remark:" in line
+        if m:
+            if m.group(1) == "Function Name":
+                cur = into.setdefault(m.group(2), {"source": src})
+            elif cur is not None:
+                cur[_KEYS[m.group(1)]] = int(m.group(2))
+        elif "-Rpass-analysis=kernel-resource-usage" not in line and "argument unused during compilation" not in line:
+            rest.append(line)
+    return "\n".join(rest)
+
+
 def needs_build() -> bool:
-    if not os.path.exists(LIB):
+    if not os.path.exists(LIB) or not os.path.exists(RESOURCES):
         return True
     t = os.path.getmtime(LIB)
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC)] + [os.path.join(PKG, "..", "include", "storygen_hip.h"),
@@ -54,12 +89,21 @@ def build(force: bool = False, verbose: bool = True) -> str:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
         objs.append(obj)
+    resources = {}
     for src, p in procs:
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out}")
-        if verbose and out.strip():
-            print(out)
+        rest = _parse_resource_remarks(out, src, resources)
+        if verbose and rest.strip():
+            print(rest)
+    with open(RESOURCES, "w") as f:
+        json.dump(resources, f, indent=1, sort_keys=True)
+    # a kernel with a private segment either spills or keeps an array in memory: both are order-of-magnitude cliffs on this
+    # hardware (the D = 160 attention instantiation once ran 6x slower that way) — refuse to ship one silently
+    bad = {k: v["scratch_bytes_per_lane"] for k, v in resources.items() if v["scratch_bytes_per_lane"]}
+    if bad and os.environ.get("SG_ALLOW_SCRATCH") != "1":
+        raise RuntimeError(f"kernels using scratch memory (set SG_ALLOW_SCRATCH=1 to build anyway): {bad}")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
     if verbose:
         print(" ".join(cmd), flush=True)

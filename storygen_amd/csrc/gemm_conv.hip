@@ -379,7 +379,8 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParam
     constexpr int EPI_BYTES = WGM * 32 * BN * 4;   // one 32-row band per wave-row (tile_epilogue)
     constexpr int SMEM = (S * STAGE > EPI_BYTES) ? S * STAGE : EPI_BYTES;
     constexpr int ISTR = NW * 1024;   // LDS bytes covered by one DMA instruction of the whole workgroup (8 rows / wave)
-    static_assert((S == 2 || S == 3) && (S - 2) * LPT < 64, "2 or 3 stages; vmcnt is a 6-bit counter");
+    static_assert(S >= 2 && S <= 4 && (S - 2) * LPT < 64, "2 to 4 stages; vmcnt is a 6-bit counter");
+    static_assert(S * STAGE <= 160 * 1024, "the ring must fit the 160 KB of LDS");
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
     const int t = threadIdx.x, lane = t & 63;
@@ -475,8 +476,9 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParam
 
     int stage = 0;
     for (int it = 0; it < nt; ++it) {
-        // S = 3: one younger slab may stay in flight while we wait for slab `it`, except at the very end
-        if (S == 3 && it + 1 < nt) wait_vmcnt<LPT>();
+        // up to S - 2 younger slabs stay in flight while we wait for slab `it` (fewer at the very end)
+        if (S >= 4 && it + 2 < nt) wait_vmcnt<(S >= 4 ? 2 : 0) * LPT>();
+        else if (S >= 3 && it + 1 < nt) wait_vmcnt<(S >= 3 ? 1 : 0) * LPT>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (!LATE && it + S - 1 < nt) {         // refill right behind the barrier
@@ -531,10 +533,23 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const MmaParams p) {
             const int gm = (int)(idx / nch), gn = (int)(idx - (long)gm * nch) * 8;
             float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             const float* s = p.ws + (size_t)gm * p.N + gn;
-            for (int z = 0; z < p.splits; ++z) {
-                const float4 a = *reinterpret_cast<const float4*>(s + z * MN);
-                const float4 b = *reinterpret_cast<const float4*>(s + z * MN + 4);
-                v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
+            // the partial tiles of up to four splits are requested together (one memory round trip instead of four) and
+            // added in split order, so the sum is bit-identical to the sequential loop
+            for (int z0 = 0; z0 < p.splits; z0 += 4) {
+                float4 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a[u] = b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (z0 + u < p.splits) {
+                        a[u] = *reinterpret_cast<const float4*>(s + (z0 + u) * MN);
+                        b[u] = *reinterpret_cast<const float4*>(s + (z0 + u) * MN + 4);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
+                    v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+                }
             }
             epi_linear8(p, gm, gn, v);
         }
@@ -546,10 +561,27 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const MmaParams p) {
             const int gv = (j >> 2) * 64 + (j & 3) * 8;
             float val[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gate[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             const float* s = p.ws + (size_t)gm * p.N + gv;
-            for (int z = 0; z < p.splits; ++z) {
-                const float* q = s + z * MN;
+            for (int z0 = 0; z0 < p.splits; z0 += 2) {      // two splits (4 x 16 B each) per memory round trip
+                float4 q[2][4];
 #pragma unroll
-                for (int e = 0; e < 8; ++e) { val[e] += q[e]; gate[e] += q[32 + e]; }
+                for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) q[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (z0 + u < p.splits) {
+                        const float* src = s + (z0 + u) * MN;
+                        q[u][0] = *reinterpret_cast<const float4*>(src);
+                        q[u][1] = *reinterpret_cast<const float4*>(src + 4);
+                        q[u][2] = *reinterpret_cast<const float4*>(src + 32);
+                        q[u][3] = *reinterpret_cast<const float4*>(src + 36);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    val[0] += q[u][0].x; val[1] += q[u][0].y; val[2] += q[u][0].z; val[3] += q[u][0].w;
+                    val[4] += q[u][1].x; val[5] += q[u][1].y; val[6] += q[u][1].z; val[7] += q[u][1].w;
+                    gate[0] += q[u][2].x; gate[1] += q[u][2].y; gate[2] += q[u][2].z; gate[3] += q[u][2].w;
+                    gate[4] += q[u][3].x; gate[5] += q[u][3].y; gate[6] += q[u][3].z; gate[7] += q[u][3].w;
+                }
             }
             epi_geglu8(p, gm, gv, val, gate);
         }
@@ -629,6 +661,12 @@ template <int WGM, int WGN, bool CONV>
 void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st, int stages) {
     const bool late = g_tune.late_issue != 0, pref = g_tune.no_frag_prefetch == 0;
     const dim3 block(64 * WGM * WGN);
+    if constexpr ((WGM + WGN) * 64 * 128 * 4 <= 128 * 1024) {   // 4-deep ring where it fits (tiles up to 128 x 128)
+        if (stages == 4) {
+            hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 4, CONV, true, true>), grid, block, 0, st, p);
+            return;
+        }
+    }
     if (stages == 2) hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 2, CONV, false, true>), grid, block, 0, st, p);
     else if (late && pref) hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV, true, true>), grid, block, 0, st, p);
     else if (late) hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV, true, false>), grid, block, 0, st, p);
@@ -665,7 +703,7 @@ int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint
     }
     dim3 grid(p.tiles_m * p.tiles_n, pl.splits);
     // ring depth: 3 stages (deeper prefetch) unless overridden; SG_STAGES=2 halves... see DESIGN.md §5.2
-    const int stages = g_tune.stages == 2 ? 2 : 3;
+    const int stages = (g_tune.stages == 2 || g_tune.stages == 4) ? g_tune.stages : 3;
     if (pipe && pl.fat) {
         if (pl.bm == 256) launch_pipe_fat<2, 2, CONV>(p, grid, st);
         else launch_pipe_fat<1, 2, CONV>(p, grid, st);

@@ -169,9 +169,171 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const GnParams p) {
     }
 }
 
+// ---- wide two-pass variant (large feature maps) ------------------------------------------------------------------
+// 1024-thread workgroups, thread (row r, column cv) owns the 8-channel vector cv of every rpp-th pixel row of its
+// chunk: one CU keeps 16 waves x 4 rows x 32 B of loads in flight, which is what it takes to pull MALL/HBM bandwidth
+// with <= 64 chunks per batch (the partial-sum table every pass-2 workgroup re-reads stays 16 KB).  Both passes use the
+// SAME (block id -> pixel rows) mapping: block b runs on XCD b % 8, so pass 2 re-reads its slab from the XCD-private
+// L2 that pass 1 pulled it into.  Needs cpg >= 8 (a vector touches at most two groups) and C <= 2560.
+constexpr int GNW_NT = 1024;
+constexpr int GNW_MAX_VPR = 320;
+
+__global__ __launch_bounds__(GNW_NT) void gn_stats_wide_kernel(const GnParams p) {
+    __shared__ float4 s_part[GNW_NT];        // per thread: (sum, sq) of its vector's low group, (sum, sq) of its high group
+    __shared__ float4 s_col[GNW_MAX_VPR];    // the same per vector column, after the fixed-order reduction over thread rows
+    const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
+    const int vpr = p.C >> 3, rpp = GNW_NT / vpr;
+    const int my_row = t / vpr, cv = t - my_row * vpr;
+    const long xb = (long)b * p.HW * p.ldx;
+    const bool f32 = p.x_f32;
+    const int p0 = chunk * p.rows_per_chunk, p1 = min(p.HW, p0 + p.rows_per_chunk);
+    const int c0 = cv * 8;
+    const int g_lo = c0 / p.cpg, g_hi = (c0 + 7) / p.cpg;
+    const int nlo = min(8, (g_lo + 1) * p.cpg - c0);      // the vector's first nlo channels belong to g_lo
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (my_row < rpp) {
+        // pivot = x[b, pixel 0, first channel of the group] (see gn_stats_kernel)
+        const float piv_lo = load1f(p.x, xb + g_lo * p.cpg, f32), piv_hi = load1f(p.x, xb + g_hi * p.cpg, f32);
+        float piv[8], s[8], q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { piv[j] = j < nlo ? piv_lo : piv_hi; s[j] = q[j] = 0.f; }
+        for (int base = p0 + my_row; base < p1; base += 4 * rpp) {      // up to 4 independent row loads in flight
+            float v[4][8];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int px = base + u * rpp;
+                if (px < p1) load8f(p.x, xb + (long)px * p.ldx + c0, f32, v[u]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) v[u][j] = piv[j];       // contributes exactly zero
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float d = v[u][j] - piv[j];
+                    s[j] += d; q[j] += d * d;
+                }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < nlo) { acc.x += s[j]; acc.y += q[j]; }
+            else { acc.z += s[j]; acc.w += q[j]; }
+        }
+    }
+    s_part[t] = acc;
+    __syncthreads();
+    if (t < vpr) {
+        float4 a = s_part[t];
+        for (int r = 1; r < rpp; ++r) {
+            const float4 o = s_part[r * vpr + t];
+            a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        }
+        s_col[t] = a;
+    }
+    __syncthreads();
+    if (t < p.G) {
+        const int cv_a = (t * p.cpg) >> 3, cv_b = ((t + 1) * p.cpg - 1) >> 3;
+        float gs = 0.f, gq = 0.f;
+        for (int c = cv_a; c <= cv_b; ++c) {
+            const float4 a = s_col[c];
+            const int lo = (c * 8) / p.cpg, hi = (c * 8 + 7) / p.cpg;
+            if (lo == t) { gs += a.x; gq += a.y; }
+            if (hi == t && hi != lo) { gs += a.z; gq += a.w; }
+        }
+        float* w = p.ws + (((long)b * p.nchunks + chunk) * p.G + t) * 2;
+        w[0] = gs; w[1] = gq;
+    }
+}
+
+__global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p) {
+    __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
+    __shared__ float s_ps[GNW_NT], s_pq[GNW_NT];
+    const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
+    const int vpr = p.C >> 3, rpp = GNW_NT / vpr;
+    const int my_row = t / vpr, cv = t - my_row * vpr;
+    const bool active = my_row < rpp;
+    const long xb = (long)b * p.HW * p.ldx;
+    const bool f32 = p.x_f32;
+    const int pw = p.pad_w;
+    const int p0 = chunk * p.rows_per_chunk, p1 = min(p.HW, p0 + p.rows_per_chunk);
+    const int c0 = cv * 8;
+    float v[4][8];
+    int base = p0 + my_row;
+    auto load_batch = [&]() {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int px = base + u * rpp;
+            if (active && px < p1) load8f(p.x, xb + (long)px * p.ldx + c0, f32, v[u]);
+        }
+    };
+    load_batch();       // the first rows travel while the statistics are being reduced
+    {   // reduce the chunk partials: thread (part, group) sums every `parts`-th chunk, then a fixed-order LDS pass
+        const int parts = GNW_NT / p.G;
+        const int grp = t % p.G, part = t / p.G;
+        float s = 0.f, q = 0.f;
+        if (part < parts)
+            for (int c = part; c < p.nchunks; c += parts) {
+                const float* w = p.ws + (((long)b * p.nchunks + c) * p.G + grp) * 2;
+                s += w[0]; q += w[1];
+            }
+        s_ps[t] = s; s_pq[t] = q;
+        __syncthreads();
+        if (t < p.G) {
+            s = 0.f; q = 0.f;
+            for (int k = 0; k < parts; ++k) { s += s_ps[k * p.G + t]; q += s_pq[k * p.G + t]; }
+            const float n = (float)p.HW * (float)p.cpg;
+            const float piv = load1f(p.x, xb + t * p.cpg, f32);
+            const float md = s / n;
+            const float var = fmaxf(q / n - md * md, 0.f);
+            s_mean[t] = piv + md;
+            s_rstd[t] = rsqrtf(var + p.eps);
+        }
+        __syncthreads();
+    }
+    if (!active) return;
+    f16* yb = pw ? p.y + ((long)b * (p.HW / pw + 2) * (pw + 2)) * p.ldy : p.y + (long)b * p.HW * p.ldy;
+    f16* cb = p.xcopy ? p.xcopy + (long)b * p.HW * p.ldxc : nullptr;
+    float sc[8], sh[8];
+    {
+        H8 g, be; g.u = ldg16(p.gamma + c0); be.u = ldg16(p.beta + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int grp = (c0 + j) / p.cpg;
+            sc[j] = s_rstd[grp] * (float)g.h[j];
+            sh[j] = (float)be.h[j] - s_mean[grp] * sc[j];
+        }
+    }
+    while (base < p1) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int px = base + u * rpp;
+            if (px < p1) {
+                float o[8];
+                if (cb) store8h(cb + (long)px * p.ldxc + c0, v[u]);
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const float r = v[u][j] * sc[j] + sh[j];
+                    o[j] = p.silu ? silu_f(r) : r;
+                }
+                long orow = px;
+                if (pw) { const int yy = px / pw, xx = px - yy * pw; orow = (long)(yy + 1) * (pw + 2) + xx + 1; }
+                store8h(yb + orow * p.ldy + c0, o);
+            }
+        }
+        base += 4 * rpp;
+        load_batch();
+    }
+}
+
 // Small feature maps (16x16 / 8x8 latent levels): one workgroup owns one (batch, group) slab, keeps it in registers,
 // computes exact two-pass statistics and writes the normalised output — one launch, one read of x.
 constexpr int GNF_MAXI = 24;   // 4-element items per thread: slabs of up to 256 * 24 * 4 = 24576 values
+// measured (tools/bench_norm.py, MI355X): the one-launch kernel wins up to 10 240-element slabs (8x8 level, 16x16 up to 1280
+// channels: 5.7-10.9 us vs 10-11 us for the two launches of the wide pair) and loses above (16x16x2560: 18.3 vs 12.9 us,
+// 32x32x640: 22.7 vs 11.9 us — 40-byte row pieces, 128 workgroups)
+constexpr long GNF_DEFAULT_MAX = 10240;
 
 __global__ __launch_bounds__(256) void gn_fused_kernel(const GnParams p) {
     __shared__ float s_red[8];
@@ -347,10 +509,28 @@ extern "C" int sg_groupnorm_nhwc_f16(const sg_groupnorm_desc* d, sg_stream_t str
     p.HW = d->HW; p.C = d->C; p.G = d->groups; p.cpg = d->C / d->groups; p.eps = d->eps; p.silu = d->silu;
     p.ws = reinterpret_cast<float*>(d->workspace);
     hipStream_t st0 = (hipStream_t)stream;
-    static const bool no_fused = [] { const char* e = getenv("SG_NO_GN_FUSED"); return e && atoi(e) != 0; }();   // development knob
-    if (p.cpg % 4 == 0 && (long)p.HW * p.cpg <= 256L * 4 * GNF_MAXI && !no_fused) {
+    // development knobs: SG_NO_GN_FUSED=1, SG_GN_FUSED_MAX=<slab elements>, SG_GN_WIDE=0
+    static const bool no_fused = [] { const char* e = getenv("SG_NO_GN_FUSED"); return e && atoi(e) != 0; }();
+    static const long fused_max = [] { const char* e = getenv("SG_GN_FUSED_MAX"); return e && *e ? atol(e) : GNF_DEFAULT_MAX; }();
+    static const bool wide = [] { const char* e = getenv("SG_GN_WIDE"); return !(e && *e) || atoi(e) != 0; }();
+    const long slab = (long)p.HW * p.cpg;
+    if (p.cpg % 4 == 0 && slab <= 256L * 4 * GNF_MAXI && slab <= fused_max && !no_fused) {
         hipLaunchKernelGGL(gn_fused_kernel, dim3(p.G, d->B), dim3(256), 0, st0, p);
         SG_CHECK_LAUNCH("gn_fused");
+        return SG_OK;
+    }
+    if (wide && p.cpg >= 8 && p.C / 8 <= GNW_MAX_VPR) {
+        const int rpp = GNW_NT / (p.C / 8);
+        int want = sg_cdiv(320, d->B);                    // ~256-384 workgroups of 16 waves (two fit a CU)
+        if (want > GN_MAX_CHUNKS) want = GN_MAX_CHUNKS;
+        p.rows_per_chunk = sg_cdiv(p.HW, want);
+        if (p.rows_per_chunk < rpp) p.rows_per_chunk = rpp;   // at least one full pass of the thread rows
+        p.nchunks = sg_cdiv(p.HW, p.rows_per_chunk);
+        const dim3 grid(p.nchunks, d->B), block(GNW_NT);
+        hipLaunchKernelGGL(gn_stats_wide_kernel, grid, block, 0, st0, p);
+        SG_CHECK_LAUNCH("gn_stats_wide");
+        hipLaunchKernelGGL(gn_apply_wide_kernel, grid, block, 0, st0, p);
+        SG_CHECK_LAUNCH("gn_apply_wide");
         return SG_OK;
     }
     int apply_blocks = 1;

@@ -55,25 +55,28 @@ def load_tile_table(path: Optional[str] = None) -> int:
 # Optional in-situ kernel timer (bench.py): when set, every MFMA-class launch is bracketed by HIP events recorded
 # on the launch stream and reported as (family, algorithmic_flops, start_event, end_event).
 PROFILE_SINK = None
+# Same for the bandwidth-bound kernels (tools/profile_step.py): (family, algorithmic_bytes, start, end, shape).
+AUX_SINK = None
 
 
 class _timed:
-    __slots__ = ("family", "flops", "start", "shape")
+    __slots__ = ("family", "flops", "start", "shape", "aux")
 
-    def __init__(self, family: str, flops: float, shape: str = ""):
-        self.family, self.flops, self.shape = family, flops, shape
+    def __init__(self, family: str, flops: float, shape: str = "", aux: bool = False):
+        self.family, self.flops, self.shape, self.aux = family, flops, shape, aux
 
     def __enter__(self):
-        if PROFILE_SINK is not None:
+        if (AUX_SINK if self.aux else PROFILE_SINK) is not None:
             self.start = torch.cuda.Event(enable_timing=True)
             self.start.record(torch.cuda.current_stream())
         return self
 
     def __exit__(self, *exc):
-        if PROFILE_SINK is not None and exc[0] is None:
+        sink = AUX_SINK if self.aux else PROFILE_SINK
+        if sink is not None and exc[0] is None:
             end = torch.cuda.Event(enable_timing=True)
             end.record(torch.cuda.current_stream())
-            PROFILE_SINK.append((self.family, self.flops, self.start, end, self.shape))
+            sink.append((self.family, self.flops, self.start, end, self.shape))
         return False
 
 
@@ -311,7 +314,8 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: tor
     d.gamma, d.beta = gamma.data_ptr(), beta.data_ptr()
     d.B, d.HW, d.C, d.groups, d.eps, d.silu = B, HW, Cc, groups, eps, int(silu)
     d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
-    check(lib.sg_groupnorm_nhwc_f16(C.byref(d), _stream()), "sg_groupnorm_nhwc_f16")
+    with _timed("groupnorm", B * HW * Cc * ((4 if x_f32 else 2) + 2 + (2 if xcopy is not None else 0)), f"B{B} HW{HW} C{Cc}", aux=True):
+        check(lib.sg_groupnorm_nhwc_f16(C.byref(d), _stream()), "sg_groupnorm_nhwc_f16")
     return out
 
 
@@ -321,9 +325,10 @@ def layernorm(x: torch.Tensor, g1: torch.Tensor, b1: torch.Tensor, y1: torch.Ten
     x_f32 = _act(x, "x")
     _f16(y1, "y1")
     M, Cc = x.shape
-    check(lib.sg_layernorm_f16(x.data_ptr(), _row_stride(x, "x"), int(x_f32), M, Cc, eps, g1.data_ptr(), b1.data_ptr(), y1.data_ptr(),
-                               _row_stride(y1, "y1"), _p(g2), _p(b2), _p(y2),
-                               0 if y2 is None else _row_stride(y2, "y2"), _stream()), "sg_layernorm_f16")
+    with _timed("layernorm", M * Cc * ((4 if x_f32 else 2) + (2 if y2 is None else 4)), f"M{M} C{Cc}{' x2' if y2 is not None else ''}", aux=True):
+        check(lib.sg_layernorm_f16(x.data_ptr(), _row_stride(x, "x"), int(x_f32), M, Cc, eps, g1.data_ptr(), b1.data_ptr(), y1.data_ptr(),
+                                   _row_stride(y1, "y1"), _p(g2), _p(b2), _p(y2),
+                                   0 if y2 is None else _row_stride(y2, "y2"), _stream()), "sg_layernorm_f16")
 
 
 def timestep_embed(t: torch.Tensor, freqs: torch.Tensor, out: torch.Tensor, flip_sin_to_cos: bool) -> torch.Tensor:
@@ -378,8 +383,9 @@ def copy_rows(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
     Bn, rows, cols = src.shape
     if tuple(dst.shape) != (Bn, rows, cols) or dst.stride(-1) != 1 or src.stride(-1) != 1:
         raise ValueError("copy_rows: shape/stride mismatch")
-    check(lib.sg_copy_rows(dst.data_ptr(), dst.stride(1), dst.stride(0), src.data_ptr(), src.stride(1), src.stride(0),
-                           Bn, rows, cols, mode, _stream()), "sg_copy_rows")
+    with _timed("copy_rows", Bn * rows * cols * ((4 if s32 else 2) + (4 if d32 else 2)), f"B{Bn} R{rows} C{cols}", aux=True):
+        check(lib.sg_copy_rows(dst.data_ptr(), dst.stride(1), dst.stride(0), src.data_ptr(), src.stride(1), src.stride(0),
+                               Bn, rows, cols, mode, _stream()), "sg_copy_rows")
     return dst
 
 

@@ -135,3 +135,19 @@ def test_product_path_has_no_cpu_fallback():
     x = torch.zeros(8, 64, dtype=torch.float16)
     with pytest.raises(TypeError):
         ops.gemm(x, x, torch.zeros(8, 8, dtype=torch.float16))
+
+
+def test_no_kernel_uses_scratch_memory():
+    """The build records every kernel's register / LDS / scratch footprint (hipcc -Rpass-analysis=kernel-resource-usage,
+    storygen_amd/lib/kernel_resources.json).  A private segment means spills or an in-memory array — a 6x cliff when it
+    happened to the D=160 attention instantiation — so no kernel may have one, and wave64 x 1024-thread launches must fit."""
+    import json
+    from storygen_amd import build as B
+    B.build(verbose=False)
+    with open(B.RESOURCES) as f:
+        res = json.load(f)
+    assert len(res) >= 40
+    assert {v["source"] for v in res.values()} == set(B.SOURCES)
+    bad = {k: v for k, v in res.items() if v["scratch_bytes_per_lane"] != 0}
+    assert not bad, bad
+    assert all(v["vgprs"] <= 256 and v["agprs"] <= 256 and v["lds_bytes_per_block"] <= 160 * 1024 for v in res.values())

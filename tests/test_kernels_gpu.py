@@ -306,7 +306,9 @@ def test_attention_shared_kv_batches(gpu, D, Nq, Nk):
 
 @pytest.mark.parametrize("B,HW,C,silu,eps", [(3, 256, 320, True, 1e-5), (2, 64, 1920, True, 1e-5), (1, 100, 2560, False, 1e-6),
                                             (3, 4096, 320, False, 1e-6), (2, 1024, 960, True, 1e-5), (1, 7, 64, True, 1e-5),
-                                            (4, 256, 1280, True, 1e-5), (2, 256, 2560, False, 1e-6), (3, 64, 640, True, 1e-5)])
+                                            (4, 256, 1280, True, 1e-5), (2, 256, 2560, False, 1e-6), (3, 64, 640, True, 1e-5),
+                                            (4, 4096, 640, True, 1e-5), (1, 4000, 960, False, 1e-5), (3, 1024, 1920, True, 1e-5),
+                                            (2, 1000, 1280, True, 1e-6), (5, 520, 2560, True, 1e-5)])
 def test_groupnorm(gpu, B, HW, C, silu, eps):
     from storygen_amd import ops
     x = (rnd((B, HW, C), gpu, 2.0, seed=1).float() + 3.0).half()      # non-zero mean
@@ -319,7 +321,8 @@ def test_groupnorm(gpu, B, HW, C, silu, eps):
     check(out, ref, "groupnorm")
 
 
-@pytest.mark.parametrize("B,H,W,C", [(3, 16, 16, 320), (2, 8, 12, 1920), (1, 4, 4, 2560)])
+@pytest.mark.parametrize("B,H,W,C", [(3, 16, 16, 320), (2, 8, 12, 1920), (1, 4, 4, 2560), (4, 64, 64, 320), (3, 63, 64, 960),
+                                     (2, 32, 32, 1280)])
 def test_groupnorm_fp32_in_padded_out_rawcopy(gpu, B, H, W, C):
     """The resnet flavour: fp32 residual-stream input, SiLU, output into the zero-bordered conv input, raw fp16 copy."""
     from storygen_amd import ops
@@ -334,6 +337,19 @@ def test_groupnorm_fp32_in_padded_out_rawcopy(gpu, B, H, W, C):
     assert float(yp[:, 0].abs().max()) == 0 and float(yp[:, -1].abs().max()) == 0
     assert float(yp[:, :, 0].abs().max()) == 0 and float(yp[:, :, -1].abs().max()) == 0
     assert torch.equal(xc, x.half())
+
+
+def test_groupnorm_row_strided_input(gpu):
+    """Input rows that are a channel window of a wider buffer (ldx > C) through the wide two-pass kernels."""
+    from storygen_amd import ops
+    B, HW, C, LD = 2, 2048, 640, 960
+    big = rnd((B, HW, LD), gpu, 2.0, seed=1, dtype=torch.float32) - 0.7
+    x = big[:, :, 320:]
+    g, b = rnd((C,), gpu, seed=2), rnd((C,), gpu, seed=3)
+    out = torch.empty(B, HW, C, dtype=torch.float16, device=gpu)
+    ws = torch.empty(ops.groupnorm_workspace_bytes(B, 32), dtype=torch.uint8, device=gpu)
+    ops.groupnorm(x, g, b, out, 32, 1e-5, False, ws)
+    check(out, F.group_norm(x.transpose(1, 2), 32, g.float(), b.float(), 1e-5).transpose(1, 2), "groupnorm strided")
 
 
 def test_layernorm_fp32_input(gpu):

@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Isolated timings of the bandwidth-bound kernels of one denoising step (GroupNorm at every shape the SD-1.5 UNet
+uses at a 64x64 latent, LayerNorm), with the bytes each launch has to move.  Development tool; the kernel variant is
+chosen by the SG_GN_* environment knobs of the process (see norm.hip), so A/B = two runs of this script."""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from storygen_amd import ops  # noqa: E402
+
+GN_SHAPES = [(64, 320), (64, 640), (64, 960), (32, 320), (32, 640), (32, 960), (32, 1280), (32, 1920),
+             (16, 640), (16, 1280), (16, 1920), (16, 2560), (8, 1280), (8, 2560)]
+LN_SHAPES = [(4096, 320), (1024, 640), (256, 1280)]
+
+
+def timed(fn, iters=30):
+    for _ in range(3):
+        fn()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    torch.cuda._sleep(20_000_000)   # ~10 ms of GPU spin: the host enqueues everything meanwhile, launches run back-to-back
+    a.record()
+    for _ in range(iters):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / iters * 1e3   # us
+
+
+def main():
+    dev = "cuda:0"
+    knobs = {k: v for k, v in os.environ.items() if k.startswith("SG_")}
+    print(f"knobs: {knobs}")
+    print(f"{'op':10s} {'B':>2s} {'side':>4s} {'C':>5s} {'MB':>7s} {'us':>8s} {'GB/s':>8s}")
+    for B in (4, 3):
+        for side, C in GN_SHAPES:
+            hw = side * side
+            x = torch.randn(B, hw, C, device=dev)
+            g, b = torch.randn(C, device=dev).half(), torch.randn(C, device=dev).half()
+            y = torch.zeros(B, side + 2, side + 2, C, dtype=torch.float16, device=dev)
+            ws = torch.empty(ops.groupnorm_workspace_bytes(B, 32), dtype=torch.uint8, device=dev)
+            us = timed(lambda: ops.groupnorm(x, g, b, y, 32, 1e-5, True, ws))
+            mb = B * hw * C * 6 / 1e6       # one fp32 read + one fp16 write
+            print(f"{'groupnorm':10s} {B:2d} {side:4d} {C:5d} {mb:7.2f} {us:8.2f} {mb / us * 1e3:8.0f}")
+    for B in (4, 3):
+        for hw, C in LN_SHAPES:
+            M = B * hw
+            x = torch.randn(M, C, device=dev)
+            g, b = torch.randn(C, device=dev).half(), torch.randn(C, device=dev).half()
+            y1, y2 = (torch.empty(M, C, dtype=torch.float16, device=dev) for _ in range(2))
+            us = timed(lambda: ops.layernorm(x, g, b, y1, 1e-5, g, b, y2))
+            mb = M * C * 8 / 1e6
+            print(f"{'layernorm2':10s} {B:2d} {hw:4d} {C:5d} {mb:7.2f} {us:8.2f} {mb / us * 1e3:8.0f}")
+
+
+def attention_d160():
+    """The 16x16-level attention shapes (head dim 160): few workgroups, long key loops."""
+    dev = "cuda:0"
+    print(f"{'op':10s} {'B':>2s} {'Nq':>5s} {'Nk':>5s} {'us':>8s} {'TFLOP/s':>8s}")
+    for B, Nq, Nk in ((3, 256, 768), (4, 256, 256), (3, 256, 256), (3, 256, 77), (3, 576, 2880)):
+        C = 1280
+        q = torch.randn(B, Nq, C, device=dev).half()
+        k = torch.randn(B, Nk, C, device=dev).half()
+        nk8 = (Nk + 7) // 8 * 8
+        vt = torch.randn(B, C, nk8, device=dev).half()
+        o = torch.empty_like(q)
+        us = timed(lambda: ops.attention(q, k, vt, o, 8, 160 ** -0.5, nk=Nk))
+        print(f"{'attn_d160':10s} {B:2d} {Nq:5d} {Nk:5d} {us:8.2f} {4.0 * B * 8 * Nq * Nk * 160 / us / 1e6:8.1f}")
+
+
+if __name__ == "__main__":
+    if "--attn" in sys.argv:
+        attention_d160()
+        sys.exit(0)
+    main()

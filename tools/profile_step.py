@@ -29,8 +29,8 @@ def main():
         smp.step()
     torch.cuda.synchronize()
     print(f"graph step: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms")
-    sink = []
-    ops.PROFILE_SINK = sink
+    sink, aux = [], []
+    ops.PROFILE_SINK, ops.AUX_SINK = sink, aux
     smp.side_main = smp.side_ref = None   # sequential: per-kernel durations without co-running neighbours
     smp.params.copy_(smp.table[8])
     torch.cuda._sleep(200_000_000)   # ~100 ms GPU spin so the (slower) eager host stays ahead of the GPU: no launch gaps
@@ -38,7 +38,7 @@ def main():
     smp._step_body()
     torch.cuda.synchronize()
     print(f"eager instrumented step: {(time.perf_counter() - t0) * 1e3:.2f} ms")
-    ops.PROFILE_SINK = None
+    ops.PROFILE_SINK = ops.AUX_SINK = None
     rows = defaultdict(lambda: [0, 0.0, 0.0])
     for fam, flops, a, b, shape in sink:
         r = rows[(fam, shape)]
@@ -50,6 +50,20 @@ def main():
     print(f"{'family':14s} {'shape':34s} {'n':>4s} {'ms':>8s} {'%':>6s} {'us/launch':>10s} {'TFLOP/s':>8s}")
     for (fam, shape), (n, ms, fl) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
         print(f"{fam:14s} {shape:34s} {n:4d} {ms:8.3f} {100 * ms / tot:6.1f} {1e3 * ms / n:10.1f} {fl / ms / 1e9:8.1f}")
+    rows = defaultdict(lambda: [0, 0.0, 0.0])
+    for fam, nbytes, a, b, shape in aux:
+        r = rows[(fam, shape)]
+        r[0] += 1
+        r[1] += a.elapsed_time(b)
+        r[2] += nbytes
+    tot_aux = sum(r[1] for r in rows.values())
+    print(f"bandwidth-class total {tot_aux:.2f} ms (groupnorm / layernorm / copy_rows; event-bracketed, so each includes ~2 us of "
+          f"launch gap)")
+    for fam in ("groupnorm", "layernorm", "copy_rows"):
+        print(f"  {fam}: {sum(r[1] for (f, _), r in rows.items() if f == fam):.3f} ms in {sum(r[0] for (f, _), r in rows.items() if f == fam)} launches")
+    print(f"{'family':14s} {'shape':34s} {'n':>4s} {'ms':>8s} {'%':>6s} {'us/launch':>10s} {'GB/s':>8s}")
+    for (fam, shape), (n, ms, nb) in sorted(rows.items(), key=lambda kv: -kv[1][1]):
+        print(f"{fam:14s} {shape:34s} {n:4d} {ms:8.3f} {100 * ms / tot_aux:6.1f} {1e3 * ms / n:10.1f} {nb / ms / 1e6:8.0f}")
 
 
 if __name__ == "__main__":
