@@ -32,7 +32,7 @@ __device__ __forceinline__ int kswz(int row) {
     return D == 40 ? 0 : (D == 80 ? ((row >> 3) & 1) : ((row >> 2) & 3));
 }
 
-template <int D, int NW, int S, int SUB = 1>
+template <int D, int NW, int S, int SUB = 1, bool PRIO = false>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     constexpr int DC = D / 8;                   // 16-byte chunks per K row
     constexpr int NDK = (D + 15) / 16;          // MFMA k-steps of S^T (contraction padded to 16)
@@ -198,11 +198,15 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
                     kf[kb][st] = *reinterpret_cast<const f16x8*>(krow + (((st * 2 + hi) ^ sw) << 4));
             }
             __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMAs (the scheduler would re-serialise them)
+            // PRIO: raise this wave's issue priority over its SIMD neighbours (other workgroups, in their softmax VALU
+            // phase) for the duration of a pure-MFMA cluster — guide T5
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int st = 0; st < NDK; ++st)
                     s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][st], qf[st], st == 0 ? zero16 : s[kb], 0, 0, 0);   // C = inline 0
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         } else {
             const char* krow0 = sK + prow * KROW;
             const char* krow1 = sK + (32 + prow) * KROW;
@@ -278,9 +282,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
                     vf[0][i] = *reinterpret_cast<const f16x8*>(sV + d * 128 + (((ks * 2 + hi) ^ ((d >> 1) & 7)) << 4));
                 }
             }
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < DT; ++i)
                 oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[VPRE ? ks : 0][i], pf, oacc[i], 0, 0, 0);
+            if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         }
         }
       }   // sub-tiles of the group
@@ -307,11 +313,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     }
 }
 
-template <int D, int NW, int S, int SUB = 1>
+template <int D, int NW, int S, int SUB = 1, bool PRIO = false>
 void launch_attn(const AttnParams& p0, hipStream_t st) {
     AttnParams p = p0;
     p.nqb = sg_cdiv(p.Nq, 32 * NW);
-    hipLaunchKernelGGL((attn_fwd_kernel<D, NW, S, SUB>), dim3(p.nqb * p.H * p.B), dim3(64 * NW), 0, st, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<D, NW, S, SUB, PRIO>), dim3(p.nqb * p.H * p.B), dim3(64 * NW), 0, st, p);
 }
 
 

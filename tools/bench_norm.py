@@ -56,18 +56,20 @@ def main():
 
 
 def attention_d160():
-    """The 16x16-level attention shapes (head dim 160): few workgroups, long key loops."""
+    """Attention shapes of the step: head dim 160 (16x16 level: few workgroups, long key loops), 80 and 40."""
     dev = "cuda:0"
     print(f"{'op':10s} {'B':>2s} {'Nq':>5s} {'Nk':>5s} {'us':>8s} {'TFLOP/s':>8s}")
-    for B, Nq, Nk in ((3, 256, 768), (4, 256, 256), (3, 256, 256), (3, 256, 77), (3, 576, 2880)):
-        C = 1280
+    for D, B, Nq, Nk in ((160, 3, 256, 768), (160, 4, 256, 256), (160, 3, 256, 256), (160, 3, 256, 77), (160, 3, 576, 2880),
+                         (80, 3, 1024, 3072), (80, 4, 1024, 1024), (80, 3, 1024, 77), (40, 3, 4096, 12288), (40, 4, 4096, 4096),
+                         (40, 4, 4096, 77)):
+        C = 8 * D
         q = torch.randn(B, Nq, C, device=dev).half()
         k = torch.randn(B, Nk, C, device=dev).half()
         nk8 = (Nk + 7) // 8 * 8
         vt = torch.randn(B, C, nk8, device=dev).half()
         o = torch.empty_like(q)
-        us = timed(lambda: ops.attention(q, k, vt, o, 8, 160 ** -0.5, nk=Nk))
-        print(f"{'attn_d160':10s} {B:2d} {Nq:5d} {Nk:5d} {us:8.2f} {4.0 * B * 8 * Nq * Nk * 160 / us / 1e6:8.1f}")
+        us = timed(lambda: ops.attention(q, k, vt, o, 8, D ** -0.5, nk=Nk), iters=10 if Nk > 4096 else 30)
+        print(f"{f'attn_d{D}':10s} {B:2d} {Nq:5d} {Nk:5d} {us:8.2f} {4.0 * B * 8 * Nq * Nk * D / us / 1e6:8.1f}")
 
 
 if __name__ == "__main__":
