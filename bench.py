@@ -123,10 +123,11 @@ def in_situ_roofline(sampler):
         k["frac_of_peak"] = k["tflops"] / PEAK_FP16_TFLOPS
     dom = max(kernels, key=lambda k: kernels[k]["ms"])
     d = kernels[dom]
-    executed_tflop = sum(f["gflop"] for f in fam.values()) / 1e3
+    g = getattr(sampler, "G", 1)      # ref_ahead: the instrumented body is one group = g steps (one batched reference pass)
+    executed_tflop = sum(f["gflop"] for f in fam.values()) / 1e3 / g
     roof = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(d["frac_of_peak"], 4), "traffic": measured_traffic(dom), "launches_per_step": d["launches"],
-            "avg_launch_us": round(d["avg_us"], 1), "gflop_per_step": round(d["gflop"], 1),
+            "frac": round(d["frac_of_peak"], 4), "traffic": measured_traffic(dom), "launches_per_step": round(d["launches"] / g, 2),
+            "avg_launch_us": round(d["avg_us"], 1), "gflop_per_step": round(d["gflop"] / g, 1), "steps_in_sample": g,
             "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
             "families": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(fam.items())}}
     return roof, executed_tflop
@@ -141,6 +142,10 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-dedup", action="store_true", help="run all 3R reference samples as written")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: reference pass, then main pass")
+    ap.add_argument("--ref-ahead", type=int, default=1,
+                    help="batch the reference passes of G consecutive steps into one UNet call (sampler ref_ahead). The timed "
+                         "window then starts on a group boundary (extra untimed warm-up steps, reported as warmup_run) and G "
+                         "must divide --steps, so that it contains exactly steps/G batched reference passes")
     ap.add_argument("--config5-shape", action="store_true",
                     help="NOT the contract workload: BASELINE configs[4]'s shape (768x768 = 96x96 latent, 5 prior frames) with the fp16 "
                          "attention kernel (the fp8 path is not built); the JSON names it in config.workload")
@@ -177,9 +182,13 @@ def main():
     arch = build_arch(SD15_CONFIG)
     sd = synthetic_state_dict(arch, 0)
     inputs = synthetic_inputs(N_PER_GPU, n_ref, hw, hw, seed=rank, cross_attention_dim=arch.config["cross_attention_dim"])
+    G = max(1, args.ref_ahead)
+    if G > 1 and args.steps % G:
+        raise SystemExit(f"--ref-ahead {G} must divide --steps {args.steps}")
+    warmup_run = -(-args.warmup // G) * G          # the timed window starts on a group boundary
     sampler = StoryGenSampler(arch, sd, dev, N_PER_GPU, hw, hw, n_ref, use_graph=not args.no_graph, dedup=not args.no_dedup,
-                              overlap=not args.no_overlap)
-    n_sched = max(T, args.steps + args.warmup)
+                              overlap=not args.no_overlap, ref_ahead=G)
+    n_sched = max(T, args.steps + warmup_run)
     sampler.prepare(inputs, n_sched, "multi-image-condition", 7.5, 3.5)
 
     def barrier():
@@ -187,7 +196,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    for _ in range(warmup_run):
         sampler.step()
     barrier()
     t0 = time.perf_counter()
@@ -220,7 +229,7 @@ def main():
                                     "frames, CFG batch 3, DDIM, SD-1.5 UNet + attn3 (909M params, synthetic fp16 weights)"),
                        "samples_per_gpu": N_PER_GPU, "parallelism": f"dp{world} (one sample per GPU, final all-gather)",
                        "hipgraph": not args.no_graph, "dedup_identical_reference_samples": not args.no_dedup,
-                       "overlap_ref_pass_of_next_step": sampler.overlap},
+                       "overlap_ref_pass_of_next_step": sampler.overlap, "ref_ahead": G, "warmup_run": warmup_run},
             "tflop_per_step_as_written": round(step_tflop, 3),
             "final_allgather_ms": round(gather_ms, 3), "latents_gathered": int(final.shape[0]), "latents_finite": finite,
         }

@@ -140,11 +140,14 @@ class HarvestPlan:
     feature of sample src + j*src_step of this pass.  One strided copy per op (src_step = 0 broadcasts one sample
     into `count` frame slots)."""
 
-    def __init__(self, ctx: Dict[str, torch.Tensor], ops_: List[tuple], kv: Optional[Dict[str, tuple]] = None):
+    def __init__(self, ctx: Dict[str, torch.Tensor], ops_: List[tuple], kv: Optional[Dict[str, tuple]] = None,
+                 src_offset: int = 0):
         # kv: feature key -> (K [rows*R*HW, C], VT [C, rows*R*HW]) buffers: when given, the reference pass also runs the
         # attn3 K / V^T projections of each finished context (they depend on nothing else), taking them off the main
         # pass's critical path.
-        self.ctx, self.ops, self.kv = ctx, list(ops_), kv
+        # src_offset: added to every op's `src` — a reference pass that batches the samples of several denoising steps
+        # (sampler ref_ahead > 1) passes one plan per step, each pointing at that step's slice of the batch.
+        self.ctx, self.ops, self.kv, self.src_offset = ctx, list(ops_), kv, int(src_offset)
 
 
 class UNetEngine:
@@ -386,16 +389,17 @@ class UNetEngine:
         h1 = L["h1"]
         ops.gemm(att, xf.w_o1, h1, bias=xf.b_o1, res1=h0, workspace=ws)
         if harvest is not None:                                                           # feature :263, written in place
-            ctx = harvest.ctx[xf.spec.feature_key]
             h1b = h1.view(B, hw, C)
-            for src, step, row, slot, cnt in harvest.ops:
-                dst = ctx[row, slot * hw:(slot + cnt) * hw, :].view(cnt, hw, C)
-                ops.copy_rows(dst, h1b[src:].as_strided((cnt, hw, C), (step * hw * C, C, 1)))
-            if harvest.kv is not None:             # attn3 K / V^T of the finished context (attention.py:215-223)
-                ki, vti = harvest.kv[xf.spec.feature_key]
-                c2d = ctx.view(ctx.shape[0] * ctx.shape[1], C)
-                ops.gemm(c2d, xf.w_k3, ki, workspace=ws)
-                ops.gemm(xf.w_v3, c2d, vti, workspace=ws)                                  # VT[C, rows*nk]
+            for plan in (harvest if isinstance(harvest, (list, tuple)) else (harvest,)):
+                ctx = plan.ctx[xf.spec.feature_key]
+                for src, step, row, slot, cnt in plan.ops:
+                    dst = ctx[row, slot * hw:(slot + cnt) * hw, :].view(cnt, hw, C)
+                    ops.copy_rows(dst, h1b[plan.src_offset + src:].as_strided((cnt, hw, C), (step * hw * C, C, 1)))
+                if plan.kv is not None:            # attn3 K / V^T of the finished context (attention.py:215-223)
+                    ki, vti = plan.kv[xf.spec.feature_key]
+                    c2d = ctx.view(ctx.shape[0] * ctx.shape[1], C)
+                    ops.gemm(c2d, xf.w_k3, ki, workspace=ws)
+                    ops.gemm(xf.w_v3, c2d, vti, workspace=ws)                              # VT[C, rows*nk]
             if stop_after_harvest:
                 return
         # --- text cross-attention :266-277 (norm2) and image cross-attention :281-291 (norm4) share statistics
@@ -469,7 +473,8 @@ class UNetEngine:
         """One UNet call on the static inputs (self.x_in fp32 NCHW, self.t_in fp32 [B], self.text_in fp16).
 
         harvest_slot=r : reference pass — no image context; sample b's features go to slot r of row b of self.ctx.
-        harvest=plan   : reference pass writing into another engine's context buffers (HarvestPlan).
+        harvest=plan   : reference pass writing into another engine's context buffers (HarvestPlan, or a list of them:
+                         one per slice of the batch, HarvestPlan.src_offset).
         harvest_only   : stop right after the last feature is harvested (the rest of the pass — text attention and FF
                          of the last block, conv_out — only produces an epsilon the loop discards, pipeline.py:433-435);
                          returns None.

@@ -26,6 +26,15 @@ MI355X-first structure
     1 (grids of 60-250 workgroups, latency-bound 5-20-slab pipelines), so the two branches fill each other's gaps;
     the arithmetic and its order inside each pass are unchanged (the eager path runs the same kernels back to back).
 
+  * `ref_ahead = G > 1` (graph + overlap mode) goes one step further down the same road: since no reference pass depends
+    on the latents, the reference samples of G consecutive steps — they differ only in their noise level — run as ONE
+    batched UNet call of G x as many samples, launched (as its own hipGraph, on a second stream) at the start of every
+    group of G steps and producing the G context sets of the NEXT group while this group's G main passes (one hipGraph
+    each, back to back on the first stream) consume theirs.  Per sample the arithmetic is unchanged; what changes is
+    the shape of the work: 4 x larger M for every GEMM / convolution of the reference half of the step (better tile
+    quantisation at the 64x64 level, weights streamed once per G steps at the weight-bound 16x16 / 8x8 levels) and 4 x
+    fewer launches.  2G context sets are kept (set = step mod 2G).
+
 Data parallelism (SURVEY §8e): one process per GPU, each running its own samples with no per-step communication;
 `gather_latents` is the single RCCL all-gather of the final [N,4,h,w] latents.
 """
@@ -47,9 +56,13 @@ class StoryGenSampler:
     def __init__(self, arch: UNetArch, state_dict: Optional[Dict[str, torch.Tensor]], device, n_samples: int = 1,
                  height: int = 64, width: int = 64, n_ref: int = 3, seq_len: int = 77,
                  schedule: Optional[DDIMSchedule] = None, use_graph: bool = True, dedup: bool = True,
-                 weights: Optional[EngineWeights] = None, overlap: bool = True):
+                 weights: Optional[EngineWeights] = None, overlap: bool = True, ref_ahead: int = 1):
         if n_ref < 1:
             raise ValueError("StoryGen's loop needs at least one prior frame")
+        if ref_ahead < 1 or (ref_ahead > 1 and not (use_graph and overlap)):
+            raise ValueError("ref_ahead > 1 batches the reference passes of several steps on a second stream: it needs "
+                             "use_graph=True and overlap=True")
+        self.G = int(ref_ahead)
         self.arch, self.dev = arch, torch.device(device)
         self.N, self.R, self.h, self.w, self.S = n_samples, n_ref, height, width, seq_len
         self.B = 3 * n_samples
@@ -121,6 +134,9 @@ class StoryGenSampler:
         if self.layout == key:
             return
         units, hops, rows, groups = self._plan(stage, share_zero)
+        G = self.G
+        self.U0 = len(units)                  # reference samples of ONE step; the reference engine batches G steps of them
+        units = units * G                     # unit g*U0 + u = sample u of the g-th step of a group
         self.units, self.U = units, len(units)
         kw = dict(weights=self.weights)
         self.main = UNetEngine(self.arch, None, self.dev, self.B, self.h, self.w, self.R, self.S, ctx_rows=rows,
@@ -129,12 +145,14 @@ class StoryGenSampler:
         # context sets: the main pass of step k reads set k%2 (only one set without overlap)
         self.ctx_sets = [self.main.ctx]
         if self.overlap:
-            self.ctx_sets.append({k: torch.empty_like(v) for k, v in self.main.ctx.items()})
+            for _ in range(2 * G - 1):         # G = 1: sets k%2; G > 1: set = step mod 2G
+                self.ctx_sets.append({k: torch.empty_like(v) for k, v in self.main.ctx.items()})
         # attn3 K / V^T per context set: computed by the reference pass right after each feature is harvested
         self.kv_sets = [{k: (torch.empty(v.shape[0] * v.shape[1], v.shape[2], dtype=v.dtype, device=self.dev),
                              torch.empty(v.shape[2], v.shape[0] * v.shape[1], dtype=v.dtype, device=self.dev))
                          for k, v in c.items()} for c in self.ctx_sets]
-        self.plans = [HarvestPlan(c, hops, kv) for c, kv in zip(self.ctx_sets, self.kv_sets)]
+        self.plans = [HarvestPlan(c, hops, kv, src_offset=(i % G) * self.U0)
+                      for i, (c, kv) in enumerate(zip(self.ctx_sets, self.kv_sets))]
         self.plan = self.plans[0]
         # side streams for the independent branches inside a pass (engine.forward(side=...)).  In overlap mode the
         # reference pass already runs on a forked stream; a second-level fork from it crashed hipGraph capture on
@@ -151,6 +169,10 @@ class StoryGenSampler:
         self.n_par = 3 * self.U + self.B + 6
         self.params = torch.zeros(self.n_par, **f32)
         self.layout, self.graph, self.graphs = key, None, []
+        self.g_ref, self.g_main = [], []       # ref_ahead > 1: one graph per group parity / per context set
+        if G > 1:
+            self.ref_stream = torch.cuda.Stream(device=self.dev)
+            self.ev_ref = [torch.cuda.Event(), torch.cuda.Event()]      # "reference pass of a group of this parity is done"
 
     def _par_views(self):
         U, B = self.U, self.B
@@ -185,29 +207,14 @@ class StoryGenSampler:
         self.ref.cache_text_kv()
         # per-step table
         ts = self.schedule.timesteps(num_inference_steps)
-        def ref_part(t):
-            ref_t = int(t) // 10                                                          # :414-415
-            tis = [ref_t * (R - i) if stage == "auto-regressive" else ref_t for i in range(R)]   # :419-427
-            tt = [float(tis[i]) for _, i, _ in self.units]
-            cc: List[float] = []
-            for _, i, _ in self.units:
-                cc += list(self.schedule.add_noise_coef(tis[i]))
-            return tt, cc
-
-        rows = []
-        for k, t in enumerate(ts):
-            # overlap: graph k runs the main pass of step k next to the reference pass of step k+1
-            tt, cc = ref_part(ts[min(k + 1, len(ts) - 1)] if self.overlap else t)
-            row = tt + [float(t)] * self.B + cc
-            row += [image_guidance_scale, guidance_scale, *self.schedule.step_coef(int(t), num_inference_steps)]
-            rows.append(row)
+        rows, row0 = step_table(self.schedule, ts, num_inference_steps, self.units[:self.U0], R, stage, self.B, self.G,
+                                self.overlap, image_guidance_scale, guidance_scale)
+        self.row0_ref = torch.tensor(row0, dtype=torch.float32).pin_memory()
         self.table = torch.tensor(rows, dtype=torch.float32).pin_memory()
-        tt, cc = ref_part(ts[0])
-        self.row0_ref = torch.tensor(tt + [float(ts[0])] * self.B + cc + [0.0] * 6, dtype=torch.float32).pin_memory()
         self.timesteps = ts
         self.num_steps = num_inference_steps
         self.k = 0
-        if self.use_graph and self.graph is None and not self.graphs:
+        if self.use_graph and self.graph is None and not self.graphs and not self.g_main:
             self._capture()
         if self.overlap:
             self._prime()
@@ -215,15 +222,21 @@ class StoryGenSampler:
     # ------------------------------------------------------------------------------------------------ the step
     def _step_body(self):
         """One whole step, sequentially (eager mode, graph warm-up, bench instrumentation): reference passes :418-438,
-        then the main pass.  NB in overlap mode `self.params` holds the reference-pass scalars of the NEXT step."""
+        then the main pass.  NB in overlap mode `self.params` holds the reference-pass scalars of the NEXT step.
+        With ref_ahead = G > 1 this is one whole GROUP: the batched reference pass of G steps and G main passes (all with
+        the scalars of one table row: good for warm-up and kernel timing, not a valid piece of a trajectory)."""
         self._ref_pass(0)
-        self._main_pass(0)
+        for g in range(self.G):
+            self._main_pass(g)
 
     def _ref_pass(self, ctx_set: int):
+        """The reference samples of step(s) -> context set `ctx_set` (ref_ahead = G > 1: of G steps -> sets ctx_set ..
+        ctx_set + G - 1, one harvest plan per step's slice of the batch)."""
         t_ref, _, an, _ = self._par_views()
         ops.add_noise(self.ref_src, self.noise, an, self.ref.x_in)                        # :419-429
         self.ref.t_in.copy_(t_ref)
-        self.ref.forward(harvest=self.plans[ctx_set], harvest_only=True, text_cache=True, side=self.side_ref)
+        plan = self.plans[ctx_set] if self.G == 1 else self.plans[ctx_set:ctx_set + self.G]
+        self.ref.forward(harvest=plan, harvest_only=True, text_cache=True, side=self.side_ref)
 
     def _main_pass(self, ctx_set: int):
         _, t_main, _, cd = self._par_views()
@@ -235,9 +248,11 @@ class StoryGenSampler:
         ops.cfg_ddim_step(eps3, self.latents, self.latents3, cd)                          # :457-461
 
     def _prime(self):
-        """Overlap mode: the reference pass of step 0 has no main pass to hide behind."""
+        """Overlap mode: the reference pass of step 0 (ref_ahead > 1: of the first group) has no main pass to hide behind."""
         self.params.copy_(self.row0_ref, non_blocking=True)
         self._ref_pass(0)
+        if self.G > 1:
+            self.ev_ref[0].record(torch.cuda.current_stream(self.dev))
 
     def _capture(self):
         dev = self.dev
@@ -254,6 +269,20 @@ class StoryGenSampler:
             with torch.cuda.graph(g):
                 self._step_body()
             self.graph = g
+        elif self.G > 1:
+            # separate graphs, overlapped at replay time by launching them on two streams (step()): the batched reference
+            # pass of a group into context sets [p*G, (p+1)*G), and the main pass reading context set s
+            self.g_ref, self.g_main = [], []
+            for p in (0, 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._ref_pass(first_ctx_set_of_group(p, self.G))
+                self.g_ref.append(g)
+            for s_ in range(2 * self.G):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._main_pass(s_)
+                self.g_main.append(g)
         else:
             side = torch.cuda.Stream(device=dev)
             self.graphs = []
@@ -280,6 +309,10 @@ class StoryGenSampler:
         if self.overlap and k != self.k:
             raise RuntimeError("overlapped sampling runs the steps in order (the graph of step k also runs the reference "
                                "pass of step k+1)")
+        if self.g_main:
+            self._step_ahead(k)
+            self.k = k + 1
+            return
         self.params.copy_(self.table[k], non_blocking=True)
         if self.graphs:
             self.graphs[k % 2].replay()
@@ -288,6 +321,30 @@ class StoryGenSampler:
         else:
             self._step_body()
         self.k = k + 1
+
+    def _step_ahead(self, k: int):
+        """ref_ahead = G > 1.  At the first step of group j: the batched reference pass of group j+1 goes to the second
+        stream (it overwrites the context sets group j-1 read, whose main passes are already enqueued on this stream:
+        the fork orders it behind them), and this stream waits for group j's own reference pass, launched one group ago
+        (or by _prime).  Then the main pass of step k, on its context set k mod 2G.
+        The parameter buffer is shared: its reference-pass part is only read by the reference graph (uploaded here, on
+        the second stream, behind the previous reference graph), its main part only by the main graphs."""
+        G, dev = self.G, self.dev
+        j, g = divmod(k, G)
+        cur = torch.cuda.current_stream(dev)
+        U, B = self.U, self.B
+        row = self.table[k]
+        if g == 0:
+            self.ref_stream.wait_stream(cur)
+            with torch.cuda.stream(self.ref_stream):
+                self.params[:U].copy_(row[:U], non_blocking=True)                         # reference timesteps
+                self.params[U + B:3 * U + B].copy_(row[U + B:3 * U + B], non_blocking=True)   # add_noise coefficients
+                self.g_ref[first_ctx_set_of_group(j + 1, G) // G].replay()
+                self.ev_ref[(j + 1) % 2].record(self.ref_stream)
+            cur.wait_event(self.ev_ref[j % 2])
+        self.params[U:U + B].copy_(row[U:U + B], non_blocking=True)                       # main timestep
+        self.params[3 * U + B:].copy_(row[3 * U + B:], non_blocking=True)                 # guidance + DDIM coefficients
+        self.g_main[ctx_set_of_step(k, G)].replay()
 
     def run(self, max_steps: Optional[int] = None, trace: Optional[list] = None) -> torch.Tensor:
         n = self.num_steps if max_steps is None else min(self.num_steps, max_steps)
@@ -298,8 +355,63 @@ class StoryGenSampler:
         return self.latents
 
     def executed_sample_forwards(self):
-        """(reference-pass samples, main-pass samples) actually computed per step — for FLOP accounting."""
-        return self.U, self.B
+        """(reference-pass samples, main-pass samples) actually computed per step — for FLOP accounting (with ref_ahead
+        = G the reference engine runs G steps' samples once per G steps)."""
+        return self.U0, self.B
+
+
+def ctx_set_of_step(k: int, G: int) -> int:
+    """Context set the main pass of step k reads (overlap mode: 2G sets; G = 1 is the classic k % 2)."""
+    return k % (2 * G)
+
+
+def first_ctx_set_of_group(j: int, G: int) -> int:
+    """First of the G consecutive context sets the batched reference pass of group j (steps jG .. jG+G-1) writes."""
+    return (j % 2) * G
+
+
+def step_table(schedule: DDIMSchedule, ts, num_inference_steps: int, units0, R: int, stage: str, B: int, G: int, overlap: bool,
+               image_guidance_scale: float, guidance_scale: float):
+    """The scalars every denoising step needs, as rows of the pinned table the sampler uploads from (pure host logic).
+
+    Row k = [U reference timesteps | B main timesteps | U x 2 add_noise coefficients | 2 guidance scales + 4 DDIM
+    coefficients], U = G * len(units0).  units0 = the (kind, frame, sample) reference samples of ONE step.
+    Which reference scalars row k carries depends on the schedule of the passes:
+      no overlap          : those of step k itself (reference pass, then main pass);
+      overlap, G = 1      : those of step k+1 (graph k runs main pass k beside reference pass k+1);
+      overlap, G > 1      : those of the G steps of group k // G + 1, step-major (uploaded only when k % G == 0: the
+                            batched reference pass of the next group starts with this group's first main pass).
+    Steps past the end repeat the last timestep (their features are never consumed).  Also returns row0: the reference
+    scalars of the very first pass / group (the one nothing overlaps with), main part zero."""
+    T = len(ts)
+
+    def ref_part(t):
+        ref_t = int(t) // 10                                                              # pipeline.py:414-415
+        tis = [ref_t * (R - i) if stage == "auto-regressive" else ref_t for i in range(R)]   # :419-427
+        tt = [float(tis[i]) for _, i, _ in units0]
+        cc: List[float] = []
+        for _, i, _ in units0:
+            cc += list(schedule.add_noise_coef(tis[i]))
+        return tt, cc
+
+    def group_ref(j):
+        tt, cc = [], []
+        for g in range(G):
+            a, b = ref_part(ts[min(j * G + g, T - 1)])
+            tt, cc = tt + a, cc + b
+        return tt, cc
+
+    rows = []
+    for k, t in enumerate(ts):
+        if G > 1:
+            tt, cc = group_ref(k // G + 1)
+        else:
+            tt, cc = ref_part(ts[min(k + 1, T - 1)] if overlap else t)
+        row = tt + [float(t)] * B + cc
+        row += [image_guidance_scale, guidance_scale, *schedule.step_coef(int(t), num_inference_steps)]
+        rows.append(row)
+    tt, cc = group_ref(0) if G > 1 else ref_part(ts[0])
+    return rows, tt + [float(ts[0])] * B + cc + [0.0] * 6
 
 
 def gather_latents(latents: torch.Tensor) -> torch.Tensor:

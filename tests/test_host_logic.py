@@ -224,3 +224,61 @@ def test_committed_bench_line_honours_the_contract():
     assert "traffic" in r and (r["traffic"] is None or r["traffic"] > 0)
     c = d["cpu_baseline"]
     assert c["kind"] in ("reference", "port") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+@pytest.mark.parametrize("G", [1, 2, 4])
+@pytest.mark.parametrize("stage", ["multi-image-condition", "auto-regressive"])
+def test_step_table_reference_scalars_follow_the_pass_schedule(G, stage):
+    """sampler.step_table: row k must carry the reference-pass scalars of the step(s) whose reference pass is launched
+    with main pass k (pipeline.py:414-427 for the values): step k (no overlap), step k+1 (overlap), or the G steps of the
+    next group (ref_ahead = G).  Also the context-set arithmetic of the look-ahead schedule."""
+    from storygen_amd.sampler import ctx_set_of_step, first_ctx_set_of_group, step_table
+    from storygen_amd.scheduler import DDIMSchedule
+    sch = DDIMSchedule()
+    T, R, B = 10, 3, 3
+    ts = sch.timesteps(T)
+    units0 = [(0, 0, 0)] + [(1, i, 0) for i in range(R)]           # zero-image sample + the R prior frames (N = 1)
+    U0 = len(units0)
+
+    def want_ref(step):
+        step = min(step, T - 1)
+        ref_t = int(ts[step]) // 10
+        tis = [ref_t * (R - i) if stage == "auto-regressive" else ref_t for i in range(R)]
+        tt = [float(tis[i]) for _, i, _ in units0]
+        cc = [c for _, i, _ in units0 for c in sch.add_noise_coef(tis[i])]
+        return tt, cc
+
+    for overlap in ((True,) if G > 1 else (False, True)):
+        rows, row0 = step_table(sch, ts, T, units0, R, stage, B, G, overlap, 3.5, 7.5)
+        U = G * U0
+        assert len(rows) == T and all(len(r) == 3 * U + B + 6 for r in rows) and len(row0) == 3 * U + B + 6
+        for k, row in enumerate(rows):
+            first = (k // G + 1) * G if G > 1 else (k + 1 if overlap else k)
+            for g in range(G):
+                tt, cc = want_ref(first + g)
+                assert row[g * U0:(g + 1) * U0] == tt
+                assert row[U + B + 2 * g * U0:U + B + 2 * (g + 1) * U0] == pytest.approx(cc)
+            assert row[U:U + B] == [float(ts[k])] * B
+            assert row[3 * U + B:3 * U + B + 2] == [3.5, 7.5]
+            assert row[3 * U + B + 2:] == pytest.approx(list(sch.step_coef(int(ts[k]), T)))
+        for g in range(G):                                          # the very first pass / group
+            tt, cc = want_ref(g)
+            assert row0[g * U0:(g + 1) * U0] == tt and row0[U + B + 2 * g * U0:U + B + 2 * (g + 1) * U0] == pytest.approx(cc)
+    # context sets: the G main passes of group j read exactly the sets its reference pass wrote, and the reference pass of
+    # group j+1 (running beside them) writes the other half
+    for k in range(6 * G):
+        j = k // G
+        mine = range(first_ctx_set_of_group(j, G), first_ctx_set_of_group(j, G) + G)
+        nxt = range(first_ctx_set_of_group(j + 1, G), first_ctx_set_of_group(j + 1, G) + G)
+        assert ctx_set_of_step(k, G) == mine[k % G]
+        assert not set(mine) & set(nxt) and set(mine) | set(nxt) == set(range(2 * G))
+
+
+def test_ref_ahead_needs_graph_and_overlap():
+    from storygen_amd.arch import build_arch
+    from storygen_amd.sampler import StoryGenSampler
+    from test_oracle_golden import _load
+    arch = build_arch(_load("tiny")["config"])
+    for kw in (dict(use_graph=False), dict(overlap=False), dict(ref_ahead=0)):
+        with pytest.raises(ValueError):
+            StoryGenSampler(arch, None, "cpu", ref_ahead=kw.pop("ref_ahead", 2), weights=object(), **kw)
