@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--config5-shape", action="store_true",
                     help="NOT the contract workload: BASELINE configs[4]'s shape (768x768 = 96x96 latent, 5 prior frames) with the fp16 "
                          "attention kernel (the fp8 path is not built); the JSON names it in config.workload")
+    ap.add_argument("--split-graphs", action="store_true", help="reference and main pass as separate hipGraphs on two streams")
+    ap.add_argument("--stream-priority", action="store_true",
+                    help="with --split-graphs / --ref-ahead: main-pass graphs on a high-priority stream")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -187,7 +190,8 @@ def main():
         raise SystemExit(f"--ref-ahead {G} must divide --steps {args.steps}")
     warmup_run = -(-args.warmup // G) * G          # the timed window starts on a group boundary
     sampler = StoryGenSampler(arch, sd, dev, N_PER_GPU, hw, hw, n_ref, use_graph=not args.no_graph, dedup=not args.no_dedup,
-                              overlap=not args.no_overlap, ref_ahead=G)
+                              overlap=not args.no_overlap, ref_ahead=G, split_graphs=args.split_graphs,
+                              stream_priority=args.stream_priority)
     n_sched = max(T, args.steps + warmup_run)
     sampler.prepare(inputs, n_sched, "multi-image-condition", 7.5, 3.5)
 
@@ -229,7 +233,8 @@ def main():
                                     "frames, CFG batch 3, DDIM, SD-1.5 UNet + attn3 (909M params, synthetic fp16 weights)"),
                        "samples_per_gpu": N_PER_GPU, "parallelism": f"dp{world} (one sample per GPU, final all-gather)",
                        "hipgraph": not args.no_graph, "dedup_identical_reference_samples": not args.no_dedup,
-                       "overlap_ref_pass_of_next_step": sampler.overlap, "ref_ahead": G, "warmup_run": warmup_run},
+                       "overlap_ref_pass_of_next_step": sampler.overlap, "ref_ahead": G, "warmup_run": warmup_run,
+                       "split_graphs": sampler.split, "stream_priority": sampler.stream_priority},
             "tflop_per_step_as_written": round(step_tflop, 3),
             "final_allgather_ms": round(gather_ms, 3), "latents_gathered": int(final.shape[0]), "latents_finite": finite,
         }

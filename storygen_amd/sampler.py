@@ -56,13 +56,23 @@ class StoryGenSampler:
     def __init__(self, arch: UNetArch, state_dict: Optional[Dict[str, torch.Tensor]], device, n_samples: int = 1,
                  height: int = 64, width: int = 64, n_ref: int = 3, seq_len: int = 77,
                  schedule: Optional[DDIMSchedule] = None, use_graph: bool = True, dedup: bool = True,
-                 weights: Optional[EngineWeights] = None, overlap: bool = True, ref_ahead: int = 1):
+                 weights: Optional[EngineWeights] = None, overlap: bool = True, ref_ahead: int = 1,
+                 split_graphs: bool = False, stream_priority: bool = False):
         if n_ref < 1:
             raise ValueError("StoryGen's loop needs at least one prior frame")
         if ref_ahead < 1 or (ref_ahead > 1 and not (use_graph and overlap)):
             raise ValueError("ref_ahead > 1 batches the reference passes of several steps on a second stream: it needs "
                              "use_graph=True and overlap=True")
         self.G = int(ref_ahead)
+        # split: reference pass and main pass are separate hipGraphs overlapped at replay time by launching them on two
+        # streams (always so for ref_ahead > 1).  Only then can the two halves run at different queue priorities
+        # (stream_priority: main pass high — it is the step's critical path — reference pass as background filler).
+        self.split = bool(split_graphs) or self.G > 1
+        if self.split and not (use_graph and overlap):
+            raise ValueError("split_graphs needs use_graph=True and overlap=True")
+        if stream_priority and not self.split:
+            raise ValueError("stream_priority only applies to separately launched graphs (split_graphs=True or ref_ahead > 1)")
+        self.stream_priority = bool(stream_priority)
         self.arch, self.dev = arch, torch.device(device)
         self.N, self.R, self.h, self.w, self.S = n_samples, n_ref, height, width, seq_len
         self.B = 3 * n_samples
@@ -170,8 +180,11 @@ class StoryGenSampler:
         self.params = torch.zeros(self.n_par, **f32)
         self.layout, self.graph, self.graphs = key, None, []
         self.g_ref, self.g_main = [], []       # ref_ahead > 1: one graph per group parity / per context set
-        if G > 1:
+        self.main_stream = None
+        if self.split:
             self.ref_stream = torch.cuda.Stream(device=self.dev)
+            if self.stream_priority:
+                self.main_stream = torch.cuda.Stream(device=self.dev, priority=-1)
             self.ev_ref = [torch.cuda.Event(), torch.cuda.Event()]      # "reference pass of a group of this parity is done"
 
     def _par_views(self):
@@ -251,7 +264,7 @@ class StoryGenSampler:
         """Overlap mode: the reference pass of step 0 (ref_ahead > 1: of the first group) has no main pass to hide behind."""
         self.params.copy_(self.row0_ref, non_blocking=True)
         self._ref_pass(0)
-        if self.G > 1:
+        if self.split:
             self.ev_ref[0].record(torch.cuda.current_stream(self.dev))
 
     def _capture(self):
@@ -269,7 +282,7 @@ class StoryGenSampler:
             with torch.cuda.graph(g):
                 self._step_body()
             self.graph = g
-        elif self.G > 1:
+        elif self.split:
             # separate graphs, overlapped at replay time by launching them on two streams (step()): the batched reference
             # pass of a group into context sets [p*G, (p+1)*G), and the main pass reading context set s
             self.g_ref, self.g_main = [], []
@@ -323,7 +336,7 @@ class StoryGenSampler:
         self.k = k + 1
 
     def _step_ahead(self, k: int):
-        """ref_ahead = G > 1.  At the first step of group j: the batched reference pass of group j+1 goes to the second
+        """Split-graph schedule (ref_ahead = G > 1, or split_graphs with G = 1).  At the first step of group j: the batched reference pass of group j+1 goes to the second
         stream (it overwrites the context sets group j-1 read, whose main passes are already enqueued on this stream:
         the fork orders it behind them), and this stream waits for group j's own reference pass, launched one group ago
         (or by _prime).  Then the main pass of step k, on its context set k mod 2G.
@@ -331,9 +344,12 @@ class StoryGenSampler:
         the second stream, behind the previous reference graph), its main part only by the main graphs."""
         G, dev = self.G, self.dev
         j, g = divmod(k, G)
-        cur = torch.cuda.current_stream(dev)
+        caller = torch.cuda.current_stream(dev)
+        cur = self.main_stream or caller            # stream_priority: the main passes run on their own high-priority stream
         U, B = self.U, self.B
         row = self.table[k]
+        if cur is not caller:
+            cur.wait_stream(caller)
         if g == 0:
             self.ref_stream.wait_stream(cur)
             with torch.cuda.stream(self.ref_stream):
@@ -342,9 +358,12 @@ class StoryGenSampler:
                 self.g_ref[first_ctx_set_of_group(j + 1, G) // G].replay()
                 self.ev_ref[(j + 1) % 2].record(self.ref_stream)
             cur.wait_event(self.ev_ref[j % 2])
-        self.params[U:U + B].copy_(row[U:U + B], non_blocking=True)                       # main timestep
-        self.params[3 * U + B:].copy_(row[3 * U + B:], non_blocking=True)                 # guidance + DDIM coefficients
-        self.g_main[ctx_set_of_step(k, G)].replay()
+        with torch.cuda.stream(cur):
+            self.params[U:U + B].copy_(row[U:U + B], non_blocking=True)                   # main timestep
+            self.params[3 * U + B:].copy_(row[3 * U + B:], non_blocking=True)             # guidance + DDIM coefficients
+            self.g_main[ctx_set_of_step(k, G)].replay()
+        if cur is not caller:
+            caller.wait_stream(cur)
 
     def run(self, max_steps: Optional[int] = None, trace: Optional[list] = None) -> torch.Tensor:
         n = self.num_steps if max_steps is None else min(self.num_steps, max_steps)
