@@ -246,6 +246,64 @@ int sg_copy_rows(void* dst, int64_t ldd, int64_t bsd, const void* src, int64_t l
 int sg_pad_cast_f16(const void* x, int64_t ldx, int32_t x_f32, sg_half* y, int64_t ldy, int32_t B, int32_t H, int32_t W,
                     int32_t C, sg_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------------------
+ * Backward pass of the stage-2 training step (BASELINE config 4; /root/reference/train_StorySalon_stage2.py:322-327:
+ * accelerator.backward(loss) through the main UNet pass, weight gradients for the attn3 modules only, :170-177).
+ * STATUS: compiled for gfx950, not yet run on hardware (round 1's GPU budget was spent before they were written);
+ * formulas and layer order are pinned on the CPU by oracle/storygen_backward.py + tests/test_oracle_backward.py.
+ * The contractions reuse the forward entry points: linear dgrad = sg_gemm_f16 with the transposed weight, weight
+ * gradient dW[n,k] = sum_m dy[m,n] x[m,k] = sg_gemm_f16(A = dy^T, W = x^T) on sg_transpose_f16 outputs, convolution
+ * dgrad = sg_conv3x3_nhwc_f16 with the 180-degree-rotated, channel-swapped weight (stride 2: on sg_zero_stuff_f16's
+ * output; nearest-2x upsampling: followed by sg_sum2x2_f32).
+ */
+
+/* LayerNorm backward: out[M,C] (fp32) = res_scale * res + rstd * (g - mean(g) - xhat * mean(g * xhat)),
+ * g = dy1 * gamma1 (+ dy2 * gamma2: norm2 and norm4 share their input, attention.py:268,283).  x fp16 / fp32 (x_f32),
+ * dy fp16 / fp32 (dy_f32, both pairs alike); res optional.  The affine parameters are frozen (no dgamma / dbeta). */
+int sg_layernorm_bwd_f16(const void* x, int64_t ldx, int32_t x_f32, const void* dy1, int64_t lddy1, const sg_half* gamma1,
+                         const void* dy2, int64_t lddy2, const sg_half* gamma2, int32_t dy_f32, const float* res,
+                         int64_t ldr, float res_scale, float* out, int64_t ldo, int32_t M, int32_t C, float eps,
+                         sg_stream_t stream);
+
+/* GEGLU backward (attention.py:381-393).  proj / dproj are [M, N8] in the 32/32-interleaved column layout of the
+ * forward GEMM's GEGLU weight (blocks of 32 value columns followed by their 32 gate columns), du = d(val * gelu(gate))
+ * is [M, N8/2]: dval = du * gelu(gate), dgate = du * val * gelu'(gate), exact erf GELU. */
+int sg_geglu_bwd_f16(const sg_half* proj, int64_t ldp, const sg_half* du, int64_t ldu, sg_half* dproj, int64_t lddp,
+                     int32_t M, int32_t N8, sg_stream_t stream);
+
+/* GroupNorm(+SiLU) backward over NHWC: d->out = (res +) dx, dx = rstd * (g - mean_g(g) - xhat * mean_g(g * xhat)),
+ * g = dy * act'(xhat * gamma + beta) * gamma.  Output either fp32 [B, HW, C] (out_f32, optional fp32 residual
+ * gradient `res`) or fp16, optionally into the interior of the zero-bordered [B, H+2, out_pad_w+2, C] image the next
+ * dgrad convolution reads.  Needs >= 8 channels per group and C <= 2560 (SG_EUNSUP otherwise). */
+typedef struct {
+    const void* x; int64_t ldx; int32_t x_f32;          /* the forward input [B, HW, C] */
+    const void* dy; int64_t lddy; int32_t dy_f32;       /* gradient w.r.t. the GroupNorm(+SiLU) output */
+    const sg_half* gamma; const sg_half* beta;
+    const float* res; int64_t ldr;                       /* optional, fp32 output only */
+    void* out; int64_t ldo; int32_t out_f32; int32_t out_pad_w;
+    int32_t B, HW, C, groups;
+    float   eps;
+    int32_t silu;
+    void*   workspace; size_t workspace_bytes;           /* sg_groupnorm_bwd_workspace_bytes(B, groups) */
+} sg_groupnorm_bwd_desc;
+
+int sg_groupnorm_bwd_nhwc_f16(const sg_groupnorm_bwd_desc* d, sg_stream_t stream);
+size_t sg_groupnorm_bwd_workspace_bytes(int32_t B, int32_t groups);
+
+/* dst[c][m] = src[m][c], fp16 out, fp16 / fp32 in (M, C multiples of 8). */
+int sg_transpose_f16(const void* src, int64_t lds, int32_t src_f32, sg_half* dst, int64_t ldd, int32_t M, int32_t C,
+                     sg_stream_t stream);
+/* Backward of nearest-2x upsampling: dx[b,y,x,:] (+)= sum of the 2x2 block of du [B, 2H, 2W, C] (fp32). */
+int sg_sum2x2_f32(const float* du, int64_t ldu, float* dx, int64_t ldx, int32_t B, int32_t H, int32_t W, int32_t C,
+                  int32_t accumulate, sg_stream_t stream);
+/* dy [B, Ho, Wo, C] -> interior of the zero-bordered fp16 image y [B, 2Ho+2, 2Wo+2, C] with dy on the even positions
+ * and zeros elsewhere: the input of the stride-1 convolution that computes a stride-2 convolution's dgrad. */
+int sg_zero_stuff_f16(const void* dy, int64_t lddy, int32_t dy_f32, sg_half* y, int64_t ldy, int32_t B, int32_t Ho, int32_t Wo,
+                      int32_t C, sg_stream_t stream);
+/* loss = mean(((pred - noise) * (1 - mask))^2) and its gradient d_pred (train_StorySalon_stage2.py:325), n elements. */
+int sg_mse_grad_f32(const float* pred, const float* noise, const float* mask, float* d_pred, float* loss, int64_t n,
+                    sg_stream_t stream);
+
 /* Diagnostic: raw per-lane MFMA register dump used by tests/test_mfma_layout.py to pin the fragment layout
  * assumptions of the kernels above.  out: fp32 [64 lanes][16 regs] of D = A(32x16) @ B(16x32) with
  * A[i][k] = a[i*16+k], B[k][j] = b[k*32+j] loaded with the kernels' own lane mapping. */

@@ -66,6 +66,20 @@ class GroupNormDesc(C.Structure):
     ]
 
 
+class GroupNormBwdDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64), ("x_f32", C.c_int32),
+        ("dy", C.c_void_p), ("lddy", C.c_int64), ("dy_f32", C.c_int32),
+        ("gamma", C.c_void_p), ("beta", C.c_void_p),
+        ("res", C.c_void_p), ("ldr", C.c_int64),
+        ("out", C.c_void_p), ("ldo", C.c_int64), ("out_f32", C.c_int32), ("out_pad_w", C.c_int32),
+        ("B", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("groups", C.c_int32),
+        ("eps", C.c_float),
+        ("silu", C.c_int32),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+    ]
+
+
 class AttnDesc(C.Structure):
     _fields_ = [
         ("q", C.c_void_p), ("ldq", C.c_int64), ("bsq", C.c_int64),
@@ -106,6 +120,19 @@ SIGNATURES = {
                                C.c_int32, C.c_int32, C.c_void_p]),
     "sg_pad_cast_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_void_p]),
+    "sg_layernorm_bwd_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
+                                       C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int64, C.c_int32,
+                                       C.c_int32, C.c_float, C.c_void_p]),
+    "sg_geglu_bwd_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32,
+                                   C.c_void_p]),
+    "sg_groupnorm_bwd_nhwc_f16": (C.c_int, [C.POINTER(GroupNormBwdDesc), C.c_void_p]),
+    "sg_groupnorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
+    "sg_transpose_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "sg_sum2x2_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                C.c_int32, C.c_void_p]),
+    "sg_zero_stuff_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                    C.c_int32, C.c_void_p]),
+    "sg_mse_grad_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "sg_debug_mfma_32x32x16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sg_debug_set_tile": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
 }

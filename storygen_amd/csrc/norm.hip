@@ -327,6 +327,200 @@ __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p)
     }
 }
 
+// ---- GroupNorm(+SiLU) backward (training step, BASELINE config 4; formulas: oracle/storygen_backward.py) ----------------
+// NOT YET RUN ON HARDWARE (tests/test_backward_gpu.py, skipped unless SG_TEST_UNVALIDATED=1).
+// y = act(xhat * gamma + beta), act = SiLU or identity.  With g = dact * gamma (dact = dy * act'(n), n = xhat*gamma+beta):
+//   dx = rstd * (g - mean_group(g) - xhat * mean_group(g * xhat)).
+// Three launches with the wide geometry: gn_stats_wide_kernel (statistics of x, exactly as in the forward pass), then
+// pass A below (per-chunk sums of g and g*xhat) and pass B (dx, optionally + a residual gradient, written as the fp32
+// stream or as the zero-bordered fp16 input of the next dgrad convolution).
+struct GnBwdParams {
+    GnParams f;                 // x, gamma, beta, geometry, eps, silu, ws (partials of x) as in the forward pass
+    const void* dy; long lddy; int dy_f32;
+    float* ws2;                 // [B][nchunks][G][2] partial sums of (g, g * xhat)
+    const float* res; long ldr; // optional residual gradient added to dx (fp32 output only)
+    float* out32; long ldo32;   // fp32 output [B, HW, C] ...
+    f16* out16; long ldo16; int pad_w;   // ... or fp16 output (pad_w > 0: interior of [B, H+2, pad_w+2, C])
+};
+
+// mean / rstd of every group of batch b from the forward statistics partials (same code as gn_apply_wide_kernel's prologue)
+__device__ __forceinline__ void gnw_group_stats(const GnParams& p, int b, long xb, float* s_mean, float* s_rstd, float* s_ps, float* s_pq) {
+    const int t = threadIdx.x;
+    const int parts = GNW_NT / p.G;
+    const int grp = t % p.G, part = t / p.G;
+    float s = 0.f, q = 0.f;
+    if (part < parts)
+        for (int c = part; c < p.nchunks; c += parts) {
+            const float* w = p.ws + (((long)b * p.nchunks + c) * p.G + grp) * 2;
+            s += w[0]; q += w[1];
+        }
+    s_ps[t] = s; s_pq[t] = q;
+    __syncthreads();
+    if (t < p.G) {
+        s = 0.f; q = 0.f;
+        for (int k = 0; k < parts; ++k) { s += s_ps[k * p.G + t]; q += s_pq[k * p.G + t]; }
+        const float n = (float)p.HW * (float)p.cpg;
+        const float piv = load1f(p.x, xb + t * p.cpg, p.x_f32);
+        const float md = s / n;
+        const float var = fmaxf(q / n - md * md, 0.f);
+        s_mean[t] = piv + md;
+        s_rstd[t] = rsqrtf(var + p.eps);
+    }
+    __syncthreads();
+}
+
+// g[j] and xhat[j] of one 8-channel vector of one pixel
+__device__ __forceinline__ void gnb_g_xhat(const float (&x)[8], const float (&dy)[8], const float (&mu)[8], const float (&rs)[8],
+                                           const float (&gm)[8], const float (&bt)[8], bool silu, float (&g)[8], float (&xh)[8]) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        xh[j] = (x[j] - mu[j]) * rs[j];
+        float d = dy[j];
+        if (silu) {
+            const float n = xh[j] * gm[j] + bt[j];
+            const float sg = 1.0f / (1.0f + __expf(-n));
+            d *= sg * (1.0f + n * (1.0f - sg));
+        }
+        g[j] = d * gm[j];
+    }
+}
+
+__global__ __launch_bounds__(GNW_NT) void gn_bwd_sums_kernel(const GnBwdParams q) {
+    __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
+    __shared__ float s_ps[GNW_NT], s_pq[GNW_NT];
+    __shared__ float4 s_col[GNW_MAX_VPR];
+    const GnParams& p = q.f;
+    const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
+    const int vpr = p.C >> 3, rpp = GNW_NT / vpr;
+    const int my_row = t / vpr, cv = t - my_row * vpr;
+    const long xb = (long)b * p.HW * p.ldx, db = (long)b * p.HW * q.lddy;
+    gnw_group_stats(p, b, xb, s_mean, s_rstd, s_ps, s_pq);
+    const int p0 = chunk * p.rows_per_chunk, p1 = min(p.HW, p0 + p.rows_per_chunk);
+    const int c0 = cv * 8;
+    const int g_lo = c0 / p.cpg;
+    const int nlo = min(8, (g_lo + 1) * p.cpg - c0);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);      // (sum g, sum g*xhat) of the vector's low group, of its high group
+    if (my_row < rpp) {
+        float mu[8], rs[8], gm[8], bt[8];
+        H8 gv, bv; gv.u = ldg16(p.gamma + c0); bv.u = ldg16(p.beta + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int grp = (c0 + j) / p.cpg;
+            mu[j] = s_mean[grp]; rs[j] = s_rstd[grp]; gm[j] = (float)gv.h[j]; bt[j] = (float)bv.h[j];
+        }
+        float sg[8], sx[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) sg[j] = sx[j] = 0.f;
+        for (int px = p0 + my_row; px < p1; px += rpp) {
+            float x[8], dy[8], g[8], xh[8];
+            load8f(p.x, xb + (long)px * p.ldx + c0, p.x_f32, x);
+            load8f(q.dy, db + (long)px * q.lddy + c0, q.dy_f32, dy);
+            gnb_g_xhat(x, dy, mu, rs, gm, bt, p.silu != 0, g, xh);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { sg[j] += g[j]; sx[j] += g[j] * xh[j]; }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            if (j < nlo) { acc.x += sg[j]; acc.y += sx[j]; }
+            else { acc.z += sg[j]; acc.w += sx[j]; }
+        }
+    }
+    // fixed-order reduction over the thread rows, then vector columns -> groups (as in gn_stats_wide_kernel)
+    __shared__ float4 s_part[GNW_NT];
+    s_part[t] = acc;
+    __syncthreads();
+    if (t < vpr) {
+        float4 a = s_part[t];
+        for (int r = 1; r < rpp; ++r) {
+            const float4 o = s_part[r * vpr + t];
+            a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w;
+        }
+        s_col[t] = a;
+    }
+    __syncthreads();
+    if (t < p.G) {
+        const int cv_a = (t * p.cpg) >> 3, cv_b = ((t + 1) * p.cpg - 1) >> 3;
+        float gs = 0.f, gq = 0.f;
+        for (int c = cv_a; c <= cv_b; ++c) {
+            const float4 a = s_col[c];
+            const int lo = (c * 8) / p.cpg, hi = (c * 8 + 7) / p.cpg;
+            if (lo == t) { gs += a.x; gq += a.y; }
+            if (hi == t && hi != lo) { gs += a.z; gq += a.w; }
+        }
+        float* w = q.ws2 + (((long)b * p.nchunks + chunk) * p.G + t) * 2;
+        w[0] = gs; w[1] = gq;
+    }
+}
+
+__global__ __launch_bounds__(GNW_NT) void gn_bwd_apply_kernel(const GnBwdParams q) {
+    __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS], s_m1[GN_MAX_GROUPS], s_m2[GN_MAX_GROUPS];
+    __shared__ float s_ps[GNW_NT], s_pq[GNW_NT];
+    const GnParams& p = q.f;
+    const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
+    const int vpr = p.C >> 3, rpp = GNW_NT / vpr;
+    const int my_row = t / vpr, cv = t - my_row * vpr;
+    const long xb = (long)b * p.HW * p.ldx, db = (long)b * p.HW * q.lddy;
+    gnw_group_stats(p, b, xb, s_mean, s_rstd, s_ps, s_pq);
+    {   // group means of g and g * xhat from pass A's partials (same fixed-order scheme)
+        const int parts = GNW_NT / p.G;
+        const int grp = t % p.G, part = t / p.G;
+        float s = 0.f, u = 0.f;
+        if (part < parts)
+            for (int c = part; c < p.nchunks; c += parts) {
+                const float* w = q.ws2 + (((long)b * p.nchunks + c) * p.G + grp) * 2;
+                s += w[0]; u += w[1];
+            }
+        s_ps[t] = s; s_pq[t] = u;
+        __syncthreads();
+        if (t < p.G) {
+            s = 0.f; u = 0.f;
+            for (int k = 0; k < parts; ++k) { s += s_ps[k * p.G + t]; u += s_pq[k * p.G + t]; }
+            const float n = (float)p.HW * (float)p.cpg;
+            s_m1[t] = s / n; s_m2[t] = u / n;
+        }
+        __syncthreads();
+    }
+    if (my_row >= rpp) return;
+    const int p0 = chunk * p.rows_per_chunk, p1 = min(p.HW, p0 + p.rows_per_chunk);
+    const int c0 = cv * 8;
+    float mu[8], rs[8], gm[8], bt[8], m1[8], m2[8];
+    {
+        H8 gv, bv; gv.u = ldg16(p.gamma + c0); bv.u = ldg16(p.beta + c0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int grp = (c0 + j) / p.cpg;
+            mu[j] = s_mean[grp]; rs[j] = s_rstd[grp]; m1[j] = s_m1[grp]; m2[j] = s_m2[grp];
+            gm[j] = (float)gv.h[j]; bt[j] = (float)bv.h[j];
+        }
+    }
+    const int pw = q.pad_w;
+    for (int px = p0 + my_row; px < p1; px += rpp) {
+        float x[8], dy[8], g[8], xh[8], o[8];
+        load8f(p.x, xb + (long)px * p.ldx + c0, p.x_f32, x);
+        load8f(q.dy, db + (long)px * q.lddy + c0, q.dy_f32, dy);
+        gnb_g_xhat(x, dy, mu, rs, gm, bt, p.silu != 0, g, xh);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = rs[j] * (g[j] - m1[j] - xh[j] * m2[j]);
+        if (q.out32) {
+            if (q.res) {
+                const float* r = q.res + ((long)b * p.HW + px) * q.ldr + c0;
+                const float4 a = *reinterpret_cast<const float4*>(r), c = *reinterpret_cast<const float4*>(r + 4);
+                o[0] += a.x; o[1] += a.y; o[2] += a.z; o[3] += a.w; o[4] += c.x; o[5] += c.y; o[6] += c.z; o[7] += c.w;
+            }
+            float* w = q.out32 + ((long)b * p.HW + px) * q.ldo32 + c0;
+            *reinterpret_cast<float4*>(w) = make_float4(o[0], o[1], o[2], o[3]);
+            *reinterpret_cast<float4*>(w + 4) = make_float4(o[4], o[5], o[6], o[7]);
+        } else {
+            long orow = (long)b * p.HW + px;
+            if (pw) {
+                const int yy = px / pw, xx = px - yy * pw;
+                orow = ((long)b * (p.HW / pw + 2) + yy + 1) * (pw + 2) + xx + 1;
+            }
+            store8h(q.out16 + orow * q.ldo16 + c0, o);
+        }
+    }
+}
+
 // Small feature maps (16x16 / 8x8 latent levels): one workgroup owns one (batch, group) slab, keeps it in registers,
 // computes exact two-pass statistics and writes the normalised output — one launch, one read of x.
 constexpr int GNF_MAXI = 24;   // 4-element items per thread: slabs of up to 256 * 24 * 4 = 24576 values
@@ -569,5 +763,55 @@ extern "C" int sg_layernorm_f16(const void* x, int64_t ldx, int32_t x_f32, int32
     else if (nv == 3) hipLaunchKernelGGL(layernorm_kernel<3>, grid, block, 0, st, p);
     else hipLaunchKernelGGL(layernorm_kernel<4>, grid, block, 0, st, p);
     SG_CHECK_LAUNCH("sg_layernorm_f16");
+    return SG_OK;
+}
+
+extern "C" size_t sg_groupnorm_bwd_workspace_bytes(int32_t B, int32_t groups) {
+    return 2 * sg_groupnorm_workspace_bytes(B, groups);     // statistics partials of x | partials of (g, g * xhat)
+}
+
+extern "C" int sg_groupnorm_bwd_nhwc_f16(const sg_groupnorm_bwd_desc* d, sg_stream_t stream) {
+    SG_REQUIRE(d != nullptr, "sg_groupnorm_bwd: null descriptor");
+    SG_REQUIRE(d->x && d->dy && d->gamma && d->beta && d->workspace && d->out, "sg_groupnorm_bwd: null pointer");
+    SG_REQUIRE(d->B > 0 && d->HW > 0 && d->C > 0 && d->groups > 0 && d->groups <= GN_MAX_GROUPS, "sg_groupnorm_bwd: bad shape");
+    SG_REQUIRE(d->C % 8 == 0 && d->C % d->groups == 0, "sg_groupnorm_bwd: C=%d must be a multiple of 8 and of groups", d->C);
+    const int cpg = d->C / d->groups;
+    if (cpg < 8 || d->C / 8 > GNW_MAX_VPR)
+        return sg_set_error(SG_EUNSUP, "sg_groupnorm_bwd: needs >= 8 channels per group and C <= %d (got C=%d, groups=%d)",
+                            GNW_MAX_VPR * 8, d->C, d->groups);
+    SG_REQUIRE(d->ldx % 8 == 0 && d->lddy % 8 == 0 && d->ldo % 8 == 0 && d->ldx >= d->C && d->lddy >= d->C && d->ldo >= d->C,
+               "sg_groupnorm_bwd: bad ld");
+    SG_REQUIRE(sg_aligned16(d->x) && sg_aligned16(d->dy) && sg_aligned16(d->out) && sg_aligned16(d->gamma) && sg_aligned16(d->beta),
+               "sg_groupnorm_bwd: 16-byte alignment");
+    SG_REQUIRE(!d->res || (d->out_f32 && sg_aligned16(d->res) && d->ldr % 8 == 0 && d->ldr >= d->C),
+               "sg_groupnorm_bwd: a residual gradient needs the fp32 output, 16-byte alignment and ldr >= C");
+    SG_REQUIRE(d->out_pad_w >= 0 && (d->out_pad_w == 0 || (!d->out_f32 && d->HW % d->out_pad_w == 0)),
+               "sg_groupnorm_bwd: out_pad_w needs the fp16 output and must divide HW");
+    SG_REQUIRE(d->workspace_bytes >= sg_groupnorm_bwd_workspace_bytes(d->B, d->groups), "sg_groupnorm_bwd: workspace too small");
+    GnBwdParams q{};
+    GnParams& p = q.f;
+    p.x = d->x; p.ldx = d->ldx; p.x_f32 = d->x_f32 ? 1 : 0;
+    p.gamma = reinterpret_cast<const f16*>(d->gamma); p.beta = reinterpret_cast<const f16*>(d->beta);
+    p.HW = d->HW; p.C = d->C; p.G = d->groups; p.cpg = cpg; p.eps = d->eps; p.silu = d->silu;
+    p.ws = reinterpret_cast<float*>(d->workspace);
+    q.ws2 = p.ws + (size_t)d->B * GN_MAX_CHUNKS * d->groups * 2;
+    q.dy = d->dy; q.lddy = d->lddy; q.dy_f32 = d->dy_f32 ? 1 : 0;
+    q.res = d->res; q.ldr = d->ldr;
+    if (d->out_f32) { q.out32 = reinterpret_cast<float*>(d->out); q.ldo32 = d->ldo; }
+    else { q.out16 = reinterpret_cast<f16*>(d->out); q.ldo16 = d->ldo; q.pad_w = d->out_pad_w; }
+    const int rpp = GNW_NT / (p.C / 8);
+    int want = sg_cdiv(320, d->B);
+    if (want > GN_MAX_CHUNKS) want = GN_MAX_CHUNKS;
+    p.rows_per_chunk = sg_cdiv(p.HW, want);
+    if (p.rows_per_chunk < rpp) p.rows_per_chunk = rpp;
+    p.nchunks = sg_cdiv(p.HW, p.rows_per_chunk);
+    const dim3 grid(p.nchunks, d->B), block(GNW_NT);
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gn_stats_wide_kernel, grid, block, 0, st, p);
+    SG_CHECK_LAUNCH("gn_bwd: stats");
+    hipLaunchKernelGGL(gn_bwd_sums_kernel, grid, block, 0, st, q);
+    SG_CHECK_LAUNCH("gn_bwd: sums");
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, block, 0, st, q);
+    SG_CHECK_LAUNCH("gn_bwd: apply");
     return SG_OK;
 }

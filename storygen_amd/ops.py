@@ -403,6 +403,127 @@ def pad_cast(x: torch.Tensor, out_padded: torch.Tensor) -> torch.Tensor:
     return out_padded
 
 
+# ------------------------------------------------------------------------------------------------ backward pass (config 4)
+# NOT YET RUN ON HARDWARE — see csrc/backward.hip.  Formulas: oracle/storygen_backward.py.
+def layernorm_bwd(x: torch.Tensor, dy1: torch.Tensor, g1: torch.Tensor, out: torch.Tensor, eps: float = 1e-5,
+                  dy2: Optional[torch.Tensor] = None, g2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
+                  res_scale: float = 1.0) -> torch.Tensor:
+    """out[M,C] (fp32) = res_scale * res + dLayerNorm(x; dy1 * g1 (+ dy2 * g2)).  x, dy fp16 or fp32 (both dy alike)."""
+    x_f32, dy_f32 = _act(x, "x"), _act(dy1, "dy1")
+    _f32(out, "out"), _f16(g1, "g1")
+    if dy2 is not None and _act(dy2, "dy2") != dy_f32:
+        raise TypeError("layernorm_bwd: dy1 and dy2 must have the same dtype")
+    if res is not None:
+        _f32(res, "res")
+    M, Cc = x.shape
+    check(lib.sg_layernorm_bwd_f16(x.data_ptr(), _row_stride(x, "x"), int(x_f32), dy1.data_ptr(), _row_stride(dy1, "dy1"),
+                                   g1.data_ptr(), _p(dy2), 0 if dy2 is None else _row_stride(dy2, "dy2"), _p(g2), int(dy_f32),
+                                   _p(res), 0 if res is None else _row_stride(res, "res"), float(res_scale), out.data_ptr(),
+                                   _row_stride(out, "out"), M, Cc, eps, _stream()), "sg_layernorm_bwd_f16")
+    return out
+
+
+def geglu_bwd(proj_il: torch.Tensor, du: torch.Tensor, dproj_il: torch.Tensor) -> torch.Tensor:
+    """proj_il / dproj_il [M, N8] fp16 in the interleaved GEGLU column layout (repack.py), du [M, N8/2] fp16."""
+    _f16(proj_il, "proj"), _f16(du, "du"), _f16(dproj_il, "dproj")
+    M, N8 = proj_il.shape
+    if tuple(du.shape) != (M, N8 // 2) or tuple(dproj_il.shape) != (M, N8):
+        raise ValueError("geglu_bwd: shape mismatch")
+    check(lib.sg_geglu_bwd_f16(proj_il.data_ptr(), _row_stride(proj_il, "proj"), du.data_ptr(), _row_stride(du, "du"),
+                               dproj_il.data_ptr(), _row_stride(dproj_il, "dproj"), M, N8, _stream()), "sg_geglu_bwd_f16")
+    return dproj_il
+
+
+def groupnorm_bwd_workspace_bytes(B: int, groups: int) -> int:
+    return lib.sg_groupnorm_bwd_workspace_bytes(B, groups)
+
+
+def groupnorm_bwd(x: torch.Tensor, dy: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, groups: int,
+                  eps: float, silu: bool, workspace: torch.Tensor, res: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x, dy [B, HW, C] (fp16 / fp32, row-strided views allowed).  out: fp32 [B, HW, C] (optionally + res, fp32 [B, HW, C]),
+    fp16 [B, HW, C], or the zero-bordered fp16 image [B, H+2, W+2, C] (interior written)."""
+    from ._lib import GroupNormBwdDesc
+    x_f32, dy_f32 = _act(x, "x"), _act(dy, "dy")
+    out_f32 = _act(out, "out")
+    _f16(gamma, "gamma"), _f16(beta, "beta")
+    B, HW, Cc = x.shape
+    if tuple(dy.shape) != (B, HW, Cc) or x.stride(0) != HW * x.stride(1) or dy.stride(0) != HW * dy.stride(1):
+        raise ValueError("groupnorm_bwd: x / dy must be [B, HW, C] with a single row stride")
+    d = GroupNormBwdDesc()
+    d.x, d.ldx, d.x_f32 = x.data_ptr(), x.stride(1), int(x_f32)
+    d.dy, d.lddy, d.dy_f32 = dy.data_ptr(), dy.stride(1), int(dy_f32)
+    d.gamma, d.beta = gamma.data_ptr(), beta.data_ptr()
+    if res is not None:
+        _f32(res, "res")
+        if tuple(res.shape) != (B, HW, Cc) or res.stride(0) != HW * res.stride(1):
+            raise ValueError("groupnorm_bwd: res must be [B, HW, C] with a single row stride")
+        d.res, d.ldr = res.data_ptr(), res.stride(1)
+    if out.dim() == 4:
+        Hp, Wp = out.shape[1], out.shape[2]
+        if out_f32 or (Hp - 2) * (Wp - 2) != HW or not out.is_contiguous():
+            raise ValueError("groupnorm_bwd: a padded output must be a contiguous fp16 [B, H+2, W+2, C] image")
+        d.out, d.ldo, d.out_f32, d.out_pad_w = out.data_ptr(), out.stride(2), 0, Wp - 2
+    else:
+        if tuple(out.shape) != (B, HW, Cc) or out.stride(0) != HW * out.stride(1):
+            raise ValueError("groupnorm_bwd: out must be [B, HW, C] with a single row stride")
+        d.out, d.ldo, d.out_f32, d.out_pad_w = out.data_ptr(), out.stride(1), int(out_f32), 0
+    d.B, d.HW, d.C, d.groups, d.eps, d.silu = B, HW, Cc, groups, eps, int(silu)
+    d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    check(lib.sg_groupnorm_bwd_nhwc_f16(C.byref(d), _stream()), "sg_groupnorm_bwd_nhwc_f16")
+    return out
+
+
+def transpose(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst [C, M] fp16 = src [M, C]^T (src fp16 or fp32)."""
+    s32 = _act(src, "src")
+    _f16(dst, "dst")
+    M, Cc = src.shape
+    if tuple(dst.shape) != (Cc, M):
+        raise ValueError("transpose: dst must be [C, M]")
+    check(lib.sg_transpose_f16(src.data_ptr(), _row_stride(src, "src"), int(s32), dst.data_ptr(), _row_stride(dst, "dst"), M, Cc,
+                               _stream()), "sg_transpose_f16")
+    return dst
+
+
+def sum2x2(du: torch.Tensor, dx: torch.Tensor, accumulate: bool = False) -> torch.Tensor:
+    """du [B, 2H, 2W, C] fp32 -> dx [B, H, W, C] fp32 (single pixel stride each)."""
+    _f32(du, "du"), _f32(dx, "dx")
+    B, H, W, Cc = dx.shape
+    if tuple(du.shape) != (B, 2 * H, 2 * W, Cc) or du.stride(-1) != 1 or dx.stride(-1) != 1:
+        raise ValueError("sum2x2: shape mismatch")
+    for t, hh, ww in ((du, 2 * H, 2 * W), (dx, H, W)):
+        if t.stride(1) != ww * t.stride(2) or t.stride(0) != hh * t.stride(1):
+            raise ValueError("sum2x2: tensors must have a single pixel stride")
+    check(lib.sg_sum2x2_f32(du.data_ptr(), du.stride(2), dx.data_ptr(), dx.stride(2), B, H, W, Cc, int(accumulate), _stream()),
+          "sg_sum2x2_f32")
+    return dx
+
+
+def zero_stuff(dy: torch.Tensor, out_padded: torch.Tensor) -> torch.Tensor:
+    """dy [B, Ho, Wo, C] (fp16 / fp32, single pixel stride) -> interior of the zero-bordered fp16 [B, 2Ho+2, 2Wo+2, C]."""
+    d32 = _act(dy, "dy")
+    _f16(out_padded, "out")
+    B, Ho, Wo, Cc = dy.shape
+    if tuple(out_padded.shape) != (B, 2 * Ho + 2, 2 * Wo + 2, Cc) or not out_padded.is_contiguous():
+        raise ValueError("zero_stuff: out must be a contiguous [B, 2Ho+2, 2Wo+2, C]")
+    if dy.stride(-1) != 1 or dy.stride(1) != Wo * dy.stride(2) or dy.stride(0) != Ho * dy.stride(1):
+        raise ValueError("zero_stuff: dy must be [B, Ho, Wo, C] with a single pixel stride")
+    check(lib.sg_zero_stuff_f16(dy.data_ptr(), dy.stride(2), int(d32), out_padded.data_ptr(), Cc, B, Ho, Wo, Cc, _stream()),
+          "sg_zero_stuff_f16")
+    return out_padded
+
+
+def mse_grad(pred: torch.Tensor, noise: torch.Tensor, mask: torch.Tensor, d_pred: torch.Tensor, loss: torch.Tensor) -> torch.Tensor:
+    """loss[0] = mean(((pred - noise) * (1 - mask))^2), d_pred = its gradient; all fp32, contiguous, same shape."""
+    for n, t in (("pred", pred), ("noise", noise), ("mask", mask), ("d_pred", d_pred), ("loss", loss)):
+        _f32(t, n)
+        if not t.is_contiguous():
+            raise ValueError(f"mse_grad: {n} must be contiguous")
+    check(lib.sg_mse_grad_f32(pred.data_ptr(), noise.data_ptr(), mask.data_ptr(), d_pred.data_ptr(), loss.data_ptr(),
+                              pred.numel(), _stream()), "sg_mse_grad_f32")
+    return d_pred
+
+
 def debug_set_tile(bm: int = 0, bn: int = 0, no_pipe: bool = False) -> None:
     """Test hook: force the GEMM/conv tile shape / kernel family (0, 0 = automatic)."""
     check(lib.sg_debug_set_tile(bm, bn, int(no_pipe)), "sg_debug_set_tile")
