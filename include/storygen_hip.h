@@ -290,6 +290,39 @@ typedef struct {
 int sg_groupnorm_bwd_nhwc_f16(const sg_groupnorm_bwd_desc* d, sg_stream_t stream);
 size_t sg_groupnorm_bwd_workspace_bytes(int32_t B, int32_t groups);
 
+/* Attention forward that also stores lse2[b, h, q] (fp32, [B, H, Nq]): the log2-domain log-sum-exp row,
+ * max + log2(sum), from which the backward recomputes P = exp2(scale * log2(e) * S - lse2).  Same descriptor, same O. */
+int sg_attn_fwd_lse_f16(const sg_attn_desc* d, float* lse2, sg_stream_t stream);
+
+/* Attention backward (oracle/storygen_backward.py::attention_core_bwd):
+ *   dV = P^T dO,  dP = dO V^T,  dS = P * (dP - delta),  dQ = scale * dS K,  dK = scale * dS^T Q,  delta = rowsum(dO * O).
+ * sg_attn_bwd_prep_f32 packs ld2[b,h,q] = (lse2, delta); sg_attn_bwd_dq_f16 writes dQ token-major [B, Nq, H*D];
+ * sg_attn_bwd_dkv_f16 writes dK and dV TRANSPOSED ([B][H*D][Nk], keys contiguous) — the layout the weight-gradient
+ * GEMMs want as their A operand.  Inputs: q, k, v, dout token-major ([B, N, H*D], token stride ld*, batch stride bs*);
+ * kt (dq) and qt, dot (dkv) are the transposed copies ([B][H*D][N], row stride ld*t) the host gets from projection GEMMs
+ * with swapped operands.  No K/V batch sharing (training has no CFG).  Nq, Nk multiples of 8; D in {40, 80, 160}.
+ * Text cross-attention (frozen K/V inputs and weights) needs only the dq call. */
+typedef struct {
+    const sg_half* q;    int64_t ldq, bsq;
+    const sg_half* qt;   int64_t ldqt, bsqt;     /* dkv only */
+    const sg_half* k;    int64_t ldk, bsk;
+    const sg_half* kt;   int64_t ldkt, bskt;     /* dq only */
+    const sg_half* v;    int64_t ldv, bsv;       /* token-major (not the forward's V^T) */
+    const sg_half* dout; int64_t lddo, bsdo;
+    const sg_half* dot;  int64_t lddot, bsdot;   /* dkv only */
+    const float*   ld2;                          /* [B, H, Nq][2] from sg_attn_bwd_prep_f32 */
+    sg_half* dq;  int64_t lddq, bsdq;            /* dq output */
+    sg_half* dkt; int64_t lddkt, bsdkt;          /* dkv outputs */
+    sg_half* dvt; int64_t lddvt, bsdvt;
+    int32_t B, H, Nq, Nk, D;
+    float   scale;
+} sg_attn_bwd_desc;
+
+int sg_attn_bwd_prep_f32(const sg_half* o, int64_t ldo, int64_t bso, const sg_half* dout, int64_t lddo, int64_t bsdo,
+                         const float* lse2, float* ld2, int32_t B, int32_t H, int32_t Nq, int32_t D, sg_stream_t stream);
+int sg_attn_bwd_dq_f16(const sg_attn_bwd_desc* d, sg_stream_t stream);
+int sg_attn_bwd_dkv_f16(const sg_attn_bwd_desc* d, sg_stream_t stream);
+
 /* dst[c][m] = src[m][c], fp16 out, fp16 / fp32 in (M, C multiples of 8). */
 int sg_transpose_f16(const void* src, int64_t lds, int32_t src_f32, sg_half* dst, int64_t ldd, int32_t M, int32_t C,
                      sg_stream_t stream);

@@ -92,6 +92,24 @@ class AttnDesc(C.Structure):
     ]
 
 
+class AttnBwdDesc(C.Structure):
+    _fields_ = [
+        ("q", C.c_void_p), ("ldq", C.c_int64), ("bsq", C.c_int64),
+        ("qt", C.c_void_p), ("ldqt", C.c_int64), ("bsqt", C.c_int64),
+        ("k", C.c_void_p), ("ldk", C.c_int64), ("bsk", C.c_int64),
+        ("kt", C.c_void_p), ("ldkt", C.c_int64), ("bskt", C.c_int64),
+        ("v", C.c_void_p), ("ldv", C.c_int64), ("bsv", C.c_int64),
+        ("dout", C.c_void_p), ("lddo", C.c_int64), ("bsdo", C.c_int64),
+        ("dot", C.c_void_p), ("lddot", C.c_int64), ("bsdot", C.c_int64),
+        ("ld2", C.c_void_p),
+        ("dq", C.c_void_p), ("lddq", C.c_int64), ("bsdq", C.c_int64),
+        ("dkt", C.c_void_p), ("lddkt", C.c_int64), ("bsdkt", C.c_int64),
+        ("dvt", C.c_void_p), ("lddvt", C.c_int64), ("bsdvt", C.c_int64),
+        ("B", C.c_int32), ("H", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("D", C.c_int32),
+        ("scale", C.c_float),
+    ]
+
+
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header.
 SIGNATURES = {
     "sg_version": (C.c_int, []),
@@ -120,6 +138,11 @@ SIGNATURES = {
                                C.c_int32, C.c_int32, C.c_void_p]),
     "sg_pad_cast_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_void_p]),
+    "sg_attn_fwd_lse_f16": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p, C.c_void_p]),
+    "sg_attn_bwd_prep_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
+                                       C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sg_attn_bwd_dq_f16": (C.c_int, [C.POINTER(AttnBwdDesc), C.c_void_p]),
+    "sg_attn_bwd_dkv_f16": (C.c_int, [C.POINTER(AttnBwdDesc), C.c_void_p]),
     "sg_layernorm_bwd_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64,
                                        C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_float, C.c_void_p, C.c_int64, C.c_int32,
                                        C.c_int32, C.c_float, C.c_void_p]),

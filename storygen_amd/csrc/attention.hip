@@ -35,7 +35,7 @@
 using namespace sgattn;
 
 
-extern "C" int sg_attn_fwd_f16(const sg_attn_desc* d, sg_stream_t stream) {
+static int attn_fwd(const sg_attn_desc* d, float* lse2, sg_stream_t stream) {
     SG_REQUIRE(d != nullptr, "sg_attn_fwd_f16: null descriptor");
     SG_REQUIRE(d->q && d->k && d->vt && d->o, "sg_attn_fwd_f16: null q/k/vt/o");
     SG_REQUIRE(d->B > 0 && d->H > 0 && d->Nq > 0 && d->Nk > 0, "sg_attn_fwd_f16: bad shape");
@@ -58,6 +58,14 @@ extern "C" int sg_attn_fwd_f16(const sg_attn_desc* d, sg_stream_t stream) {
     p.kv_batches = d->kv_batches > 0 ? d->kv_batches : d->B;
     p.scale_log2 = d->scale * 1.44269504088896340736f;
     hipStream_t st = (hipStream_t)stream;
+    if (lse2) {   // training forward (sg_attn_fwd_lse_f16): the default instantiations with the log-sum-exp rows stored
+        p.lse2 = lse2;
+        if (d->D == 40) launch_attn<40, 4, 3, 1, false, true>(p, st);
+        else if (d->D == 80) launch_attn<80, 4, 3, 1, false, true>(p, st);
+        else launch_attn<160, 4, 3, 1, false, true>(p, st);
+        SG_CHECK_LAUNCH("sg_attn_fwd_lse_f16");
+        return SG_OK;
+    }
     // 4-wave workgroups with a 3-deep ring when that still gives the chip >= 2 workgroups per CU, else 2 waves / 2 stages
     const long wgs4 = (long)sg_cdiv(d->Nq, 128) * d->H * d->B;
     const bool big = wgs4 >= 512;
@@ -90,4 +98,11 @@ extern "C" int sg_attn_fwd_f16(const sg_attn_desc* d, sg_stream_t stream) {
     }
     SG_CHECK_LAUNCH("sg_attn_fwd_f16");
     return SG_OK;
+}
+
+extern "C" int sg_attn_fwd_f16(const sg_attn_desc* d, sg_stream_t stream) { return attn_fwd(d, nullptr, stream); }
+
+extern "C" int sg_attn_fwd_lse_f16(const sg_attn_desc* d, float* lse2, sg_stream_t stream) {
+    SG_REQUIRE(lse2 != nullptr, "sg_attn_fwd_lse_f16: null lse2");
+    return attn_fwd(d, lse2, stream);
 }

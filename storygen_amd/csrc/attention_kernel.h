@@ -16,6 +16,7 @@ struct AttnParams {
     f16* o; long ldo, bso;
     int B, H, Nq, Nk, kv_batches, nqb;
     float scale_log2;   // scale * log2(e)
+    float* lse2;        // LSE instantiations only: [B, H, Nq] log2-domain log-sum-exp rows (max + log2(sum)) for the backward
 };
 
 __device__ __forceinline__ void glds16(const f16* g, char* lds_wave_base) {
@@ -32,7 +33,7 @@ __device__ __forceinline__ int kswz(int row) {
     return D == 40 ? 0 : (D == 80 ? ((row >> 3) & 1) : ((row >> 2) & 3));
 }
 
-template <int D, int NW, int S, int SUB = 1, bool PRIO = false>
+template <int D, int NW, int S, int SUB = 1, bool PRIO = false, bool LSE = false>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     constexpr int DC = D / 8;                   // 16-byte chunks per K row
     constexpr int NDK = (D + 15) / 16;          // MFMA k-steps of S^T (contraction padded to 16)
@@ -297,6 +298,9 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int qi = q0 + l31;
+    if constexpr (LSE) {    // training forward: P = exp2(s * scale_log2 - lse2) is what the backward kernels recompute
+        if (hi == 0 && qi < p.Nq) p.lse2[((long)b * p.H + h) * p.Nq + qi] = m_run + __log2f(l_tot);
+    }
     if (qi < p.Nq) {
         f16* O = p.o + (long)b * p.bso + (long)qi * p.ldo + (long)h * D;
 #pragma unroll
@@ -313,11 +317,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     }
 }
 
-template <int D, int NW, int S, int SUB = 1, bool PRIO = false>
+template <int D, int NW, int S, int SUB = 1, bool PRIO = false, bool LSE = false>
 void launch_attn(const AttnParams& p0, hipStream_t st) {
     AttnParams p = p0;
     p.nqb = sg_cdiv(p.Nq, 32 * NW);
-    hipLaunchKernelGGL((attn_fwd_kernel<D, NW, S, SUB, PRIO>), dim3(p.nqb * p.H * p.B), dim3(64 * NW), 0, st, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<D, NW, S, SUB, PRIO, LSE>), dim3(p.nqb * p.H * p.B), dim3(64 * NW), 0, st, p);
 }
 
 

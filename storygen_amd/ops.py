@@ -524,6 +524,89 @@ def mse_grad(pred: torch.Tensor, noise: torch.Tensor, mask: torch.Tensor, d_pred
     return d_pred
 
 
+def _attn_desc(q, k, vt, out, heads, scale, nk):
+    for n, t in (("q", q), ("k", k), ("vt", vt), ("out", out)):
+        _f16(t, n)
+        if t.dim() != 3 or t.stride(2) != 1:
+            raise ValueError(f"attention: {n} must be 3-D with a contiguous last dimension")
+    B, Nq, Cq = q.shape
+    Bk = k.shape[0]
+    Nk = k.shape[1] if nk is None else nk
+    D = Cq // heads
+    d = AttnDesc()
+    d.q, d.ldq, d.bsq = q.data_ptr(), q.stride(1), q.stride(0)
+    d.k, d.ldk, d.bsk = k.data_ptr(), k.stride(1), k.stride(0)
+    d.vt, d.ldvt, d.bsvt = vt.data_ptr(), vt.stride(1), vt.stride(0)
+    d.o, d.ldo, d.bso = out.data_ptr(), out.stride(1), out.stride(0)
+    d.B, d.H, d.Nq, d.Nk, d.D, d.kv_batches, d.scale = B, heads, Nq, Nk, D, (0 if Bk == B else Bk), scale
+    return d
+
+
+def attention_lse(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, lse2: torch.Tensor, heads: int,
+                  scale: float, nk: Optional[int] = None) -> torch.Tensor:
+    """Training forward: `attention` that also stores lse2 [B, H, Nq] fp32 (log2-domain log-sum-exp rows)."""
+    _f32(lse2, "lse2")
+    if tuple(lse2.shape) != (q.shape[0], heads, q.shape[1]) or not lse2.is_contiguous():
+        raise ValueError("attention_lse: lse2 must be a contiguous [B, H, Nq]")
+    d = _attn_desc(q, k, vt, out, heads, scale, nk)
+    check(lib.sg_attn_fwd_lse_f16(C.byref(d), lse2.data_ptr(), _stream()), "sg_attn_fwd_lse_f16")
+    return out
+
+
+def attention_bwd_prep(o: torch.Tensor, dout: torch.Tensor, lse2: torch.Tensor, ld2: torch.Tensor, heads: int) -> torch.Tensor:
+    """ld2 [B, H, Nq, 2] fp32 = (lse2, delta = rowsum_d(dO * O)) per (batch, head, query); o, dout [B, Nq, H*D] fp16."""
+    _f16(o, "o"), _f16(dout, "dout"), _f32(lse2, "lse2"), _f32(ld2, "ld2")
+    B, Nq, Cq = o.shape
+    if tuple(ld2.shape) != (B, heads, Nq, 2) or not ld2.is_contiguous() or not lse2.is_contiguous():
+        raise ValueError("attention_bwd_prep: ld2 must be a contiguous [B, H, Nq, 2], lse2 a contiguous [B, H, Nq]")
+    check(lib.sg_attn_bwd_prep_f32(o.data_ptr(), o.stride(1), o.stride(0), dout.data_ptr(), dout.stride(1), dout.stride(0),
+                                   lse2.data_ptr(), ld2.data_ptr(), B, heads, Nq, Cq // heads, _stream()), "sg_attn_bwd_prep_f32")
+    return ld2
+
+
+def _attn_bwd_desc(q, k, v, dout, ld2, heads, scale):
+    from ._lib import AttnBwdDesc
+    for n, t in (("q", q), ("k", k), ("v", v), ("dout", dout)):
+        _f16(t, n)
+        if t.dim() != 3 or t.stride(2) != 1:
+            raise ValueError(f"attention_bwd: {n} must be [B, N, H*D] with a contiguous last dimension")
+    _f32(ld2, "ld2")
+    B, Nq, Cq = q.shape
+    d = AttnBwdDesc()
+    d.q, d.ldq, d.bsq = q.data_ptr(), q.stride(1), q.stride(0)
+    d.k, d.ldk, d.bsk = k.data_ptr(), k.stride(1), k.stride(0)
+    d.v, d.ldv, d.bsv = v.data_ptr(), v.stride(1), v.stride(0)
+    d.dout, d.lddo, d.bsdo = dout.data_ptr(), dout.stride(1), dout.stride(0)
+    d.ld2 = ld2.data_ptr()
+    d.B, d.H, d.Nq, d.Nk, d.D, d.scale = B, heads, Nq, k.shape[1], Cq // heads, scale
+    return d
+
+
+def attention_bwd_dq(q: torch.Tensor, k: torch.Tensor, kt: torch.Tensor, v: torch.Tensor, dout: torch.Tensor, ld2: torch.Tensor,
+                     dq: torch.Tensor, heads: int, scale: float) -> torch.Tensor:
+    """dq [B, Nq, H*D] = scale * dS K.  kt [B, H*D, Nk] = K transposed (keys contiguous)."""
+    d = _attn_bwd_desc(q, k, v, dout, ld2, heads, scale)
+    _f16(kt, "kt"), _f16(dq, "dq")
+    d.kt, d.ldkt, d.bskt = kt.data_ptr(), kt.stride(1), kt.stride(0)
+    d.dq, d.lddq, d.bsdq = dq.data_ptr(), dq.stride(1), dq.stride(0)
+    check(lib.sg_attn_bwd_dq_f16(C.byref(d), _stream()), "sg_attn_bwd_dq_f16")
+    return dq
+
+
+def attention_bwd_dkv(q: torch.Tensor, qt: torch.Tensor, k: torch.Tensor, v: torch.Tensor, dout: torch.Tensor, dot: torch.Tensor,
+                      ld2: torch.Tensor, dkt: torch.Tensor, dvt: torch.Tensor, heads: int, scale: float):
+    """dkt, dvt [B, H*D, Nk] (transposed: keys contiguous).  qt, dot [B, H*D, Nq] = Q, dO transposed."""
+    d = _attn_bwd_desc(q, k, v, dout, ld2, heads, scale)
+    for n, t in (("qt", qt), ("dot", dot), ("dkt", dkt), ("dvt", dvt)):
+        _f16(t, n)
+    d.qt, d.ldqt, d.bsqt = qt.data_ptr(), qt.stride(1), qt.stride(0)
+    d.dot, d.lddot, d.bsdot = dot.data_ptr(), dot.stride(1), dot.stride(0)
+    d.dkt, d.lddkt, d.bsdkt = dkt.data_ptr(), dkt.stride(1), dkt.stride(0)
+    d.dvt, d.lddvt, d.bsdvt = dvt.data_ptr(), dvt.stride(1), dvt.stride(0)
+    check(lib.sg_attn_bwd_dkv_f16(C.byref(d), _stream()), "sg_attn_bwd_dkv_f16")
+    return dkt, dvt
+
+
 def debug_set_tile(bm: int = 0, bn: int = 0, no_pipe: bool = False) -> None:
     """Test hook: force the GEMM/conv tile shape / kernel family (0, 0 = automatic)."""
     check(lib.sg_debug_set_tile(bm, bn, int(no_pipe)), "sg_debug_set_tile")

@@ -65,7 +65,8 @@ def test_descriptor_layouts_match_a_c_compiler(tmp_path):
     """sizeof / offsetof of every descriptor as gcc sees the header vs the ctypes Structures."""
     from storygen_amd import _lib
     structs = {"sg_gemm_desc": _lib.GemmDesc, "sg_conv3x3_desc": _lib.ConvDesc, "sg_attn_desc": _lib.AttnDesc,
-               "sg_groupnorm_desc": _lib.GroupNormDesc, "sg_groupnorm_bwd_desc": _lib.GroupNormBwdDesc}
+               "sg_groupnorm_desc": _lib.GroupNormDesc, "sg_groupnorm_bwd_desc": _lib.GroupNormBwdDesc,
+               "sg_attn_bwd_desc": _lib.AttnBwdDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

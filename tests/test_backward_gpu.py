@@ -148,3 +148,39 @@ def test_mse_grad(gpu):
     want = F.mse_loss(p * keep, noise * keep)
     assert abs(float(loss) - float(want)) < 1e-5 * float(want)
     assert rel(d, torch.autograd.grad(want, p)[0]) < 1e-5
+
+
+@pytest.mark.parametrize("B_,heads,D,Nq,Nk", [(2, 8, 40, 256, 320), (1, 8, 40, 1024, 776), (2, 8, 80, 256, 256), (1, 8, 160, 64, 192),
+                                             (4, 8, 40, 4096, 4096)])
+def test_attention_backward(gpu, B_, heads, D, Nq, Nk):
+    """lse2 from the training forward, (lse2, delta) pairs, dQ, and transposed dK / dV against the CPU formulas
+    (oracle/storygen_backward.py::attention_core_bwd, itself checked against autograd)."""
+    from oracle import storygen_backward as B
+    from storygen_amd import ops
+    C = heads * D
+    big = Nq * Nk > 4_000_000
+    q, k, v = rnd((B_, Nq, C), gpu, 1.0, 1), rnd((B_, Nk, C), gpu, 1.0, 2), rnd((B_, Nk, C), gpu, 1.0, 3)
+    do = rnd((B_, Nq, C), gpu, 1.0, 4)
+    vt = v.transpose(1, 2).contiguous()
+    o = torch.empty_like(q)
+    lse2 = torch.empty(B_, heads, Nq, dtype=torch.float32, device=gpu)
+    scale = D ** -0.5
+    ops.attention_lse(q, k, vt, o, lse2, heads, scale)
+    with torch.no_grad():
+        dev = gpu if big else "cpu"              # the large case checks against the same formulas evaluated on the device
+        qf, kf, vf, dof = (t.to(dev).float() for t in (q, k, v, do))
+        o_ref, lse_ref = B.attention_core(qf, kf, vf, heads)
+        dq_ref, dk_ref, dv_ref = B.attention_core_bwd(qf, kf, vf, o_ref, lse_ref, dof, heads)
+    assert rel(o.to(dev), o_ref) < 2e-3
+    assert float((lse2.to(dev) - lse_ref * 1.4426950408889634).abs().max()) < 2e-3
+    ld2 = torch.empty(B_, heads, Nq, 2, dtype=torch.float32, device=gpu)
+    ops.attention_bwd_prep(o, do, lse2, ld2, heads)
+    delta_ref = (dof * o_ref).reshape(B_, Nq, heads, D).sum(-1).transpose(1, 2)
+    assert torch.equal(ld2[..., 0], lse2) and rel(ld2[..., 1].to(dev), delta_ref) < 5e-3
+    dq = torch.empty_like(q)
+    ops.attention_bwd_dq(q, k, k.transpose(1, 2).contiguous(), v, do, ld2, dq, heads, scale)
+    assert rel(dq.to(dev), dq_ref) < 5e-3
+    dkt, dvt = (torch.empty(B_, C, Nk, dtype=torch.float16, device=gpu) for _ in range(2))
+    ops.attention_bwd_dkv(q, q.transpose(1, 2).contiguous(), k, v, do, do.transpose(1, 2).contiguous(), ld2, dkt, dvt, heads, scale)
+    assert rel(dkt.transpose(1, 2).to(dev), dk_ref) < 5e-3
+    assert rel(dvt.transpose(1, 2).to(dev), dv_ref) < 5e-3
