@@ -300,7 +300,8 @@ int sg_attn_fwd_lse_f16(const sg_attn_desc* d, float* lse2, sg_stream_t stream);
  * sg_attn_bwd_dkv_f16 writes dK and dV TRANSPOSED ([B][H*D][Nk], keys contiguous) — the layout the weight-gradient
  * GEMMs want as their A operand.  Inputs: q, k, v, dout token-major ([B, N, H*D], token stride ld*, batch stride bs*);
  * kt (dq) and qt, dot (dkv) are the transposed copies ([B][H*D][N], row stride ld*t) the host gets from projection GEMMs
- * with swapped operands.  No K/V batch sharing (training has no CFG).  Nq, Nk multiples of 8; D in {40, 80, 160}.
+ * with swapped operands.  No K/V batch sharing (training has no CFG).  D in {40, 80, 160}; dkv needs Nq % 8 == 0; dq
+ * accepts any Nk (text: 77) provided every kt row is finite up to Nk rounded up to 8 (ldkt >= that).
  * Text cross-attention (frozen K/V inputs and weights) needs only the dq call. */
 typedef struct {
     const sg_half* q;    int64_t ldq, bsq;

@@ -294,7 +294,10 @@ static int check_bwd_desc(const sg_attn_bwd_desc* d, bool dkv, const char* who) 
     SG_REQUIRE(d->q && d->k && d->v && d->dout && d->ld2, "%s: null q/k/v/dout/ld2", who);
     SG_REQUIRE(d->B > 0 && d->H > 0 && d->Nq > 0 && d->Nk > 0, "%s: bad shape", who);
     if (d->D != 40 && d->D != 80 && d->D != 160) return sg_set_error(SG_EUNSUP, "%s: head dim %d not in {40, 80, 160}", who, d->D);
-    SG_REQUIRE(d->Nq % 8 == 0 && d->Nk % 8 == 0, "%s: Nq=%d and Nk=%d must be multiples of 8", who, d->Nq, d->Nk);
+    // dkv streams the queries: their (lse2, delta) pairs are fetched 16 bytes at a time and Q^T / dO^T rows must hold
+    // finite data up to Nq rounded up to 8.  dq streams the keys and accepts any Nk (text attention: 77) as long as the
+    // K^T rows are finite up to Nk rounded up to 8 (ldkt >= that).
+    SG_REQUIRE(!dkv || d->Nq % 8 == 0, "%s: Nq=%d must be a multiple of 8", who, d->Nq);
     const int64_t hd = (int64_t)d->H * d->D;
     SG_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldv % 8 == 0 && d->lddo % 8 == 0 && d->ldq >= hd && d->ldk >= hd &&
                    d->ldv >= hd && d->lddo >= hd, "%s: token strides", who);
@@ -309,7 +312,8 @@ static int check_bwd_desc(const sg_attn_bwd_desc* d, bool dkv, const char* who) 
         SG_REQUIRE((int64_t)d->D * d->ldqt < (1ll << 31) && (int64_t)d->D * d->lddot < (1ll << 31), "%s: 32-bit offsets", who);
     } else {
         SG_REQUIRE(d->kt && d->dq, "%s: null kt/dq", who);
-        SG_REQUIRE(d->ldkt % 8 == 0 && d->ldkt >= d->Nk && d->bskt % 8 == 0 && sg_aligned16(d->kt), "%s: transposed input", who);
+        SG_REQUIRE(d->ldkt % 8 == 0 && d->ldkt >= ((d->Nk + 7) & ~7) && d->bskt % 8 == 0 && sg_aligned16(d->kt),
+                   "%s: transposed input (ldkt must cover Nk rounded up to 8)", who);
         SG_REQUIRE(d->lddq % 4 == 0 && d->bsdq % 4 == 0 && d->lddq >= hd, "%s: dq strides", who);
         SG_REQUIRE((int64_t)d->D * d->ldkt < (1ll << 31), "%s: 32-bit offsets", who);
     }

@@ -184,3 +184,73 @@ def test_attention_backward(gpu, B_, heads, D, Nq, Nk):
     ops.attention_bwd_dkv(q, q.transpose(1, 2).contiguous(), k, v, do, do.transpose(1, 2).contiguous(), ld2, dkt, dvt, heads, scale)
     assert rel(dkt.transpose(1, 2).to(dev), dk_ref) < 5e-3
     assert rel(dvt.transpose(1, 2).to(dev), dv_ref) < 5e-3
+
+
+def _block_sd(C, ctx_dim, seed, dev="cpu"):
+    """Random BasicTransformerBlock parameters (fp16-exact values so that device and oracle see the same numbers)."""
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).half().float()      # noqa: E731
+    sd = {}
+    for n in ("norm1", "norm2", "norm3", "norm4"):
+        sd[f"b.{n}.weight"], sd[f"b.{n}.bias"] = 1.0 + r(C, sc=0.1), r(C, sc=0.1)
+    for a, kd in (("attn1", C), ("attn2", ctx_dim), ("attn3", C)):
+        sd[f"b.{a}.to_q.weight"] = r(C, C, sc=C ** -0.5)
+        sd[f"b.{a}.to_k.weight"], sd[f"b.{a}.to_v.weight"] = r(C, kd, sc=kd ** -0.5), r(C, kd, sc=kd ** -0.5)
+        sd[f"b.{a}.to_out.0.weight"], sd[f"b.{a}.to_out.0.bias"] = r(C, C, sc=C ** -0.5), r(C, sc=0.1)
+    sd["b.ff.net.0.proj.weight"], sd["b.ff.net.0.proj.bias"] = r(8 * C, C, sc=C ** -0.5), r(8 * C, sc=0.1)
+    sd["b.ff.net.2.weight"], sd["b.ff.net.2.bias"] = r(C, 4 * C, sc=(4 * C) ** -0.5), r(C, sc=0.1)
+    return sd
+
+
+def test_transformer_block_training_forward_and_backward(gpu):
+    """storygen_amd.train_blocks.TransformerBlockTrain (the composition of the backward kernels) against the hand-written
+    CPU backward of the same block: output, input gradient and the five attn3 parameter gradients."""
+    from oracle import storygen_backward as B
+    from oracle import storygen_oracle as O
+    from storygen_amd.train_blocks import TransformerBlockTrain
+    C, heads, Bn, N, S, Nc = 320, 8, 2, 256, 77, 512
+    sd = _block_sd(C, 768, 3)
+    h = rnd((Bn, N, C), "cpu", 1.0, 1, torch.float32)
+    text, ctx = rnd((Bn, S, 768), "cpu", 1.0, 2).float(), rnd((Bn, Nc, C), "cpu", 1.0, 3).float()
+    dout = rnd((Bn, N, C), "cpu", 1.0, 4, torch.float32)
+    with torch.no_grad():
+        want_out, _ = O.transformer_block(sd, "b", h, text, ctx, heads)
+        want_dh, want_g = B.transformer_block_bwd(sd, "b", h, text, ctx, heads, dout)
+    blk = TransformerBlockTrain(sd, "b", heads, gpu)
+    out = blk.forward(h.to(gpu).reshape(Bn * N, C).contiguous(), text.half().to(gpu).reshape(Bn * S, 768).contiguous(),
+                      ctx.half().to(gpu).reshape(Bn * Nc, C).contiguous(), Bn)
+    assert rel(out.cpu().view(Bn, N, C), want_out) < 2e-3
+    dh, grads = blk.backward(dout.to(gpu).reshape(Bn * N, C).contiguous())
+    torch.cuda.synchronize()
+    assert rel(dh.cpu().view(Bn, N, C), want_dh) < 1e-2
+    for k, g in grads.items():
+        assert rel(g.cpu(), want_g[f"b.attn3.{k}"]) < 1e-2, k
+
+
+@pytest.mark.parametrize("cin,cout", [(320, 320), (640, 320)])
+def test_resnet_block_training_forward_and_backward(gpu, cin, cout):
+    from oracle import storygen_backward as B
+    from oracle import storygen_oracle as O
+    from storygen_amd.train_blocks import ResnetBlockTrain
+    Bn, H, W, temb = 2, 16, 16, 1280
+    g = torch.Generator().manual_seed(5)
+    r = lambda *s, sc=1.0: (torch.randn(*s, generator=g) * sc).half().float()      # noqa: E731
+    sd = {"r.norm1.weight": 1.0 + r(cin, sc=0.1), "r.norm1.bias": r(cin, sc=0.1), "r.norm2.weight": 1.0 + r(cout, sc=0.1),
+          "r.norm2.bias": r(cout, sc=0.1), "r.conv1.weight": r(cout, cin, 3, 3, sc=(9 * cin) ** -0.5), "r.conv1.bias": r(cout, sc=0.1),
+          "r.conv2.weight": r(cout, cout, 3, 3, sc=(9 * cout) ** -0.5), "r.conv2.bias": r(cout, sc=0.1),
+          "r.time_emb_proj.weight": r(cout, temb, sc=temb ** -0.5), "r.time_emb_proj.bias": r(cout, sc=0.1)}
+    if cin != cout:
+        sd["r.conv_shortcut.weight"], sd["r.conv_shortcut.bias"] = r(cout, cin, 1, 1, sc=cin ** -0.5), r(cout, sc=0.1)
+    x = rnd((Bn, cin, H, W), "cpu", 1.0, 1, torch.float32) + 0.3
+    emb, dout = rnd((Bn, temb), "cpu", 1.0, 2, torch.float32), rnd((Bn, cout, H, W), "cpu", 1.0, 3, torch.float32)
+    with torch.no_grad():
+        want = O.resnet_block(sd, "r", x, emb, 32, 1e-5)
+        want_dx = B.resnet_block_bwd(sd, "r", x, emb, 32, 1e-5, dout)
+        tproj = F.linear(F.silu(emb), sd["r.time_emb_proj.weight"], sd["r.time_emb_proj.bias"])
+    nhwc = lambda t: t.permute(0, 2, 3, 1).reshape(Bn * H * W, -1).contiguous().to(gpu)       # noqa: E731
+    blk = ResnetBlockTrain(sd, "r", 32, 1e-5, gpu)
+    out = blk.forward(nhwc(x), tproj.to(gpu), Bn, H, W)
+    assert rel(out.cpu(), nhwc(want).cpu()) < 2e-3
+    dx = blk.backward(nhwc(dout))
+    torch.cuda.synchronize()
+    assert rel(dx.cpu(), nhwc(want_dx).cpu()) < 1e-2
