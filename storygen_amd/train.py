@@ -1,0 +1,258 @@
+"""Stage-2 training step (BASELINE config 4, /root/reference/train_StorySalon_stage2.py:291-327) on the HIP kernels:
+loss and the 80 attn3 gradients of one step.
+
+STATUS: NOT YET RUN ON HARDWARE (written after round 1's GPU budget was spent).  A correctness-first assembly of
+storygen_amd/train_blocks.py that follows oracle/storygen_backward.py (unet_forward_saving / unet_backward) record by
+record: per-call allocations, torch.cat for the skip concatenations, no hipGraph.  tests/test_backward_gpu.py compares it
+with oracle.storygen_oracle.train_step (skipped unless SG_TEST_UNVALIDATED=1).  The optimizer step, GradScaler and DDP
+all-reduce of the 49.6 M attn3 parameters (train_StorySalon_stage2.py:187-222,327-332) are the caller's stock PyTorch.
+
+Structure
+  * reference passes (no gradient reaches a trainable parameter through them: attn3 is not evaluated there): the inference
+    UNetEngine, one call per prior frame used, harvesting straight into the context buffers;
+  * main pass forward keeping each module's input, then the tape walked backwards: dgrad everywhere from conv_out down to
+    the first transformer block, weight gradients for the 16 attn3 modules only.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Tuple
+
+import torch
+
+from . import ops
+from .arch import UNetArch, XfSpec
+from .engine import EngineWeights, UNetEngine
+from .repack import conv1x1_nk, conv3x3_krsc, conv_in_kn
+from .scheduler import DDIMSchedule
+from .train_blocks import F16, F32, ResnetBlockTrain, TransformerBlockTrain, _cast16, _e, _t
+
+
+class Transformer2DTrain:
+    """Transformer2DModel (model/attention.py:26-128): GroupNorm(eps 1e-6) -> 1x1 proj_in -> block -> 1x1 proj_out -> + x."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], spec: XfSpec, groups: int, device):
+        self.dev, self.groups, self.spec, p = torch.device(device), groups, spec, spec.prefix
+        g = lambda k: sd[f"{p}.{k}"].detach().to(self.dev, F16).contiguous()     # noqa: E731
+        self.ng, self.nb = g("norm.weight"), g("norm.bias")
+        self.w_in, self.b_in = conv1x1_nk(g("proj_in.weight")), g("proj_in.bias")
+        self.w_out, self.b_out = conv1x1_nk(g("proj_out.weight")), g("proj_out.bias")
+        self.w_in_t, self.w_out_t = _t(self.w_in), _t(self.w_out)
+        self.blk = TransformerBlockTrain(sd, f"{p}.transformer_blocks.0", spec.heads, device)
+        self.saved = None
+
+    def forward(self, x: torch.Tensor, text16: torch.Tensor, ctx16: torch.Tensor, B: int) -> torch.Tensor:
+        M, C, dev = x.shape[0], x.shape[1], self.dev
+        hw = M // B
+        ws = _e(ops.groupnorm_workspace_bytes(B, self.groups), dev=dev, dtype=torch.uint8)
+        gn = _e(M, C, dev=dev)
+        ops.groupnorm(x.view(B, hw, C), self.ng, self.nb, gn.view(B, hw, C), self.groups, 1e-6, False, ws)
+        h0 = _e(M, C, dev=dev, dtype=F32)
+        ops.gemm(gn, self.w_in, h0, bias=self.b_in)
+        hb = self.blk.forward(h0, text16, ctx16, B)
+        out = _e(M, C, dev=dev, dtype=F32)
+        ops.gemm(_cast16(hb), self.w_out, out, bias=self.b_out, res1=x)
+        self.saved = dict(x=x, B=B)
+        return out
+
+    def backward(self, dout: torch.Tensor) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        x, B = self.saved["x"], self.saved["B"]
+        M, C, dev = x.shape[0], x.shape[1], self.dev
+        hw = M // B
+        dhb = _e(M, C, dev=dev, dtype=F32)
+        ops.gemm(_cast16(dout), self.w_out_t, dhb)
+        dh0, g = self.blk.backward(dhb)
+        dgn = _e(M, C, dev=dev)
+        ops.gemm(_cast16(dh0), self.w_in_t, dgn)
+        ws = _e(ops.groupnorm_bwd_workspace_bytes(B, self.groups), dev=dev, dtype=torch.uint8)
+        dx = _e(M, C, dev=dev, dtype=F32)
+        ops.groupnorm_bwd(x.view(B, hw, C), dgn.view(B, hw, C), self.ng, self.nb, dx.view(B, hw, C), self.groups, 1e-6, False, ws,
+                          res=dout.view(B, hw, C))
+        p = f"{self.spec.prefix}.transformer_blocks.0.attn3"
+        return dx, {f"{p}.{k}": v for k, v in g.items()}
+
+
+class UNetTrainer:
+    def __init__(self, arch: UNetArch, state_dict: Dict[str, torch.Tensor], device, batch: int, height: int, width: int,
+                 n_ref: int = 3, seq_len: int = 77):
+        self.arch, self.dev, self.cfg = arch, torch.device(device), arch.config
+        self.B, self.H, self.W, self.R = batch, height, width, n_ref
+        sd = state_dict
+        self.wts = EngineWeights(arch, sd, device)
+        self.ref = UNetEngine(arch, None, device, batch, height, width, n_ref, seq_len, weights=self.wts)
+        self.groups, self.eps = self.cfg["norm_num_groups"], self.cfg["norm_eps"]
+        g16 = lambda k: sd[k].detach().to(self.dev, F16).contiguous()             # noqa: E731
+        self.resnets = {r.prefix: ResnetBlockTrain(sd, r.prefix, self.groups, self.eps, device) for r in arch.resnets}
+        self.temb_proj = {r.prefix: (g16(f"{r.prefix}.time_emb_proj.weight"), g16(f"{r.prefix}.time_emb_proj.bias")) for r in arch.resnets}
+        self.xfs = {a.prefix: Transformer2DTrain(sd, a, self.groups, device)
+                    for blk in arch.down + [arch.mid] + arch.up for a in blk.attns if a is not None}
+        self.samplers = {}
+        for blk in arch.down + arch.up:
+            if blk.sampler_prefix:
+                w = sd[f"{blk.sampler_prefix}.weight"].to(self.dev, F16)
+                self.samplers[blk.sampler_prefix] = (conv3x3_krsc(w), g16(f"{blk.sampler_prefix}.bias"),
+                                                     conv3x3_krsc(w.flip(2, 3).transpose(0, 1).contiguous()))
+        self.gn_out = (g16("conv_norm_out.weight"), g16("conv_norm_out.bias"))
+        w_out = sd["conv_out.weight"].to(self.dev, F16)
+        self.w_conv_out, self.b_conv_out = conv3x3_krsc(w_out), g16("conv_out.bias")
+        self.w_conv_out_d = conv_in_kn(w_out.flip(2, 3).transpose(0, 1).contiguous())      # dgrad of conv_out = a 4 -> C conv_in
+        self.zero_bias = torch.zeros(w_out.shape[1], dtype=F16, device=self.dev)
+        self.schedule = DDIMSchedule()
+
+    # ------------------------------------------------------------------------------------------------ pieces
+    def _add_noise(self, x: torch.Tensor, noise: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
+        """DDPMScheduler.add_noise with per-sample timesteps (train_StorySalon_stage2.py:303,311); elementwise plumbing."""
+        a = self.schedule.alphas_cumprod.to(self.dev, F32)[t.long()].view(-1, 1, 1, 1)
+        return a.sqrt() * x + (1 - a).sqrt() * noise
+
+    def _down(self, prefix: str, h: torch.Tensor, hh: int, ww: int) -> torch.Tensor:
+        w, b, _ = self.samplers[prefix]
+        C = h.shape[1]
+        pad = torch.zeros(self.B, hh + 2, ww + 2, C, dtype=F16, device=self.dev)
+        ops.pad_cast(h.view(self.B, hh, ww, C), pad)
+        out = _e(self.B * (hh // 2) * (ww // 2), C, dev=self.dev, dtype=F32)
+        ops.conv3x3(pad, w, out.view(self.B, hh // 2, ww // 2, C), stride=2, bias=b, x_padded=True)
+        return out
+
+    def _down_bwd(self, prefix: str, dout: torch.Tensor, ho: int, wo: int) -> torch.Tensor:
+        C = dout.shape[1]
+        pad = torch.zeros(self.B, 2 * ho + 2, 2 * wo + 2, C, dtype=F16, device=self.dev)
+        ops.zero_stuff(dout.view(self.B, ho, wo, C), pad)
+        dx = _e(self.B * 4 * ho * wo, C, dev=self.dev, dtype=F32)
+        ops.conv3x3(pad, self.samplers[prefix][2], dx.view(self.B, 2 * ho, 2 * wo, C), x_padded=True)
+        return dx
+
+    def _up(self, prefix: str, h: torch.Tensor, hh: int, ww: int) -> torch.Tensor:
+        w, b, _ = self.samplers[prefix]
+        C = h.shape[1]
+        pad = torch.zeros(self.B, hh + 2, ww + 2, C, dtype=F16, device=self.dev)
+        ops.pad_cast(h.view(self.B, hh, ww, C), pad)
+        out = _e(self.B * 4 * hh * ww, C, dev=self.dev, dtype=F32)
+        ops.conv3x3(pad, w, out.view(self.B, 2 * hh, 2 * ww, C), upsample2x=True, bias=b, x_padded=True)
+        return out
+
+    def _up_bwd(self, prefix: str, dout: torch.Tensor, hh: int, ww: int) -> torch.Tensor:
+        """dout at the upsampled resolution [B*2hh*2ww, C] -> gradient at [B*hh*ww, C]."""
+        C = dout.shape[1]
+        pad = torch.zeros(self.B, 2 * hh + 2, 2 * ww + 2, C, dtype=F16, device=self.dev)
+        ops.pad_cast(dout.view(self.B, 2 * hh, 2 * ww, C), pad)
+        du = _e(self.B * 4 * hh * ww, C, dev=self.dev, dtype=F32)
+        ops.conv3x3(pad, self.samplers[prefix][2], du.view(self.B, 2 * hh, 2 * ww, C), x_padded=True)
+        dx = _e(self.B * hh * ww, C, dev=self.dev, dtype=F32)
+        ops.sum2x2(du.view(self.B, 2 * hh, 2 * ww, C), dx.view(self.B, hh, ww, C))
+        return dx
+
+    # ------------------------------------------------------------------------------------------------ the step
+    def train_step(self, batch: Dict[str, torch.Tensor], use_refs=(0, 1, 2)) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """`batch` as storygen_amd.synth.synthetic_train_batch / oracle.storygen_oracle.train_step.  Returns (loss [1] fp32 on
+        the device, {parameter name: fp32 gradient})."""
+        dev, B, H, W, arch = self.dev, self.B, self.H, self.W, self.arch
+        f = lambda k: batch[k].to(dev, F32)                                          # noqa: E731
+        t = batch["timesteps"].to(dev)
+        ref_t = (batch["timesteps"] / 10).long().to(dev)                             # :297-300
+        # ---- reference passes: features of the frames used, harvested into context slots 0..len(use_refs)-1
+        ref_lat, prev_text = f("ref_latents"), batch["prev_text"].to(dev, F16)
+        for slot, i in enumerate(use_refs):                                          # :309-314
+            ti = ref_t * (3 - i)
+            self.ref.set_inputs(self._add_noise(ref_lat[i], f("ref_noise"), ti), ti.float(), prev_text[i])
+            self.ref.forward(harvest_slot=slot)
+        n_used = len(use_refs)
+        ctx16 = {}
+        for key, buf in self.ref.ctx.items():                                        # [B, R*hw_k, C] -> the used slots, flattened
+            n = buf.shape[1] // self.R
+            ctx16[key] = buf[:, : n_used * n].reshape(B * n_used * n, buf.shape[2]).contiguous()
+        text16 = batch["text"].to(dev, F16).reshape(B * batch["text"].shape[1], -1).contiguous()
+        # ---- main pass forward (tape = oracle.storygen_backward.unet_forward_saving)
+        noisy = self._add_noise(f("latents"), f("noise"), t).contiguous()            # :303
+        wts = self.wts
+        boc0 = self.cfg["block_out_channels"][0]
+        temb0, temb1, temb2 = (_e(B, n, dev=dev, dtype=F32) for n in (boc0, arch.temb_dim, arch.temb_dim))
+        ops.timestep_embed(t.float().contiguous(), wts.freqs, temb0, self.cfg["flip_sin_to_cos"])
+        ops.linear_rows(temb0, wts.w_t1, wts.b_t1, temb1, act_out=True)
+        ops.linear_rows(temb1, wts.w_t2, wts.b_t2, temb2)
+        tape: List[tuple] = []
+        hh, ww = H, W
+
+        def resnet(prefix, x):
+            w, b = self.temb_proj[prefix]
+            tp = ops.linear_rows(temb2, w, b, _e(B, w.shape[0], dev=dev, dtype=F32), act_in=True)
+            tape.append(("resnet", prefix))
+            return self.resnets[prefix].forward(x, tp, B, hh, ww)
+
+        def xf(spec, x):
+            tape.append(("xf", spec.prefix))
+            return self.xfs[spec.prefix].forward(x, text16, ctx16[spec.feature_key], B)
+
+        h = _e(B * H * W, boc0, dev=dev, dtype=F32)
+        ops.conv_in(noisy, wts.w_conv_in, wts.b_conv_in, h.view(B, H, W, boc0))
+        tape.append(("conv_in",))
+        skips = [h]
+        for blk in arch.down:
+            for j, r in enumerate(blk.resnets):
+                h = resnet(r.prefix, h)
+                if blk.attns[j] is not None:
+                    h = xf(blk.attns[j], h)
+                skips.append(h)
+                tape.append(("skip_push",))
+            if blk.sampler_prefix:
+                tape.append(("down", blk.sampler_prefix, hh // 2, ww // 2))
+                h = self._down(blk.sampler_prefix, h, hh, ww)
+                hh, ww = hh // 2, ww // 2
+                skips.append(h)
+                tape.append(("skip_push",))
+        m0, m1 = arch.mid.resnets
+        h = resnet(m0.prefix, h)
+        h = xf(arch.mid.attns[0], h)
+        h = resnet(m1.prefix, h)
+        for blk in arch.up:
+            for j, r in enumerate(blk.resnets):
+                s = skips.pop()
+                tape.append(("cat", h.shape[1]))
+                h = torch.cat([h, s], dim=1)                                         # unet_2d_blocks.py:609,626,716
+                h = resnet(r.prefix, h)
+                if blk.attns[j] is not None:
+                    h = xf(blk.attns[j], h)
+            if blk.sampler_prefix:
+                tape.append(("up", blk.sampler_prefix, hh, ww))
+                h = self._up(blk.sampler_prefix, h, hh, ww)
+                hh, ww = 2 * hh, 2 * ww
+        x_out = h
+        hw = H * W
+        ws = _e(ops.groupnorm_workspace_bytes(B, self.groups), dev=dev, dtype=torch.uint8)
+        gn = _e(B * hw, boc0, dev=dev)
+        ops.groupnorm(x_out.view(B, hw, boc0), *self.gn_out, gn.view(B, hw, boc0), self.groups, self.eps, True, ws)
+        pred = _e(B, self.cfg["out_channels"], H, W, dev=dev, dtype=F32)
+        ops.conv_out(gn.view(B, H, W, boc0), self.w_conv_out, self.b_conv_out, pred)
+        # ---- loss (:325) and its gradient
+        d_pred, loss = torch.empty_like(pred), _e(1, dev=dev, dtype=F32)
+        ops.mse_grad(pred, f("noise").contiguous(), f("mask").contiguous(), d_pred, loss)
+        # ---- backward (oracle.storygen_backward.unet_backward)
+        dn = _e(B * hw, boc0, dev=dev)
+        ops.conv_in(d_pred, self.w_conv_out_d, self.zero_bias, dn.view(B, H, W, boc0))
+        ws = _e(ops.groupnorm_bwd_workspace_bytes(B, self.groups), dev=dev, dtype=torch.uint8)
+        dh = _e(B * hw, boc0, dev=dev, dtype=F32)
+        ops.groupnorm_bwd(x_out.view(B, hw, boc0), dn.view(B, hw, boc0), *self.gn_out, dh.view(B, hw, boc0), self.groups, self.eps,
+                          True, ws)
+        grads: Dict[str, torch.Tensor] = {}
+        pending: List[torch.Tensor] = []
+        n_xf = sum(1 for rec in tape if rec[0] == "xf")
+        for rec in reversed(tape):
+            kind = rec[0]
+            if kind == "up":
+                dh = self._up_bwd(rec[1], dh, rec[2], rec[3])
+            elif kind == "cat":
+                pending.append(dh[:, rec[1]:].contiguous())
+                dh = dh[:, : rec[1]].contiguous()
+            elif kind == "resnet":
+                dh = self.resnets[rec[1]].backward(dh)
+            elif kind == "xf":
+                dh, g = self.xfs[rec[1]].backward(dh)
+                grads.update(g)
+                if len(grads) == 5 * n_xf:
+                    break                                      # nothing trainable below the first transformer block
+            elif kind == "skip_push":
+                dh = dh + pending.pop()
+            elif kind == "down":
+                dh = self._down_bwd(rec[1], dh, rec[2], rec[3])
+            elif kind == "conv_in":
+                break
+        return loss, grads

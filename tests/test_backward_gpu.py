@@ -254,3 +254,29 @@ def test_resnet_block_training_forward_and_backward(gpu, cin, cout):
     dx = blk.backward(nhwc(dout))
     torch.cuda.synchronize()
     assert rel(dx.cpu(), nhwc(want_dx).cpu()) < 1e-2
+
+
+@pytest.mark.parametrize("use_refs", [(0, 1, 2), (2,)])
+def test_training_step_vs_oracle(gpu, use_refs):
+    """BASELINE config 4 end to end on a 2-level StoryGen UNet (320 / 640 channels, 16x16 latent, batch 2): loss and the
+    attn3 gradients of storygen_amd.train.UNetTrainer against oracle.storygen_oracle.train_step (autograd; pinned to the
+    reference's gradients by tests/test_oracle_golden.py).  Bar: 1e-2 rel-L2 per gradient tensor."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.arch import build_arch, load_config
+    from storygen_amd.synth import synthetic_state_dict, synthetic_train_batch
+    from storygen_amd.train import UNetTrainer
+    cfg = load_config(dict(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                           up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), cross_attention_dim=768, attention_head_dim=8,
+                           sample_size=128))
+    arch = build_arch(cfg)
+    sd = synthetic_state_dict(arch, 7)
+    batch = synthetic_train_batch(2, 16, 768, 7)
+    want_loss, want = O.train_step(sd, cfg, batch, use_refs)
+    tr = UNetTrainer(arch, sd, gpu, 2, 16, 16, n_ref=3)
+    loss, grads = tr.train_step(batch, use_refs)
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(want_loss)) <= 2e-3 * abs(float(want_loss))
+    assert set(grads) == set(want)
+    errs = {k: rel(grads[k].cpu(), want[k]) for k in want}
+    print("worst gradients:", sorted(errs.items(), key=lambda kv: -kv[1])[:3])
+    assert max(errs.values()) < 1e-2
