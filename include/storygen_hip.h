@@ -338,7 +338,7 @@ int sg_zero_stuff_f16(const void* dy, int64_t lddy, int32_t dy_f32, sg_half* y, 
 int sg_mse_grad_f32(const float* pred, const float* noise, const float* mask, float* d_pred, float* loss, int64_t n,
                     sg_stream_t stream);
 
-/* Diagnostic: raw per-lane MFMA register dump used by tests/test_mfma_layout.py to pin the fragment layout
+/* Diagnostic: raw per-lane MFMA register dump used by tests/test_kernels_gpu.py::test_mfma_fragment_layout to pin the fragment layout
  * assumptions of the kernels above.  out: fp32 [64 lanes][16 regs] of D = A(32x16) @ B(16x32) with
  * A[i][k] = a[i*16+k], B[k][j] = b[k*32+j] loaded with the kernels' own lane mapping. */
 int sg_debug_mfma_32x32x16(const sg_half* a, const sg_half* b, float* out, sg_stream_t stream);

@@ -4,7 +4,7 @@ to a GPU, so its index arithmetic — LDS-DMA source coordinates, XOR swizzles, 
 register-resident dS / P feeding the second contraction, the output mapping — is transliterated here statement by
 statement on top of a model of v_mfma_f32_32x32x16_f16 and checked against oracle.storygen_backward.attention_core_bwd).
 
-MFMA model — the operand layout the hardware-validated forward kernel is built on (tests/test_mfma_layout.py pins it on
+MFMA model — the operand layout the hardware-validated forward kernel is built on (tests/test_kernels_gpu.py::test_mfma_fragment_layout pins it on
 the device) and the C/D map of the CDNA4 guide: D[i][j] += sum_k A[i][k] B[k][j];
 A fragment of lane l = A[l & 31][8 (l >> 5) + 0..7], B fragment = B[8 (l >> 5) + 0..7][l & 31],
 accumulator register r of lane l = D[(r & 3) + 8 (r >> 2) + 4 (l >> 5)][l & 31].
