@@ -73,12 +73,15 @@ class Transformer2DTrain:
 
 class UNetTrainer:
     def __init__(self, arch: UNetArch, state_dict: Dict[str, torch.Tensor], device, batch: int, height: int, width: int,
-                 n_ref: int = 3, seq_len: int = 77):
+                 n_ref: int = 3, seq_len: int = 77, ref_engine=None):
+        """ref_engine: the object that runs the reference passes (set_inputs / forward(harvest_slot=) / .ctx); default = an
+        inference UNetEngine on the same weights (tests inject a CPU stand-in to exercise the host logic without a GPU)."""
         self.arch, self.dev, self.cfg = arch, torch.device(device), arch.config
         self.B, self.H, self.W, self.R = batch, height, width, n_ref
         sd = state_dict
         self.wts = EngineWeights(arch, sd, device)
-        self.ref = UNetEngine(arch, None, device, batch, height, width, n_ref, seq_len, weights=self.wts)
+        self.ref = ref_engine if ref_engine is not None else UNetEngine(arch, None, device, batch, height, width, n_ref, seq_len,
+                                                                        weights=self.wts)
         self.groups, self.eps = self.cfg["norm_num_groups"], self.cfg["norm_eps"]
         g16 = lambda k: sd[k].detach().to(self.dev, F16).contiguous()             # noqa: E731
         self.resnets = {r.prefix: ResnetBlockTrain(sd, r.prefix, self.groups, self.eps, device) for r in arch.resnets}
