@@ -267,6 +267,30 @@ class UNet2DConditionModel(nn.Module):
             eng = self._engines[key] = UNetEngine(self._arch, None, self.device, B, H, W, R, S, weights=wts)
         return eng
 
+    def _forward_train(self, sample, timestep, encoder_hidden_states, image_hidden_states, return_dict):
+        """Main pass under autograd: gradients for the attn3 parameters through storygen_amd.train.MainPassFunction."""
+        from ..train import MainPassFunction, UNetTrainer
+        B, _, H, W = sample.shape
+        shapes = feature_shapes(self._arch, H, W)
+        k0 = self._arch.feature_keys[0]
+        R = image_hidden_states[k0].shape[1] // shapes[k0][0]
+        key = ("train", B, H, W)
+        tr = self._engines.get(key)
+        if tr is None:
+            tr = self._engines[key] = UNetTrainer(self._arch, self.state_dict(), self.device, B, H, W, n_ref=R,
+                                                  ref_engine=object())      # reference passes go through forward(None)
+        t = timestep if torch.is_tensor(timestep) else torch.tensor([timestep])
+        t = t.to(self.device, torch.float32).reshape(-1)
+        t = t.expand(B) if t.numel() == 1 else t
+        named = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
+        keys = list(shapes)
+        feats = [image_hidden_states[k].to(self.device, torch.float16).reshape(-1, shapes[k][1]).contiguous() for k in keys]
+        text16 = encoder_hidden_states.to(self.device, torch.float16).reshape(-1, encoder_hidden_states.shape[-1]).contiguous()
+        pred = MainPassFunction.apply(tr, [n for n, _ in named], keys, sample.to(self.device, torch.float32).contiguous(), t, text16,
+                                      *feats, *[p for _, p in named])
+        out = pred.to(sample.dtype)
+        return UNet2DConditionOutput(out, {}) if return_dict else (out, {})
+
     def forward(self, sample: torch.Tensor, timestep: Union[torch.Tensor, float, int],
                 encoder_hidden_states: torch.Tensor, image_hidden_states: Optional[Dict[str, torch.Tensor]] = None,
                 class_labels: Optional[torch.Tensor] = None, cross_attention_kwargs: Optional[Dict[str, Any]] = None,
@@ -277,9 +301,22 @@ class UNet2DConditionModel(nn.Module):
             raise ValueError("cross_attention_kwargs are not supported by the HIP attention kernels")
         if self.device.type != "cuda":
             raise RuntimeError("the HIP UNet has no CPU path: move the model to a HIP device (model.to('cuda'))")
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("backward through the HIP UNet is not implemented yet (BASELINE config 4); "
-                                      "call under torch.no_grad() or freeze the parameters")
+        training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
+        if training:
+            # The HIP backward (storygen_amd/train.py) exists but has not met the hardware yet: opt-in until it has.
+            if os.environ.get("SG_ENABLE_TRAINING") != "1":
+                raise NotImplementedError("backward through the HIP UNet is not enabled (BASELINE config 4: written, not yet "
+                                          "validated on hardware — set SG_ENABLE_TRAINING=1 to use it); call under "
+                                          "torch.no_grad() or freeze the parameters")
+            other = [n for n, p in self.named_parameters() if p.requires_grad and ".attn3." not in n]
+            if other:
+                raise NotImplementedError(f"only the attn3 modules are trainable on the HIP path (stage 2, "
+                                          f"train_StorySalon_stage2.py:170-177); also trainable here: {other[:3]} ...")
+            if image_hidden_states is not None:
+                return self._forward_train(sample, timestep, encoder_hidden_states, image_hidden_states, return_dict)
+            # harvest pass: attn3 is not evaluated, so no gradient reaches a trainable parameter through it
+            with torch.no_grad():
+                return self.forward(sample, timestep, encoder_hidden_states, None, return_dict=return_dict)
         B, _, H, W = sample.shape
         S = encoder_hidden_states.shape[1]
         arch = self._arch

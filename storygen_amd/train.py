@@ -164,12 +164,29 @@ class UNetTrainer:
             n = buf.shape[1] // self.R
             ctx16[key] = buf[:, : n_used * n].reshape(B * n_used * n, buf.shape[2]).contiguous()
         text16 = batch["text"].to(dev, F16).reshape(B * batch["text"].shape[1], -1).contiguous()
-        # ---- main pass forward (tape = oracle.storygen_backward.unet_forward_saving)
         noisy = self._add_noise(f("latents"), f("noise"), t).contiguous()            # :303
+        pred = self.forward_main(noisy, t, text16, ctx16)
+        # ---- loss (:325) and its gradient
+        d_pred, loss = torch.empty_like(pred), _e(1, dev=dev, dtype=F32)
+        ops.mse_grad(pred, f("noise").contiguous(), f("mask").contiguous(), d_pred, loss)
+        return loss, self.backward_main(d_pred)
+
+    def set_attn3_parameters(self, named_params: Dict[str, torch.Tensor]) -> None:
+        """Refresh the device copies of the trainable parameters (full state-dict names, `...attn3.to_q.weight` etc.)."""
+        for prefix, xf in self.xfs.items():
+            p = f"{prefix}.transformer_blocks.0.attn3."
+            sub = {k[len(p):]: v for k, v in named_params.items() if k.startswith(p)}
+            if sub:
+                xf.blk.set_attn3(sub)
+
+    def forward_main(self, noisy: torch.Tensor, t: torch.Tensor, text16: torch.Tensor, ctx16: Dict[str, torch.Tensor]) -> torch.Tensor:
+        """Main pass (unet_2d_condition.py:338-485 in consume mode) keeping the tape for backward_main.  noisy fp32 NCHW
+        [B,4,H,W]; t [B]; text16 fp16 [B*S, 768]; ctx16: feature key -> fp16 [B*R'*hw_k, C_k].  Returns epsilon fp32 NCHW."""
+        dev, B, H, W, arch = self.dev, self.B, self.H, self.W, self.arch
         wts = self.wts
         boc0 = self.cfg["block_out_channels"][0]
         temb0, temb1, temb2 = (_e(B, n, dev=dev, dtype=F32) for n in (boc0, arch.temb_dim, arch.temb_dim))
-        ops.timestep_embed(t.float().contiguous(), wts.freqs, temb0, self.cfg["flip_sin_to_cos"])
+        ops.timestep_embed(t.to(dev, F32).contiguous(), wts.freqs, temb0, self.cfg["flip_sin_to_cos"])
         ops.linear_rows(temb0, wts.w_t1, wts.b_t1, temb1, act_out=True)
         ops.linear_rows(temb1, wts.w_t2, wts.b_t2, temb2)
         tape: List[tuple] = []
@@ -225,9 +242,15 @@ class UNetTrainer:
         ops.groupnorm(x_out.view(B, hw, boc0), *self.gn_out, gn.view(B, hw, boc0), self.groups, self.eps, True, ws)
         pred = _e(B, self.cfg["out_channels"], H, W, dev=dev, dtype=F32)
         ops.conv_out(gn.view(B, H, W, boc0), self.w_conv_out, self.b_conv_out, pred)
-        # ---- loss (:325) and its gradient
-        d_pred, loss = torch.empty_like(pred), _e(1, dev=dev, dtype=F32)
-        ops.mse_grad(pred, f("noise").contiguous(), f("mask").contiguous(), d_pred, loss)
+        self._tape, self._x_out = tape, x_out
+        return pred
+
+    def backward_main(self, d_pred: torch.Tensor) -> Dict[str, torch.Tensor]:
+        """d_pred fp32 NCHW [B,4,H,W] -> {attn3 parameter name: fp32 gradient} (the walk of oracle unet_backward)."""
+        dev, B, H, W = self.dev, self.B, self.H, self.W
+        tape, x_out = self._tape, self._x_out
+        boc0 = self.cfg["block_out_channels"][0]
+        hw = H * W
         # ---- backward (oracle.storygen_backward.unet_backward)
         dn = _e(B * hw, boc0, dev=dev)
         ops.conv_in(d_pred, self.w_conv_out_d, self.zero_bias, dn.view(B, H, W, boc0))
@@ -258,4 +281,29 @@ class UNetTrainer:
                 dh = self._down_bwd(rec[1], dh, rec[2], rec[3])
             elif kind == "conv_in":
                 break
-        return loss, grads
+        return grads
+
+
+class MainPassFunction(torch.autograd.Function):
+    """epsilon = UNet(sample, t, text, features) as an autograd node whose only differentiable inputs are the attn3
+    parameters (train_StorySalon_stage2.py:170-177): what `accelerator.backward(loss)` needs from the drop-in model.
+
+    apply(trainer, names, ctx_keys, noisy, t, text16, *features, *params): `features` are the len(ctx_keys) context
+    tensors (fp16 [B*R*hw_k, C_k]), `params` the len(names) attn3 parameters under their state-dict names.  The sample,
+    the text embeddings and the harvested features get no gradient (no trainable parameter sits upstream of them)."""
+
+    @staticmethod
+    def forward(ctx, trainer, names, ctx_keys, noisy, t, text16, *tensors):
+        nk = len(ctx_keys)
+        feats, params = tensors[:nk], tensors[nk:]
+        trainer.set_attn3_parameters(dict(zip(names, params)))
+        pred = trainer.forward_main(noisy, t, text16, dict(zip(ctx_keys, feats)))
+        ctx.trainer, ctx.names, ctx.n_feat = trainer, names, nk
+        ctx.meta = [(p.dtype, p.device) for p in params]
+        return pred
+
+    @staticmethod
+    def backward(ctx, d_pred):
+        grads = ctx.trainer.backward_main(d_pred.to(torch.float32).contiguous())
+        out = tuple(grads[n].to(dtype=dt, device=dv) for n, (dt, dv) in zip(ctx.names, ctx.meta))
+        return (None,) * (6 + ctx.n_feat) + out

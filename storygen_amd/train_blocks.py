@@ -82,6 +82,16 @@ class TransformerBlockTrain:
         self.scale = (self.C // heads) ** -0.5
         self.saved: Optional[dict] = None
 
+    def set_attn3(self, params: Dict[str, torch.Tensor]) -> None:
+        """Refresh the device copies of the trainable module after an optimizer step.  `params`: to_q.weight, to_k.weight,
+        to_v.weight, to_out.0.weight, to_out.0.bias (any dtype / device)."""
+        cp = lambda t: t.detach().to(self.dev, F16).contiguous()                     # noqa: E731
+        for m in ("to_q", "to_k", "to_v"):
+            self.w[f"attn3.{m}"] = cp(params[f"{m}.weight"])
+            self.wt[f"attn3.{m}"] = _t(self.w[f"attn3.{m}"])
+        self.w["attn3.to_out"], self.w["attn3.b_out"] = cp(params["to_out.0.weight"]), cp(params["to_out.0.bias"])
+        self.wt["attn3.to_out"] = _t(self.w["attn3.to_out"])
+
     # ------------------------------------------------------------------------------------------------ forward
     def _attend(self, name: str, x16: torch.Tensor, kv16: torch.Tensor, B: int) -> dict:
         """q from x16 [B*Nq, C], k / v from kv16 [B*Nk, Ck]; returns the tensors the backward needs."""

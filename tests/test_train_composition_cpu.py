@@ -116,3 +116,43 @@ def test_training_step_composition_vs_oracle(cpu_ops, use_refs):
     assert set(grads) == set(want) and len(grads) == 5 * len(arch.feature_keys)
     errs = {k: rel_l2(grads[k], want[k]) for k in want}
     assert max(errs.values()) < 2e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+
+
+def test_main_pass_autograd_function_routes_gradients_to_the_attn3_parameters(cpu_ops):
+    """storygen_amd.train.MainPassFunction — what the drop-in model's forward uses under autograd: a plain torch loss on
+    its output, loss.backward(), and the attn3 leaves must receive the oracle's gradients; nothing else gets one."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.arch import build_arch, load_config
+    from storygen_amd.synth import synthetic_state_dict, synthetic_train_batch
+    from storygen_amd.train import MainPassFunction, UNetTrainer
+    cfg = load_config(dict(block_out_channels=(32, 64), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                           up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), cross_attention_dim=48, attention_head_dim=2,
+                           norm_num_groups=8, sample_size=64))
+    arch = build_arch(cfg)
+    sd = synthetic_state_dict(arch, 9)
+    Bn, hw, use_refs = 2, 8, (0, 1, 2)
+    batch = synthetic_train_batch(Bn, hw, 48, 9)
+    want_loss, want = O.train_step(sd, cfg, batch, use_refs)
+    ref = _OracleRefEngine(sd, cfg, arch, Bn, 3, hw, hw)
+    tr = UNetTrainer(arch, sd, "cpu", Bn, hw, hw, n_ref=3, ref_engine=ref)
+    # the reference passes and the input noising, as the training script does them around the model call
+    sched = O.DDIM()
+    t = batch["timesteps"].long()
+    ref_t = (batch["timesteps"] / 10).long()
+    for slot, i in enumerate(use_refs):
+        ti = ref_t * (3 - i)
+        ref.set_inputs(O.ddpm_add_noise(sched, batch["ref_latents"][i], batch["ref_noise"], ti), ti, batch["prev_text"][i])
+        ref.forward(slot)
+    noisy = O.ddpm_add_noise(sched, batch["latents"], batch["noise"], t)
+    names = sorted(k for k in sd if k.endswith(O.TRAINABLE_SUFFIXES))
+    params = [sd[k].clone().requires_grad_(True) for k in names]
+    keys = list(ref.ctx)
+    feats = [ref.ctx[k].reshape(-1, ref.ctx[k].shape[2]).contiguous() for k in keys]
+    text16 = batch["text"].half().reshape(-1, 48).contiguous()
+    pred = MainPassFunction.apply(tr, names, keys, noisy.contiguous(), t.float(), text16, *feats, *params)
+    keep = 1.0 - batch["mask"]
+    loss = F.mse_loss(pred * keep, batch["noise"] * keep)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(want_loss)) <= 5e-3 * abs(float(want_loss))
+    errs = {n: rel_l2(p.grad, want[n]) for n, p in zip(names, params)}
+    assert max(errs.values()) < 2e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
