@@ -123,6 +123,40 @@ def test_host_validation_rejects_before_launch(lib):
     assert lib.sg_gemm_workspace_bytes(128, 256, 1) == 0
 
 
+def test_backward_entry_points_validate_on_the_host(lib):
+    """Same for the backward-pass entry points (BASELINE config 4): bad descriptors are refused before any launch."""
+    from storygen_amd._lib import AttnBwdDesc, AttnDesc, GroupNormBwdDesc
+    P = 0x10000
+    assert lib.sg_layernorm_bwd_f16(P, 320, 1, P, 320, P, None, 0, None, 0, None, 0, 1.0, P, 320, 16, 324, 1e-5, None) == -1   # C % 8
+    assert lib.sg_layernorm_bwd_f16(P, 320, 1, P, 320, P, P, 320, None, 0, None, 0, 1.0, P, 320, 16, 320, 1e-5, None) == -1  # dy2 w/o gamma2
+    assert b"go together" in lib.sg_last_error()
+    assert lib.sg_geglu_bwd_f16(P, 96, P, 48, P, 96, 8, 96, None) == -1                    # N8 % 64
+    assert lib.sg_transpose_f16(P, 320, 0, P, 12, 12, 320, None) == -1                     # M % 8
+    assert lib.sg_sum2x2_f32(P, 6, P, 6, 1, 4, 4, 6, 0, None) == -1                        # C % 4
+    assert lib.sg_zero_stuff_f16(P, 320, 0, P, 320, 1, 4, 4, 324, None) == -1
+    assert lib.sg_mse_grad_f32(P, P, P, P, P, 0, None) == -1
+    assert lib.sg_attn_fwd_lse_f16(C.byref(AttnDesc()), None, None) == -1 and b"lse2" in lib.sg_last_error()
+    g = GroupNormBwdDesc()
+    g.x = g.dy = g.gamma = g.beta = g.workspace = g.out = P
+    g.B, g.HW, g.C, g.groups, g.ldx, g.lddy, g.ldo, g.out_f32 = 1, 64, 32, 32, 32, 32, 32, 1
+    assert lib.sg_groupnorm_bwd_nhwc_f16(C.byref(g), None) == -2 and b"channels per group" in lib.sg_last_error()   # cpg = 1
+    g.C, g.ldx, g.lddy, g.ldo, g.workspace_bytes = 320, 320, 320, 320, 0
+    assert lib.sg_groupnorm_bwd_nhwc_f16(C.byref(g), None) == -1 and b"workspace" in lib.sg_last_error()
+    assert lib.sg_groupnorm_bwd_workspace_bytes(4, 32) == 2 * lib.sg_groupnorm_workspace_bytes(4, 32)
+    a = AttnBwdDesc()
+    a.q = a.k = a.v = a.dout = a.ld2 = a.kt = a.dq = a.qt = a.dot = a.dkt = a.dvt = P
+    a.B, a.H, a.Nq, a.Nk, a.D = 1, 8, 60, 77, 40
+    for f in ("ldq", "ldk", "ldv", "lddo", "lddq"):
+        setattr(a, f, 320)
+    a.ldkt = 72                                                       # dq accepts any Nk, but kt rows must cover Nk rounded up to 8
+    assert lib.sg_attn_bwd_dq_f16(C.byref(a), None) == -1 and b"ldkt" in lib.sg_last_error()
+    a.ldqt = a.lddot = 64
+    a.lddkt = a.lddvt = 80
+    assert lib.sg_attn_bwd_dkv_f16(C.byref(a), None) == -1 and b"multiple of 8" in lib.sg_last_error()   # Nq = 60
+    a.D = 64
+    assert lib.sg_attn_bwd_dq_f16(C.byref(a), None) == -2
+
+
 def test_product_path_has_no_cpu_fallback():
     """The package's compute modules never import the oracle, and ops refuse CPU tensors."""
     import torch
