@@ -342,6 +342,10 @@ int sg_mse_grad_f32(const float* pred, const float* noise, const float* mask, fl
  * assumptions of the kernels above.  out: fp32 [64 lanes][16 regs] of D = A(32x16) @ B(16x32) with
  * A[i][k] = a[i*16+k], B[k][j] = b[k*32+j] loaded with the kernels' own lane mapping. */
 int sg_debug_mfma_32x32x16(const sg_half* a, const sg_half* b, float* out, sg_stream_t stream);
+/* Diagnostic for BASELINE config 5 (fp8 attention, not built): one v_mfma_scale_f32_32x32x64_f8f6f4 on raw operands — a, b:
+ * [64 lanes][32 bytes] of fp8 e4m3, scale_a / scale_b: E8M0 exponents (127 = 1.0); out: fp32 [64 lanes][16 registers].
+ * tools/probe_mfma_f8.py derives the (lane, byte) -> (row / column, k) operand maps from it on the device. */
+int sg_debug_mfma_f8_32x32x64(const void* a, const void* b, float* out, int32_t scale_a, int32_t scale_b, sg_stream_t stream);
 /* Test hook: force the GEMM/conv tile shape (bm, bn in {256x128, 128x128, 256x64, 128x64, 64x128, 64x64}; 0,0 = automatic) and
  * optionally disable the LDS-DMA pipelined kernel (no_pipe = 1), so the parity tests can cover every code path.
  * Process-global; not for production use. */

@@ -157,6 +157,7 @@ SIGNATURES = {
                                     C.c_int32, C.c_void_p]),
     "sg_mse_grad_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     "sg_debug_mfma_32x32x16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sg_debug_mfma_f8_32x32x64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sg_debug_set_tile": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
 }
 

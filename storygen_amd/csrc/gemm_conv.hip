@@ -855,6 +855,31 @@ __global__ void debug_mfma_kernel(const f16* a, const f16* b, float* out) {
 }
 }  // namespace
 
+// Probe for the block-scaled fp8 MFMA (v_mfma_scale_f32_32x32x64_f8f6f4, fp8 e4m3 operands, unit scales): one wave, raw
+// per-lane operand bytes in, raw per-lane accumulator registers out.  tools/probe_mfma_f8.py uses it to establish the
+// (lane, byte) -> (row / column, k) operand maps on the device before any fp8 attention kernel (BASELINE config 5) is written.
+typedef int v8i_probe __attribute__((ext_vector_type(8)));
+__global__ void debug_mfma_f8_kernel(const int* a, const int* b, float* out, int scale_a, int scale_b) {
+    const int lane = threadIdx.x;
+    v8i_probe A, B;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) { A[i] = a[lane * 8 + i]; B[i] = b[lane * 8 + i]; }
+    f32x16 c;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) c[r] = 0.f;
+    c = __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(A, B, c, 0, 0, 0, scale_a, 0, scale_b);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) out[lane * 16 + r] = c[r];
+}
+
+extern "C" int sg_debug_mfma_f8_32x32x64(const void* a, const void* b, float* out, int32_t scale_a, int32_t scale_b, sg_stream_t stream) {
+    SG_REQUIRE(a && b && out, "sg_debug_mfma_f8: null pointer");
+    hipLaunchKernelGGL(debug_mfma_f8_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const int*>(a),
+                       reinterpret_cast<const int*>(b), out, scale_a, scale_b);
+    SG_CHECK_LAUNCH("sg_debug_mfma_f8_32x32x64");
+    return SG_OK;
+}
+
 extern "C" int sg_debug_mfma_32x32x16(const sg_half* a, const sg_half* b, float* out, sg_stream_t stream) {
     SG_REQUIRE(a && b && out, "sg_debug_mfma: null pointer");
     hipLaunchKernelGGL(debug_mfma_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const f16*>(a),

@@ -612,6 +612,18 @@ def debug_set_tile(bm: int = 0, bn: int = 0, no_pipe: bool = False) -> None:
     check(lib.sg_debug_set_tile(bm, bn, int(no_pipe)), "sg_debug_set_tile")
 
 
+def debug_mfma_f8(a_bytes: torch.Tensor, b_bytes: torch.Tensor, scale_a: int = 127, scale_b: int = 127) -> torch.Tensor:
+    """a_bytes, b_bytes: uint8 [64, 32] (raw fp8 e4m3 operand bytes per lane) -> fp32 [64, 16] accumulator registers."""
+    if a_bytes.dtype != torch.uint8 or tuple(a_bytes.shape) != (64, 32) or not a_bytes.is_cuda or not a_bytes.is_contiguous():
+        raise TypeError("debug_mfma_f8: a must be a contiguous CUDA uint8 [64, 32]")
+    if b_bytes.dtype != torch.uint8 or tuple(b_bytes.shape) != (64, 32) or not b_bytes.is_cuda or not b_bytes.is_contiguous():
+        raise TypeError("debug_mfma_f8: b must be a contiguous CUDA uint8 [64, 32]")
+    out = torch.empty(64, 16, dtype=torch.float32, device=a_bytes.device)
+    check(lib.sg_debug_mfma_f8_32x32x64(a_bytes.data_ptr(), b_bytes.data_ptr(), out.data_ptr(), scale_a, scale_b, _stream()),
+          "sg_debug_mfma_f8_32x32x64")
+    return out
+
+
 def debug_mfma(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     out = torch.empty(64, 16, dtype=torch.float32, device=a.device)
     check(lib.sg_debug_mfma_32x32x16(a.data_ptr(), b.data_ptr(), out.data_ptr(), _stream()), "sg_debug_mfma_32x32x16")
