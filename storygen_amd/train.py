@@ -284,6 +284,28 @@ class UNetTrainer:
         return grads
 
 
+def allreduce_gradients(grads: Dict[str, torch.Tensor], average: bool = True) -> Dict[str, torch.Tensor]:
+    """Data-parallel training (the reference wraps the UNet in DDP through accelerate, train_StorySalon_stage2.py:222): sum
+    (or average) the attn3 gradients over the ranks with ONE all-reduce of one flat fp32 bucket — 80 tensors, 49.6 M
+    parameters = 198 MB for SD-1.5: on xGMI's point-to-point ring a single large collective is the per-link-bandwidth
+    optimum, and there is nothing to overlap it with (the gradients exist only after the backward walk has reached the
+    first transformer block).  In place; identity when torch.distributed is not initialised."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return grads
+    names = sorted(grads)
+    flat = torch.cat([grads[n].reshape(-1).to(torch.float32) for n in names])
+    dist.all_reduce(flat)
+    if average:
+        flat /= dist.get_world_size()
+    off = 0
+    for n in names:
+        k = grads[n].numel()
+        grads[n].copy_(flat[off:off + k].view_as(grads[n]))
+        off += k
+    return grads
+
+
 class MainPassFunction(torch.autograd.Function):
     """epsilon = UNet(sample, t, text, features) as an autograd node whose only differentiable inputs are the attn3
     parameters (train_StorySalon_stage2.py:170-177): what `accelerator.backward(loss)` needs from the drop-in model.

@@ -153,6 +153,29 @@ def test_final_allgather_world2_gloo(tmp_path):
     assert [float(a[i, 0, 0, 0]) for i in range(4)] == [0.0, 1.0, 2.0, 3.0]
 
 
+def _ddp_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from storygen_amd.train import allreduce_gradients
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    grads = {"b.attn3.to_q.weight": torch.full((4, 4), float(rank + 1)), "a.attn3.to_out.0.bias": torch.arange(4.0) * (rank + 1)}
+    allreduce_gradients(grads)
+    torch.save(grads, os.path.join(out_dir, f"g{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_world2_gloo(tmp_path):
+    """Data-parallel training: one bucketed all-reduce averages the attn3 gradients over the ranks."""
+    import torch.multiprocessing as mp
+    port = _free_port()
+    mp.spawn(_ddp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "g0.pt"), torch.load(tmp_path / "g1.pt")
+    for k in a:
+        assert torch.equal(a[k], b[k])
+    assert torch.equal(a["b.attn3.to_q.weight"], torch.full((4, 4), 1.5))
+    assert torch.equal(a["a.attn3.to_out.0.bias"], torch.arange(4.0) * 1.5)
+
+
 def test_gather_is_identity_without_process_group():
     from storygen_amd.sampler import gather_latents
     x = torch.randn(1, 4, 8, 8)
