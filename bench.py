@@ -133,6 +133,40 @@ def in_situ_roofline(sampler):
     return roof, executed_tflop
 
 
+def train_step_bench(args):
+    """BASELINE configs[3] (non-contract line): storygen_amd.train.UNetTrainer.train_step, eager (no hipGraph yet)."""
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X")
+    from storygen_amd.arch import SD15_CONFIG, build_arch
+    from storygen_amd.synth import synthetic_state_dict, synthetic_train_batch
+    from storygen_amd.train import UNetTrainer
+    dev = torch.device("cuda", 0)
+    arch = build_arch(SD15_CONFIG)
+    sd = synthetic_state_dict(arch, 0)
+    bs = 4
+    batch = synthetic_train_batch(bs, HW, arch.config["cross_attention_dim"], 0)
+    tr = UNetTrainer(arch, sd, dev, bs, HW, HW, n_ref=R)
+    for _ in range(args.warmup):
+        loss, grads = tr.train_step(batch)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss, grads = tr.train_step(batch)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    # forward FLOPs: 3 reference passes + main pass per sample; backward of the main pass counted as 2x its forward for the
+    # dgrads + the attention recompute (SURVEY §8d config 4 estimate: ~23 TFLOP per step at bs=4)
+    fwd = bs * (R * REF_GF + MAIN_GF) / 1000.0
+    print(json.dumps({"metric": "stage-2 training steps/sec @512x512, bs=4, 3 reference frames (non-contract)",
+                      "value": round(args.steps / dt, 4), "unit": "it/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "dtype": "f16", "data": "synthetic",
+                      "config": {"workload": "NON-CONTRACT RUN, BASELINE configs[3]: train_StorySalon_stage2.py step, bs=4, fp16 operands / "
+                                             "fp32 residual stream and gradients, eager (no hipGraph), attn3 gradients only",
+                                 "gradients": len(grads), "loss": float(loss)},
+                      "tflop_forward_per_step": round(fwd, 3)}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,7 +186,12 @@ def main():
     ap.add_argument("--split-graphs", action="store_true", help="reference and main pass as separate hipGraphs on two streams")
     ap.add_argument("--stream-priority", action="store_true",
                     help="with --split-graphs / --ref-ahead: main-pass graphs on a high-priority stream")
+    ap.add_argument("--train-step", action="store_true",
+                    help="NOT the contract workload: BASELINE configs[3] — stage-2 training step, bs=4, 512x512, 3 reference frames "
+                         "(forward of 3 reference passes + main pass, backward of the main pass, 80 attn3 gradients); reports it/s")
     args = ap.parse_args()
+    if args.train_step:
+        return train_step_bench(args)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
