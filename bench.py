@@ -196,9 +196,17 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        # `python bench.py --gpus N` without a launcher: re-exec under torch.distributed.run, one rank per GPU (RCCL)
+        import socket
+        import subprocess
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+               "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch multi-GPU runs with torch.distributed.run (one process per GPU)")
         args.gpus = world
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no GPU visible (there is no CPU fallback for the product path)")
@@ -257,6 +265,9 @@ def main():
     gather_ms = 1e3 * (time.perf_counter() - t0)
     finite = bool(torch.isfinite(final).all())
     assert final.shape[0] == world * N_PER_GPU, f"all-gather returned {final.shape[0]} samples for {world} ranks"
+    # every rank denoised its own sample (inputs seeded by rank): the gathered latents must be pairwise different
+    distinct = all(not torch.equal(final[i], final[j]) for i in range(final.shape[0]) for j in range(i))
+    assert distinct, "two ranks produced identical latents: the batch shard is not per-rank"
 
     if rank == 0:
         value = world * N_PER_GPU * args.steps / dt
@@ -276,6 +287,7 @@ def main():
                        "split_graphs": sampler.split, "stream_priority": sampler.stream_priority},
             "tflop_per_step_as_written": round(step_tflop, 3),
             "final_allgather_ms": round(gather_ms, 3), "latents_gathered": int(final.shape[0]), "latents_finite": finite,
+            "latents_distinct_per_rank": distinct,
         }
         out["roofline"], executed = in_situ_roofline(sampler)
         if args.config5_shape:

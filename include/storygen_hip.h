@@ -231,6 +231,14 @@ int sg_add_noise_f32(const float* src, const float* noise, const float* coef, fl
                      int64_t n, sg_stream_t stream);
 int sg_cfg_ddim_step_f32(const float* eps3, float* latents, float* latents3, const float* coef, int32_t N,
                          int64_t n, sg_stream_t stream);
+/* sg_cfg_plms_step_f32: the same guidance combine followed by the PNDM / PLMS update of diffusers' PNDMScheduler with
+ *     skip_prk_steps (model/pipeline.py:7-16 accepts it, ckpt/stable-diffusion-v1-5/scheduler/scheduler_config.json names
+ *     it; call site :461): coef = {s_img, s_txt, A, Bc, w0, w1, w2, w3, slot_cur, slot1, slot2, slot3, push, use_kept,
+ *     keep} (15 floats, integers stored as floats).  e' = w0 eps + w1 history[slot1] + w2 history[slot2] + w3 history[slot3];
+ *     if push: history[slot_cur] <- eps (history = 4 x [N*n] ring of past guided epsilons); x_src = use_kept ? kept :
+ *     latents; if keep: kept <- latents; latents <- A x_src - Bc e' (and the three-fold `latents3`, if non-NULL). */
+int sg_cfg_plms_step_f32(const float* eps3, float* latents, float* latents3, float* history, float* kept,
+                         const float* coef, int32_t N, int64_t n, sg_stream_t stream);
 
 /* Strided, batched 2-D copy of rows: dst[b][r][0:cols] = src[b][r][0:cols] (cols % 8 == 0; strides in elements).
  * mode 0: fp16 -> fp16, 1: fp32 -> fp32, 2: fp32 -> fp16 (cast).

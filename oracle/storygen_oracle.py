@@ -207,6 +207,55 @@ class DDIM:
         return a_p ** 0.5 * x0 + (1 - a_p) ** 0.5 * eps
 
 
+class PNDM(DDIM):
+    """PNDMScheduler (diffusers 0.13.1) with skip_prk_steps=True — the class
+    /root/reference/ckpt/stable-diffusion-v1-5/scheduler/scheduler_config.json:2 names and /root/reference/model/pipeline.py:7-16
+    accepts.  PARITY UNPINNED: diffusers is not installed here and the reference's shipped scripts only ever build a DDIMScheduler
+    (inference.py:48), so this restates the published algorithm (`set_timesteps`, `step_plms`, `_get_prev_sample`) as written
+    there — a stateful list of past epsilons — and is the checker for the device's table-driven form of the same rule."""
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self.ets: List[Tensor] = []
+        self.counter = 0
+        self.cur_sample: Optional[Tensor] = None
+
+    def timesteps(self, n: int) -> List[int]:
+        ratio = self.n_train // n
+        base = [int(round(i * ratio)) + self.steps_offset for i in range(n)]
+        self.ets, self.counter, self.cur_sample = [], 0, None
+        return (base[:-1] + base[-2:-1] + base[-1:])[::-1]
+
+    def _prev(self, x: Tensor, t: int, prev: int, e: Tensor) -> Tensor:
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+        coeff = (a_p / a_t) ** 0.5
+        denom = a_t * (1 - a_p) ** 0.5 + (a_t * (1 - a_t) * a_p) ** 0.5
+        return coeff * x - (a_p - a_t) * e / denom
+
+    def step(self, eps: Tensor, t: int, x: Tensor, n: int) -> Tensor:
+        ratio = self.n_train // n
+        prev = t - ratio
+        if self.counter != 1:
+            self.ets = self.ets[-3:]
+            self.ets.append(eps)
+        else:
+            prev, t = t, t + ratio
+        if len(self.ets) == 1 and self.counter == 0:
+            self.cur_sample = x
+        elif len(self.ets) == 1 and self.counter == 1:
+            eps = (eps + self.ets[-1]) / 2
+            x, self.cur_sample = self.cur_sample, None
+        elif len(self.ets) == 2:
+            eps = (3 * self.ets[-1] - self.ets[-2]) / 2
+        elif len(self.ets) == 3:
+            eps = (23 * self.ets[-1] - 16 * self.ets[-2] + 5 * self.ets[-3]) / 12
+        else:
+            eps = (1 / 24) * (55 * self.ets[-1] - 59 * self.ets[-2] + 37 * self.ets[-3] - 9 * self.ets[-4])
+        self.counter += 1
+        return self._prev(x, t, prev, eps)
+
+
 # ----------------------------------------------------------------------------------------------- the loop
 def denoise_step(sd: SD, cfg: dict, sched: DDIM, latents: Tensor, t: int, n_steps: int, inputs: Dict[str, Tensor],
                  stage: str, guidance_scale: float, image_guidance_scale: float) -> Tensor:
@@ -219,14 +268,14 @@ def denoise_step(sd: SD, cfg: dict, sched: DDIM, latents: Tensor, t: int, n_step
     n_ref = imgs.shape[0]
     ref_t = int(t) // 10 if t >= 0 else 0                                                 # :414-415 (t/10).long()
     feats_all = []
-    for i in range(n_ref):
+    for i in range(n_ref if stage != "no" else 0):                                        # stage 'no': no reference pass (:436-438)
         ti = ref_t * (n_ref - i) if stage == "auto-regressive" else ref_t                 # :419-424
         noisy_img = sched.add_noise(imgs[i], noise, ti)
         noisy_zero = sched.add_noise(zero, noise, ti)
         x = torch.cat([noisy_zero, noisy_img, noisy_img])                                 # :429
         e = torch.cat([inputs["prev_uncond"][i], inputs["prev_text"][i], inputs["prev_text"][i]])  # :430
         feats_all.append(unet_forward(sd, cfg, x, ti, e, None)[1])                        # :433-435
-    ctx = {k: torch.cat([f[k] for f in feats_all], dim=1) for k in feats_all[0]}          # :440-443
+    ctx = {k: torch.cat([f[k] for f in feats_all], dim=1) for k in feats_all[0]} if feats_all else None   # :440-445
     e = torch.cat([inputs["uncond"], inputs["uncond"], inputs["text"]])                   # :448
     x = torch.cat([latents] * 3)                                                          # :450
     eps = unet_forward(sd, cfg, x, t, e, ctx)[0]                                          # :453
@@ -237,9 +286,10 @@ def denoise_step(sd: SD, cfg: dict, sched: DDIM, latents: Tensor, t: int, n_step
 
 def sample_loop(sd: SD, cfg: dict, inputs: Dict[str, Tensor], n_steps: int, stage: str = "multi-image-condition",
                 guidance_scale: float = 7.5, image_guidance_scale: float = 3.5, max_steps: Optional[int] = None,
-                trace: Optional[list] = None) -> Tensor:
-    """pipeline.py:366-367 + :411-469: all (or the first `max_steps`) DDIM steps; returns the latents."""
-    sched = DDIM()
+                trace: Optional[list] = None, scheduler: str = "ddim") -> Tensor:
+    """pipeline.py:366-367 + :411-469: all (or the first `max_steps`) steps of the DDIM (default) or PNDM loop; returns the
+    latents."""
+    sched = DDIM() if scheduler == "ddim" else PNDM()
     latents = inputs["latents"].clone()
     with torch.no_grad():
         for k, t in enumerate(sched.timesteps(n_steps)):

@@ -184,6 +184,33 @@ __global__ void cfg_ddim_kernel(const float* eps3, float* lat, float* lat3, cons
     }
 }
 
+// PNDM / PLMS update (diffusers PNDMScheduler.step_plms + _get_prev_sample, skip_prk_steps): coef = [s_img, s_txt, A, Bc,
+// w0..w3, slot_cur, slot1..slot3, push, use_kept, keep] (storygen_amd/scheduler.py::PNDMSchedule.step_row).
+__global__ void cfg_plms_kernel(const float* eps3, float* lat, float* lat3, float* hist, float* kept, const float* coef, int N,
+                                long n) {
+    const long total = (long)N * n;
+    const float s_img = coef[0], s_txt = coef[1], A = coef[2], Bc = coef[3];
+    const float w0 = coef[4], w1 = coef[5], w2 = coef[6], w3 = coef[7];
+    const int cur = (int)coef[8], s1 = (int)coef[9], s2 = (int)coef[10], s3 = (int)coef[11];
+    const bool push = coef[12] != 0.f, use_kept = coef[13] != 0.f, keep = coef[14] != 0.f;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const float eu = eps3[i], ei = eps3[total + i], ea = eps3[2 * total + i];
+        const float e = eu + s_img * (ei - eu) + s_txt * (ea - ei);
+        // history terms are read before the (optional) store: slot_cur never aliases a slot with a non-zero weight
+        float ep = w0 * e;
+        if (w1 != 0.f) ep += w1 * hist[s1 * total + i];
+        if (w2 != 0.f) ep += w2 * hist[s2 * total + i];
+        if (w3 != 0.f) ep += w3 * hist[s3 * total + i];
+        if (push) hist[cur * total + i] = e;
+        const float x = lat[i];
+        const float xs = use_kept ? kept[i] : x;
+        if (keep) kept[i] = x;
+        const float xp = A * xs - Bc * ep;
+        lat[i] = xp;
+        if (lat3) { lat3[i] = xp; lat3[total + i] = xp; lat3[2 * total + i] = xp; }
+    }
+}
+
 // mode 0: fp16 -> fp16, 1: fp32 -> fp32, 2: fp32 -> fp16 (cast); 8 elements per thread per iteration
 __global__ __launch_bounds__(256) void copy_rows_kernel(void* dst, long ldd, long bsd, const void* src, long lds, long bss,
                                                         int batches, int rows, int cols, int mode) {
@@ -300,6 +327,16 @@ extern "C" int sg_cfg_ddim_step_f32(const float* eps3, float* latents, float* la
     hipLaunchKernelGGL(cfg_ddim_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, eps3,
                        latents, latents3, coef, N, (long)n);
     SG_CHECK_LAUNCH("sg_cfg_ddim_step_f32");
+    return SG_OK;
+}
+
+extern "C" int sg_cfg_plms_step_f32(const float* eps3, float* latents, float* latents3, float* history, float* kept,
+                                    const float* coef, int32_t N, int64_t n, sg_stream_t stream) {
+    SG_REQUIRE(eps3 && latents && history && kept && coef && N > 0 && n > 0, "sg_cfg_plms_step: bad arguments");
+    const long total = (long)N * n;
+    hipLaunchKernelGGL(cfg_plms_kernel, dim3((int)min((long)1024, (total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, eps3,
+                       latents, latents3, history, kept, coef, N, (long)n);
+    SG_CHECK_LAUNCH("sg_cfg_plms_step_f32");
     return SG_OK;
 }
 

@@ -131,6 +131,47 @@ class EngineWeights:
         self.w_conv_out = conv3x3_krsc(g("conv_out.weight"))
         self.b_conv_out = g("conv_out.bias")
 
+    # ---- in-place refresh: captured hipGraphs and engines hold the ADDRESSES of the repacked tensors, so new parameter
+    # values are copied into the existing storage (same shapes) instead of re-allocating
+    def _pack_attn3(self, sd, xf: "_Xf") -> Dict[str, torch.Tensor]:
+        t = f"{xf.spec.prefix}.transformer_blocks.0"
+        g = lambda k: self._w(sd, k)  # noqa: E731
+        w_o3 = g(f"{t}.attn3.to_out.0.weight")
+        return {"w_q3": g(f"{t}.attn3.to_q.weight"), "w_k3": g(f"{t}.attn3.to_k.weight"), "w_v3": g(f"{t}.attn3.to_v.weight"),
+                "w_o3": w_o3, "b_o3": g(f"{t}.attn3.to_out.0.bias"), "w_o23": torch.cat([xf.w_o2, w_o3], dim=1),
+                "b_o23": (sd[f"{t}.attn2.to_out.0.bias"].float() + sd[f"{t}.attn3.to_out.0.bias"].float()).to(self.dev, F16)}
+
+    def refresh_attn3_(self, sd, prefixes=None):
+        """Stage-2 training changes only the attn3 modules (train_StorySalon_stage2.py:170-177): re-pack those of the given
+        Transformer2DModel prefixes (default: all) from `sd`, in place."""
+        for p, xf in self.xfs.items():
+            if prefixes is None or p in prefixes:
+                for name, val in self._pack_attn3(sd, xf).items():
+                    getattr(xf, name).copy_(val)
+
+    def reload_(self, sd):
+        """Re-pack the whole checkpoint into the existing tensors (any parameter may have changed)."""
+        fresh = EngineWeights.__new__(EngineWeights)
+        fresh.arch, fresh.dev, fresh.cfg = self.arch, self.dev, self.cfg
+        fresh._load_weights(sd)
+
+        def walk(old, new):
+            if torch.is_tensor(old):
+                old.copy_(new)
+            elif isinstance(old, dict):
+                for k in old:
+                    walk(old[k], new[k])
+            elif isinstance(old, (tuple, list)):
+                for a, b in zip(old, new):
+                    walk(a, b)
+            elif isinstance(old, (_Resnet, _Xf)):
+                for k in old.__slots__:
+                    if k != "spec" and getattr(old, k, None) is not None:
+                        walk(getattr(old, k), getattr(new, k))
+        for k, v in self.__dict__.items():
+            if k not in ("arch", "dev", "cfg"):
+                walk(v, getattr(fresh, k))
+
 
 class HarvestPlan:
     """Where a reference pass puts the features it harvests (attention.py:263).

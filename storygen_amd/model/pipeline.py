@@ -11,8 +11,11 @@ Deliberate differences from the reference, none of which changes latents:
     inner loop variable shadows `i`, pipeline.py:412,418 — SURVEY F6f);
   * `guidance_scale <= 1` raises (the reference's non-CFG branch passes a list where a tensor is required and cannot
     run, :430 — SURVEY F6g);
-  * only DDIM-style schedulers are supported (the reference ships a DDIM loop, inference.py:48); `scheduler` may be a
-    storygen_amd.scheduler.DDIMSchedule or any object whose `.config` carries the DDIM keys.
+  * schedulers: DDIM (what the reference ships and uses, inference.py:48) and PNDM with `skip_prk_steps=true` (the class
+    named by ckpt/stable-diffusion-v1-5/scheduler/scheduler_config.json); `scheduler` may be a
+    storygen_amd.scheduler.DDIMSchedule / PNDMSchedule or any object whose `.config` carries the diffusers keys
+    (`_class_name` or the object's class name selects the rule).  Anything else (Euler, LMS, DPM-solver, v-prediction,
+    clip_sample) raises instead of silently running DDIM.
 """
 from __future__ import annotations
 
@@ -22,7 +25,7 @@ from typing import Callable, List, Optional, Union
 import torch
 
 from ..sampler import STAGES, StoryGenSampler
-from ..scheduler import DDIMSchedule
+from ..scheduler import DDIMSchedule, schedule_from_config
 
 StableDiffusionPipelineOutput = namedtuple("StableDiffusionPipelineOutput", ["images", "nsfw_content_detected"])
 
@@ -32,10 +35,8 @@ def _as_schedule(scheduler) -> DDIMSchedule:
         return scheduler
     cfg = getattr(scheduler, "config", None)
     if cfg is None:
-        raise TypeError("scheduler must be a DDIMSchedule or expose a diffusers-style .config")
-    keys = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "steps_offset", "set_alpha_to_one",
-            "clip_sample", "trained_betas")
-    return DDIMSchedule(**{k: cfg[k] for k in keys if k in cfg})
+        raise TypeError("scheduler must be a DDIMSchedule / PNDMSchedule or expose a diffusers-style .config")
+    return schedule_from_config(cfg, type(scheduler).__name__)
 
 
 class StableDiffusionPipeline:
@@ -45,6 +46,7 @@ class StableDiffusionPipeline:
         self.vae_scale_factor = 2 ** (len(boc) - 1)                                       # :76
         self._sampler: Optional[StoryGenSampler] = None
         self._sampler_key = None
+        self._progress_bar_config = {}
 
     # --------------------------------------------------------------------------------------------- plumbing
     @property
@@ -65,10 +67,55 @@ class StableDiffusionPipeline:
         if hasattr(self.vae, "disable_slicing"):
             self.vae.disable_slicing()
 
+    def to(self, torch_device=None, torch_dtype=None):
+        """DiffusionPipeline.to: moves every nn.Module component (inference.py:56 `pipeline.to(device)` usage pattern)."""
+        for name in ("vae", "text_encoder", "unet"):
+            m = getattr(self, name)
+            if isinstance(m, torch.nn.Module):
+                if torch_device is not None:
+                    m.to(torch_device)
+                if torch_dtype is not None and name != "unet":      # the HIP UNet keeps its parameters in their own dtype
+                    m.to(torch_dtype)
+        return self
+
+    @property
+    def device(self) -> torch.device:
+        return self._execution_device
+
+    def set_progress_bar_config(self, **kwargs):                                          # train_StorySalon_stage2.py:157
+        self._progress_bar_config = dict(kwargs)
+
+    def progress_bar(self, iterable=None, total=None):                                    # pipeline.py:411
+        from tqdm.auto import tqdm
+        if iterable is not None:
+            return tqdm(iterable, **self._progress_bar_config)
+        if total is not None:
+            return tqdm(total=total, **self._progress_bar_config)
+        raise ValueError("Either `total` or `iterable` has to be defined.")
+
     def save_pretrained(self, save_directory: str, **kwargs):
-        """Only the UNet is this package's to write (diffusers folder layout, `unet/`)."""
+        """DiffusionPipeline.save_pretrained layout (train_StorySalon_stage2.py:348-357 saves the WHOLE pipeline): one
+        sub-folder per component that can save itself + model_index.json naming each component's [library, class]."""
+        import json
         import os
-        self.unet.save_pretrained(os.path.join(save_directory, "unet"), **kwargs)
+        os.makedirs(save_directory, exist_ok=True)
+        index = {"_class_name": type(self).__name__, "_diffusers_version": "0.13.1"}
+        for name in ("vae", "text_encoder", "tokenizer", "unet", "scheduler"):
+            comp = getattr(self, name)
+            if comp is None:
+                index[name] = [None, None]
+                continue
+            lib = type(comp).__module__.split(".")[0]
+            index[name] = [lib, type(comp).__name__]
+            sub = os.path.join(save_directory, name)
+            if name == "unet":
+                comp.save_pretrained(sub, **kwargs)
+            elif hasattr(comp, "save_pretrained"):
+                comp.save_pretrained(sub)
+            elif hasattr(comp, "save_config"):
+                comp.save_config(sub)
+        with open(os.path.join(save_directory, "model_index.json"), "w") as f:
+            json.dump(index, f, indent=2)
 
     def check_inputs(self, prompt, height, width, callback_steps):                        # :223-233
         if not isinstance(prompt, str) and not isinstance(prompt, list):
@@ -149,7 +196,7 @@ class StableDiffusionPipeline:
         width = width or self.unet.config.sample_size * self.vae_scale_factor
         self.check_inputs(prompt, height, width, callback_steps)
         if stage not in STAGES:
-            raise ValueError(f"stage must be one of {STAGES}")
+            stage = "no"                          # the reference treats every other string like 'no' (:425-427,436-438,444-445)
         if eta != 0.0:
             raise NotImplementedError("eta != 0 (stochastic DDIM) is not on the StoryGen path")
         batch_size = 1 if isinstance(prompt, str) else len(prompt)
@@ -175,19 +222,23 @@ class StableDiffusionPipeline:
         inputs = dict(latents=latents, image_prompts=imgs, zero_prompt=zero, noise=noise, text=text, uncond=uncond,
                       prev_text=torch.stack([p[n:] for p in prev]), prev_uncond=torch.stack([p[:n] for p in prev]))
         h, w = latents.shape[-2:]
-        key = (n, h, w, R, text.shape[1], id(getattr(self.unet, "_weights", None)))
+        # the repacked weights are refreshed IN PLACE when the UNet's parameters change (optimizer step, load_state_dict),
+        # so a cached sampler and its captured hipGraphs stay valid; only a new weights object (device change) rebuilds it
         wts = self.unet._engine_weights()
+        schedule = _as_schedule(self.scheduler)
+        key = (n, h, w, R, text.shape[1], id(wts), schedule.key())
         if self._sampler is None or self._sampler_key != key:
-            self._sampler = StoryGenSampler(self.unet._arch, None, device, n, h, w, R, text.shape[1],
-                                            schedule=_as_schedule(self.scheduler), weights=wts)
+            self._sampler = StoryGenSampler(self.unet._arch, None, device, n, h, w, R, text.shape[1], schedule=schedule, weights=wts)
             self._sampler_key = key
         smp = self._sampler
         smp.prepare(inputs, num_inference_steps, stage, guidance_scale, image_guidance_scale)
-        for i, t in enumerate(smp.timesteps):                                             # :411-469
-            smp.step(i)
-            if callback is not None and i % callback_steps == 0:
-                callback(i, t, smp.latents.to(dtype))
-        latents = smp.latents.to(dtype)
+        with self.progress_bar(total=len(smp.timesteps)) as bar:
+            for i, t in enumerate(smp.timesteps):                                         # :411-469
+                smp.step(i)
+                bar.update()
+                if callback is not None and i % callback_steps == 0:
+                    callback(i, t, smp.latents.to(dtype, copy=True))                      # never a view of the sampler's buffer
+        latents = smp.latents.to(dtype, copy=True)
         if output_type == "latent":
             image = latents
         else:

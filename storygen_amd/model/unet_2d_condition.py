@@ -128,6 +128,8 @@ class UNet2DConditionModel(nn.Module):
         self._engines: Dict[tuple, Any] = {}
         self._weights = None
         self._weights_tag = None
+        self._weights_dev = None
+        self._trainers = {}
 
     # ------------------------------------------------------------------------------------------ module tree
     def _register(self, dotted: str, p: nn.Parameter):
@@ -247,13 +249,27 @@ class UNet2DConditionModel(nn.Module):
 
     # ------------------------------------------------------------------------------------------ engine plumbing
     def _engine_weights(self):
+        """The repacked device weights, kept current with the module's parameters.  Staleness is tracked per parameter
+        ((data_ptr, _version) pairs); new values are copied INTO the existing repacked tensors, so engines, samplers and
+        captured hipGraphs built on them stay valid: an optimizer step on the attn3 modules (stage 2) re-packs just those,
+        anything else (load_state_dict, ...) re-packs the checkpoint in place.  Only a device change re-allocates."""
         from ..engine import EngineWeights
-        params = list(self.parameters())
-        tag = (self.device, sum(p._version for p in params), tuple(p.data_ptr() for p in params[:4]))
-        if self._weights is None or self._weights_tag != tag:
+        named = list(self.named_parameters())
+        tags = {n: (p.data_ptr(), p._version) for n, p in named}
+        if self._weights is None or self._weights_dev != self.device:
             self._weights = EngineWeights(self._arch, self.state_dict(), self.device)
-            self._weights_tag = tag
+            self._weights_dev = self.device
             self._engines.clear()
+            self._trainers.clear()
+        elif tags != self._weights_tag:
+            changed = [n for n, tg in tags.items() if self._weights_tag.get(n) != tg]
+            if all(".attn3." in n for n in changed):
+                prefixes = {n.split(".transformer_blocks.")[0] for n in changed}
+                self._weights.refresh_attn3_(self.state_dict(), prefixes)
+            else:
+                self._weights.reload_(self.state_dict())
+                self._trainers.clear()             # the trainer keeps its own repacked copies of the frozen layers
+        self._weights_tag = tags
         return self._weights
 
     def _engine(self, B: int, H: int, W: int, R: int, S: int):
@@ -274,11 +290,13 @@ class UNet2DConditionModel(nn.Module):
         shapes = feature_shapes(self._arch, H, W)
         k0 = self._arch.feature_keys[0]
         R = image_hidden_states[k0].shape[1] // shapes[k0][0]
-        key = ("train", B, H, W)
-        tr = self._engines.get(key)
+        key = (B, H, W, R)
+        tr = self._trainers.get(key)                     # kept apart from the inference engines' LRU
         if tr is None:
-            tr = self._engines[key] = UNetTrainer(self._arch, self.state_dict(), self.device, B, H, W, n_ref=R,
-                                                  ref_engine=object())      # reference passes go through forward(None)
+            self._trainers.clear()
+            tr = self._trainers[key] = UNetTrainer(self._arch, self.state_dict(), self.device, B, H, W, n_ref=R,
+                                                  ref_engine=object(),      # reference passes go through forward(None)
+                                                  weights=self._engine_weights())
         t = timestep if torch.is_tensor(timestep) else torch.tensor([timestep])
         t = t.to(self.device, torch.float32).reshape(-1)
         t = t.expand(B) if t.numel() == 1 else t
@@ -303,11 +321,6 @@ class UNet2DConditionModel(nn.Module):
             raise RuntimeError("the HIP UNet has no CPU path: move the model to a HIP device (model.to('cuda'))")
         training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if training:
-            # The HIP backward (storygen_amd/train.py) exists but has not met the hardware yet: opt-in until it has.
-            if os.environ.get("SG_ENABLE_TRAINING") != "1":
-                raise NotImplementedError("backward through the HIP UNet is not enabled (BASELINE config 4: written, not yet "
-                                          "validated on hardware — set SG_ENABLE_TRAINING=1 to use it); call under "
-                                          "torch.no_grad() or freeze the parameters")
             other = [n for n, p in self.named_parameters() if p.requires_grad and ".attn3." not in n]
             if other:
                 raise NotImplementedError(f"only the attn3 modules are trainable on the HIP path (stage 2, "

@@ -373,6 +373,19 @@ def cfg_ddim_step(eps3: torch.Tensor, latents: torch.Tensor, latents3: Optional[
     return latents
 
 
+def cfg_plms_step(eps3: torch.Tensor, latents: torch.Tensor, latents3: Optional[torch.Tensor], history: torch.Tensor,
+                  kept: torch.Tensor, coef: torch.Tensor) -> torch.Tensor:
+    """Guidance combine + PNDM/PLMS update (sg_cfg_plms_step_f32); history fp32 [4, *latents.shape], kept like latents."""
+    for n, t in (("eps3", eps3), ("latents", latents), ("history", history), ("kept", kept), ("coef", coef)):
+        _f32(t, n)
+    if history.numel() != 4 * latents.numel() or kept.numel() != latents.numel() or coef.numel() != 15:
+        raise ValueError("cfg_plms_step: history must hold 4 latents, kept 1, coef 15 floats")
+    N = latents.shape[0]
+    check(lib.sg_cfg_plms_step_f32(eps3.data_ptr(), latents.data_ptr(), _p(latents3), history.data_ptr(), kept.data_ptr(),
+                                   coef.data_ptr(), N, latents[0].numel(), _stream()), "sg_cfg_plms_step_f32")
+    return latents
+
+
 def copy_rows(dst: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
     """dst[b, r, :cols] = src[b, r, :cols] for 3-D views with unit channel stride; fp16->fp16, fp32->fp32 or
     fp32->fp16 (cast)."""

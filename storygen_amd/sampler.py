@@ -49,7 +49,9 @@ from .arch import UNetArch
 from .engine import EngineWeights, HarvestPlan, UNetEngine
 from .scheduler import DDIMSchedule
 
-STAGES = ("multi-image-condition", "auto-regressive")
+STAGES = ("multi-image-condition", "auto-regressive", "no")
+# "no" (pipeline.py:425-438,444-445; what train_StorySalon_stage1.py validates with): no reference passes, the main pass runs
+# without image context (attn3 is not evaluated) on [uncond, uncond, text] — a plain text-conditioned CFG loop.
 
 
 class StoryGenSampler:
@@ -85,11 +87,15 @@ class StoryGenSampler:
         self.main: Optional[UNetEngine] = None
         self.ref: Optional[UNetEngine] = None
         self.layout = None
+        self.no_ctx = False
         f32 = dict(dtype=torch.float32, device=self.dev)
         lat_shape = (n_samples, arch.config["in_channels"], height, width)
         self.latents = torch.zeros(lat_shape, **f32)
         self.latents3 = torch.zeros((self.B,) + lat_shape[1:], **f32)
         self.noise = torch.zeros(lat_shape, **f32)
+        if self.schedule.kind == "plms":          # PNDM: ring of the last 4 guided epsilons + the sample kept by the first call
+            self.eps_history = torch.zeros((4,) + lat_shape, **f32)
+            self.kept_sample = torch.zeros(lat_shape, **f32)
         self.table: Optional[torch.Tensor] = None
         self.num_steps = 0
         self.k = 0
@@ -141,7 +147,22 @@ class StoryGenSampler:
 
     def _build(self, stage: str, share_zero: bool):
         key = (stage if not share_zero else "shared-zero", self.dedup) if self.dedup else ("as-written", False)
+        if stage == "no":
+            key = ("no", False)
         if self.layout == key:
+            return
+        self.no_ctx = stage == "no"
+        if self.no_ctx:
+            if self.G > 1 or self.split:
+                raise ValueError("stage 'no' has no reference pass to batch or split off")
+            self.units, self.U, self.U0 = [], 0, 0
+            self.main = UNetEngine(self.arch, None, self.dev, self.B, self.h, self.w, 0, self.S, weights=self.weights)
+            self.ref, self.ctx_sets, self.kv_sets, self.plans = None, [], [], []
+            self.side_main = torch.cuda.Stream(device=self.dev) if self.use_graph else None
+            self.side_ref = None
+            self.n_par = self.B + 2 + self.schedule.row_len
+            self.params = torch.zeros(self.n_par, dtype=torch.float32, device=self.dev)
+            self.layout, self.graph, self.graphs, self.g_ref, self.g_main = key, None, [], [], []
             return
         units, hops, rows, groups = self._plan(stage, share_zero)
         G = self.G
@@ -175,8 +196,8 @@ class StoryGenSampler:
         self.side_ref = torch.cuda.Stream(device=self.dev) if want_ref else None
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.ref_src = torch.zeros((self.U,) + tuple(self.latents.shape[1:]), **f32)
-        # per-step parameters: [U] ref timesteps | [B] main timestep | [U,2] add_noise coefs | [6] guidance + DDIM coefs
-        self.n_par = 3 * self.U + self.B + 6
+        # per-step parameters: [U] ref timesteps | [B] main timestep | [U,2] add_noise coefs | guidance + update-rule coefs
+        self.n_par = 3 * self.U + self.B + 2 + self.schedule.row_len
         self.params = torch.zeros(self.n_par, **f32)
         self.layout, self.graph, self.graphs = key, None, []
         self.g_ref, self.g_main = [], []       # ref_ahead > 1: one graph per group parity / per context set
@@ -212,24 +233,25 @@ class StoryGenSampler:
         unc, txt = inputs["uncond"].to(dev, h), inputs["text"].to(dev, h)
         self.main.text_in.copy_(torch.cat([unc, unc, txt]))                               # pipeline.py:448
         zero, imgs = inputs["zero_prompt"].to(dev, torch.float32), inputs["image_prompts"].to(dev, torch.float32)
-        for u, (kind, i, n) in enumerate(self.units):                                     # :420-430
+        for u, (kind, i, n) in enumerate(self.units):                                     # :420-430 (none for stage "no")
             self.ref_src[u].copy_(zero[n] if kind == 0 else imgs[i, n])
             self.ref.text_in[u].copy_((pu[i][n] if kind == 0 else inputs["prev_text"][i][n]).to(dev, h))
         self.latents3.copy_(torch.cat([self.latents] * 3))                                # :450
         self.main.cache_text_kv()
-        self.ref.cache_text_kv()
+        if self.ref is not None:
+            self.ref.cache_text_kv()
         # per-step table
         ts = self.schedule.timesteps(num_inference_steps)
         rows, row0 = step_table(self.schedule, ts, num_inference_steps, self.units[:self.U0], R, stage, self.B, self.G,
-                                self.overlap, image_guidance_scale, guidance_scale)
+                                self.overlap and not self.no_ctx, image_guidance_scale, guidance_scale)
         self.row0_ref = torch.tensor(row0, dtype=torch.float32).pin_memory()
         self.table = torch.tensor(rows, dtype=torch.float32).pin_memory()
         self.timesteps = ts
-        self.num_steps = num_inference_steps
+        self.num_steps = len(ts)                  # PNDM: n + 1 UNet evaluations for n inference steps
         self.k = 0
         if self.use_graph and self.graph is None and not self.graphs and not self.g_main:
             self._capture()
-        if self.overlap:
+        if self.overlap and not self.no_ctx:
             self._prime()
 
     # ------------------------------------------------------------------------------------------------ the step
@@ -238,7 +260,8 @@ class StoryGenSampler:
         then the main pass.  NB in overlap mode `self.params` holds the reference-pass scalars of the NEXT step.
         With ref_ahead = G > 1 this is one whole GROUP: the batched reference pass of G steps and G main passes (all with
         the scalars of one table row: good for warm-up and kernel timing, not a valid piece of a trajectory)."""
-        self._ref_pass(0)
+        if not self.no_ctx:
+            self._ref_pass(0)
         for g in range(self.G):
             self._main_pass(g)
 
@@ -254,11 +277,15 @@ class StoryGenSampler:
     def _main_pass(self, ctx_set: int):
         _, t_main, _, cd = self._par_views()
         main = self.main
-        main.ctx, main.kv_ext = self.ctx_sets[ctx_set], self.kv_sets[ctx_set]
+        if not self.no_ctx:
+            main.ctx, main.kv_ext = self.ctx_sets[ctx_set], self.kv_sets[ctx_set]
         main.x_in.copy_(self.latents3)                                                    # :448-453
         main.t_in.copy_(t_main)
-        eps3 = main.forward(consume=True, text_cache=True, side=self.side_main)
-        ops.cfg_ddim_step(eps3, self.latents, self.latents3, cd)                          # :457-461
+        eps3 = main.forward(consume=not self.no_ctx, text_cache=True, side=self.side_main)
+        if self.schedule.kind == "plms":                                                  # :457-461
+            ops.cfg_plms_step(eps3, self.latents, self.latents3, self.eps_history, self.kept_sample, cd)
+        else:
+            ops.cfg_ddim_step(eps3, self.latents, self.latents3, cd)
 
     def _prime(self):
         """Overlap mode: the reference pass of step 0 (ref_ahead > 1: of the first group) has no main pass to hide behind."""
@@ -277,7 +304,7 @@ class StoryGenSampler:
             self._step_body()                                                             # warm-up (also validates args)
         torch.cuda.current_stream(dev).wait_stream(s)
         torch.cuda.synchronize(dev)
-        if not self.overlap:
+        if not self.overlap or self.no_ctx:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._step_body()
@@ -309,7 +336,8 @@ class StoryGenSampler:
                     self._main_pass(parity)                                               # main pass of step k
                     cur.wait_stream(side)                                                 # join
                 self.graphs.append(g)
-        self.main.ctx, self.main.kv_ext = self.ctx_sets[0], self.kv_sets[0]
+        if not self.no_ctx:
+            self.main.ctx, self.main.kv_ext = self.ctx_sets[0], self.kv_sets[0]
         self.latents.copy_(saved)
         self.latents3.copy_(torch.cat([saved] * 3))
         torch.cuda.synchronize(dev)
@@ -319,7 +347,7 @@ class StoryGenSampler:
         k = self.k if k is None else k
         if self.table is None or k >= self.table.shape[0]:
             raise RuntimeError("prepare() first / no steps left")
-        if self.overlap and k != self.k:
+        if self.overlap and not self.no_ctx and k != self.k:
             raise RuntimeError("overlapped sampling runs the steps in order (the graph of step k also runs the reference "
                                "pass of step k+1)")
         if self.g_main:
@@ -393,8 +421,8 @@ def step_table(schedule: DDIMSchedule, ts, num_inference_steps: int, units0, R: 
                image_guidance_scale: float, guidance_scale: float):
     """The scalars every denoising step needs, as rows of the pinned table the sampler uploads from (pure host logic).
 
-    Row k = [U reference timesteps | B main timesteps | U x 2 add_noise coefficients | 2 guidance scales + 4 DDIM
-    coefficients], U = G * len(units0).  units0 = the (kind, frame, sample) reference samples of ONE step.
+    Row k = [U reference timesteps | B main timesteps | U x 2 add_noise coefficients | 2 guidance scales + the update
+    rule's scalars (schedule.step_row: 4 for DDIM, 13 for PNDM/PLMS)], U = G * len(units0).  units0 = the (kind, frame, sample) reference samples of ONE step.
     Which reference scalars row k carries depends on the schedule of the passes:
       no overlap          : those of step k itself (reference pass, then main pass);
       overlap, G = 1      : those of step k+1 (graph k runs main pass k beside reference pass k+1);
@@ -427,10 +455,10 @@ def step_table(schedule: DDIMSchedule, ts, num_inference_steps: int, units0, R: 
         else:
             tt, cc = ref_part(ts[min(k + 1, T - 1)] if overlap else t)
         row = tt + [float(t)] * B + cc
-        row += [image_guidance_scale, guidance_scale, *schedule.step_coef(int(t), num_inference_steps)]
+        row += [image_guidance_scale, guidance_scale, *schedule.step_row(k, ts, num_inference_steps)]
         rows.append(row)
     tt, cc = group_ref(0) if G > 1 else ref_part(ts[0])
-    return rows, tt + [float(ts[0])] * B + cc + [0.0] * 6
+    return rows, tt + [float(ts[0])] * B + cc + [0.0] * (2 + schedule.row_len)
 
 
 def gather_latents(latents: torch.Tensor) -> torch.Tensor:

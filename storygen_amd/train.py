@@ -15,7 +15,7 @@ Structure
 """
 from __future__ import annotations
 
-from typing import Dict, List, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import torch
 
@@ -73,13 +73,13 @@ class Transformer2DTrain:
 
 class UNetTrainer:
     def __init__(self, arch: UNetArch, state_dict: Dict[str, torch.Tensor], device, batch: int, height: int, width: int,
-                 n_ref: int = 3, seq_len: int = 77, ref_engine=None):
+                 n_ref: int = 3, seq_len: int = 77, ref_engine=None, weights: Optional[EngineWeights] = None):
         """ref_engine: the object that runs the reference passes (set_inputs / forward(harvest_slot=) / .ctx); default = an
         inference UNetEngine on the same weights (tests inject a CPU stand-in to exercise the host logic without a GPU)."""
         self.arch, self.dev, self.cfg = arch, torch.device(device), arch.config
         self.B, self.H, self.W, self.R = batch, height, width, n_ref
         sd = state_dict
-        self.wts = EngineWeights(arch, sd, device)
+        self.wts = weights if weights is not None else EngineWeights(arch, sd, device)
         self.ref = ref_engine if ref_engine is not None else UNetEngine(arch, None, device, batch, height, width, n_ref, seq_len,
                                                                         weights=self.wts)
         self.groups, self.eps = self.cfg["norm_num_groups"], self.cfg["norm_eps"]
@@ -100,6 +100,13 @@ class UNetTrainer:
         self.w_conv_out_d = conv_in_kn(w_out.flip(2, 3).transpose(0, 1).contiguous())      # dgrad of conv_out = a 4 -> C conv_in
         self.zero_bias = torch.zeros(w_out.shape[1], dtype=F16, device=self.dev)
         self.schedule = DDIMSchedule()
+        # Loss scaling for the fp16 gradient operands (the reference trains under accelerate's fp16 GradScaler,
+        # train_StorySalon_stage2.py:138-141,328): the MSE gradient of a mean over B*4*H*W elements is ~1e-3 and the
+        # attention-score gradients dS = P (dP - delta) reach 1e-7..1e-8 — below fp16's subnormal range — so the backward
+        # walk runs on s * d_pred and the fp32 weight gradients are divided by s.  "auto": s = the power of two that brings
+        # max|d_pred| to 2^8 (one host read per step), retried 16x smaller if a gradient comes out non-finite.
+        self.grad_scale = "auto"
+        self.last_grad_scale = 1.0
 
     # ------------------------------------------------------------------------------------------------ pieces
     def _add_noise(self, x: torch.Tensor, noise: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
@@ -246,7 +253,27 @@ class UNetTrainer:
         return pred
 
     def backward_main(self, d_pred: torch.Tensor) -> Dict[str, torch.Tensor]:
-        """d_pred fp32 NCHW [B,4,H,W] -> {attn3 parameter name: fp32 gradient} (the walk of oracle unet_backward)."""
+        """d_pred fp32 NCHW [B,4,H,W] -> {attn3 parameter name: fp32 gradient} (the walk of oracle unet_backward), run on a
+        power-of-two multiple of d_pred (self.grad_scale) so that fp16 gradient operands keep their precision."""
+        import math
+        if self.grad_scale == "auto":
+            amax = float(d_pred.abs().max())
+            s = 2.0 ** math.floor(math.log2(256.0 / amax)) if 0.0 < amax < float("inf") else 1.0
+        else:
+            s = float(self.grad_scale)
+        while True:
+            grads = self._backward_scaled(d_pred * s if s != 1.0 else d_pred)
+            flat_ok = all(bool(torch.isfinite(g).all()) for g in grads.values()) if self.grad_scale == "auto" else True
+            if flat_ok or s <= 2.0 ** -8:
+                break
+            s /= 16.0
+        self.last_grad_scale = s
+        if s != 1.0:
+            for g in grads.values():
+                g.mul_(1.0 / s)
+        return grads
+
+    def _backward_scaled(self, d_pred: torch.Tensor) -> Dict[str, torch.Tensor]:
         dev, B, H, W = self.dev, self.B, self.H, self.W
         tape, x_out = self._tape, self._x_out
         boc0 = self.cfg["block_out_channels"][0]

@@ -1,17 +1,12 @@
 """HIP backward kernels (BASELINE config 4) against the hand-written CPU backward (oracle/storygen_backward.py, itself
 checked against torch.autograd and the reference's gradients in tests/test_oracle_backward.py).
 
-These kernels were written after round 1's GPU budget was spent: they compile for gfx950 but have NOT yet run on
-hardware, so the whole module is skipped unless SG_TEST_UNVALIDATED=1 (first thing to run in the next round)."""
-import os
-
+First hardware run: round 2, call 1 (gpurun_out/r2c1): every kernel-level and block-level test green as written."""
 import pytest
 import torch
 import torch.nn.functional as F
 
-pytestmark = [pytest.mark.gpu,
-              pytest.mark.skipif(os.environ.get("SG_TEST_UNVALIDATED") != "1",
-                                 reason="backward kernels not yet run on hardware (set SG_TEST_UNVALIDATED=1)")]
+pytestmark = pytest.mark.gpu
 
 
 def rnd(shape, dev, scale=1.0, seed=0, dtype=torch.float16):

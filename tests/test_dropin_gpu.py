@@ -125,3 +125,121 @@ def test_pipeline_call_vs_reference_golden(gpu, model):
     print(f"pipeline latents rel-L2 vs reference: {err:.2e}; callbacks {seen}")
     assert seen == [(0, 1)] or len(seen) == gold["n_steps"]
     assert err <= 1.5e-3          # fp16 latents in/out (the reference's fp16 pipeline rounds them too) on top of the 1e-3 kernel bar
+
+
+def _table_pipeline(unet, inputs, R, gpu, scheduler, table_dtype):
+    from storygen_amd.model import StableDiffusionPipeline
+    table = torch.stack([inputs["uncond"][0], inputs["text"][0]] + [inputs["prev_text"][i][0] for i in range(R)]).to(gpu, table_dtype)
+    vae = _Vae([inputs["zero_prompt"].to(gpu)] + [inputs["image_prompts"][i].to(gpu) for i in range(R)])
+    return StableDiffusionPipeline(vae=vae, text_encoder=_Enc(table), tokenizer=_Tok(["", "main"] + [f"prev{i}" for i in range(R)]),
+                                   unet=unet, scheduler=scheduler), vae
+
+
+def _call(pipe, inputs, R, hw, steps, guidance, stage, latents, **kw):
+    want_noise = inputs["noise"]
+    orig = torch.randn_like
+    torch.randn_like = lambda t, **k: want_noise.to(t.device, t.dtype)      # pipeline.py:409 draws it from the global generator
+    try:
+        return pipe(stage=stage, prompt="main", image_prompt=torch.zeros(1, R, 3, 8 * hw, 8 * hw),
+                    prev_prompt=[f"prev{i}" for i in range(R)], height=8 * hw, width=8 * hw, num_inference_steps=steps,
+                    guidance_scale=guidance[0], image_guidance_scale=guidance[1], latents=latents, output_type="latent", **kw)
+    finally:
+        torch.randn_like = orig
+
+
+def test_pipeline_call_full_depth_vs_reference_golden(gpu, model):
+    """The north-star bar through the drop-in `StableDiffusionPipeline.__call__` (inference.py:103-115): all 50 DDIM steps
+    of BASELINE config 2 (512x512, R = 3) against the FINAL latents of the reference's own pipeline run
+    (tests/golden/sd15_64_r3_full.pt).  fp32 embeddings / latents in, so the pipeline's `dtype` is fp32 and nothing but the
+    HIP loop rounds; bar 1e-3 rel-L2 at step 50 and at the probed steps 10 / 25."""
+    from storygen_amd.scheduler import DDIMSchedule
+    from storygen_amd.synth import synthetic_inputs
+    path = os.path.join(GOLDEN, "sd15_64_r3_full.pt")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated")
+    unet, _ = model
+    gold = torch.load(path, weights_only=False)
+    R = gold["n_ref"]
+    inputs = synthetic_inputs(1, R, 64, 64, gold["seed"], 768)
+    pipe, _ = _table_pipeline(unet, inputs, R, gpu, DDIMSchedule(), torch.float32)
+    pipe.set_progress_bar_config(disable=True)                       # train_StorySalon_stage2.py:157
+    seen = {}
+    out = _call(pipe, inputs, R, 64, gold["n_steps"], gold["guidance"], "multi-image-condition", inputs["latents"].to(gpu),
+                callback=lambda i, t, lat: seen.__setitem__(i, lat.float().cpu()), callback_steps=1)
+    want = gold["stages"]["multi-image-condition"]["latents"]
+    errs = {i: rel_l2(seen[i], want[i]) for i in (0, 9, 24, 49)}
+    errs["final"] = rel_l2(out.images.float().cpu(), want[-1])
+    print("pipeline latents rel-L2 vs reference:", {k: f"{v:.2e}" for k, v in errs.items()})
+    assert len(seen) == 50 and max(errs.values()) <= 1e-3, errs
+
+
+def test_pipeline_sees_new_unet_weights_between_calls(gpu):
+    """a second pipeline call after the UNet's parameters changed (training step before validation,
+    train_StorySalon_stage2.py:328-346; load_state_dict) must run on the NEW weights although the sampler and its hipGraphs
+    are cached: the repacked weights are refreshed in place."""
+    from storygen_amd.arch import build_arch, load_config
+    from storygen_amd.model import UNet2DConditionModel
+    from storygen_amd.sampler import StoryGenSampler
+    from storygen_amd.scheduler import DDIMSchedule
+    from storygen_amd.synth import synthetic_inputs, synthetic_state_dict
+    cfg = dict(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+               up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), cross_attention_dim=768, attention_head_dim=8, sample_size=128)
+    arch = build_arch(load_config(cfg))
+    sd_a, sd_b = synthetic_state_dict(arch, 1), synthetic_state_dict(arch, 2)
+    unet = UNet2DConditionModel.from_config(cfg)
+    unet.load_state_dict(sd_a)
+    unet = unet.to(gpu, torch.float16).eval()
+    R, hw = 1, 16
+    inputs = synthetic_inputs(1, R, hw, hw, 4, 768)
+    pipe, vae = _table_pipeline(unet, inputs, R, gpu, DDIMSchedule(), torch.float32)
+    pipe.set_progress_bar_config(disable=True)
+    lat = inputs["latents"].to(gpu)
+
+    def run():
+        vae.queue = [inputs["zero_prompt"].to(gpu)] + [inputs["image_prompts"][i].to(gpu) for i in range(R)]
+        return _call(pipe, inputs, R, hw, 50, (7.5, 3.5), "multi-image-condition", lat, callback=None).images.float().cpu()
+    a1 = run()
+    smp = pipe._sampler
+    # (i) every parameter changes
+    unet.load_state_dict(sd_b)
+    b1 = run()
+    assert pipe._sampler is smp, "in-place weight refresh must keep the cached sampler (and its hipGraphs)"
+    fresh = StoryGenSampler(arch, sd_b, gpu, 1, hw, hw, R)
+    fresh.prepare(inputs, 50, "multi-image-condition", 7.5, 3.5)
+    want_b = fresh.run().float().cpu()
+    assert not torch.equal(a1, b1) and rel_l2(b1, want_b) < 1e-6
+    # (ii) only attn3 changes, in place (an optimizer step of stage 2)
+    with torch.no_grad():
+        for n, p in unet.named_parameters():
+            if ".attn3." in n:
+                p.mul_(0.5)
+    sd_c = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
+    c1 = run()
+    fresh = StoryGenSampler(arch, sd_c, gpu, 1, hw, hw, R)
+    fresh.prepare(inputs, 50, "multi-image-condition", 7.5, 3.5)
+    assert not torch.equal(b1, c1) and rel_l2(c1, fresh.run().float().cpu()) < 1e-6
+    # output tensors are copies, not views of the sampler's latents buffer (ADVICE r1)
+    assert c1.data_ptr() != pipe._sampler.latents.data_ptr()
+
+
+def test_pipeline_save_pretrained_writes_the_whole_pipeline(gpu, model, tmp_path):
+    """train_StorySalon_stage2.py:348-357 saves the pipeline, not just the UNet."""
+    import json
+    from storygen_amd.scheduler import PNDMSchedule
+    unet, _ = model
+
+    class _Saver:
+        def save_pretrained(self, d):
+            os.makedirs(d, exist_ok=True)
+            open(os.path.join(d, "marker"), "w").close()
+    from storygen_amd.model import StableDiffusionPipeline
+    pipe = StableDiffusionPipeline(vae=_Saver(), text_encoder=_Saver(), tokenizer=_Saver(), unet=unet,
+                                   scheduler=PNDMSchedule(skip_prk_steps=True))
+    assert pipe.to(gpu) is pipe and pipe.device.type == "cuda"
+    pipe.save_pretrained(str(tmp_path))
+    idx = json.load(open(tmp_path / "model_index.json"))
+    assert idx["_class_name"] == "StableDiffusionPipeline" and idx["unet"][1] == "UNet2DConditionModel"
+    assert json.load(open(tmp_path / "scheduler" / "scheduler_config.json"))["_class_name"] == "PNDMScheduler"
+    for sub in ("vae", "text_encoder", "tokenizer"):
+        assert (tmp_path / sub / "marker").exists()
+    assert (tmp_path / "unet" / "config.json").exists()

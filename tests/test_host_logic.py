@@ -40,6 +40,57 @@ def test_ddim_schedule_from_shipped_json(tmp_path):
     assert s.timesteps(50)[0] == 981 and torch.equal(s.alphas_cumprod, DDIMSchedule().alphas_cumprod)
 
 
+def test_scheduler_configs_are_honoured_or_rejected():
+    """trained_betas must be used, non-epsilon prediction / unknown keys / unknown classes must raise, and the
+    config may be a dict or an attribute object (the shim's DDIMScheduler.config)."""
+    from types import SimpleNamespace
+    from storygen_amd.scheduler import DDIMSchedule, PNDMSchedule, schedule_from_config
+    betas = torch.linspace(1e-4, 2e-2, 1000).tolist()
+    s = DDIMSchedule(trained_betas=betas)
+    assert torch.allclose(s.alphas_cumprod, torch.cumprod(1 - torch.tensor(betas), 0))
+    assert not torch.equal(s.alphas_cumprod, DDIMSchedule().alphas_cumprod)
+    with pytest.raises(NotImplementedError, match="prediction_type"):
+        DDIMSchedule(prediction_type="v_prediction")
+    with pytest.raises(NotImplementedError, match="unsupported scheduler config keys"):
+        DDIMSchedule(thresholding=True)
+    cfg = dict(num_train_timesteps=1000, beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", steps_offset=1,
+               set_alpha_to_one=False, skip_prk_steps=True, trained_betas=None)
+    assert isinstance(schedule_from_config(dict(cfg, _class_name="PNDMScheduler")), PNDMSchedule)
+    assert type(schedule_from_config(SimpleNamespace(**cfg), "DDIMScheduler")) is DDIMSchedule      # attribute-style config
+    with pytest.raises(NotImplementedError, match="EulerDiscreteScheduler"):
+        schedule_from_config(cfg, "EulerDiscreteScheduler")
+    with pytest.raises(NotImplementedError, match="skip_prk_steps"):
+        PNDMSchedule(skip_prk_steps=False)
+    assert DDIMSchedule().key() == DDIMSchedule().key() != PNDMSchedule(skip_prk_steps=True).key()
+
+
+def test_plms_table_reproduces_the_stateful_pndm_rule():
+    """The device applies PNDM/PLMS from a per-call table (PNDMSchedule.step_row: weights over a 4-slot ring of past
+    epsilons); here that table, executed in plain torch exactly as sg_cfg_plms_step_f32 does, is compared with the stateful
+    restatement of diffusers' PNDMScheduler.step_plms in the oracle."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.scheduler import PNDMSchedule
+    g = torch.Generator().manual_seed(0)
+    for n in (1, 2, 3, 5, 12, 50):
+        ps, po = PNDMSchedule(skip_prk_steps=True), O.PNDM()
+        ts = ps.timesteps(n)
+        assert ts == po.timesteps(n) and len(ts) == (n + 1 if n > 1 else 1)
+        x = torch.randn(4, 8, generator=g, dtype=torch.float64)
+        xo, hist, kept = x.clone(), torch.zeros(4, 4, 8, dtype=torch.float64), torch.zeros(4, 8, dtype=torch.float64)
+        for k, t in enumerate(ts):
+            e = torch.randn(4, 8, generator=g, dtype=torch.float64)
+            A, Bc, w0, w1, w2, w3, cur, s1, s2, s3, push, use_kept, keep = ps.step_row(k, ts, n)
+            ep = w0 * e + w1 * hist[int(s1)] + w2 * hist[int(s2)] + w3 * hist[int(s3)]
+            if push:
+                hist[int(cur)] = e
+            xs = kept.clone() if use_kept else x
+            if keep:
+                kept = x.clone()
+            x = A * xs - Bc * ep
+            xo = po.step(e, t, xo, n)
+            assert torch.allclose(x, xo.double(), rtol=1e-5, atol=1e-6), (n, k)
+
+
 # ------------------------------------------------------------------------------------------------ architecture
 def test_arch_sd15_parameter_census():
     from storygen_amd.arch import SD15_CONFIG, build_arch, feature_shapes, param_shapes

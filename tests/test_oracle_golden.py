@@ -94,6 +94,18 @@ def test_oracle_loop_vs_reference_golden_tiny(stage):
     assert max(errs) < TOL, errs
 
 
+def test_oracle_loop_stage_no_vs_reference_golden_tiny():
+    """stage 'no' (pipeline.py:436-438,444-445: no reference pass, main pass without image context) against the latents the
+    reference's pipeline produced for it (tests/golden/tiny_no.pt)."""
+    from oracle import storygen_oracle as O
+    gold = _load("tiny_no")
+    arch, sd, inputs = _setup(gold)
+    want = gold["stages"]["no"]["latents"]
+    got = []
+    O.sample_loop(sd, arch.config, inputs, gold["n_steps"], "no", *gold["guidance"], max_steps=len(want), trace=got)
+    assert max(rel_l2(a, b) for a, b in zip(got, want)) < TOL
+
+
 @pytest.mark.skipif(os.environ.get("SG_SLOW_TESTS") != "1", reason="~1 min of CPU; set SG_SLOW_TESTS=1")
 def test_oracle_unet_pass_vs_reference_golden_sd15():
     from oracle import storygen_oracle as O

@@ -101,6 +101,86 @@ def test_denoise_steps_vs_reference_golden_64x64(gpu, sd15, case):
     assert max(errs) <= TOL_LATENT, errs
 
 
+@pytest.mark.parametrize("case,stage", [("sd15_64_r3_full", "multi-image-condition"), ("sd15_64_r3_ar_full", "auto-regressive")])
+def test_full_depth_50_steps_vs_reference_golden_64x64(gpu, sd15, case, stage):
+    """BASELINE config 2 at FULL depth — the north-star's bar is on the final latents: all 50 DDIM steps of the DEFAULT
+    schedule (one hipGraph per step, dedup of identical reference samples, reference pass of step k+1 overlapped with the
+    main pass of step k) against the latents the reference's own pipeline loop produced after every step
+    (oracle/make_golden.py `sd15_64_r3_full` / `sd15_64_r3_ar_full`: 512x512, R=3, guidance 7.5 / 3.5).
+    Bar: rel-L2 <= 1e-3 after EVERY step, in particular at steps 9 / 24 / 49."""
+    from storygen_amd.sampler import StoryGenSampler
+    from storygen_amd.synth import synthetic_inputs
+    path = os.path.join(GOLDEN, f"{case}.pt")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated")
+    gold = torch.load(path, weights_only=False)
+    arch, sd = sd15
+    R, hw = gold["n_ref"], gold["hw"]
+    inputs = synthetic_inputs(1, R, hw, hw, gold["seed"], arch.config["cross_attention_dim"])
+    smp = StoryGenSampler(arch, sd, gpu, 1, hw, hw, R)           # every default: graph + dedup + overlap
+    assert smp.use_graph and smp.dedup and smp.overlap
+    smp.prepare(inputs, gold["n_steps"], stage, *gold["guidance"])
+    want = gold["stages"][stage]["latents"]
+    assert len(want) == gold["n_steps"] == 50
+    trace = []
+    smp.run(trace=trace)
+    torch.cuda.synchronize()
+    errs = [rel_l2(a.cpu(), b) for a, b in zip(trace, want)]
+    print(case, "latent rel-L2 at steps 0/9/24/49:", [f"{errs[i]:.2e}" for i in (0, 9, 24, 49)], "max", f"{max(errs):.2e}")
+    assert len(errs) == 50 and max(errs) <= TOL_LATENT, errs
+
+
+def test_stage_no_vs_oracle_32x32(gpu, sd15):
+    """stage 'no' (pipeline.py:436-438,444-445; the oracle's restatement of it is pinned to the reference's own run by
+    tests/golden/tiny_no.pt): no reference pass, main pass without image context, plain text CFG."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.sampler import StoryGenSampler
+    from storygen_amd.synth import synthetic_inputs
+    arch, sd = sd15
+    inputs = synthetic_inputs(1, 2, 32, 32, 5, arch.config["cross_attention_dim"])
+    want = []
+    O.sample_loop(sd, arch.config, inputs, 50, "no", 7.5, 3.5, max_steps=3, trace=want)
+    smp = StoryGenSampler(arch, sd, gpu, 1, 32, 32, 2)
+    smp.prepare(inputs, 50, "no", 7.5, 3.5)
+    got = []
+    smp.run(max_steps=3, trace=got)
+    torch.cuda.synchronize()
+    errs = [rel_l2(a.cpu(), b) for a, b in zip(got, want)]
+    assert max(errs) <= TOL_LATENT, errs
+    # and back to a context stage on the same sampler object (the layout is rebuilt)
+    smp.prepare(inputs, 50, "multi-image-condition", 7.5, 3.5)
+    smp.run(max_steps=1)
+    torch.cuda.synchronize()
+    assert torch.isfinite(smp.latents).all()
+
+
+@pytest.mark.parametrize("stage", ["multi-image-condition", "auto-regressive"])
+def test_pndm_loop_vs_oracle_32x32(gpu, sd15, stage):
+    """PNDM / PLMS (skip_prk_steps) in the loop — the scheduler class ckpt/stable-diffusion-v1-5/scheduler/scheduler_config.json
+    names and model/pipeline.py:7-16 accepts: 5 inference steps = 6 UNet evaluations (the second timestep is visited twice),
+    which exercises every branch of the multistep rule (1, 2, 3 and 4 history terms); against the oracle's stateful
+    restatement of diffusers' PNDMScheduler (parity unpinned: diffusers is absent, see oracle.storygen_oracle.PNDM)."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.sampler import StoryGenSampler
+    from storygen_amd.scheduler import PNDMSchedule
+    from storygen_amd.synth import synthetic_inputs
+    arch, sd = sd15
+    inputs = synthetic_inputs(1, 2, 32, 32, 9, arch.config["cross_attention_dim"])
+    want = []
+    O.sample_loop(sd, arch.config, inputs, 5, stage, 7.5, 3.5, trace=want, scheduler="pndm")
+    smp = StoryGenSampler(arch, sd, gpu, 1, 32, 32, 2, schedule=PNDMSchedule(skip_prk_steps=True))
+    smp.prepare(inputs, 5, stage, 7.5, 3.5)
+    assert smp.timesteps == [801, 601, 601, 401, 201, 1] and smp.num_steps == 6
+    got = []
+    smp.run(trace=got)
+    torch.cuda.synchronize()
+    errs = [rel_l2(a.cpu(), b) for a, b in zip(got, want)]
+    print(stage, [f"{e:.2e}" for e in errs])
+    # a 5-step schedule multiplies the per-pass epsilon error by far larger coefficients than the 50-step one the 1e-3 bar
+    # is stated for: 3e-3 here
+    assert len(errs) == 6 and max(errs) <= 3e-3, errs
+
+
 def test_unet_single_pass_vs_reference_golden_64x64(gpu, sd15):
     """One harvest pass + one main pass at 64x64 against probes of the reference UNet's own outputs."""
     from oracle import storygen_oracle as O
@@ -192,8 +272,6 @@ def test_dedup_of_identical_reference_samples_is_equivalent(gpu, sd15, stage):
     assert max(errs) <= TOL_LATENT and rel_l2(outs[0], outs[1]) <= TOL_LATENT
 
 
-@pytest.mark.skipif(os.environ.get("SG_TEST_UNVALIDATED") != "1",
-                    reason="written after round 1's GPU budget was spent: not yet run on hardware (set SG_TEST_UNVALIDATED=1)")
 def test_split_graphs_with_stream_priority_is_the_same_trajectory(gpu, sd15):
     """split_graphs (+ stream_priority): the same kernels as the single-graph overlap schedule, launched as two graphs
     on two (prioritised) streams — bit-identical latents."""
