@@ -179,7 +179,6 @@ def test_pipeline_sees_new_unet_weights_between_calls(gpu):
     are cached: the repacked weights are refreshed in place."""
     from storygen_amd.arch import build_arch, load_config
     from storygen_amd.model import UNet2DConditionModel
-    from storygen_amd.sampler import StoryGenSampler
     from storygen_amd.scheduler import DDIMSchedule
     from storygen_amd.synth import synthetic_inputs, synthetic_state_dict
     cfg = dict(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
@@ -200,14 +199,20 @@ def test_pipeline_sees_new_unet_weights_between_calls(gpu):
         return _call(pipe, inputs, R, hw, 50, (7.5, 3.5), "multi-image-condition", lat, callback=None).images.float().cpu()
     a1 = run()
     smp = pipe._sampler
+
+    def fresh_run(sd):
+        """The same call through a brand-new UNet + pipeline + sampler holding `sd` (bit-exact comparison partner)."""
+        u2 = UNet2DConditionModel.from_config(cfg)
+        u2.load_state_dict(sd)
+        p2, v2 = _table_pipeline(u2.to(gpu, torch.float16).eval(), inputs, R, gpu, DDIMSchedule(), torch.float32)
+        p2.set_progress_bar_config(disable=True)
+        return _call(p2, inputs, R, hw, 50, (7.5, 3.5), "multi-image-condition", lat, callback=None).images.float().cpu()
+    assert torch.equal(a1, fresh_run(sd_a))
     # (i) every parameter changes
     unet.load_state_dict(sd_b)
     b1 = run()
     assert pipe._sampler is smp, "in-place weight refresh must keep the cached sampler (and its hipGraphs)"
-    fresh = StoryGenSampler(arch, sd_b, gpu, 1, hw, hw, R)
-    fresh.prepare(inputs, 50, "multi-image-condition", 7.5, 3.5)
-    want_b = fresh.run().float().cpu()
-    assert not torch.equal(a1, b1) and rel_l2(b1, want_b) < 1e-6
+    assert not torch.equal(a1, b1) and torch.equal(b1, fresh_run(sd_b))
     # (ii) only attn3 changes, in place (an optimizer step of stage 2)
     with torch.no_grad():
         for n, p in unet.named_parameters():
@@ -215,11 +220,12 @@ def test_pipeline_sees_new_unet_weights_between_calls(gpu):
                 p.mul_(0.5)
     sd_c = {k: v.detach().float().cpu() for k, v in unet.state_dict().items()}
     c1 = run()
-    fresh = StoryGenSampler(arch, sd_c, gpu, 1, hw, hw, R)
-    fresh.prepare(inputs, 50, "multi-image-condition", 7.5, 3.5)
-    assert not torch.equal(b1, c1) and rel_l2(c1, fresh.run().float().cpu()) < 1e-6
+    assert pipe._sampler is smp
+    assert not torch.equal(b1, c1) and torch.equal(c1, fresh_run(sd_c))
     # output tensors are copies, not views of the sampler's latents buffer
-    assert c1.data_ptr() != pipe._sampler.latents.data_ptr()
+    vae.queue = [inputs["zero_prompt"].to(gpu)] + [inputs["image_prompts"][i].to(gpu) for i in range(R)]
+    img = _call(pipe, inputs, R, hw, 2, (7.5, 3.5), "multi-image-condition", lat, callback=None).images
+    assert img.is_cuda and img.data_ptr() != pipe._sampler.latents.data_ptr()
 
 
 def test_pipeline_save_pretrained_writes_the_whole_pipeline(gpu, model, tmp_path):
@@ -243,3 +249,34 @@ def test_pipeline_save_pretrained_writes_the_whole_pipeline(gpu, model, tmp_path
     for sub in ("vae", "text_encoder", "tokenizer"):
         assert (tmp_path / sub / "marker").exists()
     assert (tmp_path / "unet" / "config.json").exists()
+
+
+@pytest.mark.parametrize("query_dim,ctx_dim,heads,dim_head,Nq,Nk", [(320, None, 8, 40, 1024, 1024), (640, 768, 8, 80, 256, 77),
+                                                                    (1280, 1280, 8, 160, 64, 192)])
+def test_hip_attention_processor_on_a_diffusers_cross_attention_module(gpu, query_dim, ctx_dim, heads, dim_head, Nq, Nk):
+    """The operator-level plug-in: HipCrossAttnProcessor installed with `set_processor` on a diffusers-0.13.1-style
+    CrossAttention module (the class model/attention.py:175-223 instantiates; here the clean-room shim's) must reproduce the
+    default processor — self-attention, text cross-attention (77 tokens: padded + masked) and image cross-attention."""
+    import sys
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "diffusers_shim")
+    sys.path.insert(0, shim)
+    try:
+        from diffusers.models.cross_attention import CrossAttention
+    finally:
+        sys.path.remove(shim)
+    from storygen_amd.model import HipCrossAttnProcessor
+    torch.manual_seed(0)
+    attn = CrossAttention(query_dim=query_dim, cross_attention_dim=ctx_dim, heads=heads, dim_head=dim_head).half()
+    attn = attn.float().half()
+    h = torch.randn(2, Nq, query_dim).half()
+    ctx = None if ctx_dim is None else torch.randn(2, Nk, ctx_dim).half()
+    with torch.no_grad():
+        want = attn.float()(h.float(), None if ctx is None else ctx.float())          # default processor, fp32, CPU
+    attn = attn.half().to(gpu)
+    attn.set_processor(HipCrossAttnProcessor())
+    got = attn(h.to(gpu), encoder_hidden_states=None if ctx is None else ctx.to(gpu))
+    torch.cuda.synchronize()
+    assert got.shape == want.shape and got.dtype == torch.float16
+    assert rel_l2(got.float().cpu(), want) < 3e-3
+    with pytest.raises(NotImplementedError):
+        attn(h.to(gpu), attention_mask=torch.zeros(1, device=gpu))
