@@ -117,6 +117,7 @@ SIGNATURES = {
     "sg_device_arch": (C.c_int, []),
     "sg_device_cus": (C.c_int, []),
     "sg_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "sg_gemm_pair_f16": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), C.c_void_p]),
     "sg_gemm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sg_conv3x3_nhwc_f16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
     "sg_conv_in_f16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
@@ -134,6 +135,7 @@ SIGNATURES = {
     "sg_add_noise_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
                                    C.c_void_p]),
     "sg_cfg_ddim_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
+    "sg_workspace_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "sg_cfg_plms_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                        C.c_void_p]),
     "sg_copy_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,

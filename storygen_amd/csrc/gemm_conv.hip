@@ -20,8 +20,10 @@
 //     row-contiguous; epilogue math is fp32; outputs and residuals may be fp16 or fp32 (the UNet's residual stream
 //     is kept in fp32, MFMA operands in fp16).
 //   * block ids are remapped so that consecutive tiles (same A row panel) run on the same XCD / L2.
-//   * small-M layers (16x16 / 8x8 latent levels at batch 3) are split along K over blockIdx.y into fp32 partial
-//     tiles; a second kernel reduces them and applies the epilogue (deterministic, no atomics).
+//   * small-M layers (16x16 / 8x8 latent levels at batch 3) are split along K into fp32 partial tiles (the slices of a
+//     tile are consecutive logical block ids, i.e. they run on one XCD); the slice that arrives LAST at the tile's
+//     ticket counter sums all partial tiles in slice order (deterministic) and applies the fused epilogue — one launch,
+//     no separate reduce kernel (agent-scope release / acquire hand-off, cdna_hip_programming.md §5 "in-launch split-K").
 #include "common.h"
 #include <stdlib.h>
 
@@ -29,6 +31,8 @@ namespace {
 
 constexpr int BK = 64;
 constexpr int MAX_AUTO_SPLIT = 16;
+constexpr size_t WS_COUNTER_BYTES = SG_WS_COUNTER_BYTES;           // tail of every workspace: per-tile arrival counters
+constexpr int MAX_SPLIT_TILES = (int)(WS_COUNTER_BYTES / sizeof(int));
 
 struct MmaParams {
     const f16* A; long lda;
@@ -45,7 +49,7 @@ struct MmaParams {
     const void* res1; long ldr1;
     const void* res2; long ldr2;
     // decomposition
-    float* ws; int splits; int kt_per_split; int tiles_m, tiles_n;
+    float* ws; int* cnt; int splits; int kt_per_split; int tiles_m, tiles_n;
     int n_major;   // tile order: 1 = consecutive ids walk M first (tiles sharing a weight panel stay on one XCD / L2)
 };
 
@@ -109,16 +113,85 @@ __device__ __forceinline__ void epi_geglu8(const MmaParams& p, int gm, int gv, f
     store_out8(p, gm, (gv >> 6) * 32 + (gv & 31), o);   // interleaved column -> output column
 }
 
+// Split-K: sum the `splits` fp32 partial tiles of output tile (m0, n0) in slice order and apply the epilogue.  Run by the
+// whole workgroup of the slice that arrived last.  Partial tiles are requested several slices at a time (one memory round
+// trip instead of one per slice) and added in slice order, so the result does not depend on the arrival order.
+template <int BM, int BN, int NT>
+__device__ __forceinline__ void reduce_tile(const MmaParams& p, int m0, int n0) {
+    const size_t MN = (size_t)p.M * p.N;
+    const int t = threadIdx.x;
+    if (p.mode == SG_EPI_LINEAR) {
+        constexpr int NCH = BN / 8;
+        for (int idx = t; idx < BM * NCH; idx += NT) {
+            const int lr = idx / NCH, ch = idx - lr * NCH;
+            const int gm = m0 + lr, gn = n0 + ch * 8;
+            if (gm >= p.M || gn >= p.N) continue;
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const float* s = p.ws + (size_t)gm * p.N + gn;
+            for (int z0 = 0; z0 < p.splits; z0 += 4) {
+                float4 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a[u] = b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (z0 + u < p.splits) {
+                        a[u] = *reinterpret_cast<const float4*>(s + (z0 + u) * MN);
+                        b[u] = *reinterpret_cast<const float4*>(s + (z0 + u) * MN + 4);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
+                    v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+                }
+            }
+            epi_linear8(p, gm, gn, v);
+        }
+    } else {
+        constexpr int OCH = BN / 16;
+        for (int idx = t; idx < BM * OCH; idx += NT) {
+            const int lr = idx / OCH, j = idx - lr * OCH;
+            const int gm = m0 + lr, gv = n0 + (j >> 2) * 64 + (j & 3) * 8;
+            if (gm >= p.M || gv >= p.N) continue;
+            float val[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gate[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const float* s = p.ws + (size_t)gm * p.N + gv;
+            for (int z0 = 0; z0 < p.splits; z0 += 2) {      // two slices (4 x 16 B each) per memory round trip
+                float4 q[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) q[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (z0 + u < p.splits) {
+                        const float* src = s + (z0 + u) * MN;
+                        q[u][0] = *reinterpret_cast<const float4*>(src);
+                        q[u][1] = *reinterpret_cast<const float4*>(src + 4);
+                        q[u][2] = *reinterpret_cast<const float4*>(src + 32);
+                        q[u][3] = *reinterpret_cast<const float4*>(src + 36);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    val[0] += q[u][0].x; val[1] += q[u][0].y; val[2] += q[u][0].z; val[3] += q[u][0].w;
+                    val[4] += q[u][1].x; val[5] += q[u][1].y; val[6] += q[u][1].z; val[7] += q[u][1].w;
+                    gate[0] += q[u][2].x; gate[1] += q[u][2].y; gate[2] += q[u][2].z; gate[3] += q[u][2].w;
+                    gate[4] += q[u][3].x; gate[5] += q[u][3].y; gate[6] += q[u][3].z; gate[7] += q[u][3].w;
+                }
+            }
+            epi_geglu8(p, gm, gv, val, gate);
+        }
+    }
+}
+
 // Shared tail of both mainloops: split-K partial store, or LDS-staged fused epilogue with 16-byte accesses.
 // Must be entered by all threads after a barrier that ends all LDS reads of the mainloop.  Wave (wm, wn) of the
 // WGM x WGN grid holds TM x TN 32x32 accumulators of its (BM/WGM) x (BN/WGN) sub-tile.
 template <int BM, int BN, int WGM, int WGN>
 __device__ __forceinline__ void tile_epilogue(const MmaParams& p, char* smem, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32],
-                                              int m0, int n0, int z) {
+                                              int m0, int n0, int z, int tile_id) {
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32, NT = 64 * WGM * WGN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, hi = lane >> 5;
-    if (p.splits > 1) {   // raw fp32 partial tile; the epilogue happens in splitk_reduce_kernel
+    if (p.splits > 1) {
+        // raw fp32 partial tile -> workspace; the LAST slice of this tile to arrive (ticket counter) reduces all of them
         float* wsz = p.ws + (size_t)z * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -131,6 +204,25 @@ __device__ __forceinline__ void tile_epilogue(const MmaParams& p, char* smem, f3
                     if (gm < p.M && gn < p.N) wsz[(size_t)gm * p.N + gn] = acc[i][j][r];
                 }
             }
+        // publish: every wave drains its stores, one lane releases at agent scope, THEN draws the ticket (this order —
+        // a release issued after a returned atomic can lose its vmcnt wait on ROCm 7.2; the asm wait restates it)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);          // the one LDS array (a second __shared__ object de-pipelines the k-loop)
+        if (t == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ticket = __hip_atomic_fetch_add(p.cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = ticket == p.splits - 1;
+            if (last) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drops this CU's L1: the other slices' tiles are read fresh
+                __hip_atomic_store(p.cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+            }
+            *flag = last;
+        }
+        __syncthreads();
+        if (!*flag) return;
+        reduce_tile<BM, BN, NT>(p, m0, n0);
         return;
     }
     // ---- fused epilogue through LDS, one 32-row band of every wave's sub-tile at a time (TM passes): the staging
@@ -240,10 +332,11 @@ __global__ __launch_bounds__(256) void mma_kernel(const MmaParams p) {
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
-    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    // logical id = tile * splits + slice: the K slices of a tile are consecutive ids (one XCD, see xcd_remap)
+    const int lid2 = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.splits);
+    const int lid = lid2 / p.splits, z = lid2 - lid * p.splits;
     const int m0 = (p.n_major ? lid % p.tiles_m : lid / p.tiles_n) * BM;
     const int n0 = (p.n_major ? lid / p.tiles_m : lid % p.tiles_n) * BN;
-    const int z = blockIdx.y;
     const int kt0 = z * p.kt_per_split;
     const int kt1 = min(p.KT, kt0 + p.kt_per_split);
 
@@ -348,7 +441,7 @@ __global__ __launch_bounds__(256) void mma_kernel(const MmaParams p) {
         if (more) store_lds(buf ^ 1);
         __syncthreads();
     }
-    tile_epilogue<BM, BN, 2, 2>(p, smem, acc, m0, n0, z);
+    tile_epilogue<BM, BN, 2, 2>(p, smem, acc, m0, n0, z, lid);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -368,8 +461,14 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+template <int WGM, int WGN, int S, int WTM = 2, int WTN = 2>
+constexpr int pipe_smem_bytes() {
+    constexpr int STAGE = (32 * WTM * WGM + 32 * WTN * WGN) * 128, EPI = WGM * 32 * (32 * WTN * WGN) * 4;
+    return S * STAGE > EPI ? S * STAGE : EPI;
+}
+
 template <int WGM, int WGN, int S, bool CONV, bool LATE, bool PREF, int WTM = 2, int WTN = 2>
-__global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParams p) {
+__device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     // every wave owns a (32 WTM) x (32 WTN) output sub-tile.  2 x 2 needs 1 KiB of LDS fragment reads per MFMA, which at
     // full MFMA rate is the whole LDS read bandwidth of the CU (8 waves x 32 B/clk); "fat" 4 x 2 waves (128 x 64, 128
     // accumulator registers, one wave per SIMD) need 0.75 KiB per MFMA and half as many waves for the same tile.
@@ -381,15 +480,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParam
     constexpr int ISTR = NW * 1024;   // LDS bytes covered by one DMA instruction of the whole workgroup (8 rows / wave)
     static_assert(S >= 2 && S <= 4 && (S - 2) * LPT < 64, "2 to 4 stages; vmcnt is a 6-bit counter");
     static_assert(S * STAGE <= 160 * 1024, "the ring must fit the 160 KB of LDS");
-    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+    static_assert(SMEM == pipe_smem_bytes<WGM, WGN, S, WTM, WTN>(), "LDS size of the wrappers");
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, hi = lane >> 5;
-    const int lid = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+    // logical id = tile * splits + slice: the K slices of a tile are consecutive ids (one XCD, see xcd_remap)
+    const int lid2 = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.splits);
+    const int lid = lid2 / p.splits, z = lid2 - lid * p.splits;
     const int m0 = (p.n_major ? lid % p.tiles_m : lid / p.tiles_n) * BM;
     const int n0 = (p.n_major ? lid / p.tiles_m : lid % p.tiles_n) * BN;
-    const int z = blockIdx.y;
     const int kt0 = z * p.kt_per_split;
     const int nt = min(p.KT, kt0 + p.kt_per_split) - kt0;
 
@@ -521,70 +621,29 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParam
         if (++stage == S) stage = 0;
     }
     __syncthreads();   // every wave is done reading the stages before the epilogue reuses LDS
-    tile_epilogue<BM, BN, WGM, WGN>(p, smem, acc, m0, n0, z);
+    tile_epilogue<BM, BN, WGM, WGN>(p, smem, acc, m0, n0, z, lid);
 }
 
-__global__ __launch_bounds__(256) void splitk_reduce_kernel(const MmaParams p) {
-    const size_t MN = (size_t)p.M * p.N;
-    if (p.mode == SG_EPI_LINEAR) {
-        const int nch = p.N / 8;
-        const long total = (long)p.M * nch;
-        for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-            const int gm = (int)(idx / nch), gn = (int)(idx - (long)gm * nch) * 8;
-            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            const float* s = p.ws + (size_t)gm * p.N + gn;
-            // the partial tiles of up to four splits are requested together (one memory round trip instead of four) and
-            // added in split order, so the sum is bit-identical to the sequential loop
-            for (int z0 = 0; z0 < p.splits; z0 += 4) {
-                float4 a[4], b[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    a[u] = b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (z0 + u < p.splits) {
-                        a[u] = *reinterpret_cast<const float4*>(s + (z0 + u) * MN);
-                        b[u] = *reinterpret_cast<const float4*>(s + (z0 + u) * MN + 4);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
-                    v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
-                }
-            }
-            epi_linear8(p, gm, gn, v);
-        }
+template <int WGM, int WGN, int S, bool CONV, bool LATE, bool PREF, int WTM = 2, int WTN = 2>
+__global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN, S, WTM, WTN>()];
+    mma_pipe_body<WGM, WGN, S, CONV, LATE, PREF, WTM, WTN>(p, smem);
+}
+
+// Two independent GEMMs in ONE launch (blockIdx.y selects the problem; blocks beyond a problem's grid exit): the q|k and V^T
+// projections of one LayerNorm output, the text / image query projections, the attn3 K and V^T projections of a finished
+// context.  Each pair shares its activation operand and is far too small to fill the chip alone, so the pair costs about one
+// launch instead of two (and one dependency boundary instead of two).  Static selection (two inlined bodies): a runtime
+// index into the kernel arguments would move them to scratch.
+struct MmaPair { MmaParams p0, p1; };
+
+template <int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_pair_kernel(const MmaPair pp) {
+    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN, 3>()];
+    if (blockIdx.y == 0) {
+        if ((int)blockIdx.x < pp.p0.tiles_m * pp.p0.tiles_n * pp.p0.splits) mma_pipe_body<WGM, WGN, 3, false, true, true>(pp.p0, smem);
     } else {
-        const int och = p.N / 16;
-        const long total = (long)p.M * och;
-        for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
-            const int gm = (int)(idx / och), j = (int)(idx - (long)gm * och);
-            const int gv = (j >> 2) * 64 + (j & 3) * 8;
-            float val[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gate[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            const float* s = p.ws + (size_t)gm * p.N + gv;
-            for (int z0 = 0; z0 < p.splits; z0 += 2) {      // two splits (4 x 16 B each) per memory round trip
-                float4 q[2][4];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) q[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (z0 + u < p.splits) {
-                        const float* src = s + (z0 + u) * MN;
-                        q[u][0] = *reinterpret_cast<const float4*>(src);
-                        q[u][1] = *reinterpret_cast<const float4*>(src + 4);
-                        q[u][2] = *reinterpret_cast<const float4*>(src + 32);
-                        q[u][3] = *reinterpret_cast<const float4*>(src + 36);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    val[0] += q[u][0].x; val[1] += q[u][0].y; val[2] += q[u][0].z; val[3] += q[u][0].w;
-                    val[4] += q[u][1].x; val[5] += q[u][1].y; val[6] += q[u][1].z; val[7] += q[u][1].w;
-                    gate[0] += q[u][2].x; gate[1] += q[u][2].y; gate[2] += q[u][2].z; gate[3] += q[u][2].w;
-                    gate[4] += q[u][3].x; gate[5] += q[u][3].y; gate[6] += q[u][3].z; gate[7] += q[u][3].w;
-                }
-            }
-            epi_geglu8(p, gm, gv, val, gate);
-        }
+        if ((int)blockIdx.x < pp.p1.tiles_m * pp.p1.tiles_n * pp.p1.splits) mma_pipe_body<WGM, WGN, 3, false, true, true>(pp.p1, smem);
     }
 }
 
@@ -613,7 +672,9 @@ static const Tune g_tune;
 //   t_bw   = (blocks a CU must run) x (bytes one block streams) / 18.5      — total bytes over the ACTIVE CUs, or by
 //   t_mfma = (waves per SIMD) x slabs x 512                                  — 16 MFMAs of 32 cycles per 64-deep slab,
 // plus a fixed prologue/epilogue.  Splitting K does not add operand bytes but multiplies the CUs that share them,
-// which is what small-M layers need; it costs a second launch that re-reads the fp32 partial tiles.
+// which is what small-M layers need; it costs the partial-tile round trip: every slice writes its fp32 tile and the
+// last one to arrive reads all of them back (same-XCD hand-off, ~110 GB/s per workgroup = ~45 B/cycle) after one
+// agent-scope release / acquire pair (~1.5 us).
 Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool pipe, int hint_bm, int hint_bn, int hint_waves) {
     static const int cand_pipe[6][2] = {{256, 128}, {128, 128}, {256, 64}, {128, 64}, {64, 128}, {64, 64}};
     static const int cand_gen[3][2] = {{128, 128}, {128, 64}, {64, 64}};
@@ -640,7 +701,7 @@ Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool p
             const double waves_per_simd = sg_cdiv((long)(blocks * waves_per_block), (long)(CUS * 4));
             const double t_mfma = waves_per_simd * slabs * mfma_per_slab;
             double cost = (t_bw > t_mfma ? t_bw : t_mfma) + 2500.0 + blocks_per_cu * (bm * bn / 16.0);
-            if (s > 1) cost += 5000.0 + (double)M * N * 4.0 * (s + 1) / 1500.0;   // second launch + partial tiles
+            if (s > 1) cost += 3500.0 + (double)bm * bn * 4.0 * s / 45.0 + (double)bm * bn * 4.0 / 64.0;   // hand-off + reduce
             if (cost < best_cost) { best_cost = cost; best = Plan{bm, bn, s, 0}; }
         }
     }
@@ -673,22 +734,30 @@ void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st, int stages) {
     else hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV, false, true>), grid, block, 0, st, p);
 }
 
+// Decomposition of one problem: tile shape, K split, tile order; fills the corresponding fields of p.  `pipe` = the LDS-DMA
+// kernel applies (no load needs a predicate: K % 64 == 0; conv input zero-bordered), else the register-staged kernel.
 template <bool CONV>
-int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_waves, void* ws, size_t ws_bytes, hipStream_t st, const char* name) {
+int plan_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_waves, void* ws, size_t ws_bytes, const char* name,
+             Plan& pl, bool& pipe) {
     p.KT = sg_cdiv(p.K, BK);
-    // LDS-DMA pipeline when no load needs a predicate (K % 64 == 0; conv input zero-bordered), else the
-    // register-staged kernel that zero-fills out-of-range chunks.
-    const bool pipe = (p.K % BK == 0) && (!CONV || p.padded) && !g_tune.no_pipe;
+    pipe = (p.K % BK == 0) && (!CONV || p.padded) && !g_tune.no_pipe;
     const size_t per_split = (size_t)p.M * p.N * 4;
-    const int max_ws_split = ws ? (int)(ws_bytes / per_split > 64 ? 64 : ws_bytes / per_split) : 1;
-    Plan pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, pipe, hint_bm, hint_bn, hint_waves);
+    const size_t ws_tiles = (ws && ws_bytes > WS_COUNTER_BYTES) ? ws_bytes - WS_COUNTER_BYTES : 0;   // room for partial tiles
+    const int max_ws_split = ws_tiles ? (int)(ws_tiles / per_split > 64 ? 64 : ws_tiles / per_split) : 1;
+    pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, pipe, hint_bm, hint_bn, hint_waves);
+    if (pl.splits > 1 && (long)sg_cdiv(p.M, pl.bm) * sg_cdiv(p.N, pl.bn) > MAX_SPLIT_TILES) {
+        if (force_split > 1)
+            return sg_set_error(SG_EINVAL, "%s: split_k with more than %d output tiles is not supported", name, MAX_SPLIT_TILES);
+        pl.splits = 1;                          // a grid that large does not need splitting
+    }
     if (pl.splits > 1) {
-        const size_t need = per_split * pl.splits;
+        const size_t need = per_split * pl.splits + WS_COUNTER_BYTES;
         if (ws == nullptr || ws_bytes < need)
             return sg_set_error(SG_EINVAL, "%s: split_k=%d needs %zu workspace bytes, got %zu", name, pl.splits, need,
                                 ws_bytes);
     }
     p.ws = reinterpret_cast<float*>(ws);
+    p.cnt = ws ? reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + (ws_bytes - WS_COUNTER_BYTES)) : nullptr;
     p.splits = pl.splits;
     p.kt_per_split = sg_cdiv(p.KT, pl.splits);
     p.tiles_m = sg_cdiv(p.M, pl.bm);
@@ -696,12 +765,18 @@ int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint
     // Each XCD has a private L2 and consecutive tile ids share one (xcd_remap): let them share the LARGER operand panel, so
     // that it is fetched from HBM / Infinity Cache by one XCD instead of by all that own a tile of it.  At the 16x16 and
     // 8x8 latent levels the weights (up to 59 MB per layer) dwarf the activations: walk M first there.
-    {
-        const double a_bytes = CONV ? 2.0 * p.M * (p.K / 9) * (p.stride == 1 && !p.ups ? 1.0 : (p.ups ? 0.25 : 4.0)) : 2.0 * p.M * p.K;
-        const double w_bytes = 2.0 * p.N * p.K;
-        p.n_major = (w_bytes > a_bytes && !g_tune.no_nmajor) ? 1 : 0;
-    }
-    dim3 grid(p.tiles_m * p.tiles_n, pl.splits);
+    const double a_bytes = CONV ? 2.0 * p.M * (p.K / 9) * (p.stride == 1 && !p.ups ? 1.0 : (p.ups ? 0.25 : 4.0)) : 2.0 * p.M * p.K;
+    const double w_bytes = 2.0 * p.N * p.K;
+    p.n_major = (w_bytes > a_bytes && !g_tune.no_nmajor) ? 1 : 0;
+    return SG_OK;
+}
+
+template <bool CONV>
+int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_waves, void* ws, size_t ws_bytes, hipStream_t st, const char* name) {
+    Plan pl;
+    bool pipe;
+    if (int rc = plan_mma<CONV>(p, force_split, hint_bm, hint_bn, hint_waves, ws, ws_bytes, name, pl, pipe)) return rc;
+    dim3 grid(p.tiles_m * p.tiles_n * pl.splits);
     // ring depth: 3 stages (deeper prefetch) unless overridden; SG_STAGES=2 halves... see DESIGN.md §5.2
     const int stages = (g_tune.stages == 2 || g_tune.stages == 4) ? g_tune.stages : 3;
     if (pipe && pl.fat) {
@@ -721,12 +796,6 @@ int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint
         else hipLaunchKernelGGL((mma_kernel<64, 64, CONV>), grid, block, 0, st, p);
     }
     SG_CHECK_LAUNCH(name);
-    if (pl.splits > 1) {
-        const long items = (long)p.M * (p.N / (p.mode == SG_EPI_GEGLU ? 16 : 8));
-        const int blocks = (int)min((long)4096, (items + 255) / 256);
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
-        SG_CHECK_LAUNCH("splitk_reduce");
-    }
     return SG_OK;
 }
 
@@ -754,34 +823,45 @@ int check_tile_hint(const char* who, int bm, int bn, int waves) {
 
 extern "C" size_t sg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
     const int s = split_k > 0 ? split_k : MAX_AUTO_SPLIT;
-    return s > 1 ? (size_t)M * (size_t)N * 4u * (size_t)s : 0;
+    return s > 1 ? (size_t)M * (size_t)N * 4u * (size_t)s + WS_COUNTER_BYTES : 0;
 }
 
-extern "C" int sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream) {
-    SG_REQUIRE(d != nullptr, "sg_gemm_f16: null descriptor");
-    SG_REQUIRE(d->A && d->W && d->C, "sg_gemm_f16: null A/W/C");
-    SG_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "sg_gemm_f16: bad shape M=%d N=%d K=%d", d->M, d->N, d->K);
-    SG_REQUIRE(d->K % 8 == 0 && d->N % 8 == 0, "sg_gemm_f16: K (%d) and N (%d) must be multiples of 8", d->K, d->N);
-    SG_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0, "sg_gemm_f16: lda/ldw must be multiples of 8");
-    SG_REQUIRE(d->lda >= d->K && d->ldw >= d->K, "sg_gemm_f16: lda/ldw smaller than K");
-    SG_REQUIRE(sg_aligned16(d->A) && sg_aligned16(d->W), "sg_gemm_f16: A/W must be 16-byte aligned");
-    SG_REQUIRE(d->epilogue == SG_EPI_LINEAR || d->epilogue == SG_EPI_GEGLU, "sg_gemm_f16: unknown epilogue %d", d->epilogue);
+extern "C" int sg_workspace_init(void* workspace, size_t workspace_bytes, sg_stream_t stream) {
+    SG_REQUIRE(workspace && workspace_bytes >= WS_COUNTER_BYTES && sg_aligned16(workspace) && workspace_bytes % 16 == 0,
+               "sg_workspace_init: need a 16-byte aligned workspace of at least %zu bytes (a multiple of 16)", WS_COUNTER_BYTES);
+    hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(workspace) + (workspace_bytes - WS_COUNTER_BYTES), 0, WS_COUNTER_BYTES,
+                                  (hipStream_t)stream);
+    if (e != hipSuccess) return sg_set_error(SG_ELAUNCH, "sg_workspace_init: %s", hipGetErrorString(e));
+    return SG_OK;
+}
+
+namespace {
+// Validates a GEMM descriptor and translates it into kernel parameters.
+int gemm_params(const sg_gemm_desc* d, MmaParams& p, const char* who) {
+    SG_REQUIRE(d != nullptr, "%s: null descriptor", who);
+    SG_REQUIRE(d->A && d->W && d->C, "%s: null A/W/C", who);
+    SG_REQUIRE(d->M > 0 && d->N > 0 && d->K > 0, "%s: bad shape M=%d N=%d K=%d", who, d->M, d->N, d->K);
+    SG_REQUIRE(d->K % 8 == 0 && d->N % 8 == 0, "%s: K (%d) and N (%d) must be multiples of 8", who, d->K, d->N);
+    SG_REQUIRE(d->lda % 8 == 0 && d->ldw % 8 == 0, "%s: lda/ldw must be multiples of 8", who);
+    SG_REQUIRE(d->lda >= d->K && d->ldw >= d->K, "%s: lda/ldw smaller than K", who);
+    SG_REQUIRE(sg_aligned16(d->A) && sg_aligned16(d->W), "%s: A/W must be 16-byte aligned", who);
+    SG_REQUIRE(d->epilogue == SG_EPI_LINEAR || d->epilogue == SG_EPI_GEGLU, "%s: unknown epilogue %d", who, d->epilogue);
     int n_out = d->N;
     if (d->epilogue == SG_EPI_GEGLU) {
-        SG_REQUIRE(d->N % 64 == 0, "sg_gemm_f16: GEGLU needs N %% 64 == 0 (got %d)", d->N);
-        SG_REQUIRE(!d->rowbias && !d->res1 && !d->res2, "sg_gemm_f16: GEGLU epilogue takes bias only");
+        SG_REQUIRE(d->N % 64 == 0, "%s: GEGLU needs N %% 64 == 0 (got %d)", who, d->N);
+        SG_REQUIRE(!d->rowbias && !d->res1 && !d->res2, "%s: GEGLU epilogue takes bias only", who);
         n_out = d->N / 2;
     }
-    if (int rc = check_out_res("sg_gemm_f16", d->flags, d->C, d->ldc, d->C2, d->ldc2, d->res1, d->ldr1, d->res2, d->ldr2, n_out))
+    if (int rc = check_out_res(who, d->flags, d->C, d->ldc, d->C2, d->ldc2, d->res1, d->ldr1, d->res2, d->ldr2, n_out))
         return rc;
-    SG_REQUIRE(!d->bias || sg_aligned16(d->bias), "sg_gemm_f16: bias must be 16-byte aligned");
+    SG_REQUIRE(!d->bias || sg_aligned16(d->bias), "%s: bias must be 16-byte aligned", who);
     SG_REQUIRE(!d->rowbias || (sg_aligned16(d->rowbias) && d->rowbias_ld % 4 == 0 && d->rows_per_batch >= 1),
-               "sg_gemm_f16: rowbias alignment / rows_per_batch");
-    SG_REQUIRE(d->split_k >= 0 && d->split_k <= 64, "sg_gemm_f16: bad split_k %d", d->split_k);
-    SG_REQUIRE(!d->workspace || sg_aligned16(d->workspace), "sg_gemm_f16: workspace alignment");
+               "%s: rowbias alignment / rows_per_batch", who);
+    SG_REQUIRE(d->split_k >= 0 && d->split_k <= 64, "%s: bad split_k %d", who, d->split_k);
+    SG_REQUIRE(!d->workspace || (sg_aligned16(d->workspace) && d->workspace_bytes % 16 == 0), "%s: workspace alignment / size %% 16", who);
     SG_REQUIRE((int64_t)d->M * d->lda < (1ll << 32) && (int64_t)d->N * d->ldw < (1ll << 32),
-               "sg_gemm_f16: operands larger than 2^32 elements are not supported (32-bit DMA offsets)");
-    MmaParams p{};
+               "%s: operands larger than 2^32 elements are not supported (32-bit DMA offsets)", who);
+    p = MmaParams{};
     p.A = reinterpret_cast<const f16*>(d->A); p.lda = d->lda;
     p.W = reinterpret_cast<const f16*>(d->W); p.ldw = d->ldw;
     p.C = d->C; p.ldc = d->ldc;
@@ -792,8 +872,50 @@ extern "C" int sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream) {
     p.rowbias = d->rowbias; p.rowbias_ld = d->rowbias_ld; p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1;
     p.res1 = d->res1; p.ldr1 = d->ldr1;
     p.res2 = d->res2; p.ldr2 = d->ldr2;
-    if (int rc = check_tile_hint("sg_gemm_f16", d->tile_m, d->tile_n, d->tile_waves)) return rc;
+    return check_tile_hint(who, d->tile_m, d->tile_n, d->tile_waves);
+}
+
+template <int WGM, int WGN>
+void launch_pair(const MmaPair& pp, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((mma_pipe_pair_kernel<WGM, WGN>), grid, dim3(64 * WGM * WGN), 0, st, pp);
+}
+}  // namespace
+
+extern "C" int sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream) {
+    MmaParams p;
+    if (int rc = gemm_params(d, p, "sg_gemm_f16")) return rc;
     return launch_mma<false>(p, d->split_k, d->tile_m, d->tile_n, d->tile_waves, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_gemm_f16");
+}
+
+extern "C" int sg_gemm_pair_f16(const sg_gemm_desc* d0, const sg_gemm_desc* d1, sg_stream_t stream) {
+    MmaPair pp;
+    if (int rc = gemm_params(d0, pp.p0, "sg_gemm_pair_f16[0]")) return rc;
+    if (int rc = gemm_params(d1, pp.p1, "sg_gemm_pair_f16[1]")) return rc;
+    SG_REQUIRE(!(d0->workspace && d1->workspace) ||
+               (reinterpret_cast<char*>(d0->workspace) + d0->workspace_bytes <= reinterpret_cast<char*>(d1->workspace) ||
+                reinterpret_cast<char*>(d1->workspace) + d1->workspace_bytes <= reinterpret_cast<char*>(d0->workspace)),
+               "sg_gemm_pair_f16: the two problems run concurrently and need disjoint workspaces");
+    hipStream_t st = (hipStream_t)stream;
+    Plan pl0, pl1;
+    bool pipe0, pipe1;
+    if (int rc = plan_mma<false>(pp.p0, d0->split_k, d0->tile_m, d0->tile_n, 0, d0->workspace, d0->workspace_bytes, "sg_gemm_pair_f16[0]", pl0, pipe0)) return rc;
+    // one kernel instantiation serves both problems: the second one is planned on the first one's tile shape
+    if (int rc = plan_mma<false>(pp.p1, d1->split_k, pl0.bm, pl0.bn, 0, d1->workspace, d1->workspace_bytes, "sg_gemm_pair_f16[1]", pl1, pipe1)) return rc;
+    if (!pipe0 || !pipe1 || pl1.bm != pl0.bm || pl1.bn != pl0.bn) {        // not pairable (K % 64, forced tile): two launches
+        if (int rc = launch_mma<false>(pp.p0, d0->split_k, d0->tile_m, d0->tile_n, d0->tile_waves, d0->workspace, d0->workspace_bytes, st, "sg_gemm_pair_f16[0]")) return rc;
+        return launch_mma<false>(pp.p1, d1->split_k, d1->tile_m, d1->tile_n, d1->tile_waves, d1->workspace, d1->workspace_bytes, st, "sg_gemm_pair_f16[1]");
+    }
+    const int g0 = pp.p0.tiles_m * pp.p0.tiles_n * pp.p0.splits, g1 = pp.p1.tiles_m * pp.p1.tiles_n * pp.p1.splits;
+    // grid.x is a multiple of 8 so that block (x, 1) sits on XCD x % 8 like block (x, 0): xcd_remap keeps its meaning
+    dim3 grid(((g0 > g1 ? g0 : g1) + 7) & ~7, 2);
+    if (pl0.bm == 256 && pl0.bn == 128) launch_pair<4, 2>(pp, grid, st);
+    else if (pl0.bm == 128 && pl0.bn == 128) launch_pair<2, 2>(pp, grid, st);
+    else if (pl0.bm == 256 && pl0.bn == 64) launch_pair<4, 1>(pp, grid, st);
+    else if (pl0.bm == 128 && pl0.bn == 64) launch_pair<2, 1>(pp, grid, st);
+    else if (pl0.bm == 64 && pl0.bn == 128) launch_pair<1, 2>(pp, grid, st);
+    else launch_pair<1, 1>(pp, grid, st);
+    SG_CHECK_LAUNCH("sg_gemm_pair_f16");
+    return SG_OK;
 }
 
 extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream) {
@@ -811,6 +933,7 @@ extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream)
     SG_REQUIRE(!d->bias || sg_aligned16(d->bias), "sg_conv3x3: bias alignment");
     SG_REQUIRE(!d->rowbias || (sg_aligned16(d->rowbias) && d->rowbias_ld % 4 == 0), "sg_conv3x3: rowbias alignment");
     SG_REQUIRE(d->split_k >= 0 && d->split_k <= 64, "sg_conv3x3: bad split_k %d", d->split_k);
+    SG_REQUIRE(!d->workspace || (sg_aligned16(d->workspace) && d->workspace_bytes % 16 == 0), "sg_conv3x3: workspace alignment / size %% 16");
     SG_REQUIRE((int64_t)d->B * (d->H + 2) * (d->W + 2) * d->ldx < (1ll << 32) && (int64_t)d->Cout * 9 * d->Cin < (1ll << 32),
                "sg_conv3x3: operands larger than 2^32 elements are not supported (32-bit DMA offsets)");
     SG_REQUIRE((int64_t)(d->W + 2) * d->ldx < (1 << 24), "sg_conv3x3: input row pitch must be below 2^24 elements");

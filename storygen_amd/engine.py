@@ -257,8 +257,9 @@ class UNetEngine:
         self.temb1 = self._buf(B, arch.temb_dim, dtype=F32)
         self.temb2 = self._buf(B, arch.temb_dim, dtype=F32)
         self.tproj = self._buf(B, self.temb_total, dtype=F32)
-        self.ws_split = self._buf(splitk_mb << 20, dtype=torch.uint8)
-        self.ws_side = self._buf(splitk_mb << 20, dtype=torch.uint8)     # split-K scratch of the side-stream branches
+        self.ws_split = ops.new_workspace(splitk_mb << 20, self.dev)      # split-K partial tiles + zeroed arrival counters
+        self.ws_side = ops.new_workspace(splitk_mb << 20, self.dev)       # split-K scratch of the side-stream branches
+        self.ws_pair = ops.new_workspace(splitk_mb << 20, self.dev)       # second problem of a paired GEMM launch
         self.side: Optional[torch.cuda.Stream] = None                   # set by forward(side=...)
         self.kv_ext: Optional[Dict[str, tuple]] = None                  # attn3 K / V^T computed by the reference pass
         self.ws_gn = self._buf(ops.groupnorm_workspace_bytes(B, self.groups), dtype=torch.uint8)
@@ -391,8 +392,8 @@ class UNetEngine:
 
     def _project_text(self, xf: _Xf, kt: torch.Tensor, vtt: torch.Tensor):
         x = self.text_pad.view(self.B * self.Sp, self.cad)
-        ops.gemm(x, xf.w_k2, kt, workspace=self.ws_split)
-        ops.gemm(xf.w_v2, x, vtt, workspace=self.ws_split)                                 # VT = Wv . X^T
+        ops.gemm_pair(((x, xf.w_k2, kt), dict(workspace=self.ws_split)),
+                      ((xf.w_v2, x, vtt), dict(workspace=self.ws_pair)))                   # VT = Wv . X^T
 
     def cache_text_kv(self):
         """Run every attn2 K / V^T projection on the current self.text_in and keep the results (use with
@@ -422,8 +423,9 @@ class UNetEngine:
         # --- self-attention :250-262
         ops.layernorm(h0, *xf.ln["norm1"], L["ln"])
         qk, vt = L["qk"], L["vt"]
-        ops.gemm(L["ln"], xf.w_qk1, qk, workspace=ws)
-        ops.gemm(xf.w_v1, L["ln"], vt, workspace=ws)                                      # VT[C, B*hw] = Wv . X^T
+        wp = self.ws_pair
+        # q|k (token-major) and V^T = Wv . X^T (the attention kernel's operand layout): two GEMMs on one LayerNorm output, one launch
+        ops.gemm_pair(((L["ln"], xf.w_qk1, qk), dict(workspace=ws)), ((xf.w_v1, L["ln"], vt), dict(workspace=wp)))
         qk3 = qk.view(B, hw, 2 * C)
         att = L["att"]
         ops.attention(qk3[:, :, :C], qk3[:, :, C:], vt.view(C, B, hw).permute(1, 0, 2), att.view(B, hw, C), heads, scale)
@@ -439,8 +441,7 @@ class UNetEngine:
                 if plan.kv is not None:            # attn3 K / V^T of the finished context (attention.py:215-223)
                     ki, vti = plan.kv[xf.spec.feature_key]
                     c2d = ctx.view(ctx.shape[0] * ctx.shape[1], C)
-                    ops.gemm(c2d, xf.w_k3, ki, workspace=ws)
-                    ops.gemm(xf.w_v3, c2d, vti, workspace=ws)                              # VT[C, rows*nk]
+                    ops.gemm_pair(((c2d, xf.w_k3, ki), dict(workspace=ws)), ((xf.w_v3, c2d, vti), dict(workspace=wp)))   # VT[C, rows*nk]
             if stop_after_harvest:
                 return
         # --- text cross-attention :266-277 (norm2) and image cross-attention :281-291 (norm4) share statistics
@@ -454,28 +455,23 @@ class UNetEngine:
             # of one [M, 2C] buffer; their out-projections, biases and both residual adds (:277,291-293) are one GEMM
             att23 = L["att23"]
             a2v, a3v = att23[:, :C].unflatten(0, (B, hw)), att23[:, C:].unflatten(0, (B, hw))
+            # both query projections in one launch (norm2 / norm4 outputs of the same statistics), then the two attentions side by side
+            q2, q3buf = L["q2"], L["q"]
+            ops.gemm_pair(((L["ln"], xf.w_q2, q2), dict(workspace=ws)), ((L["ln4"], xf.w_q3, q3buf), dict(workspace=wp)))
             forked = self._fork()
-            ws2 = self.ws_side if forked else ws
-            q2 = L["q2"] if forked else L["q"]
-
-            def text_branch():
-                ops.gemm(L["ln"], xf.w_q2, q2, workspace=ws2)
-                ops.attention(q2.view(B, hw, C), kt3, vtt3, a2v, heads, scale, nk=S)
             if forked:
                 with torch.cuda.stream(self.side):
-                    text_branch()
+                    ops.attention(q2.view(B, hw, C), kt3, vtt3, a2v, heads, scale, nk=S)
             else:
-                text_branch()
+                ops.attention(q2.view(B, hw, C), kt3, vtt3, a2v, heads, scale, nk=S)
             ctx = self.ctx[xf.spec.feature_key]
             rows, nk = ctx.shape[0], ctx.shape[1]
-            q3buf = L["q"]                         # (unforked: the text attention above has consumed its q by now)
-            ops.gemm(L["ln4"], xf.w_q3, q3buf, workspace=ws)
             if self.kv_ext is not None:
                 ki, vti = self.kv_ext[xf.spec.feature_key]
             else:
                 ki, vti = L["ki"], L["vti"]
-                ops.gemm(ctx.view(rows * nk, C), xf.w_k3, ki, workspace=ws)
-                ops.gemm(xf.w_v3, ctx.view(rows * nk, C), vti, workspace=ws)              # VT[C, rows*nk]
+                c2d = ctx.view(rows * nk, C)
+                ops.gemm_pair(((c2d, xf.w_k3, ki), dict(workspace=ws)), ((xf.w_v3, c2d, vti), dict(workspace=wp)))   # VT[C, rows*nk]
             ki3, vti3 = ki.view(rows, nk, C), vti.view(C, rows, nk).permute(1, 0, 2)
             q3 = q3buf.view(B, hw, C)
             if self.attn3_share is not None:      # one launch: batch b reads context row b (b < rows) or b - (B - rows)

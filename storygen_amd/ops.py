@@ -123,13 +123,35 @@ def gemm_workspace_bytes(M: int, N: int, split_k: int = 0) -> int:
     return lib.sg_gemm_workspace_bytes(M, N, split_k)
 
 
-def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
-         rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 1, res1: Optional[torch.Tensor] = None,
-         res2: Optional[torch.Tensor] = None, epilogue: int = EPI_LINEAR, split_k: int = 0,
-         workspace: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
-         tile: Optional[tuple] = None) -> torch.Tensor:
-    """out[M, N'] = epi(a[M,K] @ w[N,K]^T); a/out/res* may be row-strided 2-D views; out/res* fp16 or fp32;
-    out2 = optional extra fp16 copy of the result."""
+WS_COUNTER_BYTES = 16384       # SG_WS_COUNTER_BYTES
+
+
+def new_workspace(nbytes: int, device) -> torch.Tensor:
+    """A split-K workspace for gemm / conv3x3 with its arrival counters zeroed (sg_workspace_init contract)."""
+    nbytes = (max(int(nbytes), WS_COUNTER_BYTES) + 15) & ~15
+    ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
+    ws._sg_ws_ready = True
+    return ws
+
+
+def _ws(workspace: Optional[torch.Tensor], d):
+    """Attach `workspace` to a descriptor.  A tensor this module has not seen yet gets its counter region zeroed ONCE (one
+    memset on the launch stream; allocate with new_workspace() to keep that out of a hipGraph capture)."""
+    if workspace is None:
+        return
+    nbytes = (workspace.numel() * workspace.element_size()) & ~15
+    if nbytes >= WS_COUNTER_BYTES and not getattr(workspace, "_sg_ws_ready", False):
+        check(lib.sg_workspace_init(workspace.data_ptr(), nbytes, _stream()), "sg_workspace_init")
+        workspace._sg_ws_ready = True
+    d.workspace, d.workspace_bytes = workspace.data_ptr(), nbytes
+
+
+def _gemm_desc(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
+               rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 1, res1: Optional[torch.Tensor] = None,
+               res2: Optional[torch.Tensor] = None, epilogue: int = EPI_LINEAR, split_k: int = 0,
+               workspace: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
+               tile: Optional[tuple] = None, use_table: bool = True):
+    """Builds the sg_gemm_desc of one problem; returns (desc, flops, shape string)."""
     _f16(a, "a"), _f16(w, "w")
     flags = F_OUT_F32 if _act(out, "out") else 0
     M, K = a.shape
@@ -163,17 +185,35 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[
         _f16(out2, "out2")
         d.C2, d.ldc2 = out2.data_ptr(), _row_stride(out2, "out2")
     d.flags = flags
-    if workspace is not None:
-        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    _ws(workspace, d)
     sig = f"g:{M}:{N}:{K}:{epilogue}:{flags}:{int(bias is not None)}{int(rowbias is not None)}{int(res1 is not None)}{int(res2 is not None)}{int(out2 is not None)}"
-    _apply_tile(d, tile, split_k, sig)
-    if TUNE_SINK is not None:
+    if use_table or tile is not None:
+        _apply_tile(d, tile, split_k, sig)
+    if TUNE_SINK is not None and use_table:
         TUNE_SINK.append((sig, dict(kind="gemm", M=M, N=N, K=K, epilogue=epilogue, out_f32=bool(flags & F_OUT_F32), bias=bias is not None,
                                     rowbias=rowbias is not None, rows_per_batch=rows_per_batch, out2=out2 is not None,
                                     res1=None if res1 is None else str(res1.dtype), res2=None if res2 is None else str(res2.dtype))))
-    with _timed("gemm", 2.0 * M * N * K, f"M{M} N{N} K{K}{' geglu' if epilogue else ''}"):
+    return d, 2.0 * M * N * K, f"M{M} N{N} K{K}{' geglu' if epilogue else ''}"
+
+
+def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, **kw) -> torch.Tensor:
+    """out[M, N'] = epi(a[M,K] @ w[N,K]^T); a/out/res* may be row-strided 2-D views; out/res* fp16 or fp32;
+    out2 = optional extra fp16 copy of the result.  Keywords: bias, rowbias, rows_per_batch, res1, res2, epilogue, split_k,
+    workspace, out2, tile."""
+    d, flops, shape = _gemm_desc(a, w, out, **kw)
+    with _timed("gemm", flops, shape):
         check(lib.sg_gemm_f16(C.byref(d), _stream()), "sg_gemm_f16")
     return out
+
+
+def gemm_pair(first: tuple, second: tuple) -> None:
+    """Two independent GEMMs in one launch (sg_gemm_pair_f16).  Each argument is ((a, w, out), {keywords of gemm()}); the
+    outputs must not overlap and the two workspaces, if given, must be different buffers."""
+    (a0, kw0), (a1, kw1) = first, second
+    d0, f0, s0 = _gemm_desc(*a0, use_table=False, **kw0)
+    d1, f1, s1 = _gemm_desc(*a1, use_table=False, **kw1)
+    with _timed("gemm", f0 + f1, f"{s0} + {s1}"):
+        check(lib.sg_gemm_pair_f16(C.byref(d0), C.byref(d1), _stream()), "sg_gemm_pair_f16")
 
 
 def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stride: int = 1, upsample2x: bool = False,
@@ -217,8 +257,7 @@ def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stride:
         d.res1, d.ldr1 = res1.data_ptr(), pix_stride(res1, "res1")
     d.flags = flags
     d.split_k = split_k
-    if workspace is not None:
-        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    _ws(workspace, d)
     sig = f"c:{B}:{H}:{W}:{Cin}:{Cout}:{stride}:{int(upsample2x)}:{int(x_padded)}:{flags}:{int(bias is not None)}{int(rowbias is not None)}{int(res1 is not None)}"
     _apply_tile(d, tile, split_k, sig)
     if TUNE_SINK is not None:

@@ -144,6 +144,53 @@ def test_gemm_strided_views(gpu):
     assert float(cbuf[:, :64].abs().max()) == 0 and float(cbuf[:, 64 + N:].abs().max()) == 0, "wrote outside the view"
 
 
+@pytest.mark.parametrize("M,C", [(4096, 320), (768, 1280), (192, 1280), (1000, 640)])
+def test_gemm_pair_is_two_gemms_in_one_launch(gpu, M, C):
+    """sg_gemm_pair_f16 on the pairs the engine issues: q|k (token-major, N = 2C) with V^T = Wv . X^T (swapped operands), and two
+    plain projections with different inputs, residual / bias epilogues included; split-K (small M) with two workspaces."""
+    x, x4 = rnd((M, C), gpu, 1.0, 1), rnd((M, C), gpu, 1.0, 2)
+    wqk, wv, wq3 = rnd((2 * C, C), gpu, C ** -0.5, 3), rnd((C, C), gpu, C ** -0.5, 4), rnd((C, C), gpu, C ** -0.5, 5)
+    bias, res = rnd((C,), gpu, 1.0, 6), rnd((M, C), gpu, 1.0, 7, torch.float32)
+    ws0, ws1 = (torch.empty(64 << 20, dtype=torch.uint8, device=gpu) for _ in range(2))
+    qk, vt = torch.empty(M, 2 * C, dtype=torch.float16, device=gpu), torch.empty(C, M, dtype=torch.float16, device=gpu)
+    ops.gemm_pair(((x, wqk, qk), dict(workspace=ws0)), ((wv, x, vt), dict(workspace=ws1)))
+    check(qk, x.float() @ wqk.float().t(), "pair: q|k")
+    check(vt, wv.float() @ x.float().t(), "pair: V^T")
+    o0, o1 = torch.empty(M, C, dtype=torch.float32, device=gpu), torch.empty(M, C, dtype=torch.float16, device=gpu)
+    ops.gemm_pair(((x, wv, o0), dict(workspace=ws0, bias=bias, res1=res)), ((x4, wq3, o1), dict(workspace=ws1)))
+    check(o0, x.float() @ wv.float().t() + bias.float() + res, "pair: bias + fp32 residual")
+    check(o1, x4.float() @ wq3.float().t(), "pair: second input")
+    with pytest.raises(RuntimeError, match="disjoint"):
+        ops.gemm_pair(((x, wv, o0), dict(workspace=ws0)), ((x4, wq3, o1), dict(workspace=ws0)))
+    # K % 64 != 0 -> generic kernel -> the pair falls back to two launches, same results
+    xk, wk = rnd((M, 72), gpu, 1.0, 8), rnd((C, 72), gpu, 72 ** -0.5, 9)
+    ops.gemm_pair(((xk, wk, o1), {}), ((x, wv, o0), {}))
+    check(o1, xk.float() @ wk.float().t(), "pair fallback: K = 72")
+    check(o0, x.float() @ wv.float().t(), "pair fallback: second")
+
+
+def test_split_k_workspace_is_reusable_and_the_result_deterministic(gpu):
+    """The in-launch split-K reduction: the slice that arrives last sums the partial tiles in slice order and resets the
+    tile's arrival counter, so (i) one workspace serves any number of launches, of different shapes and split factors, back
+    to back; (ii) the result is bit-identical from run to run whatever the arrival order; (iii) a workspace handed over
+    full of garbage works (ops zeroes the counter region of a tensor it has not seen, sg_workspace_init)."""
+    ws = torch.full((ops.gemm_workspace_bytes(768, 1280, 8),), 0xFF, dtype=torch.uint8, device=gpu)
+    ref = {}
+    for rep in range(3):
+        for M, N, K, split in [(192, 1280, 1280, 4), (768, 1280, 2560, 8), (100, 72, 640, 3), (768, 640, 5120, 0)]:
+            a, w, bias = rnd((M, K), gpu, 1.0, 11), rnd((N, K), gpu, K ** -0.5, 12), rnd((N,), gpu, 1.0, 13)
+            r1 = rnd((M, N), gpu, 1.0, 14, torch.float32)
+            out = torch.empty(M, N, dtype=torch.float32, device=gpu)
+            ops.gemm(a, w, out, bias=bias, res1=r1, split_k=split, workspace=ws)
+            if rep == 0:
+                check(out, a.float() @ w.float().t() + bias.float() + r1, f"split_k={split}")
+                ref[(M, N, K)] = out.clone()
+            else:
+                assert torch.equal(out, ref[(M, N, K)]), (rep, M, N, K)
+    torch.cuda.synchronize()
+    assert int(ws[-ops.WS_COUNTER_BYTES:].view(torch.int32).abs().max()) == 0      # every launch left its counters at zero
+
+
 @pytest.mark.parametrize("M,C,split", [(256, 320, 1), (100, 64, 1), (192, 1280, 3)])
 def test_gemm_geglu(gpu, M, C, split):
     """GEGLU.proj + gelu gate (model/attention.py:381-393) with the 32/32 value/gate row interleave."""
