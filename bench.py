@@ -186,6 +186,9 @@ def main():
     ap.add_argument("--split-graphs", action="store_true", help="reference and main pass as separate hipGraphs on two streams")
     ap.add_argument("--stream-priority", action="store_true",
                     help="with --split-graphs / --ref-ahead: main-pass graphs on a high-priority stream")
+    ap.add_argument("--conv-patch", action="store_true",
+                    help="A/B: eligible 3x3 convolutions through the LDS-resident-input-patch kernel (experiment, default off)")
+    ap.add_argument("--no-gemm-pairs", action="store_true", help="A/B: q|k + V^T, q2 + q3, k3 + v3^T as separate launches")
     ap.add_argument("--train-step", action="store_true",
                     help="NOT the contract workload: BASELINE configs[3] — stage-2 training step, bs=4, 512x512, 3 reference frames "
                          "(forward of 3 reference passes + main pass, backward of the main pass, 80 attn3 gradients); reports it/s")
@@ -224,6 +227,12 @@ def main():
     from storygen_amd.arch import SD15_CONFIG, build_arch
     from storygen_amd.sampler import StoryGenSampler, gather_latents
     from storygen_amd.synth import synthetic_inputs, synthetic_state_dict
+    if args.conv_patch:
+        from storygen_amd import ops
+        ops.debug_set_conv_patch(True)
+    if args.no_gemm_pairs:
+        from storygen_amd import engine as _engine
+        _engine.PAIR_GEMMS = False
 
     hw, n_ref = (96, 5) if args.config5_shape else (HW, R)
     # per-sample GFLOP of one ref / main pass: 64x64 R=3, or 96x96 R=5
@@ -284,7 +293,8 @@ def main():
                        "samples_per_gpu": N_PER_GPU, "parallelism": f"dp{world} (one sample per GPU, final all-gather)",
                        "hipgraph": not args.no_graph, "dedup_identical_reference_samples": not args.no_dedup,
                        "overlap_ref_pass_of_next_step": sampler.overlap, "ref_ahead": G, "warmup_run": warmup_run,
-                       "split_graphs": sampler.split, "stream_priority": sampler.stream_priority},
+                       "split_graphs": sampler.split, "stream_priority": sampler.stream_priority,
+                       "conv_lds_patch": args.conv_patch, "paired_gemm_launches": not args.no_gemm_pairs},
             "tflop_per_step_as_written": round(step_tflop, 3),
             "final_allgather_ms": round(gather_ms, 3), "latents_gathered": int(final.shape[0]), "latents_finite": finite,
             "latents_distinct_per_rank": distinct,

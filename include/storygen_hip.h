@@ -61,16 +61,11 @@ int          sg_device_cus(void);
  *   SG_EPI_GEGLU  : W rows (and bias) are stored interleaved in groups of 64: rows [64u, 64u+32) are "value"
  *                   outputs 32u..32u+31 and rows [64u+32, 64u+64) the matching "gate" outputs;
  *                   C[m, 32u+j] = (val + bias_v) * gelu_erf(gate + bias_g); N' = N/2 (exact erf GELU).
- * split_k > 1 needs `workspace` of sg_gemm_workspace_bytes(M, N, split_k) bytes: fp32 partial tiles plus, in its LAST
- * SG_WS_COUNTER_BYTES bytes, one arrival counter per output tile — the K slice that arrives last sums the partial
- * tiles in slice order and applies the epilogue inside the same launch (no second kernel).  The counters must be ZERO
- * when a launch starts and every launch leaves them zero: call sg_workspace_init() once after allocating a workspace
- * (and again after a failed launch); one workspace must not be used by two launches that can run concurrently.
- * split_k == 0 lets the library choose: it only considers splits whose partial tiles fit the workspace it was given
- * (M*N*4 bytes per split + the counters), so any fixed scratch buffer — or NULL to forbid splitting — is valid;
- * sg_gemm_workspace_bytes(M, N, 0) is the most it can use.  workspace_bytes must be a multiple of 16.
+ * split_k > 1 needs `workspace` of sg_gemm_workspace_bytes(M, N, split_k) bytes (fp32 partial tiles, reduced
+ * by a second kernel that applies the epilogue).  split_k == 0 lets the library choose: it only considers
+ * splits whose partial tiles fit the workspace it was given (M*N*4 bytes per split), so any fixed scratch
+ * buffer — or NULL to forbid splitting — is valid; sg_gemm_workspace_bytes(M, N, 0) is the most it can use.
  */
-#define SG_WS_COUNTER_BYTES 16384
 #define SG_EPI_LINEAR 0
 #define SG_EPI_GEGLU  1
 
@@ -109,8 +104,6 @@ int    sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream);
  * tile_m / tile_n of d0 apply to both (0, 0 = heuristic); falls back to two launches when a problem needs the generic kernel. */
 int    sg_gemm_pair_f16(const sg_gemm_desc* d0, const sg_gemm_desc* d1, sg_stream_t stream);
 size_t sg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k);
-/* Zeroes the arrival counters (the last SG_WS_COUNTER_BYTES bytes) of a GEMM / convolution workspace: once per buffer. */
-int    sg_workspace_init(void* workspace, size_t workspace_bytes, sg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * 3x3 convolution, padding 1, NHWC fp16, as implicit GEMM on MFMA:
@@ -371,6 +364,10 @@ int sg_debug_mfma_f8_32x32x64(const void* a, const void* b, float* out, int32_t 
  * optionally disable the LDS-DMA pipelined kernel (no_pipe = 1), so the parity tests can cover every code path.
  * Process-global; not for production use. */
 int sg_debug_set_tile(int32_t bm, int32_t bn, int32_t no_pipe);
+/* Experiment switch: enable = 1 routes eligible 3x3 convolutions (stride 1, no upsampling, zero-bordered input, image width <= 64)
+ * through the LDS-resident-input-patch kernel instead of the gathering implicit-GEMM kernel (default 0: measured equal in time
+ * on MI355X).  Process-global. */
+int sg_debug_set_conv_patch(int32_t enable);
 
 #ifdef __cplusplus
 }

@@ -135,7 +135,6 @@ SIGNATURES = {
     "sg_add_noise_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int64,
                                    C.c_void_p]),
     "sg_cfg_ddim_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64, C.c_void_p]),
-    "sg_workspace_init": (C.c_int, [C.c_void_p, C.c_size_t, C.c_void_p]),
     "sg_cfg_plms_step_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int64,
                                        C.c_void_p]),
     "sg_copy_rows": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
@@ -163,6 +162,7 @@ SIGNATURES = {
     "sg_debug_mfma_32x32x16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sg_debug_mfma_f8_32x32x64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sg_debug_set_tile": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "sg_debug_set_conv_patch": (C.c_int, [C.c_int32]),
 }
 
 _lib = None

@@ -20,10 +20,10 @@
 //     row-contiguous; epilogue math is fp32; outputs and residuals may be fp16 or fp32 (the UNet's residual stream
 //     is kept in fp32, MFMA operands in fp16).
 //   * block ids are remapped so that consecutive tiles (same A row panel) run on the same XCD / L2.
-//   * small-M layers (16x16 / 8x8 latent levels at batch 3) are split along K into fp32 partial tiles (the slices of a
-//     tile are consecutive logical block ids, i.e. they run on one XCD); the slice that arrives LAST at the tile's
-//     ticket counter sums all partial tiles in slice order (deterministic) and applies the fused epilogue — one launch,
-//     no separate reduce kernel (agent-scope release / acquire hand-off, cdna_hip_programming.md §5 "in-launch split-K").
+//   * small-M layers (16x16 / 8x8 latent levels at batch 3) are split along K into fp32 partial tiles; a second kernel
+//     reduces them in slice order and applies the epilogue (deterministic, no atomics).  An in-launch reduction by the
+//     last-arriving slice (agent-scope release / acquire + ticket counter) was built and measured in round 2: the release
+//     fence behind 64 KB of freshly written partials costs more (+8..13 us per launch) than the kernel boundary it removes.
 #include "common.h"
 #include <stdlib.h>
 
@@ -31,8 +31,6 @@ namespace {
 
 constexpr int BK = 64;
 constexpr int MAX_AUTO_SPLIT = 16;
-constexpr size_t WS_COUNTER_BYTES = SG_WS_COUNTER_BYTES;           // tail of every workspace: per-tile arrival counters
-constexpr int MAX_SPLIT_TILES = (int)(WS_COUNTER_BYTES / sizeof(int));
 
 struct MmaParams {
     const f16* A; long lda;
@@ -49,7 +47,7 @@ struct MmaParams {
     const void* res1; long ldr1;
     const void* res2; long ldr2;
     // decomposition
-    float* ws; int* cnt; int splits; int kt_per_split; int tiles_m, tiles_n;
+    float* ws; int splits; int kt_per_split; int tiles_m, tiles_n;
     int n_major;   // tile order: 1 = consecutive ids walk M first (tiles sharing a weight panel stay on one XCD / L2)
 };
 
@@ -113,85 +111,16 @@ __device__ __forceinline__ void epi_geglu8(const MmaParams& p, int gm, int gv, f
     store_out8(p, gm, (gv >> 6) * 32 + (gv & 31), o);   // interleaved column -> output column
 }
 
-// Split-K: sum the `splits` fp32 partial tiles of output tile (m0, n0) in slice order and apply the epilogue.  Run by the
-// whole workgroup of the slice that arrived last.  Partial tiles are requested several slices at a time (one memory round
-// trip instead of one per slice) and added in slice order, so the result does not depend on the arrival order.
-template <int BM, int BN, int NT>
-__device__ __forceinline__ void reduce_tile(const MmaParams& p, int m0, int n0) {
-    const size_t MN = (size_t)p.M * p.N;
-    const int t = threadIdx.x;
-    if (p.mode == SG_EPI_LINEAR) {
-        constexpr int NCH = BN / 8;
-        for (int idx = t; idx < BM * NCH; idx += NT) {
-            const int lr = idx / NCH, ch = idx - lr * NCH;
-            const int gm = m0 + lr, gn = n0 + ch * 8;
-            if (gm >= p.M || gn >= p.N) continue;
-            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            const float* s = p.ws + (size_t)gm * p.N + gn;
-            for (int z0 = 0; z0 < p.splits; z0 += 4) {
-                float4 a[4], b[4];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    a[u] = b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (z0 + u < p.splits) {
-                        a[u] = *reinterpret_cast<const float4*>(s + (z0 + u) * MN);
-                        b[u] = *reinterpret_cast<const float4*>(s + (z0 + u) * MN + 4);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
-                    v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
-                }
-            }
-            epi_linear8(p, gm, gn, v);
-        }
-    } else {
-        constexpr int OCH = BN / 16;
-        for (int idx = t; idx < BM * OCH; idx += NT) {
-            const int lr = idx / OCH, j = idx - lr * OCH;
-            const int gm = m0 + lr, gv = n0 + (j >> 2) * 64 + (j & 3) * 8;
-            if (gm >= p.M || gv >= p.N) continue;
-            float val[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gate[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-            const float* s = p.ws + (size_t)gm * p.N + gv;
-            for (int z0 = 0; z0 < p.splits; z0 += 2) {      // two slices (4 x 16 B each) per memory round trip
-                float4 q[2][4];
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) q[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (z0 + u < p.splits) {
-                        const float* src = s + (z0 + u) * MN;
-                        q[u][0] = *reinterpret_cast<const float4*>(src);
-                        q[u][1] = *reinterpret_cast<const float4*>(src + 4);
-                        q[u][2] = *reinterpret_cast<const float4*>(src + 32);
-                        q[u][3] = *reinterpret_cast<const float4*>(src + 36);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    val[0] += q[u][0].x; val[1] += q[u][0].y; val[2] += q[u][0].z; val[3] += q[u][0].w;
-                    val[4] += q[u][1].x; val[5] += q[u][1].y; val[6] += q[u][1].z; val[7] += q[u][1].w;
-                    gate[0] += q[u][2].x; gate[1] += q[u][2].y; gate[2] += q[u][2].z; gate[3] += q[u][2].w;
-                    gate[4] += q[u][3].x; gate[5] += q[u][3].y; gate[6] += q[u][3].z; gate[7] += q[u][3].w;
-                }
-            }
-            epi_geglu8(p, gm, gv, val, gate);
-        }
-    }
-}
-
 // Shared tail of both mainloops: split-K partial store, or LDS-staged fused epilogue with 16-byte accesses.
 // Must be entered by all threads after a barrier that ends all LDS reads of the mainloop.  Wave (wm, wn) of the
 // WGM x WGN grid holds TM x TN 32x32 accumulators of its (BM/WGM) x (BN/WGN) sub-tile.
 template <int BM, int BN, int WGM, int WGN>
 __device__ __forceinline__ void tile_epilogue(const MmaParams& p, char* smem, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32],
-                                              int m0, int n0, int z, int tile_id) {
+                                              int m0, int n0, int z) {
     constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32, NT = 64 * WGM * WGN;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, hi = lane >> 5;
-    if (p.splits > 1) {
-        // raw fp32 partial tile -> workspace; the LAST slice of this tile to arrive (ticket counter) reduces all of them
+    if (p.splits > 1) {   // raw fp32 partial tile; the epilogue happens in splitk_reduce_kernel
         float* wsz = p.ws + (size_t)z * p.M * p.N;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -204,25 +133,6 @@ __device__ __forceinline__ void tile_epilogue(const MmaParams& p, char* smem, f3
                     if (gm < p.M && gn < p.N) wsz[(size_t)gm * p.N + gn] = acc[i][j][r];
                 }
             }
-        // publish: every wave drains its stores, one lane releases at agent scope, THEN draws the ticket (this order —
-        // a release issued after a returned atomic can lose its vmcnt wait on ROCm 7.2; the asm wait restates it)
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        int* flag = reinterpret_cast<int*>(smem);          // the one LDS array (a second __shared__ object de-pipelines the k-loop)
-        if (t == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            const int ticket = __hip_atomic_fetch_add(p.cnt + tile_id, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            const int last = ticket == p.splits - 1;
-            if (last) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");      // drops this CU's L1: the other slices' tiles are read fresh
-                __hip_atomic_store(p.cnt + tile_id, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
-            }
-            *flag = last;
-        }
-        __syncthreads();
-        if (!*flag) return;
-        reduce_tile<BM, BN, NT>(p, m0, n0);
         return;
     }
     // ---- fused epilogue through LDS, one 32-row band of every wave's sub-tile at a time (TM passes): the staging
@@ -441,7 +351,7 @@ __global__ __launch_bounds__(256) void mma_kernel(const MmaParams p) {
         if (more) store_lds(buf ^ 1);
         __syncthreads();
     }
-    tile_epilogue<BM, BN, 2, 2>(p, smem, acc, m0, n0, z, lid);
+    tile_epilogue<BM, BN, 2, 2>(p, smem, acc, m0, n0, z);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -621,7 +531,7 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         if (++stage == S) stage = 0;
     }
     __syncthreads();   // every wave is done reading the stages before the epilogue reuses LDS
-    tile_epilogue<BM, BN, WGM, WGN>(p, smem, acc, m0, n0, z, lid);
+    tile_epilogue<BM, BN, WGM, WGN>(p, smem, acc, m0, n0, z);
 }
 
 template <int WGM, int WGN, int S, bool CONV, bool LATE, bool PREF, int WTM = 2, int WTN = 2>
@@ -647,6 +557,231 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_pair_kernel(const Mma
     }
 }
 
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const MmaParams p) {
+    const size_t MN = (size_t)p.M * p.N;
+    if (p.mode == SG_EPI_LINEAR) {
+        const int nch = p.N / 8;
+        const long total = (long)p.M * nch;
+        for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+            const int gm = (int)(idx / nch), gn = (int)(idx - (long)gm * nch) * 8;
+            float v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const float* s = p.ws + (size_t)gm * p.N + gn;
+            // the partial tiles of up to four splits are requested together (one memory round trip instead of four) and
+            // added in split order, so the sum is bit-identical to the sequential loop
+            for (int z0 = 0; z0 < p.splits; z0 += 4) {
+                float4 a[4], b[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    a[u] = b[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (z0 + u < p.splits) {
+                        a[u] = *reinterpret_cast<const float4*>(s + (z0 + u) * MN);
+                        b[u] = *reinterpret_cast<const float4*>(s + (z0 + u) * MN + 4);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    v[0] += a[u].x; v[1] += a[u].y; v[2] += a[u].z; v[3] += a[u].w;
+                    v[4] += b[u].x; v[5] += b[u].y; v[6] += b[u].z; v[7] += b[u].w;
+                }
+            }
+            epi_linear8(p, gm, gn, v);
+        }
+    } else {
+        const int och = p.N / 16;
+        const long total = (long)p.M * och;
+        for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256) {
+            const int gm = (int)(idx / och), j = (int)(idx - (long)gm * och);
+            const int gv = (j >> 2) * 64 + (j & 3) * 8;
+            float val[8] = {0, 0, 0, 0, 0, 0, 0, 0}, gate[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            const float* s = p.ws + (size_t)gm * p.N + gv;
+            for (int z0 = 0; z0 < p.splits; z0 += 2) {      // two splits (4 x 16 B each) per memory round trip
+                float4 q[2][4];
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) q[u][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (z0 + u < p.splits) {
+                        const float* src = s + (z0 + u) * MN;
+                        q[u][0] = *reinterpret_cast<const float4*>(src);
+                        q[u][1] = *reinterpret_cast<const float4*>(src + 4);
+                        q[u][2] = *reinterpret_cast<const float4*>(src + 32);
+                        q[u][3] = *reinterpret_cast<const float4*>(src + 36);
+                    }
+                }
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    val[0] += q[u][0].x; val[1] += q[u][0].y; val[2] += q[u][0].z; val[3] += q[u][0].w;
+                    val[4] += q[u][1].x; val[5] += q[u][1].y; val[6] += q[u][1].z; val[7] += q[u][1].w;
+                    gate[0] += q[u][2].x; gate[1] += q[u][2].y; gate[2] += q[u][2].z; gate[3] += q[u][2].w;
+                    gate[4] += q[u][3].x; gate[5] += q[u][3].y; gate[6] += q[u][3].z; gate[7] += q[u][3].w;
+                }
+            }
+            epi_geglu8(p, gm, gv, val, gate);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// 3x3 convolution (stride 1, zero-bordered input) with the INPUT PATCH RESIDENT IN LDS.
+//
+// The implicit-GEMM kernel above gathers the A tile of every (tap, channel chunk) slab from global memory: each input
+// pixel of a tile crosses the CU's vector L1 nine times.  Every convolution of the step is bound by exactly that per-CU
+// operand feed, so this kernel moves fewer bytes per FLOP instead: a tile is BM consecutive output
+// pixels = BM / W whole image rows (W | BM), whose 3x3 footprint is ONE contiguous range of (BM / W + 2) (W + 2)
+// padded input pixels.  For each 64-channel chunk that patch is brought into LDS once (LDS-DMA, double-buffered:
+// the patch of chunk c + 1 lands while the nine taps of chunk c are consumed) and the MFMA A fragments of tap (ky, kx) are
+// read from it at a pixel offset of ky (W + 2) + kx.  Only the weights stream per slab (S = 3 ring, as above).
+// A-side L1 traffic drops from 9 BM x 128 B to (BM / W + 2)(W + 2) x 128 B per chunk (x 5.8 at 256 x 64-pixel rows).
+// K order = (channel chunk, tap); split-K splits whole chunks.  LDS pixel rows are 128 B with the same XOR swizzle
+// (slot = chunk ^ ((pixel >> 1) & 7), applied on the DMA source side and on the reads).
+// vmcnt bookkeeping: every iteration issues ONE group after its barrier — the weight slab two iterations ahead plus, at
+// taps 0..6 of every chunk but the last, PT pieces (1 KiB each) of the next patch — and iteration `it` needs everything
+// up to group it - 2, i.e. it may leave exactly |group it - 1| loads outstanding; group sizes are the same in every wave
+// (surplus pieces copy a valid pixel into a scrap KiB), so the counts are compile-time constants per tap position.
+template <int WGM, int WGN>
+struct PatchGeom {
+    static constexpr int NW = WGM * WGN, BM = 64 * WGM, BN = 64 * WGN;
+    static constexpr int B_IT = BN / (8 * NW);
+    static constexpr int NPIECES_MAX = ((BM / 64 + 2) * 66 + 7) / 8;              // W <= 64: the largest patch, in 8-pixel pieces
+    static constexpr int PP = (NPIECES_MAX + NW - 1) / NW;                         // pieces per wave per chunk
+    static constexpr int PT = (PP + 6) / 7;                                        // pieces per wave per tap (taps 0..6)
+    static constexpr int PATCH_BYTES = NPIECES_MAX * 1024;
+    static constexpr int W_STAGE = BN * 128, S = 3;
+    static constexpr int SCRAP = 2 * PATCH_BYTES + S * W_STAGE;
+    static constexpr int EPI_BYTES = WGM * 32 * BN * 4;
+    static constexpr int SMEM = (SCRAP + 1024 > EPI_BYTES) ? SCRAP + 1024 : EPI_BYTES;
+    static_assert(SMEM <= 160 * 1024, "patch buffers + weight ring must fit the 160 KB of LDS");
+    static_assert(B_IT + PT < 32, "vmcnt is a 6-bit counter");
+};
+
+template <int WGM, int WGN>
+__global__ __launch_bounds__(64 * WGM * WGN) void conv_patch_kernel(const MmaParams p) {
+    using G = PatchGeom<WGM, WGN>;
+    constexpr int NW = G::NW, BM = G::BM, BN = G::BN, B_IT = G::B_IT, PT = G::PT, S = G::S;
+    constexpr int ISTR = NW * 1024;
+    __shared__ __attribute__((aligned(16))) char smem[G::SMEM];
+    char* const wring = smem + 2 * G::PATCH_BYTES;
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, hi = lane >> 5;
+    const int lid2 = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.splits);
+    const int lid = lid2 / p.splits, z = lid2 - lid * p.splits;
+    const int m0 = (p.n_major ? lid % p.tiles_m : lid / p.tiles_n) * BM;
+    const int n0 = (p.n_major ? lid / p.tiles_m : lid % p.tiles_n) * BN;
+    const int cps = p.kt_per_split / 9;                       // channel chunks per K slice
+    const int c0 = z * cps, nch = min(p.cpt, c0 + cps) - c0;  // this block's chunks [c0, c0 + nch)
+    const int nt = nch * 9;
+
+    // geometry: tile = rows [y0, y0 + BM / Wd) of image b; patch = padded rows [y0, y0 + BM / Wd + 2), all Wd + 2 columns
+    const int Wd = p.Wd, wp = Wd + 2, hw = p.Ho * p.Wo;
+    const int b = m0 / hw, y0 = (m0 - b * hw) / Wd;
+    const int np = (BM / Wd + 2) * wp, npieces = (np + 7) >> 3;
+    const unsigned pix0 = (unsigned)((b * (p.H + 2) + y0) * wp);          // first padded pixel of the patch
+
+    // weight-slab staging (as in mma_pipe_kernel): tile row srow + 8 NW i, LDS slot lane & 7, source-side swizzle
+    const int srow = wave * 8 + (lane >> 3);
+    unsigned w_off[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int row = srow + 8 * NW * i;
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        w_off[i] = (unsigned)((long)min(n0 + row, p.N - 1) * p.ldw + lc * 8);
+    }
+    // A fragments: patch pixel of tap (0, 0) for this lane's row of each 32-row MFMA tile
+    int q0[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int m = wm * 64 + i * 32 + l31;
+        const int r = m / Wd;
+        q0[i] = r * wp + (m - r * Wd);
+    }
+
+    auto issue_w = [&](int it) {                               // weight slab of iteration `it` (chunk-major K order)
+        const int ci = it / 9, wt = it - ci * 9;               // scalar arithmetic (wave-uniform)
+        char* sB = wring + (it % S) * G::W_STAGE + wave * 1024;
+        const f16* Wt = p.W + (wt * p.cpt + c0 + ci) * BK;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) glds16(Wt + w_off[i], sB + i * ISTR);
+    };
+    auto issue_piece = [&](int chunk, int j) {                 // piece j of this wave of the patch of chunk `chunk` (relative)
+        const int g = j * NW + wave;                           // wave-uniform piece id
+        const int pix = min(g * 8 + (lane >> 3), np - 1);
+        const int lc = (lane & 7) ^ ((pix >> 1) & 7);
+        const f16* src = p.A + ((size_t)(pix0 + pix) * p.lda + (c0 + chunk) * BK + lc * 8);
+        char* dst = (g < npieces) ? smem + (chunk & 1) * G::PATCH_BYTES + g * 1024 : smem + G::SCRAP;
+        glds16(src, dst);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // prologue: whole patch of chunk 0, weight slabs 0 and 1
+#pragma unroll 1
+    for (int j = 0; j < 7 * PT; ++j) issue_piece(0, j);
+    issue_w(0);
+    if (nt > 1) issue_w(1);
+
+    // one rolled loop over the slabs (a 9-way unrolled tap loop hoists nine sets of fragment addresses: > 256 VGPRs);
+    // (ch, tap, ky, kx, stage) are wave-uniform counters kept in SGPRs
+    int ch = 0, tap = 0, ky = 0, kx = 0, stage = 0;
+#pragma unroll 1
+    for (int it = 0; it < nt; ++it) {
+        const bool more = ch + 1 < nch;                        // a next chunk exists: its patch is prefetched during this one
+        // leave exactly the previous iteration's group in flight (see header)
+        if (it + 1 >= nt) wait_vmcnt<0>();
+        else if (tap == 0 || tap == 8 || !more) wait_vmcnt<B_IT>();
+        else wait_vmcnt<B_IT + PT>();
+        __builtin_amdgcn_s_barrier();
+        const char* pbuf = smem + (ch & 1) * G::PATCH_BYTES;
+        const char* sB = wring + stage * G::W_STAGE;
+        const int toff = ky * wp + kx;
+        int abase[2], aswz[2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int q = q0[i] + toff;
+            abase[i] = q * 128;
+            aswz[i] = (q >> 1) & 7;
+        }
+        f16x8 af[2][2], bf[2][2];
+        auto load_frags = [&](int buf, int ks) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+                af[buf][i] = *reinterpret_cast<const f16x8*>(pbuf + abase[i] + (((ks * 2 + hi) ^ aswz[i]) << 4));
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                bf[buf][j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * 64 + j * 32 + l31, ks * 2 + hi));
+        };
+        load_frags(0, 0);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
+            if (ks == 1) {                                     // this iteration's group, behind the first MFMAs
+                if (it + 2 < nt) issue_w(it + 2);
+                if (tap < 7 && more) {
+#pragma unroll
+                    for (int j = 0; j < PT; ++j) issue_piece(ch + 1, tap * PT + j);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+        }
+        if (++stage == S) stage = 0;
+        if (++kx == 3) { kx = 0; ++ky; }
+        if (++tap == 9) { tap = 0; ky = 0; ++ch; }
+    }
+    __syncthreads();
+    tile_epilogue<BM, BN, WGM, WGN>(p, smem, acc, m0, n0, z);
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct Plan { int bm, bn, splits, fat; };
 
@@ -654,6 +789,10 @@ struct Plan { int bm, bn, splits, fat; };
 // the LDS-DMA pipeline, SG_NO_SPLIT=1 disables automatic split-K.  Unset in production.
 struct Tune {
     mutable int bm = 0, bn = 0, no_pipe = 0, no_split = 0, stages = 0, no_nmajor = 0, late_issue = 1, no_frag_prefetch = 0, fat = 0;
+    // conv_patch_kernel is OFF by default: measured on MI355X (round 2, tools/exp_feed.py) it ties the gathering kernel on
+    // every convolution of the step (47.2 vs 47.2 us at 64x64 320->320) although it moves 2-3x fewer bytes through the L1 —
+    // which is what showed that the mainloop is not bound by operand bytes.  sg_debug_set_conv_patch(1) enables it.
+    mutable int conv_patch = 0;
     Tune() {
         if (const char* e = getenv("SG_STAGES")) stages = atoi(e);
         if (const char* e = getenv("SG_NO_NMAJOR")) no_nmajor = atoi(e);
@@ -672,10 +811,11 @@ static const Tune g_tune;
 //   t_bw   = (blocks a CU must run) x (bytes one block streams) / 18.5      — total bytes over the ACTIVE CUs, or by
 //   t_mfma = (waves per SIMD) x slabs x 512                                  — 16 MFMAs of 32 cycles per 64-deep slab,
 // plus a fixed prologue/epilogue.  Splitting K does not add operand bytes but multiplies the CUs that share them,
-// which is what small-M layers need; it costs the partial-tile round trip: every slice writes its fp32 tile and the
-// last one to arrive reads all of them back (same-XCD hand-off, ~110 GB/s per workgroup = ~45 B/cycle) after one
-// agent-scope release / acquire pair (~1.5 us).
-Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool pipe, int hint_bm, int hint_bn, int hint_waves) {
+// which is what small-M layers need; it costs a second launch that re-reads the fp32 partial tiles.
+// patch_w > 0: plan for conv_patch_kernel on an image of width patch_w and hw pixels per image (tiles are whole rows; the A
+// side streams (bm / w + 2)(w + 2) pixels per 64-channel chunk instead of 9 bm; K is split in whole chunks of 9 slabs).
+Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool pipe, int hint_bm, int hint_bn, int hint_waves,
+                 int patch_w = 0, int patch_hw = 0) {
     static const int cand_pipe[6][2] = {{256, 128}, {128, 128}, {256, 64}, {128, 64}, {64, 128}, {64, 64}};
     static const int cand_gen[3][2] = {{128, 128}, {128, 64}, {64, 64}};
     static const int split_opts[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
@@ -687,6 +827,8 @@ Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool p
         const int bm = pipe ? cand_pipe[ci][0] : cand_gen[ci][0], bn = pipe ? cand_pipe[ci][1] : cand_gen[ci][1];
         if (g_tune.bm && (bm != g_tune.bm || bn != g_tune.bn)) continue;
         if (!g_tune.bm && hint_bm && (bm != hint_bm || bn != hint_bn)) continue;
+        if (patch_w && (bm % patch_w || patch_hw % bm)) continue;
+        const double a_rows = patch_w ? (bm / patch_w + 2) * (patch_w + 2) / 9.0 : bm;    // A rows streamed per 64-deep slab
         const long tiles = (long)sg_cdiv(M, bm) * sg_cdiv(N, bn);
         const double waves_per_block = pipe ? (bm / 64) * (bn / 64) : 4.0;
         const double mfma_per_slab = pipe ? 512.0 : 512.0 * (bm / 64.0) * (bn / 64.0) / 4.0;
@@ -694,18 +836,22 @@ Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool p
             if (force_split > 0 && s != force_split) continue;
             if (force_split <= 0 && s > 1 && (s > max_ws_split || KT / s < 2 || g_tune.no_split)) continue;
             if (s > KT) continue;
+            if (patch_w && s > KT / 9) continue;
             const double blocks = (double)tiles * s;
-            const double slabs = sg_cdiv(KT, s);
+            const double slabs = patch_w ? 9.0 * sg_cdiv(KT / 9, s) : sg_cdiv(KT, s);
             const double blocks_per_cu = sg_cdiv((long)blocks, (long)CUS);
-            const double t_bw = blocks_per_cu * slabs * (bm + bn) * 128.0 / BW;
+            const double t_bw = blocks_per_cu * slabs * (a_rows + bn) * 128.0 / BW;
             const double waves_per_simd = sg_cdiv((long)(blocks * waves_per_block), (long)(CUS * 4));
             const double t_mfma = waves_per_simd * slabs * mfma_per_slab;
             double cost = (t_bw > t_mfma ? t_bw : t_mfma) + 2500.0 + blocks_per_cu * (bm * bn / 16.0);
-            if (s > 1) cost += 3500.0 + (double)bm * bn * 4.0 * s / 45.0 + (double)bm * bn * 4.0 / 64.0;   // hand-off + reduce
+            if (s > 1) cost += 5000.0 + (double)M * N * 4.0 * (s + 1) / 1500.0;   // second launch + partial tiles
             if (cost < best_cost) { best_cost = cost; best = Plan{bm, bn, s, 0}; }
         }
     }
-    if (best_cost == 1e300) best = Plan{64, 64, force_split > KT ? KT : (force_split > 0 ? force_split : 1), 0};
+    if (best_cost == 1e300) {
+        if (patch_w) return Plan{0, 0, 0, 0};                 // no eligible tile: the caller falls back to the gathering kernel
+        best = Plan{64, 64, force_split > KT ? KT : (force_split > 0 ? force_split : 1), 0};
+    }
     // "fat" waves (128 x 64 per wave): 256x128 with 4 waves, 128x128 with 2 — on request (tile_waves hint) or SG_FAT=1
     const bool can_fat = pipe && ((best.bm == 256 && best.bn == 128) || (best.bm == 128 && best.bn == 128));
     const int fat_waves = best.bm == 256 ? 4 : 2;
@@ -742,22 +888,15 @@ int plan_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_w
     p.KT = sg_cdiv(p.K, BK);
     pipe = (p.K % BK == 0) && (!CONV || p.padded) && !g_tune.no_pipe;
     const size_t per_split = (size_t)p.M * p.N * 4;
-    const size_t ws_tiles = (ws && ws_bytes > WS_COUNTER_BYTES) ? ws_bytes - WS_COUNTER_BYTES : 0;   // room for partial tiles
-    const int max_ws_split = ws_tiles ? (int)(ws_tiles / per_split > 64 ? 64 : ws_tiles / per_split) : 1;
+    const int max_ws_split = ws ? (int)(ws_bytes / per_split > 64 ? 64 : ws_bytes / per_split) : 1;
     pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, pipe, hint_bm, hint_bn, hint_waves);
-    if (pl.splits > 1 && (long)sg_cdiv(p.M, pl.bm) * sg_cdiv(p.N, pl.bn) > MAX_SPLIT_TILES) {
-        if (force_split > 1)
-            return sg_set_error(SG_EINVAL, "%s: split_k with more than %d output tiles is not supported", name, MAX_SPLIT_TILES);
-        pl.splits = 1;                          // a grid that large does not need splitting
-    }
     if (pl.splits > 1) {
-        const size_t need = per_split * pl.splits + WS_COUNTER_BYTES;
+        const size_t need = per_split * pl.splits;
         if (ws == nullptr || ws_bytes < need)
             return sg_set_error(SG_EINVAL, "%s: split_k=%d needs %zu workspace bytes, got %zu", name, pl.splits, need,
                                 ws_bytes);
     }
     p.ws = reinterpret_cast<float*>(ws);
-    p.cnt = ws ? reinterpret_cast<int*>(reinterpret_cast<char*>(ws) + (ws_bytes - WS_COUNTER_BYTES)) : nullptr;
     p.splits = pl.splits;
     p.kt_per_split = sg_cdiv(p.KT, pl.splits);
     p.tiles_m = sg_cdiv(p.M, pl.bm);
@@ -771,8 +910,65 @@ int plan_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_w
     return SG_OK;
 }
 
+// second pass of a split-K launch: partial tiles -> epilogue
+int launch_reduce(const MmaParams& p, hipStream_t st) {
+    if (p.splits <= 1) return SG_OK;
+    const long items = (long)p.M * (p.N / (p.mode == SG_EPI_GEGLU ? 16 : 8));
+    const int blocks = (int)min((long)4096, (items + 255) / 256);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
+    SG_CHECK_LAUNCH("splitk_reduce");
+    return SG_OK;
+}
+
+template <int WGM, int WGN>
+void launch_patch(const MmaParams& p, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((conv_patch_kernel<WGM, WGN>), grid, dim3(64 * WGM * WGN), 0, st, p);
+}
+
+// conv_patch_kernel when the problem allows it (stride 1, no upsampling, zero-bordered input, image width <= 64 dividing a tile
+// that divides the image).  Returns 1 if launched, 0 if not applicable, < 0 on error.
+int try_launch_conv_patch(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws, size_t ws_bytes, hipStream_t st,
+                          const char* name) {
+    if (!g_tune.conv_patch || g_tune.no_pipe || !p.padded || p.stride != 1 || p.ups || p.Wd > 64 || p.Wd < 4) return 0;
+    p.KT = 9 * p.cpt;
+    const size_t per_split = (size_t)p.M * p.N * 4;
+    const int max_ws_split = ws ? (int)(ws_bytes / per_split > 64 ? 64 : ws_bytes / per_split) : 1;
+    Plan pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, true, hint_bm, hint_bn, 0, p.Wd, p.Ho * p.Wo);
+    if (pl.bm == 0) return 0;
+    const int cps = sg_cdiv(p.cpt, pl.splits);                // whole channel chunks per slice
+    pl.splits = sg_cdiv(p.cpt, cps);
+    if (pl.splits > 1 && (ws == nullptr || ws_bytes < per_split * pl.splits)) {
+        if (force_split > 1) return sg_set_error(SG_EINVAL, "%s: split_k=%d does not fit the workspace", name, pl.splits);
+        return 0;
+    }
+    p.ws = reinterpret_cast<float*>(ws);
+    p.splits = pl.splits;
+    p.kt_per_split = 9 * cps;
+    p.tiles_m = p.M / pl.bm;
+    p.tiles_n = sg_cdiv(p.N, pl.bn);
+    const double a_bytes = 2.0 * p.M * (p.K / 9), w_bytes = 2.0 * p.N * p.K;
+    p.n_major = (w_bytes > a_bytes && !g_tune.no_nmajor) ? 1 : 0;
+    dim3 grid(p.tiles_m * p.tiles_n * pl.splits);
+    if (pl.bm == 256 && pl.bn == 128) launch_patch<4, 2>(p, grid, st);
+    else if (pl.bm == 128 && pl.bn == 128) launch_patch<2, 2>(p, grid, st);
+    else if (pl.bm == 256 && pl.bn == 64) launch_patch<4, 1>(p, grid, st);
+    else if (pl.bm == 128 && pl.bn == 64) launch_patch<2, 1>(p, grid, st);
+    else if (pl.bm == 64 && pl.bn == 128) launch_patch<1, 2>(p, grid, st);
+    else launch_patch<1, 1>(p, grid, st);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return sg_set_error(SG_ELAUNCH, "%s: %s", name, hipGetErrorString(e));
+    if (int rc = launch_reduce(p, st)) return rc;
+    return 1;
+}
+
 template <bool CONV>
 int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_waves, void* ws, size_t ws_bytes, hipStream_t st, const char* name) {
+    if constexpr (CONV) {
+        if (hint_waves == 0) {
+            const int rc = try_launch_conv_patch(p, force_split, hint_bm, hint_bn, ws, ws_bytes, st, name);
+            if (rc != 0) return rc < 0 ? rc : SG_OK;
+        }
+    }
     Plan pl;
     bool pipe;
     if (int rc = plan_mma<CONV>(p, force_split, hint_bm, hint_bn, hint_waves, ws, ws_bytes, name, pl, pipe)) return rc;
@@ -796,7 +992,7 @@ int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint
         else hipLaunchKernelGGL((mma_kernel<64, 64, CONV>), grid, block, 0, st, p);
     }
     SG_CHECK_LAUNCH(name);
-    return SG_OK;
+    return launch_reduce(p, st);
 }
 
 int check_out_res(const char* who, int flags, const void* C, int64_t ldc, const void* C2, int64_t ldc2, const void* res1,
@@ -823,16 +1019,7 @@ int check_tile_hint(const char* who, int bm, int bn, int waves) {
 
 extern "C" size_t sg_gemm_workspace_bytes(int32_t M, int32_t N, int32_t split_k) {
     const int s = split_k > 0 ? split_k : MAX_AUTO_SPLIT;
-    return s > 1 ? (size_t)M * (size_t)N * 4u * (size_t)s + WS_COUNTER_BYTES : 0;
-}
-
-extern "C" int sg_workspace_init(void* workspace, size_t workspace_bytes, sg_stream_t stream) {
-    SG_REQUIRE(workspace && workspace_bytes >= WS_COUNTER_BYTES && sg_aligned16(workspace) && workspace_bytes % 16 == 0,
-               "sg_workspace_init: need a 16-byte aligned workspace of at least %zu bytes (a multiple of 16)", WS_COUNTER_BYTES);
-    hipError_t e = hipMemsetAsync(reinterpret_cast<char*>(workspace) + (workspace_bytes - WS_COUNTER_BYTES), 0, WS_COUNTER_BYTES,
-                                  (hipStream_t)stream);
-    if (e != hipSuccess) return sg_set_error(SG_ELAUNCH, "sg_workspace_init: %s", hipGetErrorString(e));
-    return SG_OK;
+    return s > 1 ? (size_t)M * (size_t)N * 4u * (size_t)s : 0;
 }
 
 namespace {
@@ -858,7 +1045,7 @@ int gemm_params(const sg_gemm_desc* d, MmaParams& p, const char* who) {
     SG_REQUIRE(!d->rowbias || (sg_aligned16(d->rowbias) && d->rowbias_ld % 4 == 0 && d->rows_per_batch >= 1),
                "%s: rowbias alignment / rows_per_batch", who);
     SG_REQUIRE(d->split_k >= 0 && d->split_k <= 64, "%s: bad split_k %d", who, d->split_k);
-    SG_REQUIRE(!d->workspace || (sg_aligned16(d->workspace) && d->workspace_bytes % 16 == 0), "%s: workspace alignment / size %% 16", who);
+    SG_REQUIRE(!d->workspace || (sg_aligned16(d->workspace)), "%s: workspace alignment", who);
     SG_REQUIRE((int64_t)d->M * d->lda < (1ll << 32) && (int64_t)d->N * d->ldw < (1ll << 32),
                "%s: operands larger than 2^32 elements are not supported (32-bit DMA offsets)", who);
     p = MmaParams{};
@@ -915,7 +1102,8 @@ extern "C" int sg_gemm_pair_f16(const sg_gemm_desc* d0, const sg_gemm_desc* d1, 
     else if (pl0.bm == 64 && pl0.bn == 128) launch_pair<1, 2>(pp, grid, st);
     else launch_pair<1, 1>(pp, grid, st);
     SG_CHECK_LAUNCH("sg_gemm_pair_f16");
-    return SG_OK;
+    if (int rc = launch_reduce(pp.p0, st)) return rc;
+    return launch_reduce(pp.p1, st);
 }
 
 extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream) {
@@ -933,7 +1121,7 @@ extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream)
     SG_REQUIRE(!d->bias || sg_aligned16(d->bias), "sg_conv3x3: bias alignment");
     SG_REQUIRE(!d->rowbias || (sg_aligned16(d->rowbias) && d->rowbias_ld % 4 == 0), "sg_conv3x3: rowbias alignment");
     SG_REQUIRE(d->split_k >= 0 && d->split_k <= 64, "sg_conv3x3: bad split_k %d", d->split_k);
-    SG_REQUIRE(!d->workspace || (sg_aligned16(d->workspace) && d->workspace_bytes % 16 == 0), "sg_conv3x3: workspace alignment / size %% 16");
+    SG_REQUIRE(!d->workspace || sg_aligned16(d->workspace), "sg_conv3x3: workspace alignment");
     SG_REQUIRE((int64_t)d->B * (d->H + 2) * (d->W + 2) * d->ldx < (1ll << 32) && (int64_t)d->Cout * 9 * d->Cin < (1ll << 32),
                "sg_conv3x3: operands larger than 2^32 elements are not supported (32-bit DMA offsets)");
     SG_REQUIRE((int64_t)(d->W + 2) * d->ldx < (1 << 24), "sg_conv3x3: input row pitch must be below 2^24 elements");
@@ -955,6 +1143,11 @@ extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream)
 }
 
 // ------------------------------------------------------------------------------------------------ diagnostics
+extern "C" int sg_debug_set_conv_patch(int32_t enable) {
+    g_tune.conv_patch = enable ? 1 : 0;
+    return SG_OK;
+}
+
 extern "C" int sg_debug_set_tile(int32_t bm, int32_t bn, int32_t no_pipe) {
     g_tune.bm = bm; g_tune.bn = bn; g_tune.no_pipe = no_pipe;
     return SG_OK;

@@ -36,6 +36,15 @@ from .arch import BlockSpec, ResnetSpec, UNetArch, XfSpec, feature_shapes
 from .repack import conv1x1_nk, conv3x3_krsc, conv_in_kn, interleave_geglu
 
 F16 = torch.float16
+PAIR_GEMMS = True     # q|k + V^T, q2 + q3, k3 + v3^T as one launch each (sg_gemm_pair_f16); False = two launches (A/B switch)
+
+
+def _pair(first, second):
+    if PAIR_GEMMS:
+        ops.gemm_pair(first, second)
+    else:
+        for args, kw in (first, second):
+            ops.gemm(*args, **kw)
 
 
 class _Resnet:
@@ -392,7 +401,7 @@ class UNetEngine:
 
     def _project_text(self, xf: _Xf, kt: torch.Tensor, vtt: torch.Tensor):
         x = self.text_pad.view(self.B * self.Sp, self.cad)
-        ops.gemm_pair(((x, xf.w_k2, kt), dict(workspace=self.ws_split)),
+        _pair(((x, xf.w_k2, kt), dict(workspace=self.ws_split)),
                       ((xf.w_v2, x, vtt), dict(workspace=self.ws_pair)))                   # VT = Wv . X^T
 
     def cache_text_kv(self):
@@ -425,7 +434,7 @@ class UNetEngine:
         qk, vt = L["qk"], L["vt"]
         wp = self.ws_pair
         # q|k (token-major) and V^T = Wv . X^T (the attention kernel's operand layout): two GEMMs on one LayerNorm output, one launch
-        ops.gemm_pair(((L["ln"], xf.w_qk1, qk), dict(workspace=ws)), ((xf.w_v1, L["ln"], vt), dict(workspace=wp)))
+        _pair(((L["ln"], xf.w_qk1, qk), dict(workspace=ws)), ((xf.w_v1, L["ln"], vt), dict(workspace=wp)))
         qk3 = qk.view(B, hw, 2 * C)
         att = L["att"]
         ops.attention(qk3[:, :, :C], qk3[:, :, C:], vt.view(C, B, hw).permute(1, 0, 2), att.view(B, hw, C), heads, scale)
@@ -441,7 +450,7 @@ class UNetEngine:
                 if plan.kv is not None:            # attn3 K / V^T of the finished context (attention.py:215-223)
                     ki, vti = plan.kv[xf.spec.feature_key]
                     c2d = ctx.view(ctx.shape[0] * ctx.shape[1], C)
-                    ops.gemm_pair(((c2d, xf.w_k3, ki), dict(workspace=ws)), ((xf.w_v3, c2d, vti), dict(workspace=wp)))   # VT[C, rows*nk]
+                    _pair(((c2d, xf.w_k3, ki), dict(workspace=ws)), ((xf.w_v3, c2d, vti), dict(workspace=wp)))   # VT[C, rows*nk]
             if stop_after_harvest:
                 return
         # --- text cross-attention :266-277 (norm2) and image cross-attention :281-291 (norm4) share statistics
@@ -457,7 +466,7 @@ class UNetEngine:
             a2v, a3v = att23[:, :C].unflatten(0, (B, hw)), att23[:, C:].unflatten(0, (B, hw))
             # both query projections in one launch (norm2 / norm4 outputs of the same statistics), then the two attentions side by side
             q2, q3buf = L["q2"], L["q"]
-            ops.gemm_pair(((L["ln"], xf.w_q2, q2), dict(workspace=ws)), ((L["ln4"], xf.w_q3, q3buf), dict(workspace=wp)))
+            _pair(((L["ln"], xf.w_q2, q2), dict(workspace=ws)), ((L["ln4"], xf.w_q3, q3buf), dict(workspace=wp)))
             forked = self._fork()
             if forked:
                 with torch.cuda.stream(self.side):
@@ -471,7 +480,7 @@ class UNetEngine:
             else:
                 ki, vti = L["ki"], L["vti"]
                 c2d = ctx.view(rows * nk, C)
-                ops.gemm_pair(((c2d, xf.w_k3, ki), dict(workspace=ws)), ((xf.w_v3, c2d, vti), dict(workspace=wp)))   # VT[C, rows*nk]
+                _pair(((c2d, xf.w_k3, ki), dict(workspace=ws)), ((xf.w_v3, c2d, vti), dict(workspace=wp)))   # VT[C, rows*nk]
             ki3, vti3 = ki.view(rows, nk, C), vti.view(C, rows, nk).permute(1, 0, 2)
             q3 = q3buf.view(B, hw, C)
             if self.attn3_share is not None:      # one launch: batch b reads context row b (b < rows) or b - (B - rows)

@@ -123,27 +123,14 @@ def gemm_workspace_bytes(M: int, N: int, split_k: int = 0) -> int:
     return lib.sg_gemm_workspace_bytes(M, N, split_k)
 
 
-WS_COUNTER_BYTES = 16384       # SG_WS_COUNTER_BYTES
-
-
 def new_workspace(nbytes: int, device) -> torch.Tensor:
-    """A split-K workspace for gemm / conv3x3 with its arrival counters zeroed (sg_workspace_init contract)."""
-    nbytes = (max(int(nbytes), WS_COUNTER_BYTES) + 15) & ~15
-    ws = torch.zeros(nbytes, dtype=torch.uint8, device=device)
-    ws._sg_ws_ready = True
-    return ws
+    """A split-K workspace for gemm / conv3x3 (fp32 partial tiles; no initialisation needed)."""
+    return torch.empty((int(nbytes) + 15) & ~15, dtype=torch.uint8, device=device)
 
 
 def _ws(workspace: Optional[torch.Tensor], d):
-    """Attach `workspace` to a descriptor.  A tensor this module has not seen yet gets its counter region zeroed ONCE (one
-    memset on the launch stream; allocate with new_workspace() to keep that out of a hipGraph capture)."""
-    if workspace is None:
-        return
-    nbytes = (workspace.numel() * workspace.element_size()) & ~15
-    if nbytes >= WS_COUNTER_BYTES and not getattr(workspace, "_sg_ws_ready", False):
-        check(lib.sg_workspace_init(workspace.data_ptr(), nbytes, _stream()), "sg_workspace_init")
-        workspace._sg_ws_ready = True
-    d.workspace, d.workspace_bytes = workspace.data_ptr(), nbytes
+    if workspace is not None:
+        d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
 
 
 def _gemm_desc(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Optional[torch.Tensor] = None,
@@ -662,6 +649,11 @@ def attention_bwd_dkv(q: torch.Tensor, qt: torch.Tensor, k: torch.Tensor, v: tor
 def debug_set_tile(bm: int = 0, bn: int = 0, no_pipe: bool = False) -> None:
     """Test hook: force the GEMM/conv tile shape / kernel family (0, 0 = automatic)."""
     check(lib.sg_debug_set_tile(bm, bn, int(no_pipe)), "sg_debug_set_tile")
+
+
+def debug_set_conv_patch(enable: bool = True) -> None:
+    """Experiment switch: True = eligible conv3x3 launches use the LDS-resident-input-patch kernel (default off)."""
+    check(lib.sg_debug_set_conv_patch(int(enable)), "sg_debug_set_conv_patch")
 
 
 def debug_mfma_f8(a_bytes: torch.Tensor, b_bytes: torch.Tensor, scale_a: int = 127, scale_b: int = 127) -> torch.Tensor:

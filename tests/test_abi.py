@@ -119,7 +119,7 @@ def test_host_validation_rejects_before_launch(lib):
     assert b"head dim" in lib.sg_last_error()
     g = GroupNormDesc()
     assert lib.sg_groupnorm_nhwc_f16(C.byref(g), None) == -1
-    assert lib.sg_gemm_workspace_bytes(128, 256, 4) == 128 * 256 * 4 * 4 + 16384     # partial tiles + SG_WS_COUNTER_BYTES
+    assert lib.sg_gemm_workspace_bytes(128, 256, 4) == 128 * 256 * 4 * 4
     assert lib.sg_gemm_workspace_bytes(128, 256, 1) == 0
 
 

@@ -377,3 +377,21 @@ def test_config5_shape_runs_96x96_r5(gpu, sd15):
     err = rel_l2(outs[0], outs[1])
     print(f"96x96 R=5: dedup vs as-written rel-L2 {err:.2e}")
     assert err <= TOL_LATENT
+
+
+def test_bench_multi_gpu_path_over_rccl_with_one_rank(gpu):
+    """The N > 1 code path of bench.py (torch.distributed.run launch, RCCL init, barrier, max-over-ranks, the single all-gather
+    of the final latents) exercised with the one GPU this box has: world_size 1 through the same launcher the driver uses."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", "29533", os.path.join(root, "bench.py"), "--gpus", "1", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["n_gpus"] == 1 and res["latents_gathered"] == 1 and res["latents_finite"] and res["latents_distinct_per_rank"]
+    assert res["config"]["parallelism"].startswith("dp1") and res["value"] > 0
