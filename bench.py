@@ -82,6 +82,16 @@ def measured_traffic(kernel: str):
     return None if e is None else e["hbm_bytes_per_launch"]
 
 
+def traffic_provenance():
+    """'current' when profiles/traffic.json was measured on a build of exactly these kernel sources, else 'stale'/'none'."""
+    path = os.path.join(ROOT, "profiles", "traffic.json")
+    if not os.path.exists(path):
+        return "none"
+    from storygen_amd.build import source_hash
+    with open(path) as f:
+        return "current" if json.load(f).get("kernel_source_hash") == source_hash() else "stale"
+
+
 def in_situ_roofline(sampler):
     """One extra eager step with every MFMA-class launch bracketed by HIP events on its launch stream."""
     from storygen_amd import ops
@@ -126,7 +136,8 @@ def in_situ_roofline(sampler):
     g = getattr(sampler, "G", 1)      # ref_ahead: the instrumented body is one group = g steps (one batched reference pass)
     executed_tflop = sum(f["gflop"] for f in fam.values()) / 1e3 / g
     roof = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(d["frac_of_peak"], 4), "traffic": measured_traffic(dom), "launches_per_step": round(d["launches"] / g, 2),
+            "frac": round(d["frac_of_peak"], 4), "traffic": measured_traffic(dom), "traffic_provenance": traffic_provenance(),
+            "launches_per_step": round(d["launches"] / g, 2),
             "avg_launch_us": round(d["avg_us"], 1), "gflop_per_step": round(d["gflop"] / g, 1), "steps_in_sample": g,
             "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
             "families": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(fam.items())}}
@@ -181,11 +192,15 @@ def main():
                          "window then starts on a group boundary (extra untimed warm-up steps, reported as warmup_run) and G "
                          "must divide --steps, so that it contains exactly steps/G batched reference passes")
     ap.add_argument("--config5-shape", action="store_true",
-                    help="NOT the contract workload: BASELINE configs[4]'s shape (768x768 = 96x96 latent, 5 prior frames) with the fp16 "
-                         "attention kernel (the fp8 path is not built); the JSON names it in config.workload")
+                    help="NOT the contract workload: BASELINE configs[4]'s shape (768x768 = 96x96 latent, 5 prior frames); fp16 "
+                         "attention unless --fp8-attention; the JSON names it in config.workload")
     ap.add_argument("--split-graphs", action="store_true", help="reference and main pass as separate hipGraphs on two streams")
     ap.add_argument("--stream-priority", action="store_true",
                     help="with --split-graphs / --ref-ahead: main-pass graphs on a high-priority stream")
+    ap.add_argument("--fp8-attention", action="store_true",
+                    help="BASELINE configs[4]'s attention path: head-dim-40 image / self attention on the e4m3 MFMA kernel (with "
+                         "--config5-shape; results differ from the fp16 path by fp8 rounding, so never the contract line)")
+    ap.add_argument("--spread", type=int, default=-1, help="A/B: placement of the ring-refill DMA instructions (sg_debug_set_spread)")
     ap.add_argument("--conv-patch", action="store_true",
                     help="A/B: eligible 3x3 convolutions through the LDS-resident-input-patch kernel (experiment, default off)")
     ap.add_argument("--no-gemm-pairs", action="store_true", help="A/B: q|k + V^T, q2 + q3, k3 + v3^T as separate launches")
@@ -230,6 +245,12 @@ def main():
     if args.conv_patch:
         from storygen_amd import ops
         ops.debug_set_conv_patch(True)
+    if os.environ.get("SG_DEV_OPTIONS") == "1":          # A/B runs of development options (tools/next_round/*.sh): never the default
+        from storygen_amd import ops
+        print("development options:", ops.apply_env_options(), file=sys.stderr)
+    if args.spread >= 0:
+        from storygen_amd import ops
+        ops.debug_set_spread(args.spread)
     if args.no_gemm_pairs:
         from storygen_amd import engine as _engine
         _engine.PAIR_GEMMS = False
@@ -247,7 +268,7 @@ def main():
     warmup_run = -(-args.warmup // G) * G          # the timed window starts on a group boundary
     sampler = StoryGenSampler(arch, sd, dev, N_PER_GPU, hw, hw, n_ref, use_graph=not args.no_graph, dedup=not args.no_dedup,
                               overlap=not args.no_overlap, ref_ahead=G, split_graphs=args.split_graphs,
-                              stream_priority=args.stream_priority)
+                              stream_priority=args.stream_priority, fp8_attention=args.fp8_attention)
     n_sched = max(T, args.steps + warmup_run)
     sampler.prepare(inputs, n_sched, "multi-image-condition", 7.5, 3.5)
 
@@ -281,13 +302,14 @@ def main():
     if rank == 0:
         value = world * N_PER_GPU * args.steps / dt
         out = {
-            "metric": ("UNet denoising steps/sec @768x768, 5 prior-frame ctx, bs=1 (non-contract)" if args.config5_shape else
+            "metric": ("UNet denoising steps/sec @768x768, 5 prior-frame ctx, bs=1 (non-contract)" if (args.config5_shape or args.fp8_attention) else
                        "UNet denoising steps/sec @512x512, 3 prior-frame ctx, bs=1"), "value": round(value, 4),
             "unit": "denoising steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f16", "data": "synthetic",
-            "config": {"workload": ("NON-CONTRACT RUN, BASELINE configs[4] shape: 768x768 (96x96x4 latent), R=5 prior frames, fp16 "
-                                    "attention (fp8 path not built)" if args.config5_shape else
+            "vs_baseline": None, "dtype": "f16 (attention operands e4m3)" if args.fp8_attention else "f16", "data": "synthetic",
+            "config": {"workload": ("NON-CONTRACT RUN, BASELINE configs[4]: 768x768 (96x96x4 latent), R=5 prior frames, "
+                                    + ("fp8 (e4m3) MFMA attention for the head-dim-40 image / self attention" if args.fp8_attention
+                                       else "fp16 attention") if args.config5_shape else
                                     "BASELINE configs[1]: StoryGen denoising loop, 512x512 (64x64x4 latent), R=3 prior "
                                     "frames, CFG batch 3, DDIM, SD-1.5 UNet + attn3 (909M params, synthetic fp16 weights)"),
                        "samples_per_gpu": N_PER_GPU, "parallelism": f"dp{world} (one sample per GPU, final all-gather)",

@@ -223,6 +223,23 @@ int sg_linear_rows_f32(const float* x, int64_t ldx, const sg_half* W, int64_t ld
                        sg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * fp8 (OCP e4m3) attention for head dim 40 — BASELINE config 5 ("768x768 latent, 5 prior-frame context, fp8 MFMA attention
+ * path"): the D = 40 self- and image cross-attention core, model/attention.py:255-260,285-290 at the 96x96 level.
+ * v_mfma_scale_f32_32x32x64_f8f6f4 with unit scales, fp32 softmax; results differ from sg_attn_fwd_f16 by e4m3 rounding of
+ * Q, K, V and P (3 mantissa bits): ~2-4e-2 relative on the attention output (tests/test_kernels_gpu.py states the bound).
+ *   sg_attn_f8_bytes(B, H, N, transposed)  size of a packed operand image
+ *   sg_attn_f8_pack   fp16 operand exactly as sg_attn_fwd_f16 takes it -> e4m3 image:
+ *                     transposed = 0: Q or K  [B, N, H*40] (ld = token stride, bs = batch stride) -> [B][H][N][64] (bytes 40..63 zero)
+ *                     transposed = 1: V^T     [B, H*40, >= N rounded up to 8] (ld = row stride)   -> [B][H][64][N rounded up to 64],
+ *                                     keys permuted inside every 64-key tile into the MFMA's contraction order, keys >= N zero
+ *   sg_attn_fwd_f8_d40  O[b, q, h*40 + d] fp16 from the three images; kv_batches as in sg_attn_desc. */
+size_t sg_attn_f8_bytes(int32_t B, int32_t H, int32_t N, int32_t transposed);
+int sg_attn_f8_pack(const sg_half* src, int64_t ld, int64_t bs, void* dst, int32_t B, int32_t H, int32_t N, int32_t transposed,
+                    sg_stream_t stream);
+int sg_attn_fwd_f8_d40(const void* q8, const void* k8, const void* vt8, sg_half* o, int64_t ldo, int64_t bso, int32_t B, int32_t H,
+                       int32_t Nq, int32_t Nk, int32_t kv_batches, float scale, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Sampling-loop elementwise steps (model/pipeline.py:412-461), all fp32 NCHW [*,C,H,W] with `n` = elements per
  * sample.  Per-step scalars live in DEVICE memory (`coef`) so a captured hipGraph can be replayed for every step.
  * sg_add_noise_f32 (scheduler.add_noise, :419-427): out[u] = coef[2u]*src[u] + coef[2u+1]*noise[u % N] for the U
@@ -364,10 +381,24 @@ int sg_debug_mfma_f8_32x32x64(const void* a, const void* b, float* out, int32_t 
  * optionally disable the LDS-DMA pipelined kernel (no_pipe = 1), so the parity tests can cover every code path.
  * Process-global; not for production use. */
 int sg_debug_set_tile(int32_t bm, int32_t bn, int32_t no_pipe);
-/* Experiment switch: enable = 1 routes eligible 3x3 convolutions (stride 1, no upsampling, zero-bordered input, image width <= 64)
- * through the LDS-resident-input-patch kernel instead of the gathering implicit-GEMM kernel (default 0: measured equal in time
- * on MI355X).  Process-global. */
-int sg_debug_set_conv_patch(int32_t enable);
+/* Mainloop anatomy (development): the same launch as sg_gemm_f16 / sg_conv3x3_nhwc_f16, through an instrumented instantiation of
+ * the pipelined kernel that stamps s_memtime around the phases of every 64-deep slab.  prof: 10 uint64 per wave,
+ * [block][wave][10] = {slabs, vmcnt wait, barrier, first fragment reads + k-step 0, k-step 1 up to the DMA issue, DMA issue, rest
+ * of the slab, prologue, epilogue, total} in shader cycles; prof_bytes >= blocks * waves * 80.  tools/anatomy.py prints it. */
+int sg_debug_gemm_anatomy(const sg_gemm_desc* d, void* prof, size_t prof_bytes, sg_stream_t stream);
+int sg_debug_conv_anatomy(const sg_conv3x3_desc* d, void* prof, size_t prof_bytes, sg_stream_t stream);
+/* Development options — kernel-variant selectors for the tuning / anatomy tools and the parity tests.  Process-global; the
+ * library never reads the environment (storygen_amd/ops.py maps the SG_* variables of its tools onto this call).  name / value:
+ *   "tile_m", "tile_n"   force a GEMM / conv tile (same effect as sg_debug_set_tile)      "no_pipe", "no_split"  1 = disable
+ *   "stages"             LDS ring depth of the pipelined kernel: 0 = default (3), 2, 4     "fat"       1 = 128x64-per-wave tiles
+ *   "no_nmajor", "late_issue", "no_frag_prefetch"                                          mainloop schedule switches
+ *   "spread"             placement of the ring-refill DMA instructions: 0 one block after k-step 0 (default), 1 a third before
+ *                        each of k-steps 1-3, 2 behind every MFMA of k-steps 1-3 — bit-identical results
+ *   "conv_patch"         1 = eligible 3x3 convolutions through the LDS-resident-input-patch kernel (default 0: equal in time)
+ *   "attn_sub2", "attn_prio", "attn_d80" (0..2), "attn_d160" (0..3)                        attention instantiation selectors
+ *   "gn_no_fused", "gn_wide", "gn_fused_max"                                               GroupNorm kernel selection
+ *   "reset"              every option back to its default */
+int sg_debug_set_option(const char* name, int64_t value);
 
 #ifdef __cplusplus
 }

@@ -141,6 +141,10 @@ SIGNATURES = {
                                C.c_int32, C.c_int32, C.c_void_p]),
     "sg_pad_cast_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_void_p]),
+    "sg_attn_f8_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "sg_attn_f8_pack": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sg_attn_fwd_f8_d40": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                     C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
     "sg_attn_fwd_lse_f16": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p, C.c_void_p]),
     "sg_attn_bwd_prep_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
@@ -162,7 +166,9 @@ SIGNATURES = {
     "sg_debug_mfma_32x32x16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sg_debug_mfma_f8_32x32x64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sg_debug_set_tile": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
-    "sg_debug_set_conv_patch": (C.c_int, [C.c_int32]),
+    "sg_debug_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
+    "sg_debug_gemm_anatomy": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sg_debug_conv_anatomy": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 _lib = None

@@ -18,14 +18,14 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libstorygen_hip.so")
-SOURCES = ["gemm_conv.hip", "attention.hip", "norm.hip", "misc.hip", "backward.hip", "attention_bwd.hip"]
+SOURCES = ["gemm_conv.hip", "attention.hip", "attention_f8.hip", "norm.hip", "misc.hip", "backward.hip", "attention_bwd.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-Rpass-analysis=kernel-resource-usage"]          # remarks only: parsed into lib/kernel_resources.json
 RESOURCES = os.path.join(LIBDIR, "kernel_resources.json")
 # attention keeps its O^T accumulators live across the softmax VALU code of every tile: with MFMA results in AGPRs the
 # compiler shuttles them through v_accvgpr_read/write around each tile (137 of 281 VALU instructions per tile,
 # profiles/r01d_pmc_kernels.txt); the VGPR form of MFMA (gfx950's register file is unified) removes all of them.
-EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "attention_f8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc() -> str:
@@ -64,6 +64,18 @@ def _parse_resource_remarks(out: str, src: str, into: dict) -> str:
         elif "-Rpass-analysis=kernel-resource-usage" not in line and "argument unused during compilation" not in line:
             rest.append(line)
     return "\n".join(rest)
+
+
+def source_hash() -> str:
+    """sha256 over the kernel sources and the C ABI header (16 hex digits): stamped into profiles/traffic.json by
+    tools/traffic_from_pmc.py so that bench.py can tell whether the PMC traffic on file was measured on THIS build."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(CSRC)) + [os.path.join("..", "..", "include", "storygen_hip.h")]:
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode())
+            h.update(fh.read())
+    return h.hexdigest()[:16]
 
 
 def needs_build() -> bool:

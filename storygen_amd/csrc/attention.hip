@@ -69,8 +69,8 @@ static int attn_fwd(const sg_attn_desc* d, float* lse2, sg_stream_t stream) {
     // 4-wave workgroups with a 3-deep ring when that still gives the chip >= 2 workgroups per CU, else 2 waves / 2 stages
     const long wgs4 = (long)sg_cdiv(d->Nq, 128) * d->H * d->B;
     const bool big = wgs4 >= 512;
-    static const int sub2 = [] { const char* e = getenv("SG_ATTN_SUB2"); return e ? atoi(e) : 0; }();   // development knob
-    static const int prio = [] { const char* e = getenv("SG_ATTN_PRIO"); return e ? atoi(e) : 0; }();   // development knob
+    const SgOptions& opt = sg_options();          // development options (sg_debug_set_option), defaults in common.h
+    const int sub2 = opt.attn_sub2, prio = opt.attn_prio;
     if (d->D == 40) {
         if (big && sub2 && d->Nk >= 256) launch_attn<40, 4, 2, 2>(p, st);   // 128 keys per barrier, 2-stage ring
         else if (big && prio) launch_attn<40, 4, 3, 1, true>(p, st);
@@ -79,18 +79,18 @@ static int attn_fwd(const sg_attn_desc* d, float* lse2, sg_stream_t stream) {
     }
     else if (d->D == 80) {
         // measured (tools/bench_norm.py --attn, B3 Nq1024 Nk3072): 2 waves x 2 stages 76.6 us, 2 x 3 59.8, 4 x 3 55.2 — the
-        // deeper ring matters more than the number of workgroups here.  SG_ATTN_D80 (development knob): 1 = always 4 x 3
+        // deeper ring matters more than the number of workgroups here.  option attn_d80 (sg_debug_set_option): 1 = always 4 x 3
         // (default), 0 = 4 x 3 only when the grid fills the chip else 2 x 2, 2 = always 2 x 3
-        static const int v80 = [] { const char* e = getenv("SG_ATTN_D80"); return e && *e ? atoi(e) : 1; }();
+        const int v80 = opt.attn_d80;
         if (v80 == 1 || (v80 == 0 && big)) launch_attn<80, 4, 3>(p, st);
         else if (v80 == 2) launch_attn<80, 2, 3>(p, st);
         else launch_attn<80, 2, 2>(p, st);
     }
     else {
         // the 16x16 level has few workgroups with long key loops; measured (tools/bench_norm.py --attn, B3 Nq256 Nk768):
-        // 2 waves x 2 stages 30.3 us, 2 x 3 30.2, 4 x 2 25.6, 4 x 3 25.4 -> 4 waves x 3 stages.  SG_ATTN_D160 = 0..3 picks
+        // 2 waves x 2 stages 30.3 us, 2 x 3 30.2, 4 x 2 25.6, 4 x 3 25.4 -> 4 waves x 3 stages.  option attn_d160 = 0..3 picks
         // one of the four (development knob).
-        static const int v160 = [] { const char* e = getenv("SG_ATTN_D160"); return e && *e ? atoi(e) : 3; }();
+        const int v160 = opt.attn_d160;
         if (v160 == 1) launch_attn<160, 2, 3>(p, st);
         else if (v160 == 2) launch_attn<160, 4, 2>(p, st);
         else if (v160 == 3) launch_attn<160, 4, 3>(p, st);

@@ -31,6 +31,22 @@ int sg_set_error(int code, const char* fmt, ...);
 static inline bool sg_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 static inline int sg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// Development options (kernel-variant selectors used by the tuning / anatomy tools and the parity tests).  ONE process-global
+// table, defined in misc.hip, written only through sg_debug_set_option(): the library never reads the environment, so a
+// product run cannot be altered by a stray variable (tools map SG_* environment variables onto it in Python, storygen_amd/ops.py).
+struct SgOptions {
+    int tile_m = 0, tile_n = 0;        // force a GEMM / conv tile (0, 0 = heuristic / caller's hint)
+    int no_pipe = 0, no_split = 0;     // register-staged kernel only / no automatic split-K
+    int stages = 0;                    // LDS ring depth of the pipelined kernel: 0 = default (3), 2, 4 (tiles <= 128x128)
+    int no_nmajor = 0, late_issue = 1, no_frag_prefetch = 0, fat = 0;
+    int spread = 0;                    // placement of the ring-refill DMA instructions (mma_pipe_body SPREAD)
+    int conv_patch = 0;                // LDS-resident-input-patch convolution kernel
+    int attn_sub2 = 0, attn_prio = 0, attn_d80 = 1, attn_d160 = 3;
+    int gn_no_fused = 0, gn_wide = 1;
+    long gn_fused_max = -1;            // -1 = the kernel's default threshold
+};
+SgOptions& sg_options();
+
 // ---------------------------------------------------------------------------------------------- device side
 __device__ __forceinline__ uint4 ldg16(const void* p) { return *reinterpret_cast<const uint4*>(p); }
 __device__ __forceinline__ void stg16(void* p, uint4 v) { *reinterpret_cast<uint4*>(p) = v; }

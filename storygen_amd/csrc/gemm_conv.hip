@@ -48,6 +48,7 @@ struct MmaParams {
     const void* res2; long ldr2;
     // decomposition
     float* ws; int splits; int kt_per_split; int tiles_m, tiles_n;
+    unsigned long long* prof;   // PROF instantiations only (sg_debug_*_anatomy): per-wave cycle totals of the mainloop phases
     int n_major;   // tile order: 1 = consecutive ids walk M first (tiles sharing a weight panel stay on one XCD / L2)
 };
 
@@ -377,8 +378,25 @@ constexpr int pipe_smem_bytes() {
     return S * STAGE > EPI ? S * STAGE : EPI;
 }
 
-template <int WGM, int WGN, int S, bool CONV, bool LATE, bool PREF, int WTM = 2, int WTN = 2>
+// SPREAD: how the LDS-DMA instructions of the slab two ahead are placed among the 16 MFMAs of the current slab.  0: all of them
+// between k-step 0 and k-step 1 (the matrix pipe drains while 6-16 DMA instructions are issued: ~400-550 of ~1400-2000 cycles
+// per slab, tools/anatomy.py); 1: a third each in front of k-steps 1, 2, 3; 2: one or two behind every MFMA of k-steps 1-3, order
+// pinned with sched_barrier.
+template <int WGM, int WGN, int S, bool CONV, bool LATE, bool PREF, int WTM = 2, int WTN = 2, bool PROF = false, int SPREAD = 0>
 __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
+    // PROF: s_memtime stamps around the phases of every slab, summed per wave (sg_debug_gemm_anatomy / _conv_anatomy):
+    // [0] slabs [1] vmcnt wait [2] barrier [3] first fragment reads + k-step 0 [4] k-step 1 up to the DMA issue [5] DMA issue
+    // [6] rest of the slab [7] prologue (entry -> loop) [8] epilogue (loop end -> exit)
+    unsigned long long pf_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+    unsigned long long pf_t = 0, pf_entry = 0;
+    auto stamp = [&](int slot) __attribute__((always_inline)) {
+        if constexpr (PROF) {
+            const unsigned long long now = __builtin_readcyclecounter();
+            pf_acc[slot] += now - pf_t;
+            pf_t = now;
+        }
+    };
+    if constexpr (PROF) pf_entry = pf_t = __builtin_readcyclecounter();
     // every wave owns a (32 WTM) x (32 WTN) output sub-tile.  2 x 2 needs 1 KiB of LDS fragment reads per MFMA, which at
     // full MFMA rate is the whole LDS read bandwidth of the CU (8 waves x 32 B/clk); "fat" 4 x 2 waves (128 x 64, 128
     // accumulator registers, one wave per SIMD) need 0.75 KiB per MFMA and half as many waves for the same tile.
@@ -443,7 +461,8 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         w_off[i] = (unsigned)((long)min(n0 + row, p.N - 1) * p.ldw + lc * 8);
     }
 
-    auto issue = [&](int kt, int stage) {
+    // part / nparts: only the loads whose index (A loads first, then W loads) is congruent to `part` modulo `nparts` (all: 0, 1)
+    auto issue = [&](int kt, int stage, int part = 0, int nparts = 1) __attribute__((always_inline)) {
         char* sA = smem + stage * STAGE + wave * 1024;
         char* sB = sA + A_BYTES;
         if constexpr (CONV) {
@@ -452,12 +471,14 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
             if (!p.ups) {
                 const f16* At = p.A + ((long)(ky * wp + kx) * p.lda + cc * BK);
 #pragma unroll
-                for (int i = 0; i < A_IT; ++i) glds16(At + a_off[i], sA + i * ISTR);
+                for (int i = 0; i < A_IT; ++i)
+                    if (i % nparts == part) glds16(At + a_off[i], sA + i * ISTR);
             } else {
                 const f16* At = p.A + cc * BK;
                 const unsigned rs = (unsigned)(wp * (int)p.lda), cs = (unsigned)p.lda;     // < 2^24 (validated on the host)
 #pragma unroll
                 for (int i = 0; i < A_IT; ++i) {
+                    if (i % nparts != part) continue;
                     const unsigned dy = ((unsigned)ky + (a_par[i] & 1u)) >> 1, dx = ((unsigned)kx + (a_par[i] >> 1)) >> 1;
                     glds16(At + (a_off[i] + __umul24(dy, rs) + __umul24(dx, cs)), sA + i * ISTR);
                 }
@@ -465,11 +486,13 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         } else {
             const f16* At = p.A + kt * BK;
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) glds16(At + a_off[i], sA + i * ISTR);
+            for (int i = 0; i < A_IT; ++i)
+                if (i % nparts == part) glds16(At + a_off[i], sA + i * ISTR);
         }
         const f16* Wt = p.W + kt * BK;
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) glds16(Wt + w_off[i], sB + i * ISTR);
+        for (int i = 0; i < B_IT; ++i)
+            if ((A_IT + i) % nparts == part) glds16(Wt + w_off[i], sB + i * ISTR);
     };
 
     f32x16 acc[WTM][WTN];
@@ -485,12 +508,15 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         if (s < nt) issue(kt0 + s, s);
 
     int stage = 0;
+    stamp(7);
     for (int it = 0; it < nt; ++it) {
         // up to S - 2 younger slabs stay in flight while we wait for slab `it` (fewer at the very end)
         if (S >= 4 && it + 2 < nt) wait_vmcnt<(S >= 4 ? 2 : 0) * LPT>();
         else if (S >= 3 && it + 1 < nt) wait_vmcnt<(S >= 3 ? 1 : 0) * LPT>();
         else wait_vmcnt<0>();
+        stamp(1);
         __builtin_amdgcn_s_barrier();
+        stamp(2);
         if (!LATE && it + S - 1 < nt) {         // refill right behind the barrier
             int st = stage + S - 1;
             if (st >= S) st -= S;
@@ -517,21 +543,56 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
             // the refill of the ring (slab it+S-1 into the stage every wave has just left) is issued behind the first
             // k-step's fragment reads rather than between the barrier and them: its address arithmetic then overlaps
             // matrix work instead of delaying it
-            if (LATE && ks == 1 && it + S - 1 < nt) {
-                int st = stage + S - 1;
-                if (st >= S) st -= S;
+            int st = stage + S - 1;
+            if (st >= S) st -= S;
+            const bool refill = LATE && it + S - 1 < nt;
+            if (SPREAD == 0 && ks == 1 && refill) {
+                stamp(4);
                 issue(kt0 + it + S - 1, st);
+                stamp(5);
             }
+            if (SPREAD == 1 && ks >= 1 && refill) issue(kt0 + it + S - 1, st, ks - 1, 3);
 #pragma unroll
             for (int i = 0; i < WTM; ++i)
 #pragma unroll
-                for (int j = 0; j < WTN; ++j)
+                for (int j = 0; j < WTN; ++j) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
+                    if (SPREAD == 2 && ks >= 1) {
+                        __builtin_amdgcn_sched_barrier(0);
+                        if (refill) issue(kt0 + it + S - 1, st, (ks - 1) * WTM * WTN + i * WTN + j, 3 * WTM * WTN);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                }
+            if (ks == 0) stamp(3);
         }
         if (++stage == S) stage = 0;
+        stamp(6);
+        if constexpr (PROF) pf_acc[0] += 1;
     }
     __syncthreads();   // every wave is done reading the stages before the epilogue reuses LDS
     tile_epilogue<BM, BN, WGM, WGN>(p, smem, acc, m0, n0, z);
+    if constexpr (PROF) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(8);
+        if (lane == 0 && p.prof) {
+            unsigned long long* dst = p.prof + ((size_t)blockIdx.x * NW + wave) * 10;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) dst[k] = pf_acc[k];
+            dst[9] = pf_t - pf_entry;
+        }
+    }
+}
+
+template <int WGM, int WGN, bool CONV, int SPREAD>
+__global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_prof_kernel(const MmaParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN, 3>()];
+    mma_pipe_body<WGM, WGN, 3, CONV, true, true, 2, 2, true, SPREAD>(p, smem);
+}
+
+template <int WGM, int WGN, bool CONV, int SPREAD>
+__global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_spread_kernel(const MmaParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN, 3>()];
+    mma_pipe_body<WGM, WGN, 3, CONV, true, true, 2, 2, false, SPREAD>(p, smem);
 }
 
 template <int WGM, int WGN, int S, bool CONV, bool LATE, bool PREF, int WTM = 2, int WTN = 2>
@@ -785,26 +846,17 @@ __global__ __launch_bounds__(64 * WGM * WGN) void conv_patch_kernel(const MmaPar
 // ------------------------------------------------------------------------------------------------ host side
 struct Plan { int bm, bn, splits, fat; };
 
-// Development knobs (read once from the environment): SG_TILE="bm,bn" forces a tile shape, SG_NO_PIPE=1 disables
-// the LDS-DMA pipeline, SG_NO_SPLIT=1 disables automatic split-K.  Unset in production.
-struct Tune {
-    mutable int bm = 0, bn = 0, no_pipe = 0, no_split = 0, stages = 0, no_nmajor = 0, late_issue = 1, no_frag_prefetch = 0, fat = 0;
-    // conv_patch_kernel is OFF by default: measured on MI355X (round 2, tools/exp_feed.py) it ties the gathering kernel on
-    // every convolution of the step (47.2 vs 47.2 us at 64x64 320->320) although it moves 2-3x fewer bytes through the L1 —
-    // which is what showed that the mainloop is not bound by operand bytes.  sg_debug_set_conv_patch(1) enables it.
-    mutable int conv_patch = 0;
-    Tune() {
-        if (const char* e = getenv("SG_STAGES")) stages = atoi(e);
-        if (const char* e = getenv("SG_NO_NMAJOR")) no_nmajor = atoi(e);
-        if (const char* e = getenv("SG_LATE_ISSUE")) late_issue = atoi(e);
-        if (const char* e = getenv("SG_NO_FRAG_PREFETCH")) no_frag_prefetch = atoi(e);
-        if (const char* e = getenv("SG_FAT")) fat = atoi(e);
-        if (const char* e = getenv("SG_TILE")) sscanf(e, "%d,%d", &bm, &bn);
-        if (const char* e = getenv("SG_NO_PIPE")) no_pipe = atoi(e);
-        if (const char* e = getenv("SG_NO_SPLIT")) no_split = atoi(e);
-    }
+// Development options: storygen_amd/csrc/common.h SgOptions (set through sg_debug_set_option; never from the environment).
+// conv_patch is OFF by default: measured on MI355X (round 2, tools/exp_feed.py) conv_patch_kernel ties the gathering kernel on
+// every convolution of the step (47.2 vs 47.2 us at 64x64 320->320) although it moves 2-3x fewer bytes through the L1 — which is
+// what showed that the mainloop is not bound by operand bytes.
+struct TuneView {
+    SgOptions& o = sg_options();
+    int& bm = o.tile_m; int& bn = o.tile_n; int& no_pipe = o.no_pipe; int& no_split = o.no_split; int& stages = o.stages;
+    int& no_nmajor = o.no_nmajor; int& late_issue = o.late_issue; int& no_frag_prefetch = o.no_frag_prefetch; int& fat = o.fat;
+    int& conv_patch = o.conv_patch; int& spread = o.spread;
 };
-static const Tune g_tune;
+static const TuneView g_tune;
 
 // Cost model (cycles at ~2.4 GHz).  Measured on MI355X (tools/bench_gemm.py): a CU pulls operand slabs from L2 into
 // LDS at ~18.5 B/cycle however many waves ask (L1 miss-level parallelism x L2 latency), so a launch is bound by
@@ -868,6 +920,17 @@ template <int WGM, int WGN, bool CONV>
 void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st, int stages) {
     const bool late = g_tune.late_issue != 0, pref = g_tune.no_frag_prefetch == 0;
     const dim3 block(64 * WGM * WGN);
+    if (p.prof) {
+        if (g_tune.spread == 2) hipLaunchKernelGGL((mma_pipe_prof_kernel<WGM, WGN, CONV, 2>), grid, block, 0, st, p);
+        else if (g_tune.spread == 1) hipLaunchKernelGGL((mma_pipe_prof_kernel<WGM, WGN, CONV, 1>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((mma_pipe_prof_kernel<WGM, WGN, CONV, 0>), grid, block, 0, st, p);
+        return;
+    }
+    if (g_tune.spread && stages == 3) {
+        if (g_tune.spread == 2) hipLaunchKernelGGL((mma_pipe_spread_kernel<WGM, WGN, CONV, 2>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((mma_pipe_spread_kernel<WGM, WGN, CONV, 1>), grid, block, 0, st, p);
+        return;
+    }
     if constexpr ((WGM + WGN) * 64 * 128 * 4 <= 128 * 1024) {   // 4-deep ring where it fits (tiles up to 128 x 128)
         if (stages == 4) {
             hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 4, CONV, true, true>), grid, block, 0, st, p);
@@ -880,12 +943,15 @@ void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st, int stages) {
     else hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV, false, true>), grid, block, 0, st, p);
 }
 
+thread_local unsigned long long* g_prof = nullptr;     // set by sg_debug_*_anatomy around one launch
+
 // Decomposition of one problem: tile shape, K split, tile order; fills the corresponding fields of p.  `pipe` = the LDS-DMA
 // kernel applies (no load needs a predicate: K % 64 == 0; conv input zero-bordered), else the register-staged kernel.
 template <bool CONV>
 int plan_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_waves, void* ws, size_t ws_bytes, const char* name,
              Plan& pl, bool& pipe) {
     p.KT = sg_cdiv(p.K, BK);
+    p.prof = g_prof;
     pipe = (p.K % BK == 0) && (!CONV || p.padded) && !g_tune.no_pipe;
     const size_t per_split = (size_t)p.M * p.N * 4;
     const int max_ws_split = ws ? (int)(ws_bytes / per_split > 64 ? 64 : ws_bytes / per_split) : 1;
@@ -1143,9 +1209,22 @@ extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream)
 }
 
 // ------------------------------------------------------------------------------------------------ diagnostics
-extern "C" int sg_debug_set_conv_patch(int32_t enable) {
-    g_tune.conv_patch = enable ? 1 : 0;
-    return SG_OK;
+// Mainloop anatomy: the same launch as sg_gemm_f16 / sg_conv3x3_nhwc_f16 through the instrumented instantiation of the pipelined
+// kernel; prof receives 10 uint64 per wave ([block][wave][10], see mma_pipe_body).  Needs the LDS-DMA path, no fat waves, S = 3.
+extern "C" int sg_debug_gemm_anatomy(const sg_gemm_desc* d, void* prof, size_t prof_bytes, sg_stream_t stream) {
+    SG_REQUIRE(d && prof && prof_bytes >= (size_t)8 * 10 * 8 * 65536 / 64, "sg_debug_gemm_anatomy: need a profile buffer (>= 80 B per wave)");
+    g_prof = reinterpret_cast<unsigned long long*>(prof);
+    const int rc = sg_gemm_f16(d, stream);
+    g_prof = nullptr;
+    return rc;
+}
+
+extern "C" int sg_debug_conv_anatomy(const sg_conv3x3_desc* d, void* prof, size_t prof_bytes, sg_stream_t stream) {
+    SG_REQUIRE(d && prof && prof_bytes >= (size_t)8 * 10 * 8 * 65536 / 64, "sg_debug_conv_anatomy: need a profile buffer (>= 80 B per wave)");
+    g_prof = reinterpret_cast<unsigned long long*>(prof);
+    const int rc = sg_conv3x3_nhwc_f16(d, stream);
+    g_prof = nullptr;
+    return rc;
 }
 
 extern "C" int sg_debug_set_tile(int32_t bm, int32_t bn, int32_t no_pipe) {

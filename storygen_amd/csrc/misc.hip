@@ -6,6 +6,37 @@
 // ------------------------------------------------------------------------------------------------ bookkeeping
 static thread_local char g_err[512] = "";
 
+SgOptions& sg_options() {
+    static SgOptions o;
+    return o;
+}
+
+extern "C" int sg_debug_set_option(const char* name, int64_t value) {
+    if (!name) return sg_set_error(SG_EINVAL, "sg_debug_set_option: null name");
+    SgOptions& o = sg_options();
+    struct Entry { const char* n; int* p; };
+    const Entry table[] = {{"tile_m", &o.tile_m}, {"tile_n", &o.tile_n}, {"no_pipe", &o.no_pipe}, {"no_split", &o.no_split},
+                           {"stages", &o.stages}, {"no_nmajor", &o.no_nmajor}, {"late_issue", &o.late_issue},
+                           {"no_frag_prefetch", &o.no_frag_prefetch}, {"fat", &o.fat}, {"spread", &o.spread},
+                           {"conv_patch", &o.conv_patch}, {"attn_sub2", &o.attn_sub2}, {"attn_prio", &o.attn_prio},
+                           {"attn_d80", &o.attn_d80}, {"attn_d160", &o.attn_d160}, {"gn_no_fused", &o.gn_no_fused},
+                           {"gn_wide", &o.gn_wide}};
+    for (const Entry& e : table)
+        if (strcmp(e.n, name) == 0) {
+            *e.p = (int)value;
+            return SG_OK;
+        }
+    if (strcmp(name, "gn_fused_max") == 0) {
+        o.gn_fused_max = (long)value;
+        return SG_OK;
+    }
+    if (strcmp(name, "reset") == 0) {
+        o = SgOptions{};
+        return SG_OK;
+    }
+    return sg_set_error(SG_EINVAL, "sg_debug_set_option: unknown option '%s'", name);
+}
+
 int sg_set_error(int code, const char* fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

@@ -703,10 +703,10 @@ extern "C" int sg_groupnorm_nhwc_f16(const sg_groupnorm_desc* d, sg_stream_t str
     p.HW = d->HW; p.C = d->C; p.G = d->groups; p.cpg = d->C / d->groups; p.eps = d->eps; p.silu = d->silu;
     p.ws = reinterpret_cast<float*>(d->workspace);
     hipStream_t st0 = (hipStream_t)stream;
-    // development knobs: SG_NO_GN_FUSED=1, SG_GN_FUSED_MAX=<slab elements>, SG_GN_WIDE=0
-    static const bool no_fused = [] { const char* e = getenv("SG_NO_GN_FUSED"); return e && atoi(e) != 0; }();
-    static const long fused_max = [] { const char* e = getenv("SG_GN_FUSED_MAX"); return e && *e ? atol(e) : GNF_DEFAULT_MAX; }();
-    static const bool wide = [] { const char* e = getenv("SG_GN_WIDE"); return !(e && *e) || atoi(e) != 0; }();
+    // development options (sg_debug_set_option): gn_no_fused, gn_fused_max = <slab elements>, gn_wide
+    const SgOptions& opt = sg_options();
+    const bool no_fused = opt.gn_no_fused != 0, wide = opt.gn_wide != 0;
+    const long fused_max = opt.gn_fused_max >= 0 ? opt.gn_fused_max : GNF_DEFAULT_MAX;
     const long slab = (long)p.HW * p.cpg;
     if (p.cpg % 4 == 0 && slab <= 256L * 4 * GNF_MAXI && slab <= fused_max && !no_fused) {
         hipLaunchKernelGGL(gn_fused_kernel, dim3(p.G, d->B), dim3(256), 0, st0, p);

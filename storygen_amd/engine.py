@@ -204,7 +204,7 @@ class UNetEngine:
     def __init__(self, arch: UNetArch, state_dict: Optional[Dict[str, torch.Tensor]], device, batch: int, height: int,
                  width: int, n_ref: int = 0, seq_len: int = 77, splitk_workspace_mb: int = 96,
                  weights: Optional[EngineWeights] = None, ctx_rows: Optional[int] = None,
-                 attn3_groups: Optional[List[tuple]] = None):
+                 attn3_groups: Optional[List[tuple]] = None, fp8_attention: bool = False):
         """batch = samples per UNet call; n_ref = R prior frames (sizes the context buffers; 0 = an engine that only
         harvests, into another engine's buffers).  ctx_rows = number of distinct context rows (default: one per
         sample); attn3_groups = [(q0, n, c0), ...]: samples [q0, q0+n) cross-attend to context rows [c0, c0+n) — lets
@@ -235,6 +235,9 @@ class UNetEngine:
         share = sorted(self.attn3_groups) == ([(0, batch, 0)] if rows == batch else [(0, rows, 0), (rows, batch - rows, 2 * rows - batch)])
         self.attn3_share = rows if share else None
         self.wts = weights if weights is not None else EngineWeights(arch, state_dict, device)
+        # BASELINE config 5: the head-dim-40 self / image attentions (the 46 080-key context of the 96x96 level) on the fp8 MFMA
+        # path (sg_attn_fwd_f8_d40); text attention and the D = 80 / 160 levels stay fp16
+        self.fp8_attention = bool(fp8_attention)
         self.text_cache: Dict[str, torch.Tensor] = {}
         self._alloc(splitk_workspace_mb)
 
@@ -272,6 +275,15 @@ class UNetEngine:
         self.side: Optional[torch.cuda.Stream] = None                   # set by forward(side=...)
         self.kv_ext: Optional[Dict[str, tuple]] = None                  # attn3 K / V^T computed by the reference pass
         self.ws_gn = self._buf(ops.groupnorm_workspace_bytes(B, self.groups), dtype=torch.uint8)
+        self.f8_scratch = None
+        if self.fp8_attention:
+            heads = self.cfg["attention_head_dim"] if isinstance(self.cfg["attention_head_dim"], int) else self.cfg["attention_head_dim"][0]
+            hw0 = self.hw[0]
+            nk = max(hw0, self.R * hw0)
+            kb = max(B, self.ctx_rows if self.R else B)
+            need = (ops.attention_f8_bytes(B, heads, hw0, False) + ops.attention_f8_bytes(kb, heads, nk, False)
+                    + ops.attention_f8_bytes(kb, heads, nk, True) + 4096)
+            self.f8_scratch = self._buf(need, dtype=torch.uint8)
         # per level: widest resnet input (concat) and the level's channel count; every conv-input channel count
         cmax, cout = [0] * nlev, [0] * nlev
         conv_in_ch = [set() for _ in range(nlev)]
@@ -361,6 +373,15 @@ class UNetEngine:
     def _join(self):
         torch.cuda.current_stream(self.dev).wait_stream(self.side)
 
+    def _attention(self, q, k, vt, out, heads: int, scale: float, nk: Optional[int] = None):
+        """softmax(scale q k^T) v on the HIP kernels: fp16 MFMA, or e4m3 MFMA for the D = 40 image / self attentions when the
+        engine was built with fp8_attention (text attention — 77 keys — and every other head dim stay fp16)."""
+        n_keys = k.shape[1] if nk is None else nk
+        if self.fp8_attention and q.shape[2] == heads * 40 and n_keys >= 256:
+            ops.attention_f8(q, k, vt, out, heads, scale, self.f8_scratch, nk=nk)
+        else:
+            ops.attention(q, k, vt, out, heads, scale, nk=nk)
+
     def _resnet(self, rn: _Resnet, x: torch.Tensor, out: torch.Tensor, lvl: int):
         """diffusers ResnetBlock2D.  x fp32 [M,Cin] contiguous; out fp32 [M,Cout], possibly a column
         slice of a concat buffer."""
@@ -437,7 +458,7 @@ class UNetEngine:
         _pair(((L["ln"], xf.w_qk1, qk), dict(workspace=ws)), ((xf.w_v1, L["ln"], vt), dict(workspace=wp)))
         qk3 = qk.view(B, hw, 2 * C)
         att = L["att"]
-        ops.attention(qk3[:, :, :C], qk3[:, :, C:], vt.view(C, B, hw).permute(1, 0, 2), att.view(B, hw, C), heads, scale)
+        self._attention(qk3[:, :, :C], qk3[:, :, C:], vt.view(C, B, hw).permute(1, 0, 2), att.view(B, hw, C), heads, scale)
         h1 = L["h1"]
         ops.gemm(att, xf.w_o1, h1, bias=xf.b_o1, res1=h0, workspace=ws)
         if harvest is not None:                                                           # feature :263, written in place
@@ -484,10 +505,10 @@ class UNetEngine:
             ki3, vti3 = ki.view(rows, nk, C), vti.view(C, rows, nk).permute(1, 0, 2)
             q3 = q3buf.view(B, hw, C)
             if self.attn3_share is not None:      # one launch: batch b reads context row b (b < rows) or b - (B - rows)
-                ops.attention(q3, ki3, vti3, a3v, heads, scale)
+                self._attention(q3, ki3, vti3, a3v, heads, scale)
             else:
                 for q0, n, c0 in self.attn3_groups:
-                    ops.attention(q3[q0:q0 + n], ki3[c0:c0 + n], vti3[c0:c0 + n], a3v[q0:q0 + n], heads, scale)
+                    self._attention(q3[q0:q0 + n], ki3[c0:c0 + n], vti3[c0:c0 + n], a3v[q0:q0 + n], heads, scale)
             if forked:
                 self._join()
             h3 = L["h3"]

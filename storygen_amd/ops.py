@@ -42,11 +42,12 @@ def _apply_tile(d, tile, split_k, sig):
 
 
 def load_tile_table(path: Optional[str] = None) -> int:
+    """Loads the per-shape tile table (default: tuning/mi355x_tiles.json); path="none" empties it (heuristic tiles only)."""
     import json
     import os
     path = path or os.path.join(os.path.dirname(os.path.abspath(__file__)), "tuning", "mi355x_tiles.json")
     TILE_TABLE.clear()
-    if os.path.exists(path) and os.environ.get("SG_NO_TILE_TABLE") != "1":
+    if os.path.exists(path) and path != "none":
         with open(path) as f:
             TILE_TABLE.update({k: tuple(v) for k, v in json.load(f)["tiles"].items()})
     return len(TILE_TABLE)
@@ -123,6 +124,11 @@ def gemm_workspace_bytes(M: int, N: int, split_k: int = 0) -> int:
     return lib.sg_gemm_workspace_bytes(M, N, split_k)
 
 
+# Development: when set to an int64 CUDA tensor, gemm() / conv3x3() launch the instrumented mainloop (sg_debug_*_anatomy) and
+# the tensor receives 10 cycle counters per wave (tools/anatomy.py).
+ANATOMY: Optional[torch.Tensor] = None
+
+
 def new_workspace(nbytes: int, device) -> torch.Tensor:
     """A split-K workspace for gemm / conv3x3 (fp32 partial tiles; no initialisation needed)."""
     return torch.empty((int(nbytes) + 15) & ~15, dtype=torch.uint8, device=device)
@@ -189,7 +195,11 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, **kw) -> torch.Ten
     workspace, out2, tile."""
     d, flops, shape = _gemm_desc(a, w, out, **kw)
     with _timed("gemm", flops, shape):
-        check(lib.sg_gemm_f16(C.byref(d), _stream()), "sg_gemm_f16")
+        if ANATOMY is not None:
+            check(lib.sg_debug_gemm_anatomy(C.byref(d), ANATOMY.data_ptr(), ANATOMY.numel() * ANATOMY.element_size(), _stream()),
+                  "sg_debug_gemm_anatomy")
+        else:
+            check(lib.sg_gemm_f16(C.byref(d), _stream()), "sg_gemm_f16")
     return out
 
 
@@ -253,7 +263,11 @@ def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stride:
                                     res1=None if res1 is None else str(res1.dtype))))
     with _timed("conv3x3", 2.0 * B * Ho * Wo * Cout * 9 * Cin,
                 f"B{B} {Ho}x{Wo} {Cin}->{Cout} s{stride}{' up' if upsample2x else ''}"):
-        check(lib.sg_conv3x3_nhwc_f16(C.byref(d), _stream()), "sg_conv3x3_nhwc_f16")
+        if ANATOMY is not None:
+            check(lib.sg_debug_conv_anatomy(C.byref(d), ANATOMY.data_ptr(), ANATOMY.numel() * ANATOMY.element_size(), _stream()),
+                  "sg_debug_conv_anatomy")
+        else:
+            check(lib.sg_conv3x3_nhwc_f16(C.byref(d), _stream()), "sg_conv3x3_nhwc_f16")
     return out
 
 
@@ -305,6 +319,42 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
     d.scale = scale
     with _timed(f"attention_d{D}", 4.0 * B * heads * Nq * Nk * D, f"B{B} H{heads} Nq{Nq} Nk{Nk}"):
         check(lib.sg_attn_fwd_f16(C.byref(d), _stream()), "sg_attn_fwd_f16")
+    return out
+
+
+def attention_f8_bytes(B: int, heads: int, N: int, transposed: bool) -> int:
+    return lib.sg_attn_f8_bytes(B, heads, N, int(transposed))
+
+
+def attention_f8(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, heads: int, scale: float,
+                 scratch: torch.Tensor, nk: Optional[int] = None) -> torch.Tensor:
+    """`attention` for head dim 40 on the fp8 (e4m3) MFMA path: packs q / k / vt (same operands and layouts as attention()) into
+    e4m3 images inside `scratch` (uint8, >= the three attention_f8_bytes) and runs sg_attn_fwd_f8_d40."""
+    for n, t in (("q", q), ("k", k), ("vt", vt), ("out", out)):
+        _f16(t, n)
+        if t.dim() != 3 or t.stride(-1) != 1:
+            raise ValueError(f"attention_f8: {n} must be 3-D with a contiguous last dimension")
+    B, Nq, Cq = q.shape
+    Bk = k.shape[0]
+    Nk = k.shape[1] if nk is None else nk
+    if Cq != heads * 40:
+        raise ValueError("attention_f8: head dim must be 40")
+    if vt.shape[0] != Bk or vt.shape[1] != Cq or k.shape[2] != Cq or Nk > k.shape[1] or vt.shape[2] < ((Nk + 7) & ~7):
+        raise ValueError(f"attention_f8: k {tuple(k.shape)} / vt {tuple(vt.shape)} do not match q {tuple(q.shape)}, nk={Nk}")
+    nq8, nk8, nv8 = attention_f8_bytes(B, heads, Nq, False), attention_f8_bytes(Bk, heads, Nk, False), attention_f8_bytes(Bk, heads, Nk, True)
+    if scratch.dtype != torch.uint8 or not scratch.is_cuda or scratch.numel() < nq8 + nk8 + nv8 + 512:
+        raise ValueError(f"attention_f8: scratch must be a CUDA uint8 tensor of at least {nq8 + nk8 + nv8 + 512} bytes")
+    base = (scratch.data_ptr() + 255) & ~255
+    q8, k8, v8 = base, base + ((nq8 + 255) & ~255), base + ((nq8 + 255) & ~255) + ((nk8 + 255) & ~255)
+    if v8 + nv8 > scratch.data_ptr() + scratch.numel():
+        raise ValueError("attention_f8: scratch too small after alignment")
+    st = _stream()
+    check(lib.sg_attn_f8_pack(q.data_ptr(), q.stride(1), q.stride(0), q8, B, heads, Nq, 0, st), "sg_attn_f8_pack(q)")
+    check(lib.sg_attn_f8_pack(k.data_ptr(), k.stride(1), k.stride(0), k8, Bk, heads, Nk, 0, st), "sg_attn_f8_pack(k)")
+    check(lib.sg_attn_f8_pack(vt.data_ptr(), vt.stride(1), vt.stride(0), v8, Bk, heads, Nk, 1, st), "sg_attn_f8_pack(vt)")
+    with _timed("attention_f8_d40", 4.0 * B * heads * Nq * Nk * 40, f"B{B} H{heads} Nq{Nq} Nk{Nk}"):
+        check(lib.sg_attn_fwd_f8_d40(q8, k8, v8, out.data_ptr(), out.stride(1), out.stride(0), B, heads, Nq, Nk, Bk, scale, st),
+              "sg_attn_fwd_f8_d40")
     return out
 
 
@@ -651,9 +701,40 @@ def debug_set_tile(bm: int = 0, bn: int = 0, no_pipe: bool = False) -> None:
     check(lib.sg_debug_set_tile(bm, bn, int(no_pipe)), "sg_debug_set_tile")
 
 
+def debug_set_option(name: str, value: int) -> None:
+    """Development option of the library (sg_debug_set_option; names in include/storygen_hip.h)."""
+    check(lib.sg_debug_set_option(name.encode(), int(value)), "sg_debug_set_option")
+
+
+def debug_set_spread(mode: int) -> None:
+    debug_set_option("spread", mode)
+
+
 def debug_set_conv_patch(enable: bool = True) -> None:
-    """Experiment switch: True = eligible conv3x3 launches use the LDS-resident-input-patch kernel (default off)."""
-    check(lib.sg_debug_set_conv_patch(int(enable)), "sg_debug_set_conv_patch")
+    debug_set_option("conv_patch", int(enable))
+
+
+# The development tools (tools/*.py, tests) historically selected kernel variants through SG_* environment variables.  The
+# library no longer reads the environment: this maps the variables onto sg_debug_set_option, and only when a tool asks for it.
+_ENV_OPTIONS = {"SG_STAGES": "stages", "SG_NO_NMAJOR": "no_nmajor", "SG_LATE_ISSUE": "late_issue", "SG_NO_FRAG_PREFETCH": "no_frag_prefetch",
+                "SG_FAT": "fat", "SG_NO_PIPE": "no_pipe", "SG_NO_SPLIT": "no_split", "SG_SPREAD": "spread", "SG_CONV_PATCH": "conv_patch",
+                "SG_ATTN_SUB2": "attn_sub2", "SG_ATTN_PRIO": "attn_prio", "SG_ATTN_D80": "attn_d80", "SG_ATTN_D160": "attn_d160",
+                "SG_NO_GN_FUSED": "gn_no_fused", "SG_GN_WIDE": "gn_wide", "SG_GN_FUSED_MAX": "gn_fused_max"}
+
+
+def apply_env_options() -> dict:
+    """Development tools only (never called by the product path): SG_* variables -> sg_debug_set_option.  Returns what was set."""
+    import os
+    done = {}
+    for var, name in _ENV_OPTIONS.items():
+        if os.environ.get(var, "") != "":
+            debug_set_option(name, int(os.environ[var]))
+            done[name] = int(os.environ[var])
+    if os.environ.get("SG_TILE"):
+        bm, bn = (int(v) for v in os.environ["SG_TILE"].split(","))
+        debug_set_option("tile_m", bm), debug_set_option("tile_n", bn)
+        done["tile"] = (bm, bn)
+    return done
 
 
 def debug_mfma_f8(a_bytes: torch.Tensor, b_bytes: torch.Tensor, scale_a: int = 127, scale_b: int = 127) -> torch.Tensor:

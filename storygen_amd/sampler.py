@@ -59,7 +59,8 @@ class StoryGenSampler:
                  height: int = 64, width: int = 64, n_ref: int = 3, seq_len: int = 77,
                  schedule: Optional[DDIMSchedule] = None, use_graph: bool = True, dedup: bool = True,
                  weights: Optional[EngineWeights] = None, overlap: bool = True, ref_ahead: int = 1,
-                 split_graphs: bool = False, stream_priority: bool = False):
+                 split_graphs: bool = False, stream_priority: bool = False, fp8_attention: bool = False,
+                 side_streams: str = "auto"):
         if n_ref < 1:
             raise ValueError("StoryGen's loop needs at least one prior frame")
         if ref_ahead < 1 or (ref_ahead > 1 and not (use_graph and overlap)):
@@ -75,6 +76,10 @@ class StoryGenSampler:
         if stream_priority and not self.split:
             raise ValueError("stream_priority only applies to separately launched graphs (split_graphs=True or ref_ahead > 1)")
         self.stream_priority = bool(stream_priority)
+        if side_streams not in ("auto", "none", "main", "both"):
+            raise ValueError("side_streams must be auto, none, main or both")
+        self.side_streams = side_streams               # intra-pass side-stream forks (engine.forward(side=...)); measured neutral
+        self.fp8_attention = bool(fp8_attention)       # BASELINE config 5: D = 40 image / self attention on the e4m3 MFMA path
         self.arch, self.dev = arch, torch.device(device)
         self.N, self.R, self.h, self.w, self.S = n_samples, n_ref, height, width, seq_len
         self.B = 3 * n_samples
@@ -156,7 +161,8 @@ class StoryGenSampler:
             if self.G > 1 or self.split:
                 raise ValueError("stage 'no' has no reference pass to batch or split off")
             self.units, self.U, self.U0 = [], 0, 0
-            self.main = UNetEngine(self.arch, None, self.dev, self.B, self.h, self.w, 0, self.S, weights=self.weights)
+            self.main = UNetEngine(self.arch, None, self.dev, self.B, self.h, self.w, 0, self.S, weights=self.weights,
+                                   fp8_attention=self.fp8_attention)
             self.ref, self.ctx_sets, self.kv_sets, self.plans = None, [], [], []
             self.side_main = torch.cuda.Stream(device=self.dev) if self.use_graph else None
             self.side_ref = None
@@ -169,7 +175,7 @@ class StoryGenSampler:
         self.U0 = len(units)                  # reference samples of ONE step; the reference engine batches G steps of them
         units = units * G                     # unit g*U0 + u = sample u of the g-th step of a group
         self.units, self.U = units, len(units)
-        kw = dict(weights=self.weights)
+        kw = dict(weights=self.weights, fp8_attention=self.fp8_attention)
         self.main = UNetEngine(self.arch, None, self.dev, self.B, self.h, self.w, self.R, self.S, ctx_rows=rows,
                                attn3_groups=groups, **kw)
         self.ref = UNetEngine(self.arch, None, self.dev, self.U, self.h, self.w, 0, self.S, **kw)
@@ -188,8 +194,7 @@ class StoryGenSampler:
         # side streams for the independent branches inside a pass (engine.forward(side=...)).  In overlap mode the
         # reference pass already runs on a forked stream; a second-level fork from it crashed hipGraph capture on
         # ROCm 7.2 (segfault in the runtime), so only the main pass, which runs on the capture stream, forks.
-        import os
-        knob = os.environ.get("SG_SIDE", "auto")          # development knob: auto | none | main | both
+        knob = self.side_streams
         want_main = self.use_graph and knob != "none"
         want_ref = self.use_graph and (knob == "both" or (knob == "auto" and not self.overlap))
         self.side_main = torch.cuda.Stream(device=self.dev) if want_main else None

@@ -186,3 +186,18 @@ def test_no_kernel_uses_scratch_memory():
     bad = {k: v for k, v in res.items() if v["scratch_bytes_per_lane"] != 0}
     assert not bad, bad
     assert all(v["vgprs"] <= 256 and v["agprs"] <= 256 and v["lds_bytes_per_block"] <= 160 * 1024 for v in res.values())
+
+
+def test_library_never_reads_the_environment():
+    """Development options live behind sg_debug_set_option (kernel selection must not depend on environment
+    variables): no getenv in any kernel source, unknown option names are rejected, "reset" restores the defaults."""
+    import glob
+    import os
+    from storygen_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for path in glob.glob(os.path.join(root, "storygen_amd", "csrc", "*")):
+        with open(path) as f:
+            assert "getenv" not in f.read(), path
+    lib = _lib.load()
+    assert lib.sg_debug_set_option(b"spread", 1) == 0 and lib.sg_debug_set_option(b"reset", 0) == 0
+    assert lib.sg_debug_set_option(b"no_such_option", 1) != 0

@@ -227,6 +227,19 @@ def test_gradient_allreduce_world2_gloo(tmp_path):
     assert torch.equal(a["a.attn3.to_out.0.bias"], torch.arange(4.0) * 1.5)
 
 
+def test_traffic_on_file_was_measured_on_this_build():
+    """roofline.traffic comes from profiles/traffic.json (rocprofv3 PMC passes of bench.py): it must carry the hash of the
+    kernel sources it was measured on, and that hash must be the current one — a kernel edit without a re-measurement fails here
+    (the number on file was several kernel changes old)."""
+    import json
+    from storygen_amd.build import source_hash
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
+    with open(path) as f:
+        t = json.load(f)
+    assert t.get("kernel_source_hash") == source_hash(), "re-run tools/next_round/03_traffic.sh on the GPU box and copy traffic.json"
+    assert t["kernels"]["mma_pipe_kernel (gemm + conv3x3)"]["hbm_bytes_per_launch"] > 0
+
+
 def test_gather_is_identity_without_process_group():
     from storygen_amd.sampler import gather_latents
     x = torch.randn(1, 4, 8, 8)

@@ -261,6 +261,74 @@ def test_conv3x3_padded_input_all_tiles(gpu, tile, B, H, W, Cin, Cout, stride, u
     check(out.permute(0, 3, 1, 2), ref, "conv3x3 padded", l2=2e-6, mx=2e-5)
 
 
+@pytest.mark.parametrize("B,Bk,Nq,Nk", [(2, 2, 256, 320), (1, 1, 200, 77), (3, 2, 1024, 3000), (2, 2, 4096, 4096), (1, 1, 96, 1)])
+def test_attention_fp8_d40(gpu, B, Bk, Nq, Nk):
+    """sg_attn_f8_pack + sg_attn_fwd_f8_d40 (e4m3 Q / K / V / P, fp32 softmax; BASELINE config 5's attention path) against the
+    fp32 softmax reference on the same fp16 operands, and against the fp16 kernel.  Stated bound: e4m3 keeps 3 mantissa bits
+    (relative rounding error up to 2^-4 per element), which leaves 2-4e-2 rel-L2 on the attention output for unit-variance
+    operands (measured 5.0-5.6e-2) — 8e-2 is asserted; the fp16 kernel sits at ~3e-4 on the same inputs.  Also: shared K/V batches (kv_batches < B),
+    ragged key tails, a single key."""
+    from storygen_amd import ops
+    H, D = 8, 40
+    C = H * D
+    q, k, v = rnd((B, Nq, C), gpu, 1.0, 1), rnd((Bk, Nk, C), gpu, 1.0, 2), rnd((Bk, Nk, C), gpu, 1.0, 3)
+    vt = _vt(v)
+    scale = D ** -0.5
+    kmap = [b if b < Bk else b - (B - Bk) for b in range(B)]
+    qh = q.float().view(B, Nq, H, D).permute(0, 2, 1, 3)
+    kh = k.float().view(Bk, Nk, H, D).permute(0, 2, 1, 3)[kmap]
+    vh = v.float().view(Bk, Nk, H, D).permute(0, 2, 1, 3)[kmap]
+    ref = (torch.softmax(qh @ kh.transpose(-1, -2) * scale, dim=-1) @ vh).permute(0, 2, 1, 3).reshape(B, Nq, C)
+    nbytes = (ops.attention_f8_bytes(B, H, Nq, False) + ops.attention_f8_bytes(Bk, H, Nk, False) + ops.attention_f8_bytes(Bk, H, Nk, True) + 4096)
+    scratch = torch.full((nbytes,), 0x7F, dtype=torch.uint8, device=gpu)          # 0x7F = NaN in e4m3: padding must not leak
+    out8 = torch.full((B, Nq, C), float("nan"), dtype=torch.float16, device=gpu)
+    ops.attention_f8(q, k, vt, out8, H, scale, scratch)
+    out16 = torch.empty_like(out8)
+    ops.attention(q, k, vt, out16, H, scale)
+    torch.cuda.synchronize()
+    e8, e16 = rel_l2(out8.float(), ref), rel_l2(out16.float(), ref)
+    print(f"fp8 attention rel-L2 {e8:.2e} (fp16 kernel {e16:.2e})")
+    assert torch.isfinite(out8).all() and e16 < 2e-3 and e8 < 8e-2          # measured 2.7e-2 .. 5.6e-2 (round 2, MI355X)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_dma_spread_modes_are_bit_identical(gpu, mode):
+    """sg_debug_set_spread only moves the ring-refill LDS-DMA instructions among the MFMAs of a slab: same loads, same order
+    of accumulation — GEMM, GEGLU GEMM, split-K and 3x3 convolution (stride 1 / 2, upsampled) must match mode 0 bit for bit."""
+    from storygen_amd import ops
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=gpu)
+
+    def run_all():
+        outs = []
+        for M, N, K, split in [(4096, 320, 320, 1), (768, 1280, 1280, 4), (300, 640, 2560, 0)]:
+            a, w = rnd((M, K), gpu, 1.0, 1), rnd((N, K), gpu, K ** -0.5, 2)
+            o = torch.empty(M, N, dtype=torch.float32, device=gpu)
+            ops.gemm(a, w, o, bias=rnd((N,), gpu, 1.0, 3), res1=rnd((M, N), gpu, 1.0, 4, torch.float32), split_k=split, workspace=ws)
+            outs.append(o)
+        a, w = rnd((1024, 640), gpu, 1.0, 5), rnd((5120, 640), gpu, 640 ** -0.5, 6)
+        o = torch.empty(1024, 2560, dtype=torch.float16, device=gpu)
+        ops.gemm(a, w, o, bias=rnd((5120,), gpu, 1.0, 7), epilogue=ops.EPI_GEGLU, workspace=ws)
+        outs.append(o)
+        for B, H, W, Ci, Co, stride, ups in [(2, 32, 32, 320, 320, 1, False), (2, 16, 16, 640, 128, 2, False), (1, 16, 16, 128, 192, 1, True)]:
+            xp = torch.zeros(B, H + 2, W + 2, Ci, dtype=torch.float16, device=gpu)
+            xp[:, 1:-1, 1:-1] = rnd((B, H, W, Ci), gpu, 1.0, 8)
+            wk = rnd((Co, 3, 3, Ci), gpu, (9 * Ci) ** -0.5, 9)
+            Ho, Wo = (H * (2 if ups else 1) - 1) // stride + 1, (W * (2 if ups else 1) - 1) // stride + 1
+            o = torch.empty(B, Ho, Wo, Co, dtype=torch.float32, device=gpu)
+            ops.conv3x3(xp, wk, o, stride=stride, upsample2x=ups, bias=rnd((Co,), gpu, 1.0, 10), workspace=ws, x_padded=True)
+            outs.append(o)
+        torch.cuda.synchronize()
+        return outs
+    base = run_all()
+    try:
+        ops.debug_set_spread(mode)
+        got = run_all()
+    finally:
+        ops.debug_set_spread(0)
+    for a, b in zip(got, base):
+        assert torch.equal(a, b)
+
+
 PATCH_CASES = [
     # B, H, W, Cin, Cout, split, tile
     (3, 64, 64, 320, 320, 0, None), (3, 64, 64, 320, 320, 1, (256, 128)), (2, 64, 64, 128, 64, 1, (128, 64)), (1, 64, 64, 64, 72, 1, (64, 64)),

@@ -8,6 +8,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from storygen_amd import ops  # noqa: E402
 
+ops.apply_env_options()      # SG_* development variables -> sg_debug_set_option
+
 dev = torch.device("cuda:0")
 TILES = [(0, 0, False), (256, 128, False), (128, 128, False), (256, 64, False), (128, 64, False), (64, 128, False), (64, 64, False), (128, 128, True),
          (128, 64, True)]

@@ -10,6 +10,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from storygen_amd import ops  # noqa: E402
 
+ops.apply_env_options()      # SG_* development variables -> sg_debug_set_option
+
 GN_SHAPES = [(64, 320), (64, 640), (64, 960), (32, 320), (32, 640), (32, 960), (32, 1280), (32, 1920),
              (16, 640), (16, 1280), (16, 1920), (16, 2560), (8, 1280), (8, 2560)]
 LN_SHAPES = [(4096, 320), (1024, 640), (256, 1280)]

@@ -12,6 +12,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from storygen_amd import ops  # noqa: E402
 
+ops.apply_env_options()      # SG_* development variables -> sg_debug_set_option
+
 dev = torch.device("cuda:0")
 TILES = [(256, 128), (128, 128), (256, 64), (128, 64), (64, 128), (64, 64)]
 SPLITS = [1, 2, 3, 4, 6, 8]

@@ -10,6 +10,8 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from storygen_amd import ops  # noqa: E402
 
+ops.apply_env_options()      # SG_* development variables -> sg_debug_set_option
+
 dev = torch.device("cuda:0")
 which = set(sys.argv[1:]) or {"attn", "conv", "gemm", "gn"}
 REP = 3

@@ -10,6 +10,8 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from storygen_amd import ops  # noqa: E402
+
+ops.apply_env_options()      # SG_* development variables -> sg_debug_set_option
 from storygen_amd.arch import SD15_CONFIG, build_arch  # noqa: E402
 from storygen_amd.sampler import StoryGenSampler  # noqa: E402
 from storygen_amd.synth import synthetic_inputs, synthetic_state_dict  # noqa: E402

@@ -13,8 +13,9 @@ import json
 import os
 import sys
 
-GROUPS = {"mma_pipe_kernel (gemm + conv3x3)": ("mma_pipe_kernel", "mma_kernel", "splitk_reduce_kernel"),
-          "attn_fwd_kernel": ("attn_fwd_kernel",)}
+GROUPS = {"mma_pipe_kernel (gemm + conv3x3)": ("mma_pipe_kernel", "mma_pipe_pair_kernel", "mma_kernel", "splitk_reduce_kernel"),
+          "attn_fwd_kernel": ("attn_fwd_kernel",),
+          "groupnorm": ("gn_stats", "gn_apply", "gn_fused"), "layernorm": ("layernorm_kernel",)}
 
 
 def load(path, counter):
@@ -38,7 +39,10 @@ def main():
     fpath, wpath, note = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "")
     ft, fn = load(fpath, "FETCH_SIZE")
     wt, wn = load(wpath, "WRITE_SIZE")
-    out = {"note": note, "formula": "2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), averaged over every launch of the run", "kernels": {}}
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from storygen_amd.build import source_hash
+    out = {"note": note, "kernel_source_hash": source_hash(),
+           "formula": "2*FETCH_SIZE + WRITE_SIZE (KiB -> bytes), averaged over every launch of the run", "kernels": {}}
     for g in GROUPS:
         if fn[g] == 0 or wn[g] == 0:
             continue

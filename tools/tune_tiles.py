@@ -15,8 +15,10 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-os.environ["SG_NO_TILE_TABLE"] = "1"
 from storygen_amd import ops  # noqa: E402
+
+ops.load_tile_table("none")  # tune from the heuristic tiles, not from a previous table
+ops.apply_env_options()      # SG_* development variables -> sg_debug_set_option
 from storygen_amd.arch import SD15_CONFIG, build_arch  # noqa: E402
 from storygen_amd.sampler import StoryGenSampler  # noqa: E402
 from storygen_amd.synth import synthetic_inputs, synthetic_state_dict  # noqa: E402
