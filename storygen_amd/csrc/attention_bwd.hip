@@ -1,5 +1,5 @@
 // Attention backward for the stage-2 training step (BASELINE config 4: "fwd+bwd of HIP attention"), gfx950.
-// STATUS: compiled, NOT YET RUN ON HARDWARE (tests/test_backward_gpu.py, skipped unless SG_TEST_UNVALIDATED=1).
+// STATUS: validated on MI355X in round 2 (tests/test_backward_gpu.py: D = 40 / 80 / 160, partial tiles, 4096 x 4096).
 // Formulas: oracle/storygen_backward.py::attention_core_bwd (checked against torch.autograd on the CPU):
 //   P = exp2(scale_log2 * S - lse2)          lse2 = the forward pass's log2-domain log-sum-exp row (sg_attn_fwd_lse_f16)
 //   delta[q] = sum_d dO[q,d] O[q,d]          (sg_attn_bwd_prep_f32 packs (lse2, delta) pairs)

@@ -328,7 +328,7 @@ __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p)
 }
 
 // ---- GroupNorm(+SiLU) backward (training step, BASELINE config 4; formulas: oracle/storygen_backward.py) ----------------
-// NOT YET RUN ON HARDWARE (tests/test_backward_gpu.py, skipped unless SG_TEST_UNVALIDATED=1).
+// Validated on MI355X in round 2 (tests/test_backward_gpu.py::test_groupnorm_bwd).
 // y = act(xhat * gamma + beta), act = SiLU or identity.  With g = dact * gamma (dact = dy * act'(n), n = xhat*gamma+beta):
 //   dx = rstd * (g - mean_group(g) - xhat * mean_group(g * xhat)).
 // Three launches with the wide geometry: gn_stats_wide_kernel (statistics of x, exactly as in the forward pass), then

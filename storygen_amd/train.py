@@ -1,10 +1,11 @@
 """Stage-2 training step (BASELINE config 4, /root/reference/train_StorySalon_stage2.py:291-327) on the HIP kernels:
 loss and the 80 attn3 gradients of one step.
 
-STATUS: NOT YET RUN ON HARDWARE (written after round 1's GPU budget was spent).  A correctness-first assembly of
+STATUS: validated on MI355X in round 2 (tests/test_backward_gpu.py::test_training_step_vs_oracle: loss and all 80 gradients
+against oracle.storygen_oracle.train_step, <= 1e-2, with the loss scaling of UNetTrainer.backward_main); BASELINE config 4
+measures 10.3 it/s at bs 4 (profiles/r02a_train_step_bench.json).  A correctness-first assembly of
 storygen_amd/train_blocks.py that follows oracle/storygen_backward.py (unet_forward_saving / unet_backward) record by
-record: per-call allocations, torch.cat for the skip concatenations, no hipGraph.  tests/test_backward_gpu.py compares it
-with oracle.storygen_oracle.train_step (skipped unless SG_TEST_UNVALIDATED=1).  The optimizer step, GradScaler and DDP
+record: per-call allocations, torch.cat for the skip concatenations, no hipGraph yet.  The optimizer step, GradScaler and DDP
 all-reduce of the 49.6 M attn3 parameters (train_StorySalon_stage2.py:187-222,327-332) are the caller's stock PyTorch.
 
 Structure

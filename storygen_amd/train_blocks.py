@@ -1,10 +1,9 @@
 """Training-step building blocks on the HIP kernels: forward-with-saved-tensors and backward of one BasicTransformerBlock
 and one ResnetBlock2D (BASELINE config 4, /root/reference/train_StorySalon_stage2.py:322-327).
 
-STATUS: NOT YET RUN ON HARDWARE.  Written after round 1's GPU budget was spent, as the composition layer between the
-backward kernels (csrc/backward.hip, csrc/attention_bwd.hip, the GroupNorm backward in csrc/norm.hip) and the future
-training engine; tests/test_backward_gpu.py (skipped unless SG_TEST_UNVALIDATED=1) checks both blocks against
-oracle/storygen_backward.py.  The op order follows that oracle line by line; tensors are allocated per call (no graph
+STATUS: validated on MI355X in round 2.  The composition layer between the backward kernels (csrc/backward.hip,
+csrc/attention_bwd.hip, the GroupNorm backward in csrc/norm.hip) and storygen_amd/train.py; tests/test_backward_gpu.py checks
+both blocks against oracle/storygen_backward.py.  The op order follows that oracle line by line; tensors are allocated per call (no graph
 capture yet) — this is a correctness-first layer.
 
 Conventions: activations are [M, C] row-major with M = B * tokens; the residual stream and its gradients are fp32, MFMA
