@@ -157,12 +157,13 @@ def train_step_bench(args):
     bs = 4
     batch = synthetic_train_batch(bs, HW, arch.config["cross_attention_dim"], 0)
     tr = UNetTrainer(arch, sd, dev, bs, HW, HW, n_ref=R)
-    for _ in range(args.warmup):
-        loss, grads = tr.train_step(batch)
+    step = tr.train_step if args.no_graph else tr.train_step_graph      # default: the whole step replayed as one hipGraph
+    for _ in range(args.warmup + (0 if args.no_graph else 1)):          # (+1: the capturing call)
+        loss, grads = step(batch)
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss, grads = tr.train_step(batch)
+        loss, grads = step(batch)
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
     # forward FLOPs: 3 reference passes + main pass per sample; backward of the main pass counted as 2x its forward for the
@@ -173,8 +174,9 @@ def train_step_bench(args):
                       "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                       "dtype": "f16", "data": "synthetic",
                       "config": {"workload": "NON-CONTRACT RUN, BASELINE configs[3]: train_StorySalon_stage2.py step, bs=4, fp16 operands / "
-                                             "fp32 residual stream and gradients, eager (no hipGraph), attn3 gradients only",
-                                 "gradients": len(grads), "loss": float(loss)},
+                                             "fp32 residual stream and gradients, attn3 gradients only; "
+                                             + ("eager launches" if args.no_graph else "whole step = one hipGraph replay, loss-scaled fp16 gradient operands"),
+                                 "hipgraph": not args.no_graph, "grad_scale": tr.last_grad_scale, "gradients": len(grads), "loss": float(loss)},
                       "tflop_forward_per_step": round(fwd, 3)}), flush=True)
 
 
@@ -203,6 +205,7 @@ def main():
     ap.add_argument("--spread", type=int, default=-1, help="A/B: placement of the ring-refill DMA instructions (sg_debug_set_spread)")
     ap.add_argument("--conv-patch", action="store_true",
                     help="A/B: eligible 3x3 convolutions through the LDS-resident-input-patch kernel (experiment, default off)")
+    ap.add_argument("--no-gn-epilogue", action="store_true", help="A/B: every GroupNorm makes its own statistics pass")
     ap.add_argument("--no-gemm-pairs", action="store_true", help="A/B: q|k + V^T, q2 + q3, k3 + v3^T as separate launches")
     ap.add_argument("--train-step", action="store_true",
                     help="NOT the contract workload: BASELINE configs[3] — stage-2 training step, bs=4, 512x512, 3 reference frames "
@@ -254,6 +257,9 @@ def main():
     if args.no_gemm_pairs:
         from storygen_amd import engine as _engine
         _engine.PAIR_GEMMS = False
+    if args.no_gn_epilogue:
+        from storygen_amd import engine as _engine
+        _engine.GN_EPILOGUE_STATS = False
 
     hw, n_ref = (96, 5) if args.config5_shape else (HW, R)
     # per-sample GFLOP of one ref / main pass: 64x64 R=3, or 96x96 R=5
@@ -316,7 +322,8 @@ def main():
                        "hipgraph": not args.no_graph, "dedup_identical_reference_samples": not args.no_dedup,
                        "overlap_ref_pass_of_next_step": sampler.overlap, "ref_ahead": G, "warmup_run": warmup_run,
                        "split_graphs": sampler.split, "stream_priority": sampler.stream_priority,
-                       "conv_lds_patch": args.conv_patch, "paired_gemm_launches": not args.no_gemm_pairs},
+                       "conv_lds_patch": args.conv_patch, "paired_gemm_launches": not args.no_gemm_pairs,
+                       "groupnorm_stats_from_epilogues": not args.no_gn_epilogue},
             "tflop_per_step_as_written": round(step_tflop, 3),
             "final_allgather_ms": round(gather_ms, 3), "latents_gathered": int(final.shape[0]), "latents_finite": finite,
             "latents_distinct_per_rank": distinct,

@@ -94,9 +94,21 @@ typedef struct sg_gemm_desc {
     const void*    res1; int64_t ldr1;   /* fp16, or fp32 with SG_F_RES1_F32 */
     const void*    res2; int64_t ldr2;   /* fp16, or fp32 with SG_F_RES2_F32 */
     void*          workspace; size_t workspace_bytes;
+    float*         stats;             /* optional: GroupNorm partial statistics of the output, see below (NULL = none) */
+    int32_t        stats_batch_rows;  /* rows of C per image (B*HW rows = B images); tiles must not straddle images */
 } sg_gemm_desc;
 
 int    sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream);
+/* GroupNorm statistics as an epilogue (north-star: "GroupNorm/SiLU ... as fused epilogue kernels"; the consumers are ResnetBlock2D
+ * norm1 / norm2, Transformer2DModel.norm model/attention.py:55,99 and conv_norm_out model/unet_2d_condition.py:259-262,477-479):
+ * with `stats` set, the fused linear epilogue also writes, for every output row tile t (T rows) and column n,
+ *     stats[(t*2 + 0)*N + n] = sum over the tile's rows of C[m, n],   stats[(t*2 + 1)*N + n] = sum of C[m, n]^2
+ * (final fp32 values: bias, row bias and residuals included, before any fp16 rounding; deterministic, no atomics), which
+ * sg_groupnorm_nhwc_f16 accepts instead of its own statistics pass (sg_groupnorm_desc.pstats).  T is the launch's tile height:
+ * sg_gemm_stats_tile_rows / sg_conv3x3_stats_tile_rows return it for a descriptor (the plan is a pure function of the descriptor),
+ * or 0 when that launch cannot emit statistics (split-K, GEGLU, a tile that does not divide the image) — in which case a launch
+ * with `stats` set fails with SG_EINVAL.  Size: (M / T) * 2 * N floats. */
+int    sg_gemm_stats_tile_rows(const sg_gemm_desc* d);
 /* Two independent GEMMs in ONE launch (same results as two sg_gemm_f16 calls): the pairs of projections that share an
  * activation operand and are each too small to fill the chip — attn1.to_q|to_k with attn1.to_v (model/attention.py:250-262 via
  * CrossAttention), attn2.to_q with attn3.to_q (:266-276,281-290), attn3.to_k with attn3.to_v of a harvested context.  The two
@@ -135,9 +147,11 @@ typedef struct sg_conv3x3_desc {
     int32_t        split_k;           /* as in sg_gemm_desc */
     int32_t        tile_m, tile_n, tile_waves;   /* as in sg_gemm_desc */
     void*          workspace; size_t workspace_bytes;   /* sg_gemm_workspace_bytes(B*Ho*Wo, Cout, split_k) */
+    float*         stats;             /* optional GroupNorm partial statistics of y, as sg_gemm_desc.stats (image = Ho*Wo rows) */
 } sg_conv3x3_desc;
 
 int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream);
+int sg_conv3x3_stats_tile_rows(const sg_conv3x3_desc* d);
 
 /* conv_in: x fp32 NCHW [B, Cin<=8, H, W] -> y NHWC [B,H,W,Cout] (fp16, or fp32 when y_f32), 3x3 pad 1
  * (unet_2d_condition.py:124,411).
@@ -195,10 +209,20 @@ typedef struct sg_groupnorm_desc {
     float   eps;
     int32_t silu;
     void*   workspace; size_t workspace_bytes;
+    /* Statistics from the producers' epilogues (sg_gemm_desc.stats / sg_conv3x3_desc.stats) instead of a statistics pass over x.
+     * Up to two sources, because x may be a channel concatenation [h | skip] (model/unet_2d_blocks.py:609,626,716) whose halves
+     * were written by different launches: source i covers channels [pstats_c0[i], pstats_c0[i] + pstats_nc[i]) of x with
+     * partials over pstats_rows[i] pixels each (pstats_nc = the producer's N).  The sources must cover all C channels.
+     * pstats[0] == NULL: none (the kernel makes its own pass).  Only the wide variant uses them (sg_groupnorm_uses_pstats). */
+    const float* pstats[2];
+    int32_t pstats_rows[2], pstats_c0[2], pstats_nc[2];
 } sg_groupnorm_desc;
 
 int sg_groupnorm_nhwc_f16(const sg_groupnorm_desc* d, sg_stream_t stream);
 size_t sg_groupnorm_workspace_bytes(int32_t B, int32_t groups);
+/* 1 if a GroupNorm of this shape would consume producer statistics (the two-launch "wide" variant), 0 if it runs the
+ * single-launch register-resident variant, which reads x once anyway: producers then need not emit any. */
+int sg_groupnorm_uses_pstats(int32_t HW, int32_t C, int32_t groups);
 
 /* LayerNorm over the last dim of x[M, C] (row stride ldx), eps, affine; optionally a second affine output from
  * the same statistics (norm2 and norm4 both normalise the post-self-attention state, attention.py:268,283).

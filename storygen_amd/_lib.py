@@ -29,6 +29,7 @@ class GemmDesc(C.Structure):
         ("res1", C.c_void_p), ("ldr1", C.c_int64),
         ("res2", C.c_void_p), ("ldr2", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("stats", C.c_void_p), ("stats_batch_rows", C.c_int32),
     ]
 
 
@@ -48,6 +49,7 @@ class ConvDesc(C.Structure):
         ("split_k", C.c_int32),
         ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("tile_waves", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("stats", C.c_void_p),
     ]
 
 
@@ -63,6 +65,8 @@ class GroupNormDesc(C.Structure):
         ("eps", C.c_float),
         ("silu", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("pstats", C.c_void_p * 2),
+        ("pstats_rows", C.c_int32 * 2), ("pstats_c0", C.c_int32 * 2), ("pstats_nc", C.c_int32 * 2),
     ]
 
 
@@ -117,6 +121,9 @@ SIGNATURES = {
     "sg_device_arch": (C.c_int, []),
     "sg_device_cus": (C.c_int, []),
     "sg_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
+    "sg_gemm_stats_tile_rows": (C.c_int, [C.POINTER(GemmDesc)]),
+    "sg_conv3x3_stats_tile_rows": (C.c_int, [C.POINTER(ConvDesc)]),
+    "sg_groupnorm_uses_pstats": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "sg_gemm_pair_f16": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), C.c_void_p]),
     "sg_gemm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sg_conv3x3_nhwc_f16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),

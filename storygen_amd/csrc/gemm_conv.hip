@@ -48,6 +48,7 @@ struct MmaParams {
     const void* res2; long ldr2;
     // decomposition
     float* ws; int splits; int kt_per_split; int tiles_m, tiles_n;
+    float* stats; int stats_batch_rows;   // optional GroupNorm partial statistics of the output (tile_epilogue), else nullptr
     unsigned long long* prof;   // PROF instantiations only (sg_debug_*_anatomy): per-wave cycle totals of the mainloop phases
     int n_major;   // tile order: 1 = consecutive ids walk M first (tiles sharing a weight panel stay on one XCD / L2)
 };
@@ -147,6 +148,9 @@ __device__ __forceinline__ void tile_epilogue(const MmaParams& p, char* smem, f3
         // loads are issued BEFORE the band is staged: the HBM latency overlaps the LDS round trip instead of following it.
         constexpr int NCH = BN / 8, IT = BR * NCH / NT;
         static_assert(IT * NT == BR * NCH, "items per thread must be integral");
+        static_assert(NT % NCH == 0 && 64 % NCH == 0, "a thread's items share one column chunk");
+        const bool want_stats = p.stats != nullptr;
+        float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
         for (int ip = 0; ip < TM; ++ip) {
             float add[IT][8];
@@ -196,6 +200,46 @@ __device__ __forceinline__ void tile_epilogue(const MmaParams& p, char* smem, f3
                 float v[8] = {v0.x + add[it][0], v0.y + add[it][1], v0.z + add[it][2], v0.w + add[it][3],
                               v1.x + add[it][4], v1.y + add[it][5], v1.z + add[it][6], v1.w + add[it][7]};
                 store_out8(p, gmv[it], gnv[it], v);
+                if (want_stats) {
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) { cs[j] += v[j]; cq[j] = fmaf(v[j], v[j], cq[j]); }
+                }
+            }
+        }
+        if (want_stats) {
+            // GroupNorm statistics as an epilogue: per-(row tile, channel) sums of the FINAL fp32 values (bias / temb / residual
+            // included, before the fp16 rounding).  A thread's items all sit in column chunk t % NCH (NT % NCH == 0), so: lanes
+            // with equal lane % NCH -> one lane (shuffles), waves -> LDS -> fixed-order sum: deterministic, no atomics.
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+#pragma unroll
+                for (int o = 32; o >= NCH; o >>= 1) {
+                    cs[j] += __shfl_xor(cs[j], o, 64);
+                    cq[j] += __shfl_xor(cq[j], o, 64);
+                }
+            }
+            __syncthreads();                    // the last band's LDS reads are done: sC can be reused
+            float* sred = reinterpret_cast<float*>(smem);            // [wave][NCH][16]
+            if (lane < NCH) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    sred[(wave * NCH + lane) * 16 + j] = cs[j];
+                    sred[(wave * NCH + lane) * 16 + 8 + j] = cq[j];
+                }
+            }
+            __syncthreads();
+            if (t < NCH * 2) {                   // thread (plane = t / NCH, ch = t % NCH): 8 consecutive columns of one plane
+                const int plane = t / NCH, ch = t - plane * NCH;
+                const int gn = n0 + ch * 8;
+                if (gn < p.N) {
+                    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                    for (int w = 0; w < NT / 64; ++w)
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) a[j] += sred[(w * NCH + ch) * 16 + plane * 8 + j];
+                    float* dst = p.stats + ((size_t)(m0 / BM) * 2 + plane) * p.N + gn;
+                    *reinterpret_cast<float4*>(dst) = make_float4(a[0], a[1], a[2], a[3]);
+                    *reinterpret_cast<float4*>(dst + 4) = make_float4(a[4], a[5], a[6], a[7]);
+                }
             }
         }
         return;
@@ -944,6 +988,20 @@ void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st, int stages) {
 }
 
 thread_local unsigned long long* g_prof = nullptr;     // set by sg_debug_*_anatomy around one launch
+thread_local int g_query_rows = 0;                     // result of a stats query (rows per partial = the tile height), 0 = none
+thread_local bool g_stats_query = false;               // sg_*_stats_tile_rows: plan only, report eligibility instead of failing
+
+// GroupNorm statistics from the epilogue (MmaParams::stats) need whole tiles inside one image, the fused (non split-K) linear
+// epilogue, and N % 8 == 0.  A launch that was asked for them but cannot deliver fails (the caller asks sg_*_stats_tile_rows first).
+int check_stats(MmaParams& p, int bm, const char* name) {
+    if (!p.stats) return SG_OK;
+    const bool ok = p.splits == 1 && p.mode == SG_EPI_LINEAR && p.stats_batch_rows > 0 && p.stats_batch_rows % bm == 0 &&
+                    p.M % p.stats_batch_rows == 0;
+    if (ok) return SG_OK;
+    if (g_stats_query) { p.stats = nullptr; return SG_OK; }
+    return sg_set_error(SG_EINVAL, "%s: epilogue statistics need a %d-row tile that divides the %d rows of an image and no split-K "
+                        "(split %d): query sg_*_stats_tile_rows first", name, bm, p.stats_batch_rows, p.splits);
+}
 
 // Decomposition of one problem: tile shape, K split, tile order; fills the corresponding fields of p.  `pipe` = the LDS-DMA
 // kernel applies (no load needs a predicate: K % 64 == 0; conv input zero-bordered), else the register-staged kernel.
@@ -973,7 +1031,7 @@ int plan_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_w
     const double a_bytes = CONV ? 2.0 * p.M * (p.K / 9) * (p.stride == 1 && !p.ups ? 1.0 : (p.ups ? 0.25 : 4.0)) : 2.0 * p.M * p.K;
     const double w_bytes = 2.0 * p.N * p.K;
     p.n_major = (w_bytes > a_bytes && !g_tune.no_nmajor) ? 1 : 0;
-    return SG_OK;
+    return check_stats(p, pl.bm, name);
 }
 
 // second pass of a split-K launch: partial tiles -> epilogue
@@ -1014,6 +1072,11 @@ int try_launch_conv_patch(MmaParams& p, int force_split, int hint_bm, int hint_b
     p.tiles_n = sg_cdiv(p.N, pl.bn);
     const double a_bytes = 2.0 * p.M * (p.K / 9), w_bytes = 2.0 * p.N * p.K;
     p.n_major = (w_bytes > a_bytes && !g_tune.no_nmajor) ? 1 : 0;
+    if (int rc = check_stats(p, pl.bm, name)) return rc;
+    if (g_stats_query) {
+        g_query_rows = p.stats ? pl.bm : 0;
+        return 1;
+    }
     dim3 grid(p.tiles_m * p.tiles_n * pl.splits);
     if (pl.bm == 256 && pl.bn == 128) launch_patch<4, 2>(p, grid, st);
     else if (pl.bm == 128 && pl.bn == 128) launch_patch<2, 2>(p, grid, st);
@@ -1038,6 +1101,10 @@ int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint
     Plan pl;
     bool pipe;
     if (int rc = plan_mma<CONV>(p, force_split, hint_bm, hint_bn, hint_waves, ws, ws_bytes, name, pl, pipe)) return rc;
+    if (g_stats_query) {
+        g_query_rows = p.stats ? pl.bm : 0;
+        return SG_OK;
+    }
     dim3 grid(p.tiles_m * p.tiles_n * pl.splits);
     // ring depth: 3 stages (deeper prefetch) unless overridden; SG_STAGES=2 halves... see DESIGN.md §5.2
     const int stages = (g_tune.stages == 2 || g_tune.stages == 4) ? g_tune.stages : 3;
@@ -1125,6 +1192,8 @@ int gemm_params(const sg_gemm_desc* d, MmaParams& p, const char* who) {
     p.rowbias = d->rowbias; p.rowbias_ld = d->rowbias_ld; p.rows_per_batch = d->rows_per_batch > 0 ? d->rows_per_batch : 1;
     p.res1 = d->res1; p.ldr1 = d->ldr1;
     p.res2 = d->res2; p.ldr2 = d->ldr2;
+    SG_REQUIRE(!d->stats || (sg_aligned16(d->stats) && d->stats_batch_rows > 0), "%s: stats alignment / stats_batch_rows", who);
+    p.stats = d->stats; p.stats_batch_rows = d->stats_batch_rows;
     return check_tile_hint(who, d->tile_m, d->tile_n, d->tile_waves);
 }
 
@@ -1204,8 +1273,29 @@ extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream)
     p.bias = reinterpret_cast<const f16*>(d->bias);
     p.rowbias = d->rowbias; p.rowbias_ld = d->rowbias_ld; p.rows_per_batch = Ho * Wo;
     p.res1 = d->res1; p.ldr1 = d->ldr1;
+    SG_REQUIRE(!d->stats || sg_aligned16(d->stats), "sg_conv3x3: stats alignment");
+    p.stats = d->stats; p.stats_batch_rows = Ho * Wo;
     if (int rc = check_tile_hint("sg_conv3x3", d->tile_m, d->tile_n, d->tile_waves)) return rc;
     return launch_mma<true>(p, d->split_k, d->tile_m, d->tile_n, d->tile_waves, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_conv3x3_nhwc_f16");
+}
+
+// Would a launch with this descriptor emit epilogue statistics, and with which tile height?  (Plans the launch exactly as
+// sg_gemm_f16 / sg_conv3x3_nhwc_f16 would — the plan is a pure function of the descriptor and the development options — without
+// launching.)  Returns the rows per partial (> 0), 0 when the launch cannot emit them, < 0 on an invalid descriptor.
+extern "C" int sg_gemm_stats_tile_rows(const sg_gemm_desc* d) {
+    SG_REQUIRE(d && d->stats, "sg_gemm_stats_tile_rows: descriptor with a stats buffer required");
+    g_stats_query = true; g_query_rows = 0;
+    const int rc = sg_gemm_f16(d, nullptr);
+    g_stats_query = false;
+    return rc ? rc : g_query_rows;
+}
+
+extern "C" int sg_conv3x3_stats_tile_rows(const sg_conv3x3_desc* d) {
+    SG_REQUIRE(d && d->stats, "sg_conv3x3_stats_tile_rows: descriptor with a stats buffer required");
+    g_stats_query = true; g_query_rows = 0;
+    const int rc = sg_conv3x3_nhwc_f16(d, nullptr);
+    g_stats_query = false;
+    return rc ? rc : g_query_rows;
 }
 
 // ------------------------------------------------------------------------------------------------ diagnostics

@@ -16,6 +16,9 @@ struct GnParams {
     int HW, C, G, cpg, nchunks, rows_per_chunk, apply_rows;   // apply_rows: pixel rows per workgroup of pass 2
     float eps; int silu;
     float* ws;   // [B][nchunks][G][2] shifted partial sums
+    // statistics from the producers' epilogues (sg_gemm_desc.stats): source i covers channels [ps_c0[i], ps_c0[i] + ps_nc[i]) of x
+    // with per-(row tile of ps_rows[i] pixels, channel) sums: ps[i][((b * tiles_i + tile) * 2 + plane) * ps_nc[i] + (c - ps_c0[i])]
+    const float* ps[2]; int ps_rows[2], ps_c0[2], ps_nc[2];
 };
 
 __device__ __forceinline__ float load1f(const void* base, long off, bool f32) {
@@ -269,6 +272,60 @@ __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p)
         }
     };
     load_batch();       // the first rows travel while the statistics are being reduced
+    if (p.ps[0]) {
+        // Statistics from the producers' epilogue partials.  Entry e of group g = (channel c of the group, row tile of c's source):
+        // n_e rows, S1 = sum x, S2 = sum x^2.  Two passes over the (few hundred) entries, both tree-reduced in a fixed order:
+        //   mean = sum_e S1 / N;   M2 = sum_e [ (S2 - S1^2 / n_e) + n_e (S1 / n_e - mean)^2 ]   (Chan et al.: no cancellation
+        //   between the group mean and the sum of squares — each entry is centred on its own mean first)
+        const int parts = GNW_NT / p.G;
+        const int grp = t % p.G, part = t / p.G;
+        const int t0 = p.HW / p.ps_rows[0], t1 = p.ps[1] ? p.HW / p.ps_rows[1] : 0;
+        const int tmax = t0 > t1 ? t0 : t1;
+        const int nent = p.cpg * tmax;
+        auto entry = [&](int e, float& s1, float& s2, float& n) -> bool {
+            const int cl = e / tmax, tile = e - cl * tmax;
+            const int c = grp * p.cpg + cl;
+            const int src = (p.ps[1] && c >= p.ps_c0[1]) ? 1 : 0;
+            const int tiles = src ? t1 : t0;
+            if (tile >= tiles) return false;
+            const float* base = p.ps[src] + ((long)(b * tiles + tile) * 2) * p.ps_nc[src] + (c - p.ps_c0[src]);
+            s1 = base[0]; s2 = base[p.ps_nc[src]]; n = (float)p.ps_rows[src];
+            return true;
+        };
+        float acc = 0.f;
+        if (part < parts)
+            for (int e = part; e < nent; e += parts) {
+                float s1, s2, n;
+                if (entry(e, s1, s2, n)) acc += s1;
+            }
+        s_ps[t] = acc;
+        __syncthreads();
+        const float ntot = (float)p.HW * (float)p.cpg;
+        if (t < p.G) {
+            float s = 0.f;
+            for (int k = 0; k < parts; ++k) s += s_ps[k * p.G + t];
+            s_mean[t] = s / ntot;
+        }
+        __syncthreads();
+        const float mean = s_mean[grp];
+        acc = 0.f;
+        if (part < parts)
+            for (int e = part; e < nent; e += parts) {
+                float s1, s2, n;
+                if (entry(e, s1, s2, n)) {
+                    const float me = s1 / n, dm = me - mean;
+                    acc += fmaxf(s2 - s1 * me, 0.f) + n * dm * dm;
+                }
+            }
+        s_pq[t] = acc;
+        __syncthreads();
+        if (t < p.G) {
+            float q = 0.f;
+            for (int k = 0; k < parts; ++k) q += s_pq[k * p.G + t];
+            s_rstd[t] = rsqrtf(q / ntot + p.eps);
+        }
+        __syncthreads();
+    } else
     {   // reduce the chunk partials: thread (part, group) sums every `parts`-th chunk, then a fixed-order LDS pass
         const int parts = GNW_NT / p.G;
         const int grp = t % p.G, part = t / p.G;
@@ -682,6 +739,16 @@ extern "C" size_t sg_groupnorm_workspace_bytes(int32_t B, int32_t groups) {
     return (size_t)B * GN_MAX_CHUNKS * (size_t)groups * 2 * sizeof(float);
 }
 
+extern "C" int sg_groupnorm_uses_pstats(int32_t HW, int32_t C, int32_t groups) {
+    if (HW <= 0 || C <= 0 || groups <= 0 || C % groups) return 0;
+    const SgOptions& opt = sg_options();
+    const long fused_max = opt.gn_fused_max >= 0 ? opt.gn_fused_max : GNF_DEFAULT_MAX;
+    const int cpg = C / groups;
+    const long slab = (long)HW * cpg;
+    if (cpg % 4 == 0 && slab <= 256L * 4 * GNF_MAXI && slab <= fused_max && !opt.gn_no_fused) return 0;      // gn_fused_kernel
+    return (opt.gn_wide != 0 && cpg >= 8 && C / 8 <= GNW_MAX_VPR) ? 1 : 0;
+}
+
 extern "C" int sg_groupnorm_nhwc_f16(const sg_groupnorm_desc* d, sg_stream_t stream) {
     SG_REQUIRE(d != nullptr, "sg_groupnorm: null descriptor");
     SG_REQUIRE(d->x && d->y && d->gamma && d->beta && d->workspace, "sg_groupnorm: null pointer");
@@ -702,6 +769,16 @@ extern "C" int sg_groupnorm_nhwc_f16(const sg_groupnorm_desc* d, sg_stream_t str
     p.gamma = reinterpret_cast<const f16*>(d->gamma); p.beta = reinterpret_cast<const f16*>(d->beta);
     p.HW = d->HW; p.C = d->C; p.G = d->groups; p.cpg = d->C / d->groups; p.eps = d->eps; p.silu = d->silu;
     p.ws = reinterpret_cast<float*>(d->workspace);
+    if (d->pstats[0]) {
+        int covered = 0;
+        for (int i = 0; i < 2 && d->pstats[i]; ++i) {
+            SG_REQUIRE(d->pstats_rows[i] > 0 && d->HW % d->pstats_rows[i] == 0 && d->pstats_nc[i] > 0 && d->pstats_c0[i] == covered,
+                       "sg_groupnorm: pstats[%d]: rows must divide HW and the sources must tile the channels in order", i);
+            p.ps[i] = d->pstats[i]; p.ps_rows[i] = d->pstats_rows[i]; p.ps_c0[i] = d->pstats_c0[i]; p.ps_nc[i] = d->pstats_nc[i];
+            covered += d->pstats_nc[i];
+        }
+        SG_REQUIRE(covered == d->C, "sg_groupnorm: pstats cover %d of %d channels", covered, d->C);
+    }
     hipStream_t st0 = (hipStream_t)stream;
     // development options (sg_debug_set_option): gn_no_fused, gn_fused_max = <slab elements>, gn_wide
     const SgOptions& opt = sg_options();
@@ -721,12 +798,15 @@ extern "C" int sg_groupnorm_nhwc_f16(const sg_groupnorm_desc* d, sg_stream_t str
         if (p.rows_per_chunk < rpp) p.rows_per_chunk = rpp;   // at least one full pass of the thread rows
         p.nchunks = sg_cdiv(p.HW, p.rows_per_chunk);
         const dim3 grid(p.nchunks, d->B), block(GNW_NT);
-        hipLaunchKernelGGL(gn_stats_wide_kernel, grid, block, 0, st0, p);
-        SG_CHECK_LAUNCH("gn_stats_wide");
+        if (!p.ps[0]) {            // no statistics from the producers' epilogues: own pass over x
+            hipLaunchKernelGGL(gn_stats_wide_kernel, grid, block, 0, st0, p);
+            SG_CHECK_LAUNCH("gn_stats_wide");
+        }
         hipLaunchKernelGGL(gn_apply_wide_kernel, grid, block, 0, st0, p);
         SG_CHECK_LAUNCH("gn_apply_wide");
         return SG_OK;
     }
+    p.ps[0] = p.ps[1] = nullptr;       // the narrow pair keeps its own statistics pass
     int apply_blocks = 1;
     gn_geometry(d->B, d->HW, d->C, d->x_f32 != 0, &p.nchunks, &p.rows_per_chunk, &apply_blocks, &p.apply_rows);
     dim3 grid(p.nchunks, d->B), block(256);

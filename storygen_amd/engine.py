@@ -36,6 +36,7 @@ from .arch import BlockSpec, ResnetSpec, UNetArch, XfSpec, feature_shapes
 from .repack import conv1x1_nk, conv3x3_krsc, conv_in_kn, interleave_geglu
 
 F16 = torch.float16
+GN_EPILOGUE_STATS = True   # GroupNorm statistics from the producing conv / GEMM epilogues (False = every GroupNorm makes its own pass)
 PAIR_GEMMS = True     # q|k + V^T, q2 + q3, k3 + v3^T as one launch each (sg_gemm_pair_f16); False = two launches (A/B switch)
 
 
@@ -238,6 +239,13 @@ class UNetEngine:
         # BASELINE config 5: the head-dim-40 self / image attentions (the 46 080-key context of the 96x96 level) on the fp8 MFMA
         # path (sg_attn_fwd_f8_d40); text attention and the D = 80 / 160 levels stay fp16
         self.fp8_attention = bool(fp8_attention)
+        # GroupNorm statistics as producer epilogues (north-star): a conv / GEMM whose output feeds a wide GroupNorm also
+        # writes per-(row tile, channel) sums, and that GroupNorm skips its own statistics pass.  Per producer site: one buffer and
+        # the cached answer of sg_*_stats_tile_rows (0 = this launch cannot emit them -> the consumer makes its own pass).
+        self.gn_epilogue_stats = GN_EPILOGUE_STATS
+        self._stats_buf: Dict[str, torch.Tensor] = {}
+        self._stats_rows: Dict[str, int] = {}
+        self._pstats: Dict[int, tuple] = {}           # data_ptr of a produced tensor -> (buffer, rows per partial, channels)
         self.text_cache: Dict[str, torch.Tensor] = {}
         self._alloc(splitk_workspace_mb)
 
@@ -373,6 +381,38 @@ class UNetEngine:
     def _join(self):
         torch.cuda.current_stream(self.dev).wait_stream(self.side)
 
+    # ---- GroupNorm statistics from producer epilogues
+    def _stats_for(self, site: str, lvl: int, n_out: int, query) -> Optional[torch.Tensor]:
+        """The statistics buffer a producer at `site` (output [B*hw[lvl], n_out]) should write, or None.  `query(buf)` -> rows per
+        partial of exactly that launch (ops.*_stats_rows); asked once per site (the plan depends only on the shapes)."""
+        if not self.gn_epilogue_stats or not ops.groupnorm_uses_pstats(self.hw[lvl], n_out, self.groups):
+            return None
+        rows = self._stats_rows.get(site)
+        if rows is None:
+            M = self.B * self.hw[lvl]
+            buf = torch.empty((M // 64) * 2 * n_out, dtype=torch.float32, device=self.dev)    # enough for any tile height >= 64
+            rows = self._stats_rows[site] = int(query(buf))
+            if rows:
+                self._stats_buf[site] = buf
+        return self._stats_buf.get(site) if rows else None
+
+    def _publish(self, out: torch.Tensor, site: str, n_out: int):
+        self._pstats[out.data_ptr()] = (self._stats_buf[site], self._stats_rows[site], n_out)
+
+    def _pstats_of(self, x: torch.Tensor) -> Optional[list]:
+        """Producer statistics covering x [M, C] (one producer, or two for a channel concat [h | skip]), else None."""
+        C = x.shape[1]
+        a = self._pstats.get(x.data_ptr())
+        if a is None:
+            return None
+        if a[2] == C:
+            return [a]
+        if a[2] < C:
+            b = self._pstats.get(x[:, a[2]:].data_ptr())
+            if b is not None and a[2] + b[2] == C:
+                return [a, b]
+        return None
+
     def _attention(self, q, k, vt, out, heads: int, scale: float, nk: Optional[int] = None):
         """softmax(scale q k^T) v on the HIP kernels: fp16 MFMA, or e4m3 MFMA for the D = 40 image / self attentions when the
         engine was built with fp8_attention (text attention — 77 keys — and every other head dim stay fp16)."""
@@ -390,7 +430,7 @@ class UNetEngine:
         p_in, p_mid = self.padded[(lvl, r.cin)], self.padded[(lvl, r.cout)]
         x16 = L["x16"][: M * r.cin].view(M, r.cin) if rn.wsc is not None else None
         ops.groupnorm(x.unflatten(0, (B, hw)), rn.n1g, rn.n1b, p_in, self.groups, self.eps, True, self.ws_gn,
-                      xcopy=None if x16 is None else x16.unflatten(0, (B, hw)))
+                      xcopy=None if x16 is None else x16.unflatten(0, (B, hw)), pstats=self._pstats_of(x))
         res, forked = x, False
         if rn.wsc is not None:                     # 1x1 shortcut: independent of conv1 -> norm2, runs beside them
             forked = self._fork()
@@ -402,11 +442,26 @@ class UNetEngine:
             res = L["sc"]
         h1 = L["c1"]
         rb = self.tproj[:, rn.temb_off: rn.temb_off + r.cout]
-        ops.conv3x3(p_in, rn.w1, self._img(h1, lvl), rowbias=rb, workspace=ws, x_padded=True)
-        ops.groupnorm(h1.unflatten(0, (B, hw)), rn.n2g, rn.n2b, p_mid, self.groups, self.eps, True, self.ws_gn)
+        kw1 = dict(rowbias=rb, workspace=ws, x_padded=True)
+        s1 = self._stats_for(r.prefix + ".conv1", lvl, r.cout,
+                             lambda buf: ops.conv3x3_stats_rows(p_in, rn.w1, self._img(h1, lvl), stats=buf, **kw1))
+        ops.conv3x3(p_in, rn.w1, self._img(h1, lvl), stats=s1, **kw1)
+        if s1 is not None:
+            self._publish(h1, r.prefix + ".conv1", r.cout)
+        else:
+            self._pstats.pop(h1.data_ptr(), None)
+        ops.groupnorm(h1.unflatten(0, (B, hw)), rn.n2g, rn.n2b, p_mid, self.groups, self.eps, True, self.ws_gn,
+                      pstats=self._pstats_of(h1))
         if forked:
             self._join()
-        ops.conv3x3(p_mid, rn.w2, self._img(out, lvl), bias=rn.b2, res1=self._img(res, lvl), workspace=ws, x_padded=True)
+        kw2 = dict(bias=rn.b2, res1=self._img(res, lvl), workspace=ws, x_padded=True)
+        s2 = self._stats_for(r.prefix + ".conv2", lvl, r.cout,
+                             lambda buf: ops.conv3x3_stats_rows(p_mid, rn.w2, self._img(out, lvl), stats=buf, **kw2))
+        ops.conv3x3(p_mid, rn.w2, self._img(out, lvl), stats=s2, **kw2)
+        if s2 is not None:
+            self._publish(out, r.prefix + ".conv2", r.cout)
+        else:
+            self._pstats.pop(out.data_ptr(), None)
 
     def _text_kv(self, xf: _Xf, lvl: int, use_cache: bool):
         """K and V^T projections of the text embeddings for attn2 (attention.py:192-199): timestep-invariant, so the
@@ -447,7 +502,7 @@ class UNetEngine:
         scale = xf.spec.dim_head ** -0.5
         ws = self.ws_split
         ops.groupnorm(x.unflatten(0, (B, hw)), xf.ng, xf.nb, L["gn"].unflatten(0, (B, hw)), self.groups, 1e-6, False,
-                      self.ws_gn)                                                         # :99 (eps 1e-6, :55)
+                      self.ws_gn, pstats=self._pstats_of(x))                              # :99 (eps 1e-6, :55)
         h0 = L["h0"]
         ops.gemm(L["gn"], xf.w_in, h0, bias=xf.b_in, workspace=ws)                        # proj_in :101
         # --- self-attention :250-262
@@ -522,7 +577,14 @@ class UNetEngine:
         ops.layernorm(h3, *xf.ln["norm3"], L["ln"])
         ops.gemm(L["ln"], xf.w_ff1, L["ffi"], bias=xf.b_ff1, epilogue=ops.EPI_GEGLU, workspace=ws)
         ops.gemm(L["ffi"], xf.w_ff2, L["h4"], bias=xf.b_ff2, res1=h3, workspace=ws)       # fp16: only feeds proj_out
-        ops.gemm(L["h4"], xf.w_out, out, bias=xf.b_out, res1=x, workspace=ws)             # proj_out + residual :121-123
+        kwo = dict(bias=xf.b_out, res1=x, workspace=ws)                                   # proj_out + residual :121-123
+        site = xf.spec.prefix + ".proj_out"
+        so = self._stats_for(site, lvl, C, lambda buf: ops.gemm_stats_rows(L["h4"], xf.w_out, out, stats=(buf, hw), **kwo))
+        ops.gemm(L["h4"], xf.w_out, out, stats=None if so is None else (so, hw), **kwo)
+        if so is not None:
+            self._publish(out, site, C)
+        else:
+            self._pstats.pop(out.data_ptr(), None)
 
     def _sampler_conv(self, prefix: str, h: torch.Tensor, out: torch.Tensor, lvl: int, out_lvl: int, down: bool):
         """Downsample2D (3x3 stride 2) / Upsample2D (nearest 2x + 3x3): the fp32 stream tensor is cast into the
@@ -530,8 +592,14 @@ class UNetEngine:
         w, b = self.samplers[prefix]
         pbuf = self.padded[(lvl, h.shape[1])]
         ops.pad_cast(self._img(h, lvl), pbuf)
-        ops.conv3x3(pbuf, w, self._img(out, out_lvl), stride=2 if down else 1, upsample2x=not down, bias=b,
-                    workspace=self.ws_split, x_padded=True)
+        kw = dict(stride=2 if down else 1, upsample2x=not down, bias=b, workspace=self.ws_split, x_padded=True)
+        n_out = out.shape[1]
+        st = self._stats_for(prefix, out_lvl, n_out, lambda buf: ops.conv3x3_stats_rows(pbuf, w, self._img(out, out_lvl), stats=buf, **kw))
+        ops.conv3x3(pbuf, w, self._img(out, out_lvl), stats=st, **kw)
+        if st is not None:
+            self._publish(out, prefix, n_out)
+        else:
+            self._pstats.pop(out.data_ptr(), None)
 
     # ------------------------------------------------------------------------------------------ forward
     def forward(self, harvest_slot: Optional[int] = None, consume: bool = False, harvest: Optional[HarvestPlan] = None,
@@ -634,7 +702,7 @@ class UNetEngine:
         # --- out :477-480
         L = self.lv[0]
         ops.groupnorm(h.unflatten(0, (self.B, self.hw[0])), *self.gn_out, L["gn"].unflatten(0, (self.B, self.hw[0])),
-                      self.groups, self.eps, True, self.ws_gn)
+                      self.groups, self.eps, True, self.ws_gn, pstats=self._pstats_of(h))
         ops.conv_out(self._img(L["gn"], 0), self.w_conv_out, self.b_conv_out, self.eps_out)
         return self.eps_out
 

@@ -143,8 +143,9 @@ def _gemm_desc(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Opt
                rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 1, res1: Optional[torch.Tensor] = None,
                res2: Optional[torch.Tensor] = None, epilogue: int = EPI_LINEAR, split_k: int = 0,
                workspace: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
-               tile: Optional[tuple] = None, use_table: bool = True):
-    """Builds the sg_gemm_desc of one problem; returns (desc, flops, shape string)."""
+               tile: Optional[tuple] = None, use_table: bool = True, stats: Optional[tuple] = None):
+    """Builds the sg_gemm_desc of one problem; returns (desc, flops, shape string).  stats = (fp32 buffer, rows per image): the
+    epilogue also writes the GroupNorm partial statistics of the output (sg_gemm_desc.stats)."""
     _f16(a, "a"), _f16(w, "w")
     flags = F_OUT_F32 if _act(out, "out") else 0
     M, K = a.shape
@@ -179,6 +180,9 @@ def _gemm_desc(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Opt
         d.C2, d.ldc2 = out2.data_ptr(), _row_stride(out2, "out2")
     d.flags = flags
     _ws(workspace, d)
+    if stats is not None:
+        _f32(stats[0], "stats")
+        d.stats, d.stats_batch_rows = stats[0].data_ptr(), int(stats[1])
     sig = f"g:{M}:{N}:{K}:{epilogue}:{flags}:{int(bias is not None)}{int(rowbias is not None)}{int(res1 is not None)}{int(res2 is not None)}{int(out2 is not None)}"
     if use_table or tile is not None:
         _apply_tile(d, tile, split_k, sig)
@@ -203,6 +207,16 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, **kw) -> torch.Ten
     return out
 
 
+def gemm_stats_rows(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, **kw) -> int:
+    """Rows per partial (= the tile height) a gemm() call with these arguments (incl. stats=...) will write statistics for, or 0
+    when that launch cannot emit them (sg_gemm_stats_tile_rows; no launch happens)."""
+    d, _, _ = _gemm_desc(a, w, out, **kw)
+    rc = lib.sg_gemm_stats_tile_rows(C.byref(d))
+    if rc < 0:
+        check(rc, "sg_gemm_stats_tile_rows")
+    return rc
+
+
 def gemm_pair(first: tuple, second: tuple) -> None:
     """Two independent GEMMs in one launch (sg_gemm_pair_f16).  Each argument is ((a, w, out), {keywords of gemm()}); the
     outputs must not overlap and the two workspaces, if given, must be different buffers."""
@@ -213,12 +227,11 @@ def gemm_pair(first: tuple, second: tuple) -> None:
         check(lib.sg_gemm_pair_f16(C.byref(d0), C.byref(d1), _stream()), "sg_gemm_pair_f16")
 
 
-def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stride: int = 1, upsample2x: bool = False,
-            bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
-            res1: Optional[torch.Tensor] = None, split_k: int = 0, workspace: Optional[torch.Tensor] = None,
-            x_padded: bool = False, tile: Optional[tuple] = None) -> torch.Tensor:
-    """x [B,H,W,Cin] (channels-last, pixel-strided view allowed; or the zero-bordered [B,H+2,W+2,Cin] with
-    x_padded=True) -> out [B,Ho,Wo,Cout] (fp16 or fp32); w_krsc [Cout,3,3,Cin]; res1 fp16 or fp32."""
+def _conv_desc(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stride: int = 1, upsample2x: bool = False,
+               bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
+               res1: Optional[torch.Tensor] = None, split_k: int = 0, workspace: Optional[torch.Tensor] = None,
+               x_padded: bool = False, tile: Optional[tuple] = None, stats: Optional[torch.Tensor] = None):
+    """Builds the sg_conv3x3_desc; returns (desc, flops, shape string)."""
     _f16(x, "x"), _f16(w_krsc, "w")
     flags = F_OUT_F32 if _act(out, "out") else 0
     B, H, W, Cin = x.shape
@@ -255,20 +268,39 @@ def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stride:
     d.flags = flags
     d.split_k = split_k
     _ws(workspace, d)
+    if stats is not None:
+        _f32(stats, "stats")
+        d.stats = stats.data_ptr()
     sig = f"c:{B}:{H}:{W}:{Cin}:{Cout}:{stride}:{int(upsample2x)}:{int(x_padded)}:{flags}:{int(bias is not None)}{int(rowbias is not None)}{int(res1 is not None)}"
     _apply_tile(d, tile, split_k, sig)
     if TUNE_SINK is not None:
         TUNE_SINK.append((sig, dict(kind="conv", B=B, H=H, W=W, Cin=Cin, Cout=Cout, stride=stride, ups=bool(upsample2x), padded=bool(x_padded),
                                     out_f32=bool(flags & F_OUT_F32), bias=bias is not None, rowbias=rowbias is not None,
                                     res1=None if res1 is None else str(res1.dtype))))
-    with _timed("conv3x3", 2.0 * B * Ho * Wo * Cout * 9 * Cin,
-                f"B{B} {Ho}x{Wo} {Cin}->{Cout} s{stride}{' up' if upsample2x else ''}"):
+    return d, 2.0 * B * Ho * Wo * Cout * 9 * Cin, f"B{B} {Ho}x{Wo} {Cin}->{Cout} s{stride}{' up' if upsample2x else ''}"
+
+
+def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, **kw) -> torch.Tensor:
+    """x [B,H,W,Cin] (channels-last, pixel-strided view allowed; or the zero-bordered [B,H+2,W+2,Cin] with
+    x_padded=True) -> out [B,Ho,Wo,Cout] (fp16 or fp32); w_krsc [Cout,3,3,Cin]; res1 fp16 or fp32.  Keywords: stride, upsample2x,
+    bias, rowbias, res1, split_k, workspace, x_padded, tile, stats (fp32 buffer: GroupNorm partial statistics of the output)."""
+    d, flops, shape = _conv_desc(x, w_krsc, out, **kw)
+    with _timed("conv3x3", flops, shape):
         if ANATOMY is not None:
             check(lib.sg_debug_conv_anatomy(C.byref(d), ANATOMY.data_ptr(), ANATOMY.numel() * ANATOMY.element_size(), _stream()),
                   "sg_debug_conv_anatomy")
         else:
             check(lib.sg_conv3x3_nhwc_f16(C.byref(d), _stream()), "sg_conv3x3_nhwc_f16")
     return out
+
+
+def conv3x3_stats_rows(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, **kw) -> int:
+    """Rows per partial a conv3x3() call with these arguments (incl. stats=...) will write statistics for, or 0 (no launch)."""
+    d, _, _ = _conv_desc(x, w_krsc, out, **kw)
+    rc = lib.sg_conv3x3_stats_tile_rows(C.byref(d))
+    if rc < 0:
+        check(rc, "sg_conv3x3_stats_tile_rows")
+    return rc
 
 
 def conv_in(x_nchw: torch.Tensor, w_kn: torch.Tensor, bias: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
@@ -362,10 +394,17 @@ def groupnorm_workspace_bytes(B: int, groups: int) -> int:
     return lib.sg_groupnorm_workspace_bytes(B, groups)
 
 
+def groupnorm_uses_pstats(HW: int, Cc: int, groups: int) -> bool:
+    """True when a GroupNorm of this shape consumes producer statistics (the two-launch wide variant)."""
+    return bool(lib.sg_groupnorm_uses_pstats(HW, Cc, groups))
+
+
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, groups: int, eps: float,
-              silu: bool, workspace: torch.Tensor, xcopy: Optional[torch.Tensor] = None) -> torch.Tensor:
+              silu: bool, workspace: torch.Tensor, xcopy: Optional[torch.Tensor] = None, pstats: Optional[list] = None) -> torch.Tensor:
     """x [B, HW, C] channels-last fp16/fp32 (row-strided views allowed).  out is either [B, HW, C] fp16 or the
-    zero-bordered image [B, H+2, W+2, C] (then only the interior is written); xcopy = optional fp16 [B, HW, C] raw copy."""
+    zero-bordered image [B, H+2, W+2, C] (then only the interior is written); xcopy = optional fp16 [B, HW, C] raw copy.
+    pstats = [(buffer, rows per partial, channels), ...] (one or two sources, in channel order): statistics written by the
+    producers' epilogues (gemm / conv3x3 stats=...) — the wide variant then skips its own statistics pass."""
     x_f32 = _act(x, "x")
     _f16(gamma, "gamma"), _f16(beta, "beta"), _f16(out, "out")
     B, HW, Cc = x.shape
@@ -390,6 +429,12 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: tor
     d.gamma, d.beta = gamma.data_ptr(), beta.data_ptr()
     d.B, d.HW, d.C, d.groups, d.eps, d.silu = B, HW, Cc, groups, eps, int(silu)
     d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
+    if pstats:
+        c0 = 0
+        for i, (buf, rows, nc) in enumerate(pstats):
+            _f32(buf, "pstats")
+            d.pstats[i], d.pstats_rows[i], d.pstats_c0[i], d.pstats_nc[i] = buf.data_ptr(), int(rows), c0, int(nc)
+            c0 += int(nc)
     with _timed("groupnorm", B * HW * Cc * ((4 if x_f32 else 2) + 2 + (2 if xcopy is not None else 0)), f"B{B} HW{HW} C{Cc}", aux=True):
         check(lib.sg_groupnorm_nhwc_f16(C.byref(d), _stream()), "sg_groupnorm_nhwc_f16")
     return out

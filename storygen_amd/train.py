@@ -108,11 +108,14 @@ class UNetTrainer:
         # max|d_pred| to 2^8 (one host read per step), retried 16x smaller if a gradient comes out non-finite.
         self.grad_scale = "auto"
         self.last_grad_scale = 1.0
+        self._graphs: Dict[tuple, dict] = {}       # train_step_graph: use_refs -> captured hipGraph + static inputs / outputs
+        self.check_finite = True                   # train_step_graph: one host read of the gradients' finiteness per step
+        self._alphas_dev = self.schedule.alphas_cumprod.to(self.dev, F32)
 
     # ------------------------------------------------------------------------------------------------ pieces
     def _add_noise(self, x: torch.Tensor, noise: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
         """DDPMScheduler.add_noise with per-sample timesteps (train_StorySalon_stage2.py:303,311); elementwise plumbing."""
-        a = self.schedule.alphas_cumprod.to(self.dev, F32)[t.long()].view(-1, 1, 1, 1)
+        a = self._alphas_dev[t.long()].view(-1, 1, 1, 1)
         return a.sqrt() * x + (1 - a).sqrt() * noise
 
     def _down(self, prefix: str, h: torch.Tensor, hh: int, ww: int) -> torch.Tensor:
@@ -153,31 +156,77 @@ class UNetTrainer:
         return dx
 
     # ------------------------------------------------------------------------------------------------ the step
-    def train_step(self, batch: Dict[str, torch.Tensor], use_refs=(0, 1, 2)) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
-        """`batch` as storygen_amd.synth.synthetic_train_batch / oracle.storygen_oracle.train_step.  Returns (loss [1] fp32 on
-        the device, {parameter name: fp32 gradient})."""
-        dev, B, H, W, arch = self.dev, self.B, self.H, self.W, self.arch
-        f = lambda k: batch[k].to(dev, F32)                                          # noqa: E731
-        t = batch["timesteps"].to(dev)
-        ref_t = (batch["timesteps"] / 10).long().to(dev)                             # :297-300
+    def _stage_inputs(self, batch: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+        """The batch on the device in the dtypes the step consumes (host -> device copies happen only here)."""
+        dev = self.dev
+        f = lambda k: batch[k].to(dev, F32).contiguous()                             # noqa: E731
+        return dict(latents=f("latents"), noise=f("noise"), ref_latents=f("ref_latents"), ref_noise=f("ref_noise"), mask=f("mask"),
+                    timesteps=batch["timesteps"].to(dev).long(), text=batch["text"].to(dev, F16).contiguous(),
+                    prev_text=batch["prev_text"].to(dev, F16).contiguous())
+
+    def _step_device(self, inp: Dict[str, torch.Tensor], use_refs) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """The whole step on device-resident inputs (no host <-> device traffic unless grad_scale is "auto"): reference passes,
+        main pass, masked MSE, backward walk.  This is the function train_step_graph captures."""
+        dev, B = self.dev, self.B
+        t = inp["timesteps"]
+        ref_t = torch.div(t, 10, rounding_mode="floor")                              # (timesteps / 10).long(), :297-300
         # ---- reference passes: features of the frames used, harvested into context slots 0..len(use_refs)-1
-        ref_lat, prev_text = f("ref_latents"), batch["prev_text"].to(dev, F16)
         for slot, i in enumerate(use_refs):                                          # :309-314
             ti = ref_t * (3 - i)
-            self.ref.set_inputs(self._add_noise(ref_lat[i], f("ref_noise"), ti), ti.float(), prev_text[i])
+            self.ref.set_inputs(self._add_noise(inp["ref_latents"][i], inp["ref_noise"], ti), ti.float(), inp["prev_text"][i])
             self.ref.forward(harvest_slot=slot)
         n_used = len(use_refs)
         ctx16 = {}
         for key, buf in self.ref.ctx.items():                                        # [B, R*hw_k, C] -> the used slots, flattened
             n = buf.shape[1] // self.R
             ctx16[key] = buf[:, : n_used * n].reshape(B * n_used * n, buf.shape[2]).contiguous()
-        text16 = batch["text"].to(dev, F16).reshape(B * batch["text"].shape[1], -1).contiguous()
-        noisy = self._add_noise(f("latents"), f("noise"), t).contiguous()            # :303
+        text16 = inp["text"].reshape(B * inp["text"].shape[1], -1)
+        noisy = self._add_noise(inp["latents"], inp["noise"], t).contiguous()        # :303
         pred = self.forward_main(noisy, t, text16, ctx16)
         # ---- loss (:325) and its gradient
         d_pred, loss = torch.empty_like(pred), _e(1, dev=dev, dtype=F32)
-        ops.mse_grad(pred, f("noise").contiguous(), f("mask").contiguous(), d_pred, loss)
+        ops.mse_grad(pred, inp["noise"], inp["mask"], d_pred, loss)
         return loss, self.backward_main(d_pred)
+
+    def train_step(self, batch: Dict[str, torch.Tensor], use_refs=(0, 1, 2)) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """`batch` as storygen_amd.synth.synthetic_train_batch / oracle.storygen_oracle.train_step.  Returns (loss [1] fp32 on
+        the device, {parameter name: fp32 gradient}).  Eager: every kernel is launched from the host."""
+        return self._step_device(self._stage_inputs(batch), tuple(use_refs))
+
+    def train_step_graph(self, batch: Dict[str, torch.Tensor], use_refs=(0, 1, 2)) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+        """The same step replayed as ONE hipGraph (~3 000 kernel nodes): the first call with a given `use_refs` stages the batch
+        into static device tensors, fixes the gradient scale from one eager step ("auto" needs a host read, a graph cannot), warms
+        up and captures `_step_device` (its per-call allocations come from the graph's private pool, so replays reuse the same
+        addresses); later calls copy the new batch into the static inputs and replay.  The returned loss / gradients are the
+        graph's static outputs: consume them (optimizer step, all-reduce) before the next call.  A non-finite gradient drops
+        the captured graph, lowers the scale 16x and re-captures."""
+        use_refs = tuple(use_refs)
+        staged = self._stage_inputs(batch)
+        st = self._graphs.get(use_refs)
+        if st is None:
+            static = {k: v.clone() for k, v in staged.items()}
+            if self.grad_scale == "auto":                                             # settle the scale eagerly, then freeze it
+                self._step_device(static, use_refs)
+                self.grad_scale = float(self.last_grad_scale)
+            torch.cuda.synchronize(self.dev)
+            side = torch.cuda.Stream(device=self.dev)
+            side.wait_stream(torch.cuda.current_stream(self.dev))
+            with torch.cuda.stream(side):
+                self._step_device(static, use_refs)                                  # warm-up on the capture stream's allocator
+            torch.cuda.current_stream(self.dev).wait_stream(side)
+            torch.cuda.synchronize(self.dev)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss, grads = self._step_device(static, use_refs)
+            st = self._graphs[use_refs] = dict(graph=g, inputs=static, loss=loss, grads=grads)
+        for k, v in staged.items():                  # (capture only records: the capturing call replays like every other)
+            st["inputs"][k].copy_(v, non_blocking=True)
+        st["graph"].replay()
+        if self.check_finite and not all(bool(torch.isfinite(v).all()) for v in st["grads"].values()):
+            self._graphs.pop(use_refs)
+            self.grad_scale = float(self.grad_scale) / 16.0 if self.grad_scale != "auto" else "auto"
+            return self.train_step_graph(batch, use_refs)
+        return st["loss"], st["grads"]
 
     def set_attn3_parameters(self, named_params: Dict[str, torch.Tensor]) -> None:
         """Refresh the device copies of the trainable parameters (full state-dict names, `...attn3.to_q.weight` etc.)."""

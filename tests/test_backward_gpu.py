@@ -275,3 +275,27 @@ def test_training_step_vs_oracle(gpu, use_refs):
     errs = {k: rel(grads[k].cpu(), want[k]) for k in want}
     print("worst gradients:", sorted(errs.items(), key=lambda kv: -kv[1])[:3])
     assert max(errs.values()) < 1e-2
+
+
+def test_training_step_graph_replay_matches_eager(gpu):
+    """UNetTrainer.train_step_graph — the whole stage-2 step (reference passes, main pass, loss, backward) captured once and
+    replayed as one hipGraph — must return the eager step's loss and 80 gradients, also for a NEW batch fed to the captured graph."""
+    from storygen_amd.arch import build_arch, load_config
+    from storygen_amd.synth import synthetic_state_dict, synthetic_train_batch
+    from storygen_amd.train import UNetTrainer
+    cfg = load_config(dict(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                           up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), cross_attention_dim=768, attention_head_dim=8,
+                           sample_size=128))
+    arch = build_arch(cfg)
+    sd = synthetic_state_dict(arch, 7)
+    b1, b2 = synthetic_train_batch(2, 16, 768, 7), synthetic_train_batch(2, 16, 768, 8)
+    tr = UNetTrainer(arch, sd, gpu, 2, 16, 16, n_ref=3)
+    tr.train_step(b1)                                   # settles the automatic gradient scale
+    tr.grad_scale = float(tr.last_grad_scale)           # same fixed scale for both paths
+    want = [(float(l), {k: v.clone() for k, v in g.items()}) for l, g in (tr.train_step(b1), tr.train_step(b2))]
+    for b, (wl, wg) in zip((b1, b2), want):             # first call captures, second replays with new inputs
+        loss, grads = tr.train_step_graph(b)
+        torch.cuda.synchronize()
+        assert abs(float(loss) - wl) <= 1e-6 * abs(wl)
+        assert max(rel(grads[k], wg[k]) for k in wg) < 1e-6
+    assert len(tr._graphs) == 1

@@ -291,6 +291,64 @@ def test_attention_fp8_d40(gpu, B, Bk, Nq, Nk):
     assert torch.isfinite(out8).all() and e16 < 2e-3 and e8 < 8e-2          # measured 2.7e-2 .. 5.6e-2 (round 2, MI355X)
 
 
+@pytest.mark.parametrize("B,H,W,C1,C2", [(3, 64, 64, 320, 320), (2, 32, 32, 640, 320), (2, 32, 32, 320, 640)])
+def test_groupnorm_statistics_from_producer_epilogues(gpu, B, H, W, C1, C2):
+    """North-star: GroupNorm as an epilogue.  (i) a conv3x3 and a GEMM write per-(row tile, channel) sums of their final outputs
+    (bias / row bias / residual included) — checked against torch column sums; (ii) sg_groupnorm_nhwc_f16 fed with those
+    partials (one source, and two sources for a channel concat [conv output | GEMM output]) matches torch's GroupNorm+SiLU like the
+    self-contained kernel does; (iii) a launch that cannot emit statistics (split-K) reports 0 rows and refuses them."""
+    from storygen_amd import ops
+    HW, M = H * W, B * H * W
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=gpu)
+    # producer 1: conv3x3 (+ bias, temb row bias, fp32 residual) -> fp32 [M, C1]
+    xp = torch.zeros(B, H + 2, W + 2, 64, dtype=torch.float16, device=gpu)
+    xp[:, 1:-1, 1:-1] = rnd((B, H, W, 64), gpu, 1.0, 1)
+    wk, bias, rb = rnd((C1, 3, 3, 64), gpu, 0.05, 2), rnd((C1,), gpu, 1.0, 3), rnd((B, C1), gpu, 1.0, 4, torch.float32)
+    res = rnd((B, H, W, C1), gpu, 1.0, 5, torch.float32) + 2.0                     # a large mean: the cancellation case
+    cat = torch.empty(M, C1 + C2, dtype=torch.float32, device=gpu)               # [conv output | GEMM output]
+    y1 = cat[:, :C1]
+    st1 = torch.full((M // 64 * 2 * C1,), float("nan"), dtype=torch.float32, device=gpu)
+    kw1 = dict(bias=bias, rowbias=rb, res1=res, workspace=ws, x_padded=True)
+    rows1 = ops.conv3x3_stats_rows(xp, wk, y1.view(B, H, W, C1), stats=st1, **kw1)
+    assert rows1 in (64, 128, 256)
+    ops.conv3x3(xp, wk, y1.view(B, H, W, C1), stats=st1, **kw1)
+    # producer 2: GEMM (+ bias, fp32 residual) -> fp32 [M, C2]
+    a, w2 = rnd((M, 320), gpu, 1.0, 6), rnd((C2, 320), gpu, 320 ** -0.5, 7)
+    y2 = cat[:, C1:]
+    st2 = torch.full((M // 64 * 2 * C2,), float("nan"), dtype=torch.float32, device=gpu)
+    kw2 = dict(bias=rnd((C2,), gpu, 1.0, 8), res1=rnd((M, C2), gpu, 1.0, 9, torch.float32), workspace=ws)
+    rows2 = ops.gemm_stats_rows(a, w2, y2, stats=(st2, HW), **kw2)
+    assert rows2 in (64, 128, 256)
+    ops.gemm(a, w2, y2, stats=(st2, HW), **kw2)
+    torch.cuda.synchronize()
+    for y, st, rows, C in ((y1, st1, rows1, C1), (y2, st2, rows2, C2)):
+        got = st[: M // rows * 2 * C].view(M // rows, 2, C)
+        tiles = y.reshape(M // rows, rows, C).double()
+        assert rel_l2(got[:, 0].double(), tiles.sum(1)) < 1e-6 and rel_l2(got[:, 1].double(), (tiles * tiles).sum(1)) < 1e-6
+    # consumers
+    wsg = torch.empty(ops.groupnorm_workspace_bytes(B, 32), dtype=torch.uint8, device=gpu)
+    for x, pst in ((y1, [(st1, rows1, C1)]), (cat, [(st1, rows1, C1), (st2, rows2, C2)])):
+        C = x.shape[1]
+        assert ops.groupnorm_uses_pstats(HW, C, 32)
+        gamma, beta = rnd((C,), gpu, 1.0, 10) + 1.0, rnd((C,), gpu, 1.0, 11)
+        xc = x.contiguous()
+        want = F.silu(F.group_norm(xc.view(B, HW, C).permute(0, 2, 1).float(), 32, gamma.float(), beta.float(), 1e-5)).permute(0, 2, 1)
+        outs = []
+        for p in (pst, None):
+            o = torch.full((B, HW, C), float("nan"), dtype=torch.float16, device=gpu)
+            ops.groupnorm(x.view(B, HW, C), gamma, beta, o, 32, 1e-5, True, wsg, pstats=p)
+            outs.append(o)
+        check(outs[0], want, "groupnorm from epilogue statistics")
+        check(outs[1], want, "groupnorm, own statistics")
+        assert rel_l2(outs[0].float(), outs[1].float()) < 3e-4
+    # split-K cannot emit statistics: the query says so and the launch refuses
+    a3, w3 = rnd((768, 5120), gpu, 1.0, 12), rnd((640, 5120), gpu, 0.01, 13)
+    o3, st3 = torch.empty(768, 640, dtype=torch.float32, device=gpu), torch.zeros(768 // 64 * 2 * 640, dtype=torch.float32, device=gpu)
+    assert ops.gemm_stats_rows(a3, w3, o3, stats=(st3, 256), split_k=4, workspace=ws) == 0
+    with pytest.raises(RuntimeError, match="statistics"):
+        ops.gemm(a3, w3, o3, stats=(st3, 256), split_k=4, workspace=ws)
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_dma_spread_modes_are_bit_identical(gpu, mode):
     """sg_debug_set_spread only moves the ring-refill LDS-DMA instructions among the MFMAs of a slab: same loads, same order
