@@ -95,8 +95,8 @@ def traffic_provenance():
 def in_situ_roofline(sampler):
     """One extra eager step with every MFMA-class launch bracketed by HIP events on its launch stream."""
     from storygen_amd import ops
-    sink = []
-    ops.PROFILE_SINK = sink
+    sink, aux = [], []
+    ops.PROFILE_SINK, ops.AUX_SINK = sink, aux
     sides = (sampler.side_main, sampler.side_ref)
     sampler.side_main = sampler.side_ref = None     # one stream: per-kernel durations without co-running neighbours
     try:
@@ -107,7 +107,7 @@ def in_situ_roofline(sampler):
         sampler._step_body()
         torch.cuda.synchronize()
     finally:
-        ops.PROFILE_SINK = None
+        ops.PROFILE_SINK = ops.AUX_SINK = None
         sampler.side_main, sampler.side_ref = sides
     fam = {}
     for name, flops, a, b, _shape in sink:
@@ -139,9 +139,27 @@ def in_situ_roofline(sampler):
             "frac": round(d["frac_of_peak"], 4), "traffic": measured_traffic(dom), "traffic_provenance": traffic_provenance(),
             "launches_per_step": round(d["launches"] / g, 2),
             "avg_launch_us": round(d["avg_us"], 1), "gflop_per_step": round(d["gflop"] / g, 1), "steps_in_sample": g,
+            "hbm_families": hbm_families(aux, g),
             "kernels": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(kernels.items())},
             "families": {k: {kk: round(vv, 3) for kk, vv in v.items()} for k, v in sorted(fam.items())}}
     return roof, executed_tflop
+
+
+def hbm_families(aux, g):
+    """The bandwidth-class kernels (GroupNorm, LayerNorm, feature copies) of the instrumented step: algorithmic bytes / event time
+    per family (each event pair includes ~2 us of launch gap, so these are lower bounds on the kernels' own GB/s)."""
+    fam = {}
+    for name, nbytes, a, b, _shape in aux:
+        f = fam.setdefault(name, {"launches": 0, "ms": 0.0, "mbytes": 0.0})
+        f["launches"] += 1
+        f["ms"] += a.elapsed_time(b)
+        f["mbytes"] += nbytes / 1e6
+    for f in fam.values():
+        f["hbm_gbps"] = round(f["mbytes"] / f["ms"], 1) if f["ms"] > 0 else 0.0
+        f["frac_of_8tbps"] = round(f["hbm_gbps"] / 8000.0, 4)
+        f["launches"] = round(f["launches"] / g, 2)
+        f["ms"], f["mbytes"] = round(f["ms"] / g, 3), round(f["mbytes"] / g, 1)
+    return fam
 
 
 def train_step_bench(args):
