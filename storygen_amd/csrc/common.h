@@ -41,6 +41,7 @@ struct SgOptions {
     int no_nmajor = 0, late_issue = 1, no_frag_prefetch = 0, fat = 0;
     int spread = 0;                    // placement of the ring-refill DMA instructions (mma_pipe_body SPREAD)
     int conv_patch = 0;                // LDS-resident-input-patch convolution kernel
+    int pingpong = 0;                  // mma_pp_kernel: two wave groups alternate compute / load on even / odd K slabs
     int attn_sub2 = 0, attn_prio = 0, attn_d80 = 1, attn_d160 = 3;
     int gn_no_fused = 0, gn_wide = 1;
     long gn_fused_max = -1;            // -1 = the kernel's default threshold

@@ -116,12 +116,60 @@ __device__ __forceinline__ void epi_geglu8(const MmaParams& p, int gm, int gv, f
 // Shared tail of both mainloops: split-K partial store, or LDS-staged fused epilogue with 16-byte accesses.
 // Must be entered by all threads after a barrier that ends all LDS reads of the mainloop.  Wave (wm, wn) of the
 // WGM x WGN grid holds TM x TN 32x32 accumulators of its (BM/WGM) x (BN/WGN) sub-tile.
-template <int BM, int BN, int WGM, int WGN>
+// DUAL (mma_pp_kernel): the workgroup is TWO groups of WGM x WGN waves that each hold a partial accumulator of the same tile
+// (even / odd K slabs); a band is staged by group 0 and then added to by group 1, and all 2 x 64 WGM WGN threads consume it.
+template <int BM, int BN, int WGM, int WGN, bool DUAL = false>
 __device__ __forceinline__ void tile_epilogue(const MmaParams& p, char* smem, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32],
                                               int m0, int n0, int z) {
-    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32, NT = 64 * WGM * WGN;
+    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32, NWG = WGM * WGN, NT = (DUAL ? 128 : 64) * NWG;
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, hi = lane >> 5;
+    const int group = DUAL ? wave / NWG : 0, wv = DUAL ? wave - group * NWG : wave;
+    const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
+    // one 32-row band of every wave row -> sC [WGM*32][BN] fp32 (DUAL: group 0 stores, group 1 adds); ends with a barrier
+    auto stage_band = [&](int ip, bool first) __attribute__((always_inline)) {
+        float* sC = reinterpret_cast<float*>(smem);
+        if (!first) __syncthreads();   // previous band fully consumed
+        if (group == 0) {
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const int n = wn * WN + j * 32 + l31;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) sC[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * BN + n] = acc[ip][j][r];
+            }
+        }
+        __syncthreads();
+        if constexpr (DUAL) {
+            if (group == 1) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const int n = wn * WN + j * 32 + l31;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) sC[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * BN + n] += acc[ip][j][r];
+                }
+            }
+            __syncthreads();
+        }
+    };
+    if constexpr (DUAL) {
+        if (p.splits > 1) {   // merged partial tile -> workspace, 32 bytes per thread and item
+            float* wsz = p.ws + (size_t)z * p.M * p.N;
+            constexpr int NCHs = BN / 8, BRs = WGM * 32;
+#pragma unroll
+            for (int ip = 0; ip < TM; ++ip) {
+                stage_band(ip, ip == 0);
+                const float* sC = reinterpret_cast<const float*>(smem);
+                for (int idx = t; idx < BRs * NCHs; idx += NT) {
+                    const int lr = idx / NCHs, ch = idx - lr * NCHs;
+                    const int gm = m0 + (lr >> 5) * WM + ip * 32 + (lr & 31), gn = n0 + ch * 8;
+                    if (gm >= p.M || gn >= p.N) continue;
+                    float* dst = wsz + (size_t)gm * p.N + gn;
+                    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(sC + lr * BN + ch * 8);
+                    *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(sC + lr * BN + ch * 8 + 4);
+                }
+            }
+            return;
+        }
+    }
     if (p.splits > 1) {   // raw fp32 partial tile; the epilogue happens in splitk_reduce_kernel
         float* wsz = p.ws + (size_t)z * p.M * p.N;
 #pragma unroll
@@ -179,17 +227,7 @@ __device__ __forceinline__ void tile_epilogue(const MmaParams& p, char* smem, f3
                     if (p.res2) add_res8(p.res2, p.ldr2, p.flags & SG_F_RES2_F32, gmv[it], gnv[it], add[it]);
                 }
             }
-            if (ip) __syncthreads();   // previous band fully consumed
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = wn * WN + j * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    sC[m * BN + n] = acc[ip][j][r];
-                }
-            }
-            __syncthreads();
+            stage_band(ip, ip == 0);
 #pragma unroll
             for (int it = 0; it < IT; ++it) {
                 if (gmv[it] >= p.M || gnv[it] >= p.N) continue;
@@ -247,17 +285,7 @@ __device__ __forceinline__ void tile_epilogue(const MmaParams& p, char* smem, f3
     // GEGLU: bias only (tiny, cached); one band at a time
 #pragma unroll
     for (int ip = 0; ip < TM; ++ip) {
-        if (ip) __syncthreads();
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int n = wn * WN + j * 32 + l31;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                sC[m * BN + n] = acc[ip][j][r];
-            }
-        }
-        __syncthreads();
+        stage_band(ip, ip == 0);
         constexpr int OCH = BN / 16;
         for (int idx = t; idx < BR * OCH; idx += NT) {
             const int lr = idx / OCH, j = idx - lr * OCH;
@@ -639,6 +667,162 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_spread_kernel(const M
     mma_pipe_body<WGM, WGN, 3, CONV, true, true, 2, 2, false, SPREAD>(p, smem);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Ping-pong variant of the pipelined kernel (round 2; the answer to tools/anatomy.py's finding that the phases of a slab ADD
+// because all waves of a workgroup move in lock step).  The workgroup is TWO groups of WGM x WGN waves working on the SAME
+// output tile: group 0 accumulates the even K slabs, group 1 the odd ones, each from its own 2-stage LDS ring filled by its own
+// waves.  Every interval between two workgroup barriers one group computes a slab (fragment reads + 16 MFMAs per wave) while the
+// other issues the LDS-DMA of its slab after next and waits for its next one — each SIMD hosts one wave of either group, so
+// DMA issue, vmcnt wait and barrier latency of one group run beside the matrix work of the other.  The two partial accumulators
+// are added in the LDS-staged epilogue (tile_epilogue<..., DUAL>).  Same loads, one more fp32 addition per output: results agree
+// with mma_pipe_kernel to fp32 summation order.
+// Protocol of group g (its slab i is K slab 2 i + g; n_g slabs; stage = i & 1), identical barrier count for both groups:
+//   prologue: issue slab 0 and slab 1; group 0 waits for slab 0.
+//   interval k = 0 .. nt-1:  s_barrier;
+//       k % 2 == g : compute slab i = k / 2                      (landed: waited for in interval k-1, published by this barrier)
+//       else       : i' = (k + 1) / 2 = the slab computed next;  issue slab i'+1 (if >= 2: its stage held slab i'-1, computed in
+//                    interval k-1, before this barrier), then wait until slab i' has landed (leaving slab i'+1 in flight).
+template <int WGM, int WGN, bool CONV>
+__global__ __launch_bounds__(128 * WGM * WGN) void mma_pp_kernel(const MmaParams p) {
+    constexpr int NW = WGM * WGN, WM = 64, WN = 64, BM = WM * WGM, BN = WN * WGN;
+    constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW), LPT = A_IT + B_IT;   // LDS-DMA instructions / lane / slab (one group)
+    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
+    constexpr int EPI_BYTES = WGM * 32 * BN * 4;
+    constexpr int SMEM = (4 * STAGE > EPI_BYTES) ? 4 * STAGE : EPI_BYTES;
+    constexpr int ISTR = NW * 1024;
+    static_assert(4 * STAGE <= 160 * 1024, "two 2-stage rings must fit the 160 KB of LDS");
+    static_assert(LPT < 64, "vmcnt is a 6-bit counter");
+    __shared__ __attribute__((aligned(16))) char smem[SMEM];
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int g = wave / NW, wv = wave - g * NW;               // group, wave within the group
+    const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
+    const int lid2 = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.splits);
+    const int lid = lid2 / p.splits, z = lid2 - lid * p.splits;
+    const int m0 = (p.n_major ? lid % p.tiles_m : lid / p.tiles_n) * BM;
+    const int n0 = (p.n_major ? lid / p.tiles_m : lid % p.tiles_n) * BN;
+    const int kt0 = z * p.kt_per_split;
+    const int nt = min(p.KT, kt0 + p.kt_per_split) - kt0;      // K slabs of this block
+    const int ng = (nt - g + 1) >> 1;                           // ... of this group: slabs kt0 + 2 i + g
+    char* const ring = smem + g * 2 * STAGE;
+
+    const int srow = wv * 8 + (lane >> 3);
+    const int wp = p.Wd + 2;
+    unsigned a_off[A_IT], a_par[A_IT];
+#pragma unroll
+    for (int i = 0; i < A_IT; ++i) {
+        const int row = srow + 8 * NW * i;
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        const int gm = min(m0 + row, p.M - 1);
+        if constexpr (CONV) {
+            const int hw = p.Ho * p.Wo;
+            const int b = gm / hw, rem = gm - b * hw;
+            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const long img = (long)b * (p.H + 2) * wp;
+            if (!p.ups) {
+                a_off[i] = (unsigned)((img + (long)(oy * p.stride) * wp + ox * p.stride) * p.lda + lc * 8);
+                a_par[i] = 0;
+            } else {
+                a_off[i] = (unsigned)((img + (long)(((oy - 1) >> 1) + 1) * wp + ((ox - 1) >> 1) + 1) * p.lda + lc * 8);
+                a_par[i] = (unsigned)(((oy - 1) & 1) | (((ox - 1) & 1) << 1));
+            }
+        } else {
+            a_off[i] = (unsigned)((long)gm * p.lda + lc * 8);
+            a_par[i] = 0;
+        }
+    }
+    unsigned w_off[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int row = srow + 8 * NW * i;
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        w_off[i] = (unsigned)((long)min(n0 + row, p.N - 1) * p.ldw + lc * 8);
+    }
+    auto issue = [&](int i) __attribute__((always_inline)) {   // this group's slab i -> stage i & 1
+        const int kt = kt0 + 2 * i + g;
+        char* sA = ring + (i & 1) * STAGE + wv * 1024;
+        char* sB = sA + A_BYTES;
+        if constexpr (CONV) {
+            const int tap = kt / p.cpt, cc = kt - tap * p.cpt;
+            const int ky = tap / 3, kx = tap - ky * 3;
+            if (!p.ups) {
+                const f16* At = p.A + ((long)(ky * wp + kx) * p.lda + cc * BK);
+#pragma unroll
+                for (int j = 0; j < A_IT; ++j) glds16(At + a_off[j], sA + j * ISTR);
+            } else {
+                const f16* At = p.A + cc * BK;
+                const unsigned rs = (unsigned)(wp * (int)p.lda), cs = (unsigned)p.lda;
+#pragma unroll
+                for (int j = 0; j < A_IT; ++j) {
+                    const unsigned dy = ((unsigned)ky + (a_par[j] & 1u)) >> 1, dx = ((unsigned)kx + (a_par[j] >> 1)) >> 1;
+                    glds16(At + (a_off[j] + __umul24(dy, rs) + __umul24(dx, cs)), sA + j * ISTR);
+                }
+            }
+        } else {
+            const f16* At = p.A + kt * BK;
+#pragma unroll
+            for (int j = 0; j < A_IT; ++j) glds16(At + a_off[j], sA + j * ISTR);
+        }
+        const f16* Wt = p.W + kt * BK;
+#pragma unroll
+        for (int j = 0; j < B_IT; ++j) glds16(Wt + w_off[j], sB + j * ISTR);
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    if (ng > 0) issue(0);
+    if (ng > 1) issue(1);
+    if (g == 0) {
+        if (ng > 1) wait_vmcnt<LPT>();
+        else wait_vmcnt<0>();
+    }
+#pragma unroll 1
+    for (int k = 0; k < nt; ++k) {
+        __builtin_amdgcn_s_barrier();
+        if ((k & 1) == g) {
+            const int i = k >> 1;
+            const char* sA = ring + (i & 1) * STAGE;
+            const char* sB = sA + A_BYTES;
+            f16x8 af[2][2], bf[2][2];
+            auto load_frags = [&](int buf, int ks) __attribute__((always_inline)) {
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    af[buf][u] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WM + u * 32 + l31, ks * 2 + hi));
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    bf[buf][u] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WN + u * 32 + l31, ks * 2 + hi));
+            };
+            load_frags(0, 0);
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+#pragma unroll
+                    for (int v = 0; v < 2; ++v)
+                        acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][u], bf[ks & 1][v], acc[u][v], 0, 0, 0);
+            }
+        } else {
+            const int in = (k + 1) >> 1;                       // the slab this group computes in the next interval
+            if (in < ng) {
+                const bool more = in + 1 < ng;
+                if (more && in + 1 >= 2) issue(in + 1);
+                if (more) wait_vmcnt<LPT>();
+                else wait_vmcnt<0>();
+            }
+        }
+    }
+    __syncthreads();   // every wave is done reading its ring before the epilogue reuses LDS
+    tile_epilogue<BM, BN, WGM, WGN, true>(p, smem, acc, m0, n0, z);
+}
+
 template <int WGM, int WGN, int S, bool CONV, bool LATE, bool PREF, int WTM = 2, int WTN = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParams p) {
     __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN, S, WTM, WTN>()];
@@ -898,7 +1082,7 @@ struct TuneView {
     SgOptions& o = sg_options();
     int& bm = o.tile_m; int& bn = o.tile_n; int& no_pipe = o.no_pipe; int& no_split = o.no_split; int& stages = o.stages;
     int& no_nmajor = o.no_nmajor; int& late_issue = o.late_issue; int& no_frag_prefetch = o.no_frag_prefetch; int& fat = o.fat;
-    int& conv_patch = o.conv_patch; int& spread = o.spread;
+    int& conv_patch = o.conv_patch; int& spread = o.spread; int& pingpong = o.pingpong;
 };
 static const TuneView g_tune;
 
@@ -969,6 +1153,12 @@ void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st, int stages) {
         else if (g_tune.spread == 1) hipLaunchKernelGGL((mma_pipe_prof_kernel<WGM, WGN, CONV, 1>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((mma_pipe_prof_kernel<WGM, WGN, CONV, 0>), grid, block, 0, st, p);
         return;
+    }
+    if constexpr ((WGM + WGN) * 64 * 128 * 4 <= 160 * 1024) {      // the two 2-stage rings fit: every tile but 256 x 128
+        if (g_tune.pingpong) {
+            hipLaunchKernelGGL((mma_pp_kernel<WGM, WGN, CONV>), grid, dim3(128 * WGM * WGN), 0, st, p);
+            return;
+        }
     }
     if (g_tune.spread && stages == 3) {
         if (g_tune.spread == 2) hipLaunchKernelGGL((mma_pipe_spread_kernel<WGM, WGN, CONV, 2>), grid, block, 0, st, p);

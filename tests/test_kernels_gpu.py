@@ -387,6 +387,62 @@ def test_dma_spread_modes_are_bit_identical(gpu, mode):
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("tile", [(256, 64), (128, 128), (128, 64), (64, 128), (64, 64)])
+def test_pingpong_mainloop_matches_the_pipelined_kernel(gpu, tile):
+    """mma_pp_kernel (two wave groups alternating compute / load on even / odd K slabs, partial accumulators merged in the
+    epilogue) against the fp32 reference and the single-group kernel: GEMM (odd and even slab counts, K = 64: one group idle),
+    GEGLU, split-K, 3x3 convolution incl. stride 2 and the upsampled gather, epilogue statistics."""
+    from storygen_amd import ops
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=gpu)
+
+    def run_all():
+        outs = []
+        for M, N, K, split in [(4096, 320, 320, 1), (768, 1280, 1280, 4), (300, 640, 2560, 0), (512, 256, 64, 1), (1024, 1280, 704, 1)]:
+            a, w = rnd((M, K), gpu, 1.0, 1), rnd((N, K), gpu, K ** -0.5, 2)
+            o = torch.full((M, N), float("nan"), dtype=torch.float32, device=gpu)
+            ops.gemm(a, w, o, bias=rnd((N,), gpu, 1.0, 3), res1=rnd((M, N), gpu, 1.0, 4, torch.float32), split_k=split, workspace=ws, tile=tile)
+            outs.append((o, a.float() @ w.float().t() + rnd((N,), gpu, 1.0, 3).float() + rnd((M, N), gpu, 1.0, 4, torch.float32)))
+        a, w = rnd((1024, 640), gpu, 1.0, 5), rnd((5120, 640), gpu, 640 ** -0.5, 6)
+        o = torch.full((1024, 2560), float("nan"), dtype=torch.float16, device=gpu)
+        ops.gemm(a, w, o, bias=rnd((5120,), gpu, 1.0, 7), epilogue=ops.EPI_GEGLU, workspace=ws, tile=tile)
+        outs.append((o, None))
+        for B, H, W, Ci, Co, stride, ups in [(2, 32, 32, 320, 320, 1, False), (2, 16, 16, 640, 128, 2, False), (1, 16, 16, 128, 192, 1, True)]:
+            x = rnd((B, Ci, H, W), gpu, 1.0, 8)
+            xp = torch.zeros(B, H + 2, W + 2, Ci, dtype=torch.float16, device=gpu)
+            xp[:, 1:-1, 1:-1] = x.permute(0, 2, 3, 1)
+            wk = rnd((Co, Ci, 3, 3), gpu, (9 * Ci) ** -0.5, 9)
+            xin = F.interpolate(x.float(), scale_factor=2.0, mode="nearest") if ups else x.float()
+            ref = F.conv2d(xin, wk.float(), rnd((Co,), gpu, 1.0, 10).float(), stride=stride, padding=1)
+            o = torch.full((B, ref.shape[2], ref.shape[3], Co), float("nan"), dtype=torch.float32, device=gpu)
+            ops.conv3x3(xp, wk.permute(0, 2, 3, 1).contiguous(), o, stride=stride, upsample2x=ups, bias=rnd((Co,), gpu, 1.0, 10),
+                        workspace=ws, x_padded=True, tile=tile)
+            outs.append((o, ref.permute(0, 2, 3, 1)))
+        # epilogue statistics through the dual epilogue
+        a, w = rnd((4096, 320), gpu, 1.0, 11), rnd((320, 320), gpu, 320 ** -0.5, 12)
+        o = torch.empty(4096, 320, dtype=torch.float32, device=gpu)
+        st = torch.zeros(4096 // 64 * 2 * 320, dtype=torch.float32, device=gpu)
+        rows = ops.gemm_stats_rows(a, w, o, stats=(st, 1024), workspace=ws, tile=tile)
+        if rows:
+            ops.gemm(a, w, o, stats=(st, 1024), workspace=ws, tile=tile)
+            t = o.view(4096 // rows, rows, 320).double()
+            got = st[: 4096 // rows * 2 * 320].view(4096 // rows, 2, 320).double()
+            assert rel_l2(got[:, 0], t.sum(1)) < 1e-6 and rel_l2(got[:, 1], (t * t).sum(1)) < 1e-6
+        torch.cuda.synchronize()
+        return outs
+    base = run_all()
+    try:
+        ops.debug_set_option("pingpong", 1)
+        got = run_all()
+    finally:
+        ops.debug_set_option("pingpong", 0)
+    for (o, ref), (ob, _) in zip(got, base):
+        assert torch.isfinite(o.float()).all()
+        if ref is not None:
+            check(o, ref, "ping-pong vs fp32 reference", l2=2e-6, mx=2e-5)
+        check(o.float(), ob.float(), "ping-pong vs single-group kernel", l2=1e-3 if o.dtype == torch.float16 else 2e-6,
+              mx=3e-3 if o.dtype == torch.float16 else 2e-5)
+
+
 PATCH_CASES = [
     # B, H, W, Cin, Cout, split, tile
     (3, 64, 64, 320, 320, 0, None), (3, 64, 64, 320, 320, 1, (256, 128)), (2, 64, 64, 128, 64, 1, (128, 64)), (1, 64, 64, 64, 72, 1, (64, 64)),
