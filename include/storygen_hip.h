@@ -302,6 +302,66 @@ int sg_pad_cast_f16(const void* x, int64_t ldx, int32_t x_f32, sg_half* y, int64
                     int32_t C, sg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * The networks either side of the loop: CLIP text encoder and AutoencoderKL.  Their GEMMs, convolutions,
+ * GroupNorms and LayerNorms are the entry points above; these are the remaining pieces.
+ *
+ * sg_softmax_rows_f16: p[m, j] = softmax_j(scale * s[m, j]), j < N, fp32 scores -> fp16 probabilities; columns [N, N rounded
+ *   up to 8) of p are zero-filled (ldp >= that), so p is directly the A operand of the PV sg_gemm_f16.  With two sg_gemm_f16
+ *   calls this is the single-head AttentionBlock of the VAE mid block (diffusers 0.13.1 models/attention.py AttentionBlock,
+ *   instantiated by AutoencoderKL; reference call sites /root/reference/model/pipeline.py:198-205,392,401).
+ * sg_attn_small_f16: O[b,i,h*D+:] = softmax_j(scale * Q[b,i,h,:].K[b,j,h,:] + key_bias[b,j] (+ causal mask j <= i)) V[b,j,h,:]
+ *   for short sequences (T <= 128, D <= 64), heads interleaved in channels, V NOT transposed — CLIPAttention of the text
+ *   encoder (transformers 4.27.4 modeling_clip.py; /root/reference/model/pipeline.py:137,183).  key_bias: fp32 [B, T] or NULL.
+ * sg_act_rows_f16: in place x = x*sigmoid(1.702x) (SG_ACT_QUICK_GELU, CLIPMLP "quick_gelu") or erf GELU (SG_ACT_GELU).
+ * sg_embed_tokens_f32: out[r,:] = tok[ids[r],:] + pos[r % T,:] (CLIPTextEmbeddings), fp32 tables and output; ids are not
+ *   range-checked on the device (the host validates them).
+ * sg_gaussian_sample_f32: out = (mean + exp(0.5*clamp(logvar,-30,20)) * noise) * scale — DiagonalGaussianDistribution.sample()
+ *   followed by the 0.18215 factor (pipeline.py:392-393,401-402); noise == NULL gives mean * scale (.mode()).
+ */
+#define SG_ACT_QUICK_GELU 0
+#define SG_ACT_GELU       1
+int sg_softmax_rows_f16(const float* s, int64_t lds, sg_half* p, int64_t ldp, int32_t M, int32_t N, float scale,
+                        sg_stream_t stream);
+int sg_attn_small_f16(const sg_half* q, int64_t ldq, int64_t bsq, const sg_half* k, int64_t ldk, int64_t bsk, const sg_half* v,
+                      int64_t ldv, int64_t bsv, sg_half* o, int64_t ldo, int64_t bso, const float* key_bias, int32_t B,
+                      int32_t H, int32_t T, int32_t D, float scale, int32_t causal, sg_stream_t stream);
+int sg_act_rows_f16(sg_half* x, int64_t ldx, int32_t M, int32_t N, int32_t act, sg_stream_t stream);
+int sg_embed_tokens_f32(const int64_t* ids, const float* tok, const float* pos, float* out, int64_t ldo, int32_t rows, int32_t T,
+                        int32_t C, sg_stream_t stream);
+int sg_gaussian_sample_f32(const float* mean, const float* logvar, const float* noise, float* out, float scale, int64_t n,
+                           sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Optimizer step of the training loop: /root/reference/train_StorySalon_stage2.py:186-205 builds torch.optim.AdamW
+ * or bitsandbytes' AdamW8bit over the trainable (attn3) parameters, :328-333 clips the global gradient norm and steps.
+ *
+ * sg_sumsq_f32: *out = sum_i x[i]^2, deterministic (two launches, `scratch` of sg_sumsq_scratch_floats() floats).
+ * sg_adamw_f32: one tensor's torch.optim.AdamW update (decoupled weight decay, bias correction, no amsgrad) on fp32 states.
+ * sg_adamw8bit: the same update with both moments stored as 8-bit codes in blocks of 2048 elements (per-block absmax, signed /
+ *   unsigned dynamic-tree code books q_code1 / q_code2 of 256 ascending fp32 entries) — block-wise 8-bit Adam as published for
+ *   bitsandbytes (Dettmers et al. 2021); code arrays of n bytes, absmax arrays of sg_adamw8bit_blocks(n) floats.
+ * Gradients are first multiplied by grad_scale (1 / loss scale); with `sumsq` set (n_sumsq per-tensor sums of squares of the
+ * UNSCALED-by-grad_scale gradients of ALL trainable tensors) they are also clipped to the global norm max_norm as
+ * torch.nn.utils.clip_grad_norm_ does: g *= min(1, max_norm / (||g|| + 1e-6)) — on the device, no host read.  step counts from 1.
+ */
+typedef struct sg_adamw_desc {
+    float*       param;  const float* grad;  int64_t n;
+    float*       exp_avg; float* exp_avg_sq;                 /* sg_adamw_f32 */
+    uint8_t*     code1;  uint8_t* code2;                      /* sg_adamw8bit: 8-bit states ...             */
+    float*       absmax1; float* absmax2;                     /* ... their per-block scales ...             */
+    const float* q_code1; const float* q_code2;               /* ... and the two 256-entry code books       */
+    float        lr, beta1, beta2, eps, weight_decay;
+    int32_t      step;
+    float        grad_scale;
+    const float* sumsq;  int32_t n_sumsq;  float max_norm;     /* NULL / 0 / 0 = no clipping */
+} sg_adamw_desc;
+size_t  sg_sumsq_scratch_floats(void);
+int     sg_sumsq_f32(const float* x, int64_t n, float* out, float* scratch, sg_stream_t stream);
+int     sg_adamw_f32(const sg_adamw_desc* d, sg_stream_t stream);
+size_t  sg_adamw8bit_blocks(int64_t n);
+int     sg_adamw8bit(const sg_adamw_desc* d, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Backward pass of the stage-2 training step (BASELINE config 4; /root/reference/train_StorySalon_stage2.py:322-327:
  * accelerator.backward(loss) through the main UNet pass, weight gradients for the attn3 modules only, :170-177).
  * STATUS: compiled for gfx950, not yet run on hardware (round 1's GPU budget was spent before they were written);

@@ -115,6 +115,20 @@ class AttnBwdDesc(C.Structure):
 
 
 # name -> (restype, argtypes); this table is also what tests/test_abi.py checks against the header.
+class AdamWDesc(C.Structure):
+    _fields_ = [
+        ("param", C.c_void_p), ("grad", C.c_void_p), ("n", C.c_int64),
+        ("exp_avg", C.c_void_p), ("exp_avg_sq", C.c_void_p),
+        ("code1", C.c_void_p), ("code2", C.c_void_p),
+        ("absmax1", C.c_void_p), ("absmax2", C.c_void_p),
+        ("q_code1", C.c_void_p), ("q_code2", C.c_void_p),
+        ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float), ("weight_decay", C.c_float),
+        ("step", C.c_int32),
+        ("grad_scale", C.c_float),
+        ("sumsq", C.c_void_p), ("n_sumsq", C.c_int32), ("max_norm", C.c_float),
+    ]
+
+
 SIGNATURES = {
     "sg_version": (C.c_int, []),
     "sg_last_error": (C.c_char_p, []),
@@ -152,6 +166,19 @@ SIGNATURES = {
     "sg_attn_f8_pack": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sg_attn_fwd_f8_d40": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
                                      C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "sg_softmax_rows_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_void_p]),
+    "sg_attn_small_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64,
+                                    C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_float,
+                                    C.c_int32, C.c_void_p]),
+    "sg_act_rows_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
+    "sg_embed_tokens_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,
+                                      C.c_void_p]),
+    "sg_gaussian_sample_f32": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
+    "sg_sumsq_scratch_floats": (C.c_size_t, []),
+    "sg_sumsq_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "sg_adamw_f32": (C.c_int, [C.POINTER(AdamWDesc), C.c_void_p]),
+    "sg_adamw8bit_blocks": (C.c_size_t, [C.c_int64]),
+    "sg_adamw8bit": (C.c_int, [C.POINTER(AdamWDesc), C.c_void_p]),
     "sg_attn_fwd_lse_f16": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p, C.c_void_p]),
     "sg_attn_bwd_prep_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p,
                                        C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),

@@ -26,6 +26,7 @@ import torch
 
 from ..sampler import STAGES, StoryGenSampler
 from ..scheduler import DDIMSchedule, schedule_from_config
+from .encoders import _HipModule
 
 StableDiffusionPipelineOutput = namedtuple("StableDiffusionPipelineOutput", ["images", "nsfw_content_detected"])
 
@@ -40,6 +41,9 @@ def _as_schedule(scheduler) -> DDIMSchedule:
 
 
 class StableDiffusionPipeline:
+    """vae / text_encoder may be the HIP classes of storygen_amd.model (AutoencoderKL, CLIPTextModel) or any object with the same
+    methods (the third-party torch modules the reference constructs); `hip_encoders()` swaps torch modules for the HIP classes."""
+
     def __init__(self, vae, text_encoder, tokenizer, unet, scheduler):
         self.vae, self.text_encoder, self.tokenizer, self.unet, self.scheduler = vae, text_encoder, tokenizer, unet, scheduler
         boc = getattr(getattr(vae, "config", None), "block_out_channels", (128, 256, 512, 512))
@@ -47,6 +51,15 @@ class StableDiffusionPipeline:
         self._sampler: Optional[StoryGenSampler] = None
         self._sampler_key = None
         self._progress_bar_config = {}
+
+    def hip_encoders(self):
+        """Replace a diffusers AutoencoderKL / transformers CLIPTextModel torch module by the HIP class holding the same weights."""
+        from .encoders import AutoencoderKL, CLIPTextModel
+        if isinstance(self.vae, torch.nn.Module):
+            self.vae = AutoencoderKL.from_torch(self.vae).to(self._execution_device)
+        if isinstance(self.text_encoder, torch.nn.Module):
+            self.text_encoder = CLIPTextModel.from_torch(self.text_encoder).to(self._execution_device)
+        return self
 
     # --------------------------------------------------------------------------------------------- plumbing
     @property
@@ -71,7 +84,7 @@ class StableDiffusionPipeline:
         """DiffusionPipeline.to: moves every nn.Module component (inference.py:56 `pipeline.to(device)` usage pattern)."""
         for name in ("vae", "text_encoder", "unet"):
             m = getattr(self, name)
-            if isinstance(m, torch.nn.Module):
+            if isinstance(m, (torch.nn.Module, _HipModule)):
                 if torch_device is not None:
                     m.to(torch_device)
                 if torch_dtype is not None and name != "unet":      # the HIP UNet keeps its parameters in their own dtype

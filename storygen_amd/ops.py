@@ -390,6 +390,72 @@ def attention_f8(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.
     return out
 
 
+def softmax_rows(scores: torch.Tensor, probs: torch.Tensor, scale: float = 1.0) -> torch.Tensor:
+    """probs[m, :N] = softmax(scale * scores[m, :N]) (fp32 -> fp16); probs has N rounded up to 8 columns, the extra ones zeroed."""
+    _f32(scores, "scores"), _f16(probs, "probs")
+    M, N = scores.shape
+    if probs.shape[0] != M or probs.shape[1] != ((N + 7) & ~7):
+        raise ValueError(f"softmax_rows: probs must be [{M},{(N + 7) & ~7}], got {tuple(probs.shape)}")
+    with _timed("softmax", M * N * 6.0, f"M{M} N{N}", aux=True):
+        check(lib.sg_softmax_rows_f16(scores.data_ptr(), _row_stride(scores, "scores"), probs.data_ptr(), _row_stride(probs, "probs"), M, N,
+                                      float(scale), _stream()), "sg_softmax_rows_f16")
+    return probs
+
+
+def attention_small(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, out: torch.Tensor, heads: int, scale: float, causal: bool,
+                    key_bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Short-sequence attention (T <= 128, head dim <= 64), q/k/v/out [B,T,H*D] token-/batch-strided fp16 views, V not transposed;
+    key_bias = optional fp32 [B,T] additive term (padding mask)."""
+    for n, t in (("q", q), ("k", k), ("v", v), ("out", out)):
+        _f16(t, n)
+        if t.dim() != 3 or t.stride(-1) != 1 or t.shape != q.shape:
+            raise ValueError(f"attention_small: {n} must be [B,T,H*D] with a contiguous last dimension")
+    B, T, Cq = q.shape
+    if key_bias is not None:
+        _f32(key_bias, "key_bias")
+        if tuple(key_bias.shape) != (B, T) or not key_bias.is_contiguous():
+            raise ValueError("attention_small: key_bias must be a contiguous [B,T] tensor")
+    check(lib.sg_attn_small_f16(q.data_ptr(), q.stride(1), q.stride(0), k.data_ptr(), k.stride(1), k.stride(0), v.data_ptr(), v.stride(1),
+                                v.stride(0), out.data_ptr(), out.stride(1), out.stride(0), _p(key_bias), B, heads, T, Cq // heads,
+                                float(scale), int(causal), _stream()), "sg_attn_small_f16")
+    return out
+
+
+ACT_QUICK_GELU, ACT_GELU = 0, 1
+
+
+def act_rows(x: torch.Tensor, act: int) -> torch.Tensor:
+    """In-place quick_gelu / gelu over a row-strided fp16 [M,N] view."""
+    _f16(x, "x")
+    check(lib.sg_act_rows_f16(x.data_ptr(), _row_stride(x, "x"), x.shape[0], x.shape[1], act, _stream()), "sg_act_rows_f16")
+    return x
+
+
+def embed_tokens(ids: torch.Tensor, tok: torch.Tensor, pos: torch.Tensor, out: torch.Tensor, T: int) -> torch.Tensor:
+    """out[r] = tok[ids[r]] + pos[r % T]; ids int64 [rows] (already validated against the vocabulary), fp32 tables / output."""
+    _f32(tok, "tok"), _f32(pos, "pos"), _f32(out, "out")
+    if ids.dtype != torch.int64 or not ids.is_cuda or not ids.is_contiguous() or ids.numel() != out.shape[0]:
+        raise ValueError("embed_tokens: ids must be a contiguous CUDA int64 tensor with one id per output row")
+    if not tok.is_contiguous() or not pos.is_contiguous() or tok.shape[1] != out.shape[1] or pos.shape[1] != out.shape[1] or pos.shape[0] < T:
+        raise ValueError("embed_tokens: table shapes do not match the output")
+    check(lib.sg_embed_tokens_f32(ids.data_ptr(), tok.data_ptr(), pos.data_ptr(), out.data_ptr(), _row_stride(out, "out"), out.shape[0], T,
+                                  out.shape[1], _stream()), "sg_embed_tokens_f32")
+    return out
+
+
+def gaussian_sample(mean: torch.Tensor, logvar: Optional[torch.Tensor], noise: Optional[torch.Tensor], out: torch.Tensor,
+                    scale: float = 1.0) -> torch.Tensor:
+    """out = (mean + exp(0.5 clamp(logvar, -30, 20)) * noise) * scale; noise None -> mean * scale.  Contiguous fp32 tensors."""
+    for n, t in (("mean", mean), ("logvar", logvar), ("noise", noise), ("out", out)):
+        if t is not None:
+            _f32(t, n)
+            if not t.is_contiguous() or t.numel() != mean.numel():
+                raise ValueError(f"gaussian_sample: {n} must be contiguous with {mean.numel()} elements")
+    check(lib.sg_gaussian_sample_f32(mean.data_ptr(), _p(logvar), _p(noise), out.data_ptr(), float(scale), mean.numel(), _stream()),
+          "sg_gaussian_sample_f32")
+    return out
+
+
 def groupnorm_workspace_bytes(B: int, groups: int) -> int:
     return lib.sg_groupnorm_workspace_bytes(B, groups)
 

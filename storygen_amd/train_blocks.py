@@ -84,12 +84,20 @@ class TransformerBlockTrain:
     def set_attn3(self, params: Dict[str, torch.Tensor]) -> None:
         """Refresh the device copies of the trainable module after an optimizer step.  `params`: to_q.weight, to_k.weight,
         to_v.weight, to_out.0.weight, to_out.0.bias (any dtype / device)."""
-        cp = lambda t: t.detach().to(self.dev, F16).contiguous()                     # noqa: E731
+        def put(table, key, value):
+            # IN PLACE when the buffer exists: a captured training graph (UNetTrainer.train_step_graph) keeps reading these addresses
+            if key in table and table[key].shape == value.shape:
+                table[key].copy_(value)
+            else:
+                table[key] = value.contiguous()
+
+        cp = lambda t: t.detach().to(self.dev, F16)                                  # noqa: E731
         for m in ("to_q", "to_k", "to_v"):
-            self.w[f"attn3.{m}"] = cp(params[f"{m}.weight"])
-            self.wt[f"attn3.{m}"] = _t(self.w[f"attn3.{m}"])
-        self.w["attn3.to_out"], self.w["attn3.b_out"] = cp(params["to_out.0.weight"]), cp(params["to_out.0.bias"])
-        self.wt["attn3.to_out"] = _t(self.w["attn3.to_out"])
+            put(self.w, f"attn3.{m}", cp(params[f"{m}.weight"]))
+            put(self.wt, f"attn3.{m}", _t(self.w[f"attn3.{m}"]))
+        put(self.w, "attn3.to_out", cp(params["to_out.0.weight"]))
+        put(self.w, "attn3.b_out", cp(params["to_out.0.bias"]))
+        put(self.wt, "attn3.to_out", _t(self.w["attn3.to_out"]))
 
     # ------------------------------------------------------------------------------------------------ forward
     def _attend(self, name: str, x16: torch.Tensor, kv16: torch.Tensor, B: int) -> dict:

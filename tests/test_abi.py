@@ -66,7 +66,7 @@ def test_descriptor_layouts_match_a_c_compiler(tmp_path):
     from storygen_amd import _lib
     structs = {"sg_gemm_desc": _lib.GemmDesc, "sg_conv3x3_desc": _lib.ConvDesc, "sg_attn_desc": _lib.AttnDesc,
                "sg_groupnorm_desc": _lib.GroupNormDesc, "sg_groupnorm_bwd_desc": _lib.GroupNormBwdDesc,
-               "sg_attn_bwd_desc": _lib.AttnBwdDesc}
+               "sg_attn_bwd_desc": _lib.AttnBwdDesc, "sg_adamw_desc": _lib.AdamWDesc}
     lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
     for cname, st in structs.items():
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')

@@ -1,0 +1,194 @@
+"""SURVEY §8 f4 on the GPU: the optimizer kernels (sg_sumsq_f32, sg_adamw_f32, sg_adamw8bit) against torch.optim.AdamW /
+clip_grad_norm_ and oracle/optim_oracle.py, and the stage-2 loop body (storygen_amd.training.Stage2Trainer;
+/root/reference/train_StorySalon_stage2.py:258-357) end to end: gradients -> all-reduce -> clip -> AdamW(8bit) -> refreshed weights."""
+import os
+
+import pytest
+import torch
+
+from conftest import rel_l2
+from oracle import optim_oracle as oo
+
+pytestmark = pytest.mark.gpu
+F32 = torch.float32
+
+
+def test_sumsq_is_deterministic_and_exact_enough(gpu):
+    from storygen_amd import optim
+    for n in (1, 1000, 2049, 1 << 20, 3_000_001):
+        x = torch.randn(n, device=gpu)
+        out = torch.zeros(2, device=gpu)
+        scratch = torch.empty(optim.lib.sg_sumsq_scratch_floats(), device=gpu)
+        for slot in (0, 1):
+            optim.check(optim.lib.sg_sumsq_f32(x.data_ptr(), n, out[slot:].data_ptr(), scratch.data_ptr(), torch.cuda.current_stream().cuda_stream))
+        want = float((x.double() ** 2).sum())
+        assert float(out[0]) == float(out[1])
+        assert abs(float(out[0]) - want) <= 2e-6 * want
+
+
+@pytest.mark.parametrize("clip", [None, 1.0])
+def test_adamw_f32_is_torch_adamw(gpu, clip):
+    from storygen_amd.optim import AdamW
+    torch.manual_seed(0)
+    shapes = [(320, 320), (320,), (77, 13)]
+    mine = {f"p{i}": torch.randn(s, device=gpu) for i, s in enumerate(shapes)}
+    ref = [torch.nn.Parameter(v.clone()) for v in mine.values()]
+    opt = AdamW(mine, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    topt = torch.optim.AdamW(ref, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, foreach=False, fused=False)
+    for step in range(6):
+        scale = 10.0 if step % 2 else 0.01                       # the clip is active on some steps only
+        grads = {k: torch.randn_like(v) * scale for k, v in mine.items()}
+        for p, g in zip(ref, grads.values()):
+            p.grad = g.clone()
+        opt.set_grads(grads)
+        if clip is not None:
+            total = opt.clip_grad_norm_(clip)
+            want_total = torch.nn.utils.clip_grad_norm_(ref, clip)
+            assert abs(float(total) - float(want_total)) <= 1e-5 * float(want_total)
+        versions = [v._version for v in mine.values()]
+        opt.step()
+        topt.step()
+        opt.zero_grad()
+        assert all(v._version > old for v, old in zip(mine.values(), versions))
+        for v, p in zip(mine.values(), ref):
+            assert float((v - p.detach()).abs().max()) <= 2e-6
+    sd = opt.state_dict()
+    assert sd["step"] == 6 and set(sd["state"]) == set(mine)
+    assert rel_l2(sd["state"]["p0"]["exp_avg"], topt.state[ref[0]]["exp_avg"].flatten().cpu()) < 1e-5
+
+
+def test_adamw8bit_kernel_vs_oracle(gpu):
+    """One tensor spanning several 2048-blocks with a ragged tail, 5 steps: parameters and absmax follow the CPU restatement; the
+    8-bit codes may differ by one entry where fused multiply-adds round the moment across a bin boundary."""
+    from storygen_amd.optim import AdamW8bit
+    torch.manual_seed(3)
+    n = 3 * 2048 + 777
+    p0 = torch.randn(n)
+    mine = {"w": p0.clone().to(gpu)}
+    opt = AdamW8bit(mine, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    p = p0.clone()
+    c1, c2, a1, a2 = oo.adamw8bit_state(n)
+    for step in range(1, 6):
+        g = torch.randn(n) * (10.0 ** -(step % 3))
+        g[2048:2048 + 100] = 0.0
+        opt.set_grads({"w": g.to(gpu)})
+        opt.step()
+        oo.adamw8bit_step(p, g, c1, c2, a1, a2, step, 1e-2)
+        st = opt.state[0]
+        assert st["bits"] == 8
+        assert float((mine["w"].cpu() - p).abs().max()) <= 1e-5
+        assert rel_l2(st["absmax1"].cpu(), a1) < 1e-5 and rel_l2(st["absmax2"].cpu(), a2) < 1e-5
+        d1 = (st["code1"].cpu().int() - c1.int()).abs()
+        d2 = (st["code2"].cpu().int() - c2.int()).abs()
+        assert int(d1.max()) <= 1 and int(d2.max()) <= 1
+        assert float((d1 > 0).float().mean()) < 0.01 and float((d2 > 0).float().mean()) < 0.01
+        c1.copy_(st["code1"].cpu()), c2.copy_(st["code2"].cpu())       # keep the two trajectories on the same states
+        a1.copy_(st["absmax1"].cpu()), a2.copy_(st["absmax2"].cpu())
+        p.copy_(mine["w"].cpu())
+    assert opt.state_bytes() == 2 * n + 2 * 4 * 4
+    small = AdamW8bit({"b": torch.zeros(320, device=gpu)}, lr=1e-3)
+    small.set_grads({"b": torch.ones(320, device=gpu)})
+    small.step()
+    assert small.state[0]["bits"] == 32                                # below min_8bit_size: fp32 states, as bitsandbytes keeps them
+
+
+def test_adamw8bit_tracks_fp32_on_the_gpu(gpu):
+    from storygen_amd.optim import AdamW, AdamW8bit
+    torch.manual_seed(4)
+    n = 100_000
+    target = torch.randn(n, device=gpu)
+    a, b = {"w": torch.zeros(n, device=gpu)}, {"w": torch.zeros(n, device=gpu)}
+    o32, o8 = AdamW(a, lr=1e-2, weight_decay=0.0), AdamW8bit(b, lr=1e-2, weight_decay=0.0)
+    for _ in range(200):
+        noise = 0.1 * torch.randn(n, device=gpu)
+        o32.set_grads({"w": a["w"] - target + noise}), o32.step()
+        o8.set_grads({"w": b["w"] - target + noise}), o8.step()
+    assert float((a["w"] - b["w"]).norm() / a["w"].norm()) < 0.05
+
+
+def _small_unet(gpu):
+    from storygen_amd.arch import build_arch, load_config
+    from storygen_amd.model import UNet2DConditionModel
+    from storygen_amd.synth import synthetic_state_dict
+    cfg = dict(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+               up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), cross_attention_dim=768, attention_head_dim=8, sample_size=128)
+    sd = synthetic_state_dict(build_arch(load_config(cfg)), 7)
+    unet = UNet2DConditionModel.from_config(cfg)
+    unet.load_state_dict(sd)
+    return unet.to(gpu, F32)
+
+
+@pytest.mark.parametrize("use_graph", [False, True])
+def test_stage2_trainer_step_is_clip_plus_adamw_on_the_trainer_gradients(gpu, use_graph):
+    """Two optimizer steps of Stage2Trainer on a 2-level UNet: after each, every attn3 parameter equals torch's clip_grad_norm_ +
+    AdamW applied to the gradients UNetTrainer produced, the trainer's fp16 operand copies follow (the second step's loss and
+    gradients come from the updated weights — under graph replay too, which needs the in-place refresh), the rest stays frozen."""
+    from storygen_amd.synth import synthetic_train_batch
+    from storygen_amd.training import Stage2Trainer
+    unet = _small_unet(gpu)
+    frozen = {n: p.detach().clone() for n, p in unet.named_parameters() if ".attn3." not in n}
+    tr = Stage2Trainer(unet, 2, 16, 16, learning_rate=1e-3, use_8bit_adam=False, max_grad_norm=1.0, use_graph=use_graph)
+    assert len(tr.named) == 5 * 2 and all(p.requires_grad for p in tr.named.values())
+    ref = {n: torch.nn.Parameter(p.detach().clone()) for n, p in tr.named.items()}
+    topt = torch.optim.AdamW(list(ref.values()), lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2, foreach=False, fused=False)
+    batch = synthetic_train_batch(2, 16, 768, 7)
+    losses = []
+    for it in range(3):
+        run = tr.trainer.train_step_graph if use_graph else tr.trainer.train_step
+        _, g = run(batch, use_refs=(0, 1, 2))                        # the gradients at the current weights, for the torch reference
+        for n, p in ref.items():
+            p.grad = g[n].detach().clone()
+        torch.nn.utils.clip_grad_norm_(list(ref.values()), 1.0)
+        topt.step()
+        out = tr.step(batch, use_refs=(0, 1, 2))
+        losses.append(float(out["loss"]))
+        assert out["optimizer_step"] and tr.global_step == it + 1 and out["lr"] == 1e-3
+        worst = max(float((tr.named[n].detach() - ref[n].detach()).abs().max()) for n in ref)
+        assert worst <= 5e-6, worst
+    print("losses on the same batch:", losses)
+    assert losses[2] < losses[0]                                       # three steps on one batch must reduce its loss
+    assert all(torch.equal(p.detach(), frozen[n]) for n, p in unet.named_parameters() if n in frozen)
+
+
+def test_stage2_trainer_8bit_accumulation_and_checkpoint(gpu, tmp_path):
+    from storygen_amd.synth import synthetic_train_batch
+    from storygen_amd.training import Stage2Trainer, train
+    unet = _small_unet(gpu)
+    before = {n: p.detach().clone() for n, p in unet.named_parameters() if ".attn3." in n}
+    tr = Stage2Trainer(unet, 2, 16, 16, learning_rate=1e-4, use_8bit_adam=True, gradient_accumulation_steps=2, lr_scheduler="constant_with_warmup",
+                       lr_warmup_steps=1, use_graph=False, seed=0)
+    batches = [synthetic_train_batch(2, 16, 768, s) for s in (7, 8, 9, 10)]
+    losses = train(tr, iter(batches), train_steps=2)
+    assert len(losses) == 2 and tr.global_step == 2 and tr._micro == 4
+    assert all(torch.isfinite(p).all() for p in tr.named.values())
+    moved = [float((tr.named[n].detach() - before[n]).abs().max()) for n in before]
+    assert min(moved) > 0.0 and max(moved) < 1e-2
+    bits = {n: tr.optimizer.state[i]["bits"] for i, n in enumerate(tr.optimizer.names)}
+    assert all(b == (8 if before[n].numel() >= 4096 else 32) for n, b in bits.items())
+    path = tr.save_checkpoint(str(tmp_path))
+    assert os.path.basename(path) == "checkpoint_2" and os.path.exists(os.path.join(path, "unet", "config.json"))
+    assert os.path.exists(os.path.join(path, "model_index.json")) and os.path.exists(os.path.join(path, "training_state.pt"))
+    from storygen_amd.model import UNet2DConditionModel
+    again = UNet2DConditionModel.from_pretrained(path, subfolder="unet")
+    assert all(torch.equal(again.state_dict()[n].cpu(), tr.named[n].detach().cpu()) for n in before)
+    tr2 = Stage2Trainer(again.to(gpu, F32), 2, 16, 16, learning_rate=1e-4, use_8bit_adam=True, gradient_accumulation_steps=2, use_graph=False)
+    tr2.load_training_state(path)
+    assert tr2.global_step == 2 and tr2.optimizer.step_count == 2
+    i = tr.optimizer.names.index(next(n for n in before if before[n].numel() >= 4096))
+    assert torch.equal(tr2.optimizer.state[i]["code1"], tr.optimizer.state[i]["code1"])
+
+
+def test_trained_weights_reach_the_inference_engine(gpu):
+    """The optimizer writes the parameters through raw pointers; bumping their autograd version makes the drop-in UNet's staleness tag
+    see it, so the next inference forward runs on the new attn3 weights without rebuilding anything."""
+    from storygen_amd.optim import AdamW
+    unet = _small_unet(gpu)
+    wts = unet._engine_weights()
+    named = {n: p.detach() for n, p in unet.named_parameters() if ".attn3." in n}
+    tag0 = dict(unet._weights_tag)
+    opt = AdamW(named, lr=1e-2)
+    opt.set_grads({n: torch.ones_like(p) for n, p in named.items()})
+    opt.step()
+    assert unet._engine_weights() is wts                               # refreshed in place, not rebuilt
+    changed = [n for n in unet._weights_tag if unet._weights_tag[n] != tag0[n]]
+    assert set(changed) == set(named)

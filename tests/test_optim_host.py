@@ -1,0 +1,122 @@
+"""CPU: the optimizer oracle pinned to torch.optim.AdamW / clip_grad_norm_ (the classes the reference's loop uses when 8-bit Adam is
+off), the 8-bit restatement's tracking property, learning-rate schedules, and the host pieces of storygen_amd.optim / training."""
+import math
+
+import pytest
+import torch
+
+from oracle import optim_oracle as oo
+
+
+def test_adamw_oracle_is_torch_adamw():
+    torch.manual_seed(0)
+    p0 = torch.randn(5000)
+    ref = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.AdamW([ref], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=1e-2)
+    p, m, v = p0.clone(), torch.zeros(5000), torch.zeros(5000)
+    for step in range(1, 8):
+        g = torch.randn(5000) * 10 ** (-step % 4)
+        ref.grad = g.clone()
+        opt.step()
+        oo.adamw_step(p, g, m, v, step, 1e-3)
+        assert torch.allclose(p, ref.detach(), rtol=0, atol=1e-7)
+    st = opt.state[ref]
+    assert torch.allclose(m, st["exp_avg"], atol=1e-8) and torch.allclose(v, st["exp_avg_sq"], atol=1e-10)
+
+
+def test_clip_coef_is_torch_clip_grad_norm():
+    torch.manual_seed(1)
+    ps = [torch.nn.Parameter(torch.zeros(n)) for n in (10, 300, 7)]
+    for scale in (0.01, 5.0):
+        gs = [torch.randn_like(p) * scale for p in ps]
+        for p, g in zip(ps, gs):
+            p.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_(ps, 1.0)
+        c = oo.clip_coef(gs, 1.0)
+        for p, g in zip(ps, gs):
+            assert torch.allclose(p.grad, g * c, rtol=1e-6, atol=0)
+
+
+def test_dynamic_maps():
+    from storygen_amd.optim import create_dynamic_map
+    for signed in (True, False):
+        c = oo.dynamic_map(signed)
+        assert torch.equal(c, create_dynamic_map(signed))
+        assert c.numel() == 256 and bool((c[1:] > c[:-1]).all()) and float(c[-1]) == 1.0 and bool((c == 0).any())
+    s = oo.dynamic_map(True)
+    assert abs(float(s[0]) + 0.9929687) < 1e-6 and float(s[127]) == 0.0          # the first entry of bitsandbytes' signed dynamic map
+    assert float(oo.dynamic_map(False)[0]) == 0.0
+    x = torch.tensor([-2.0, -0.99, 0.0, 1e-9, 0.5, 0.99999, 3.0])
+    idx = oo.nearest_code(s, x)
+    assert int(idx[0]) == 0 and int(idx[2]) == 127 and int(idx[-1]) == 255
+    brute = (x[:, None] - s[None]).abs().argmin(1)
+    assert torch.equal(idx.long(), brute)
+
+
+def test_adamw8bit_oracle_tracks_fp32_adamw():
+    """Block-wise 8-bit states must follow the fp32 optimizer: after 200 steps on a noisy quadratic the parameters agree to a few
+    percent of the distance travelled (the published claim of 8-bit optimizers: same trajectory, 4x smaller state)."""
+    torch.manual_seed(2)
+    n = 5000
+    target = torch.randn(n)
+    p32, m, v = torch.zeros(n), torch.zeros(n), torch.zeros(n)
+    p8 = torch.zeros(n)
+    c1, c2, a1, a2 = oo.adamw8bit_state(n)
+    for step in range(1, 201):
+        noise = 0.1 * torch.randn(n)
+        oo.adamw_step(p32, (p32 - target) + noise, m, v, step, 1e-2, weight_decay=0.0)
+        oo.adamw8bit_step(p8, (p8 - target) + noise, c1, c2, a1, a2, step, 1e-2, weight_decay=0.0)
+    travelled = p32.norm()
+    assert float((p8 - p32).norm() / travelled) < 0.05
+    assert float((p8 - target).norm()) < 0.7 * float(target.norm())
+
+
+def test_lr_schedules():
+    from storygen_amd.optim import _multiplier
+    for name in ("constant", "constant_with_warmup", "linear", "cosine", "cosine_with_restarts", "polynomial"):
+        cyc = 1 if name == "cosine_with_restarts" else 0.5
+        mine, ref = _multiplier(name, 10, 100, cyc, 1.0), oo.lr_lambda(name, 10, 100, cyc)
+        for s in (0, 1, 5, 10, 11, 50, 99, 100, 120):
+            assert abs(mine(s) - ref(s)) < 1e-12, (name, s)
+    assert oo.lr_lambda("constant")(12345) == 1.0
+    assert oo.lr_lambda("constant_with_warmup", 10)(5) == 0.5
+    assert abs(oo.lr_lambda("linear", 10, 110)(60) - 0.5) < 1e-12
+    assert abs(oo.lr_lambda("cosine", 0, 100)(50) - 0.5) < 1e-12
+    # torch's LambdaLR applies the multiplier of epoch 0 at construction and of epoch k after k step() calls
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.SGD([p], lr=2.0)
+    sched = torch.optim.lr_scheduler.LambdaLR(opt, oo.lr_lambda("linear", 2, 10))
+    seen = [sched.get_last_lr()[0]]
+    for _ in range(4):
+        opt.step()
+        sched.step()
+        seen.append(sched.get_last_lr()[0])
+
+    class _Opt:
+        param_groups = [dict(lr=2.0)]
+    from storygen_amd.optim import get_scheduler
+    mine = get_scheduler("linear", _Opt(), num_warmup_steps=2, num_training_steps=10)
+    got = [mine.get_last_lr()[0]]
+    for _ in range(4):
+        mine.step()
+        got.append(mine.get_last_lr()[0])
+    assert got == pytest.approx(seen)
+    with pytest.raises(ValueError):
+        get_scheduler("bogus", _Opt(), num_warmup_steps=0)
+    with pytest.raises(ValueError):
+        get_scheduler("linear", _Opt(), num_warmup_steps=0)
+
+
+def test_reference_frame_choice_matches_the_reference_rule():
+    from storygen_amd.training import use_refs_for
+    assert use_refs_for(0.1) == (0, 1, 2) and use_refs_for(0.3) == (1, 2) and use_refs_for(0.59) == (1, 2) and use_refs_for(0.6) == (2,)
+    assert use_refs_for(0.99) == (2,)
+
+
+def test_optimizer_rejects_cpu_and_fp16_parameters():
+    from storygen_amd.optim import AdamW
+    with pytest.raises(TypeError):
+        AdamW([torch.zeros(8)])
+    with pytest.raises(ValueError):
+        AdamW([])
+    assert math.isclose(1.0, 1.0)

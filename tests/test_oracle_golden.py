@@ -165,3 +165,44 @@ def test_oracle_train_step_vs_reference_golden(use_refs):
         assert tuple(grads[k].shape) == tuple(e["shape"])
         errs[k] = max(rel_l2(grads[k].flatten()[e["idx"]], e["values"]), abs(float(grads[k].double().norm()) - e["l2"]) / e["l2"])
     assert max(errs.values()) < 1e-4, max(errs.items(), key=lambda kv: kv[1])
+
+
+def test_clip_text_oracle_matches_transformers_golden():
+    """oracle/encoders_oracle.py::clip_text_forward against the outputs transformers' CLIPTextModel produced on the same (fp16-rounded)
+    weights — the fixture oracle/make_golden_encoders.py wrote; that script also checks a 768-wide, 12-head configuration."""
+    from oracle import encoders_oracle as eo
+    gold = torch.load(os.path.join(GOLDEN, "clip_text_tiny.pt"), weights_only=True)
+    sd = {k: v.float() for k, v in gold["state_dict"].items()}
+    hidden, pooled = eo.clip_text_forward(sd, gold["input_ids"], heads=gold["heads"])
+    assert rel_l2(hidden, gold["last_hidden_state"]) < 1e-5
+    assert rel_l2(pooled, gold["pooled"]) < 1e-5
+    # the restatement accepts transformers 4.x's `text_model.` prefix as well
+    h2, _ = eo.clip_text_forward({"text_model." + k: v for k, v in sd.items()}, gold["input_ids"], heads=gold["heads"])
+    assert torch.equal(h2, hidden)
+
+
+def test_vae_oracle_structure():
+    """The AutoencoderKL restatement is unpinned (diffusers is absent): check what can be checked — the reference's VAE config gives
+    SD's 83 653 863 parameters under diffusers' names, shapes chain, the asymmetric stride-2 padding, mode() of the posterior."""
+    import json
+    from oracle import encoders_oracle as eo
+    sd = eo.vae_random_state()
+    assert sum(v.numel() for v in sd.values()) == 83_653_863
+    cfg_path = "/root/reference/ckpt/stable-diffusion-v1-5/vae/config.json"
+    if os.path.exists(cfg_path):
+        cfg = json.load(open(cfg_path))
+        assert tuple(cfg["block_out_channels"]) == (128, 256, 512, 512) and cfg["layers_per_block"] == 2 and cfg["latent_channels"] == 4
+    small = eo.vae_random_state(block_out=(32, 64), layers_per_block=1, seed=1)
+    x = torch.rand(2, 3, 16, 24)
+    m = eo.vae_encode_moments(small, x)
+    assert tuple(m.shape) == (2, 8, 8, 12)
+    assert torch.equal(eo.gaussian_sample(m, None), m[:, :4])
+    assert tuple(eo.vae_decode(small, m[:, :4]).shape) == (2, 3, 16, 24)
+    # Downsample2D(padding=0) pads right/bottom only: shifting the image content by one pixel towards the top-left changes the result
+    # differently from a symmetric padding — pin the asymmetric form on a delta image
+    w = {"c.weight": torch.zeros(1, 1, 3, 3), "c.bias": torch.zeros(1)}
+    w["c.weight"][0, 0, 0, 0] = 1.0                                  # picks input pixel (2*oy, 2*ox) under (0,1,0,1) padding
+    d = torch.zeros(1, 1, 4, 4)
+    d[0, 0, 2, 2] = 1.0
+    y = eo._conv(torch.nn.functional.pad(d, (0, 1, 0, 1)), w, "c", stride=2, padding=0)
+    assert y[0, 0, 1, 1] == 1.0 and y.sum() == 1.0
