@@ -174,8 +174,22 @@ def train_step_bench(args):
     sd = synthetic_state_dict(arch, 0)
     bs = 4
     batch = synthetic_train_batch(bs, HW, arch.config["cross_attention_dim"], 0)
-    tr = UNetTrainer(arch, sd, dev, bs, HW, HW, n_ref=R)
-    step = tr.train_step if args.no_graph else tr.train_step_graph      # default: the whole step replayed as one hipGraph
+    if args.optimizer != "none":
+        # the whole loop body of train_StorySalon_stage2.py:304-333: gradients, global-norm clip, AdamW / 8-bit AdamW, refreshed weights
+        from storygen_amd.model import UNet2DConditionModel
+        from storygen_amd.training import Stage2Trainer
+        unet = UNet2DConditionModel.from_config(SD15_CONFIG)
+        unet.load_state_dict(sd)
+        st2 = Stage2Trainer(unet.to(dev, torch.float32), bs, HW, HW, n_ref=R, use_8bit_adam=args.optimizer == "adamw8bit",
+                            use_graph=not args.no_graph)
+        tr = st2.trainer
+
+        def step(b):
+            out = st2.step(b, use_refs=(0, 1, 2))
+            return out["loss"], st2.named
+    else:
+        tr = UNetTrainer(arch, sd, dev, bs, HW, HW, n_ref=R)
+        step = tr.train_step if args.no_graph else tr.train_step_graph      # default: the whole step replayed as one hipGraph
     for _ in range(args.warmup + (0 if args.no_graph else 1)):          # (+1: the capturing call)
         loss, grads = step(batch)
     torch.cuda.synchronize(dev)
@@ -194,7 +208,8 @@ def train_step_bench(args):
                       "config": {"workload": "NON-CONTRACT RUN, BASELINE configs[3]: train_StorySalon_stage2.py step, bs=4, fp16 operands / "
                                              "fp32 residual stream and gradients, attn3 gradients only; "
                                              + ("eager launches" if args.no_graph else "whole step = one hipGraph replay, loss-scaled fp16 gradient operands"),
-                                 "hipgraph": not args.no_graph, "grad_scale": tr.last_grad_scale, "gradients": len(grads), "loss": float(loss)},
+                                 "hipgraph": not args.no_graph, "grad_scale": tr.last_grad_scale, "gradients": len(grads), "loss": float(loss),
+                                 "optimizer": args.optimizer + ("" if args.optimizer == "none" else " + clip_grad_norm_(1.0), in the timed step")},
                       "tflop_forward_per_step": round(fwd, 3)}), flush=True)
 
 
@@ -225,6 +240,8 @@ def main():
                     help="A/B: eligible 3x3 convolutions through the LDS-resident-input-patch kernel (experiment, default off)")
     ap.add_argument("--no-gn-epilogue", action="store_true", help="A/B: every GroupNorm makes its own statistics pass")
     ap.add_argument("--no-gemm-pairs", action="store_true", help="A/B: q|k + V^T, q2 + q3, k3 + v3^T as separate launches")
+    ap.add_argument("--optimizer", choices=("none", "adamw", "adamw8bit"), default="none",
+                    help="with --train-step: include the reference's clip_grad_norm_ + optimizer step (storygen_amd.training.Stage2Trainer)")
     ap.add_argument("--train-step", action="store_true",
                     help="NOT the contract workload: BASELINE configs[3] — stage-2 training step, bs=4, 512x512, 3 reference frames "
                          "(forward of 3 reference passes + main pass, backward of the main pass, 80 attn3 gradients); reports it/s")

@@ -197,7 +197,7 @@ def test_pipeline_with_hip_vae_and_clip_matches_oracle_encoders(gpu):
     from storygen_amd.arch import SD15_CONFIG
     from storygen_amd.model import AutoencoderKL, CLIPTextModel, StableDiffusionPipeline, UNet2DConditionModel
     from storygen_amd.scheduler import DDIMSchedule
-    R, hw = 2, 8
+    R, hw = 2, 32                       # the 4-level UNet needs a latent of at least 32x32 (8 tokens at the deepest attention)
     unet = UNet2DConditionModel.from_config(SD15_CONFIG).to(gpu, F16).eval()
     boc = (64, 64, 128, 128)
     vae = AutoencoderKL(block_out_channels=boc, down_block_types=("DownEncoderBlock2D",) * 4, up_block_types=("UpDecoderBlock2D",) * 4,
