@@ -41,36 +41,39 @@ __global__ __launch_bounds__(256) void softmax_rows_kernel(const float* s, long 
 
 constexpr int AS_MAXT = 128, AS_MAXD = 64, AS_LD = AS_MAXD + 2;   // +2 halfs: a row is 33 dwords, lane-per-row reads spread over banks
 
-// grid (heads, batches); one wave per query row at a time, lane j owns keys j and j + 64.
+constexpr int AS_ROWS = 16;     // query rows per workgroup (4 per wave): CLIP's 77 tokens x 12 heads x B spread over 60 B workgroups
+
+// grid (heads, batches, row chunks); one wave per query row at a time, lane j owns keys j and j + 64.  A causal chunk only needs the
+// keys up to its last row.
 __global__ __launch_bounds__(256) void attn_small_kernel(const f16* q, long ldq, long bsq, const f16* k, long ldk, long bsk,
                                                          const f16* v, long ldv, long bsv, f16* o, long ldo, long bso,
                                                          const float* key_bias, int T, int D, float scale, int causal) {
     __shared__ f16 sK[AS_MAXT][AS_LD], sV[AS_MAXT][AS_LD];
     __shared__ float sQ[4][AS_MAXD], sP[4][AS_MAXT];
-    const int h = blockIdx.x, b = blockIdx.y, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int h = blockIdx.x, b = blockIdx.y, r0 = blockIdx.z * AS_ROWS, t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int Tk = causal ? min(T, r0 + AS_ROWS) : T;             // keys this chunk can see
     const f16* kb = k + (long)b * bsk + h * D;
     const f16* vb = v + (long)b * bsv + h * D;
-    for (int idx = t; idx < T * D; idx += 256) {
+    for (int idx = t; idx < Tk * D; idx += 256) {
         const int j = idx / D, d = idx - j * D;
         sK[j][d] = kb[(long)j * ldk + d];
         sV[j][d] = vb[(long)j * ldv + d];
     }
     __syncthreads();
-    const int rounds = (T + 3) / 4;
-    for (int r = 0; r < rounds; ++r) {
-        const int i = r * 4 + w;
+    for (int r = 0; r < AS_ROWS / 4; ++r) {
+        const int i = r0 + r * 4 + w;
         const bool live = i < T;
         if (live && lane < D) sQ[w][lane] = (float)q[(long)b * bsq + (long)i * ldq + h * D + lane] * scale;
         __syncthreads();
         float s0 = -INFINITY, s1 = -INFINITY;
         if (live) {
             const int j0 = lane, j1 = lane + 64;
-            if (j0 < T && !(causal && j0 > i)) {
+            if (j0 < Tk && !(causal && j0 > i)) {
                 float a = 0.f;
                 for (int d = 0; d < D; ++d) a += sQ[w][d] * (float)sK[j0][d];
                 s0 = a + (key_bias ? key_bias[(long)b * T + j0] : 0.f);
             }
-            if (j1 < T && !(causal && j1 > i)) {
+            if (j1 < Tk && !(causal && j1 > i)) {
                 float a = 0.f;
                 for (int d = 0; d < D; ++d) a += sQ[w][d] * (float)sK[j1][d];
                 s1 = a + (key_bias ? key_bias[(long)b * T + j1] : 0.f);
@@ -83,7 +86,7 @@ __global__ __launch_bounds__(256) void attn_small_kernel(const f16* q, long ldq,
         sP[w][lane + 64] = e1;
         __syncthreads();
         if (live && lane < D) {
-            const int jn = causal ? min(T, i + 1) : T;
+            const int jn = causal ? min(Tk, i + 1) : Tk;
             float acc = 0.f;
             for (int j = 0; j < jn; ++j) acc += sP[w][j] * (float)sV[j][lane];
             o[(long)b * bso + (long)i * ldo + h * D + lane] = (f16)(acc / sum);
@@ -156,7 +159,7 @@ extern "C" int sg_attn_small_f16(const sg_half* q, int64_t ldq, int64_t bsq, con
                AS_MAXT, AS_MAXD, T, D);
     SG_REQUIRE(ldq >= (int64_t)H * D && ldk >= (int64_t)H * D && ldv >= (int64_t)H * D && ldo >= (int64_t)H * D, "sg_attn_small: token stride below H*D");
     SG_REQUIRE(causal == 0 || causal == 1, "sg_attn_small: causal must be 0 or 1");
-    hipLaunchKernelGGL(attn_small_kernel, dim3(H, B), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f16*>(q), (long)ldq, (long)bsq,
+    hipLaunchKernelGGL(attn_small_kernel, dim3(H, B, (T + AS_ROWS - 1) / AS_ROWS), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const f16*>(q), (long)ldq, (long)bsq,
                        reinterpret_cast<const f16*>(k), (long)ldk, (long)bsk, reinterpret_cast<const f16*>(v), (long)ldv, (long)bsv,
                        reinterpret_cast<f16*>(o), (long)ldo, (long)bso, key_bias, T, D, scale, causal);
     SG_CHECK_LAUNCH("sg_attn_small_f16");

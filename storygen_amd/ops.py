@@ -604,7 +604,7 @@ def pad_cast(x: torch.Tensor, out_padded: torch.Tensor) -> torch.Tensor:
 
 
 # ------------------------------------------------------------------------------------------------ backward pass (config 4)
-# NOT YET RUN ON HARDWARE — see csrc/backward.hip.  Formulas: oracle/storygen_backward.py.
+# Validated on MI355X in round 2 (tests/test_backward_gpu.py).  Kernels: csrc/backward.hip, attention_bwd.hip; formulas: oracle/storygen_backward.py.
 def layernorm_bwd(x: torch.Tensor, dy1: torch.Tensor, g1: torch.Tensor, out: torch.Tensor, eps: float = 1e-5,
                   dy2: Optional[torch.Tensor] = None, g2: Optional[torch.Tensor] = None, res: Optional[torch.Tensor] = None,
                   res_scale: float = 1.0) -> torch.Tensor:
