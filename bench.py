@@ -238,7 +238,11 @@ def main():
     ap.add_argument("--spread", type=int, default=-1, help="A/B: placement of the ring-refill DMA instructions (sg_debug_set_spread)")
     ap.add_argument("--conv-patch", action="store_true",
                     help="A/B: eligible 3x3 convolutions through the LDS-resident-input-patch kernel (experiment, default off)")
+    ap.add_argument("--fp16-block-stream", action="store_true",
+                    help="A/B (changes results, never the contract line): fp16 residual stream inside the transformer blocks")
     ap.add_argument("--no-gn-epilogue", action="store_true", help="A/B: every GroupNorm makes its own statistics pass")
+    ap.add_argument("--fp16-block-stream", action="store_true",
+                    help="A/B (changes results, never the contract line): fp16 residual stream inside the transformer blocks")
     ap.add_argument("--no-gemm-pairs", action="store_true", help="A/B: q|k + V^T, q2 + q3, k3 + v3^T as separate launches")
     ap.add_argument("--optimizer", choices=("none", "adamw", "adamw8bit"), default="none",
                     help="with --train-step: include the reference's clip_grad_norm_ + optimizer step (storygen_amd.training.Stage2Trainer)")
@@ -295,6 +299,9 @@ def main():
     if args.no_gn_epilogue:
         from storygen_amd import engine as _engine
         _engine.GN_EPILOGUE_STATS = False
+    if args.fp16_block_stream:
+        from storygen_amd import engine as _engine
+        _engine.FP16_BLOCK_STREAM = True
 
     hw, n_ref = (96, 5) if args.config5_shape else (HW, R)
     # per-sample GFLOP of one ref / main pass: 64x64 R=3, or 96x96 R=5
@@ -358,7 +365,7 @@ def main():
                        "overlap_ref_pass_of_next_step": sampler.overlap, "ref_ahead": G, "warmup_run": warmup_run,
                        "split_graphs": sampler.split, "stream_priority": sampler.stream_priority,
                        "conv_lds_patch": args.conv_patch, "paired_gemm_launches": not args.no_gemm_pairs,
-                       "groupnorm_stats_from_epilogues": not args.no_gn_epilogue},
+                       "groupnorm_stats_from_epilogues": not args.no_gn_epilogue, "fp16_block_stream": args.fp16_block_stream},
             "tflop_per_step_as_written": round(step_tflop, 3),
             "final_allgather_ms": round(gather_ms, 3), "latents_gathered": int(final.shape[0]), "latents_finite": finite,
             "latents_distinct_per_rank": distinct,

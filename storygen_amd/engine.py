@@ -37,6 +37,10 @@ from .repack import conv1x1_nk, conv3x3_krsc, conv_in_kn, interleave_geglu
 
 F16 = torch.float16
 GN_EPILOGUE_STATS = True   # GroupNorm statistics from the producing conv / GEMM epilogues (False = every GroupNorm makes its own pass)
+# Experiment, default off: the residual stream INSIDE a transformer block (h0: proj_in output, h1: after
+# self-attention, h2/h3: after the cross-attentions) in fp16 instead of fp32; block inputs / outputs and the resnets stay fp32.  Halves
+# the bytes of 3 GEMM outputs, 3 residual reads and 3 LayerNorm reads per block; costs fp16 rounding of the stream.  tools/exp_fp16_stream.py
+FP16_BLOCK_STREAM = False
 PAIR_GEMMS = True     # q|k + V^T, q2 + q3, k3 + v3^T as one launch each (sg_gemm_pair_f16); False = two launches (A/B switch)
 
 
@@ -324,7 +328,7 @@ class UNetEngine:
             d = dict(
                 # fp32 residual stream
                 r=f32(M, C), t_out=f32(M, C), sc=f32(M, C),
-                h0=f32(M, C), h1=f32(M, C), h2=f32(M, C), h3=f32(M, C),
+                **{n: (self._buf(M, C) if FP16_BLOCK_STREAM else f32(M, C)) for n in ("h0", "h1", "h2", "h3")},
                 # fp16 MFMA operands
                 gn=self._buf(M, C), x16=self._buf(M * Cw), c1=self._buf(M, C), h4=self._buf(M, C),
                 ln=self._buf(M, C), ln4=self._buf(M, C), qk=self._buf(M, 2 * C), vt=self._buf(C, M), q=self._buf(M, C),
