@@ -6,7 +6,9 @@ state train_StorySalon_stage2.py:166-177 puts it in (everything frozen, paramete
 (the CLIP / VAE plumbing is outside the path).  Stored: the loss, and for every trainable tensor its L2 norm plus a
 fixed random index sample.  As a self-check the restatement oracle.storygen_oracle.train_step must reproduce them.
 
-Usage:  python oracle/make_golden_train.py        (build container only; writes tests/golden/tiny_train.pt)
+Usage:  python oracle/make_golden_train.py            (build container only; writes tests/golden/tiny_train.pt)
+        python oracle/make_golden_train.py stage1     (train_StorySalon_stage1.py:171-179,262-291: modules named `*attn1` trainable, no
+                                                       reference pass, image_hidden_states=None; writes tests/golden/tiny_train_stage1.pt)
 """
 from __future__ import annotations
 
@@ -34,18 +36,20 @@ def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
-def main():
+def main(stage1: bool = False):
     cfg = load_config(TINY_CONFIG)
     arch = build_arch(cfg)
     seed, b, hw = 5, 2, 64            # the reference's consume path needs a 64..94 latent
     sd = synthetic_state_dict(arch, seed)
     batch = synthetic_train_batch(b, hw, cfg["cross_attention_dim"], seed)
-    out = dict(case="tiny_train", config=cfg, seed=seed, batch=b, hw=hw, made_by="oracle/make_golden_train.py", cases={})
-    for use_refs in ((0, 1, 2), (2,)):
+    target = "attn1" if stage1 else "attn3"
+    out = dict(case="tiny_train_stage1" if stage1 else "tiny_train", config=cfg, seed=seed, batch=b, hw=hw, trainable=target,
+               made_by="oracle/make_golden_train.py", cases={})
+    for use_refs in (((),) if stage1 else ((0, 1, 2), (2,))):
         unet = build_reference_unet(cfg, sd)
         unet.requires_grad_(False)                                                        # :166-168
         for name, module in unet.named_modules():                                         # :170-175
-            if name.endswith("attn3"):
+            if name.endswith(target):
                 for p in module.parameters():
                     p.requires_grad = True
         unet.train()                                                                      # :263
@@ -58,14 +62,14 @@ def main():
         for i in use_refs:
             x = O.ddpm_add_noise(sched, batch["ref_latents"][i], batch["ref_noise"], ref_t * (3 - i))
             feats.append(unet(x, ref_t * (3 - i), encoder_hidden_states=batch["prev_text"][i], return_dict=False)[1])
-        ctx = {k: torch.cat([f[k] for f in feats], dim=1) for k in feats[0]}
+        ctx = {k: torch.cat([f[k] for f in feats], dim=1) for k in feats[0]} if feats else None
         pred = unet(noisy, t, encoder_hidden_states=batch["text"], image_hidden_states=ctx, return_dict=False)[0]
         loss = F.mse_loss(pred.float() * (1.0 - batch["mask"]), batch["noise"].float() * (1 - batch["mask"]), reduction="mean")
         loss.backward()
         grads = {n: p.grad.detach().clone() for n, p in unet.named_parameters() if p.requires_grad}
-        assert all(k.endswith(O.TRAINABLE_SUFFIXES) for k in grads) and len(grads) == 5 * len(arch.feature_keys)
+        assert all(k.endswith(O.trainable_suffixes(target)) for k in grads) and len(grads) == 5 * len(arch.feature_keys)
         print(f"reference train step refs={use_refs}: loss {float(loss):.6f}, {len(grads)} grads, {time.time() - t0:.1f}s", flush=True)
-        o_loss, o_grads = O.train_step(sd, cfg, batch, use_refs)
+        o_loss, o_grads = O.train_step(sd, cfg, batch, use_refs, trainable=target)
         errs = [abs(float(o_loss) - float(loss)) / abs(float(loss))] + [rel_l2(o_grads[k], grads[k]) for k in grads]
         print(f"restatement vs reference: max rel err {max(errs):.2e}", flush=True)
         assert max(errs) < 1e-4, errs
@@ -75,11 +79,11 @@ def main():
             idx = torch.randint(0, g.numel(), (min(N_PROBE, g.numel()),), generator=gi)
             entry["grads"][k] = dict(shape=tuple(g.shape), l2=float(g.double().norm()), idx=idx, values=g.flatten()[idx].clone())
         out["cases"]["refs_" + "".join(map(str, use_refs))] = entry
-    path = os.path.join(GOLDEN, "tiny_train.pt")
+    path = os.path.join(GOLDEN, out["case"] + ".pt")
     torch.save(out, path)
     print(f"wrote {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
 
 
 if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count() or 1)
-    main()
+    main(stage1=len(sys.argv) > 1 and sys.argv[1] == "stage1")

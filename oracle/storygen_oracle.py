@@ -308,19 +308,28 @@ TRAINABLE_SUFFIXES = (".attn3.to_q.weight", ".attn3.to_k.weight", ".attn3.to_v.w
                       ".attn3.to_out.0.bias")
 
 
+def trainable_suffixes(module: str = "attn3") -> Tuple[str, ...]:
+    """Parameter-name suffixes of the modules `name.endswith(module)` selects: "attn3" in stage 2 / COCO
+    (train_StorySalon_stage2.py:170-177), "attn1" in stage 1 (train_StorySalon_stage1.py:175-179)."""
+    return tuple(f".{module}.{leaf}" for leaf in ("to_q.weight", "to_k.weight", "to_v.weight", "to_out.0.weight", "to_out.0.bias"))
+
+
 def ddpm_add_noise(sched: DDIM, x: Tensor, noise: Tensor, t: Tensor) -> Tensor:
     """DDPMScheduler.add_noise with a per-sample timestep vector (train_StorySalon_stage2.py:303,311)."""
     a = sched.alphas_cumprod[t.long()].view(-1, 1, 1, 1)
     return a.sqrt() * x + (1 - a).sqrt() * noise
 
 
-def train_step(sd: SD, cfg: dict, batch: Dict[str, Tensor], use_refs=(0, 1, 2)) -> Tuple[Tensor, Dict[str, Tensor]]:
+def train_step(sd: SD, cfg: dict, batch: Dict[str, Tensor], use_refs=(0, 1, 2), trainable: str = "attn3") -> Tuple[Tensor, Dict[str, Tensor]]:
     """Loss and attn3 gradients of one stage-2 training step, train_StorySalon_stage2.py:291-327 after its CLIP / VAE
     plumbing: `batch` holds latents [b,4,h,w], ref_latents [3,b,4,h,w], noise, ref_noise, timesteps [b] (int64), text
     [b,77,c], prev_text [3,b,77,c] and the already 1/8-downsampled mask [b,4,h,w] (:268-270).  `use_refs` replaces the
     random draw of :306-310 (p < 0.3 -> (0,1,2); 0.3 <= p < 0.6 -> (1,2); else (2,)).  The reference-frame noise level
-    is ref_t * (3 - i) with the literal 3 of :311, whatever the number of frames used."""
-    params = {k: (v.detach().clone().requires_grad_(True) if k.endswith(TRAINABLE_SUFFIXES) else v) for k, v in sd.items()}
+    is ref_t * (3 - i) with the literal 3 of :311, whatever the number of frames used.
+    Stage 1 (train_StorySalon_stage1.py:262-291) is the same step with use_refs=() — no reference pass, the main pass runs with
+    image_hidden_states=None — and trainable="attn1"."""
+    suffixes = trainable_suffixes(trainable)
+    params = {k: (v.detach().clone().requires_grad_(True) if k.endswith(suffixes) else v) for k, v in sd.items()}
     sched = DDIM()
     t = batch["timesteps"].long()
     ref_t = (batch["timesteps"] / 10).long()                                             # :297-300
@@ -330,10 +339,10 @@ def train_step(sd: SD, cfg: dict, batch: Dict[str, Tensor], use_refs=(0, 1, 2)) 
         ti = ref_t * (3 - i)
         x = ddpm_add_noise(sched, batch["ref_latents"][i], batch["ref_noise"], ti)
         feats.append(unet_forward(params, cfg, x, ti, batch["prev_text"][i], None)[1])
-    ctx = {k: torch.cat([f[k] for f in feats], dim=1) for k in feats[0]}                  # :316-318
+    ctx = {k: torch.cat([f[k] for f in feats], dim=1) for k in feats[0]} if feats else None   # :316-318 (stage 1: None, :288)
     pred = unet_forward(params, cfg, noisy, t, batch["text"], ctx)[0]                     # :322
     keep = 1.0 - batch["mask"]
     loss = F.mse_loss(pred.float() * keep, batch["noise"].float() * keep, reduction="mean")   # :325
-    names = [k for k in params if k.endswith(TRAINABLE_SUFFIXES)]
+    names = [k for k in params if k.endswith(suffixes)]
     grads = torch.autograd.grad(loss, [params[k] for k in names])                         # :327
     return loss.detach(), dict(zip(names, grads))

@@ -41,6 +41,7 @@ GN_EPILOGUE_STATS = True   # GroupNorm statistics from the producing conv / GEMM
 # self-attention, h2/h3: after the cross-attentions) in fp16 instead of fp32; block inputs / outputs and the resnets stay fp32.  Halves
 # the bytes of 3 GEMM outputs, 3 residual reads and 3 LayerNorm reads per block; costs fp16 rounding of the stream.  tools/exp_fp16_stream.py
 FP16_BLOCK_STREAM = False
+FP16_RESNET_STREAM = False   # same experiment for the rest of the stream: resnet / transformer / shortcut outputs and the skip-concat buffers
 PAIR_GEMMS = True     # q|k + V^T, q2 + q3, k3 + v3^T as one launch each (sg_gemm_pair_f16); False = two launches (A/B switch)
 
 
@@ -327,7 +328,7 @@ class UNetEngine:
             f32 = lambda *sh: self._buf(*sh, dtype=F32)  # noqa: E731
             d = dict(
                 # fp32 residual stream
-                r=f32(M, C), t_out=f32(M, C), sc=f32(M, C),
+                **{n: (self._buf(M, C) if FP16_RESNET_STREAM else f32(M, C)) for n in ("r", "t_out", "sc")},
                 **{n: (self._buf(M, C) if FP16_BLOCK_STREAM else f32(M, C)) for n in ("h0", "h1", "h2", "h3")},
                 # fp16 MFMA operands
                 gn=self._buf(M, C), x16=self._buf(M * Cw), c1=self._buf(M, C), h4=self._buf(M, C),
@@ -346,7 +347,7 @@ class UNetEngine:
         lvl = nlev - 1
         for blk in arch.up:
             for j, r in enumerate(blk.resnets):
-                buf = self._buf(B * self.hw[lvl], r.cin, dtype=F32)
+                buf = self._buf(B * self.hw[lvl], r.cin, dtype=F16 if FP16_RESNET_STREAM else F32)
                 self.up_cats.append(buf)
                 skip_views.append(buf[:, r.cin - blk.skip_channels[j]:])
             if blk.sampler_prefix:

@@ -31,17 +31,17 @@ from .train_blocks import F16, F32, ResnetBlockTrain, TransformerBlockTrain, _ca
 class Transformer2DTrain:
     """Transformer2DModel (model/attention.py:26-128): GroupNorm(eps 1e-6) -> 1x1 proj_in -> block -> 1x1 proj_out -> + x."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], spec: XfSpec, groups: int, device):
+    def __init__(self, sd: Dict[str, torch.Tensor], spec: XfSpec, groups: int, device, trainable: str = "attn3"):
         self.dev, self.groups, self.spec, p = torch.device(device), groups, spec, spec.prefix
         g = lambda k: sd[f"{p}.{k}"].detach().to(self.dev, F16).contiguous()     # noqa: E731
         self.ng, self.nb = g("norm.weight"), g("norm.bias")
         self.w_in, self.b_in = conv1x1_nk(g("proj_in.weight")), g("proj_in.bias")
         self.w_out, self.b_out = conv1x1_nk(g("proj_out.weight")), g("proj_out.bias")
         self.w_in_t, self.w_out_t = _t(self.w_in), _t(self.w_out)
-        self.blk = TransformerBlockTrain(sd, f"{p}.transformer_blocks.0", spec.heads, device)
+        self.blk = TransformerBlockTrain(sd, f"{p}.transformer_blocks.0", spec.heads, device, trainable)
         self.saved = None
 
-    def forward(self, x: torch.Tensor, text16: torch.Tensor, ctx16: torch.Tensor, B: int) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, text16: torch.Tensor, ctx16: Optional[torch.Tensor], B: int) -> torch.Tensor:
         M, C, dev = x.shape[0], x.shape[1], self.dev
         hw = M // B
         ws = _e(ops.groupnorm_workspace_bytes(B, self.groups), dev=dev, dtype=torch.uint8)
@@ -68,26 +68,31 @@ class Transformer2DTrain:
         dx = _e(M, C, dev=dev, dtype=F32)
         ops.groupnorm_bwd(x.view(B, hw, C), dgn.view(B, hw, C), self.ng, self.nb, dx.view(B, hw, C), self.groups, 1e-6, False, ws,
                           res=dout.view(B, hw, C))
-        p = f"{self.spec.prefix}.transformer_blocks.0.attn3"
+        p = f"{self.spec.prefix}.transformer_blocks.0.{self.blk.trainable}"
         return dx, {f"{p}.{k}": v for k, v in g.items()}
 
 
 class UNetTrainer:
     def __init__(self, arch: UNetArch, state_dict: Dict[str, torch.Tensor], device, batch: int, height: int, width: int,
-                 n_ref: int = 3, seq_len: int = 77, ref_engine=None, weights: Optional[EngineWeights] = None):
-        """ref_engine: the object that runs the reference passes (set_inputs / forward(harvest_slot=) / .ctx); default = an
+                 n_ref: int = 3, seq_len: int = 77, ref_engine=None, weights: Optional[EngineWeights] = None, trainable: str = "attn3"):
+        """trainable: "attn3" (stage 2 / COCO: train_step with 1-3 reference frames) or "attn1" (stage 1: train_step(use_refs=()),
+        no reference pass, no image context — train_StorySalon_stage1.py:175-179,288).
+        ref_engine: the object that runs the reference passes (set_inputs / forward(harvest_slot=) / .ctx); default = an
         inference UNetEngine on the same weights (tests inject a CPU stand-in to exercise the host logic without a GPU)."""
         self.arch, self.dev, self.cfg = arch, torch.device(device), arch.config
         self.B, self.H, self.W, self.R = batch, height, width, n_ref
         sd = state_dict
         self.wts = weights if weights is not None else EngineWeights(arch, sd, device)
+        if ref_engine is None and n_ref == 0:
+            ref_engine = object()                                                     # stage 1: no reference pass ever runs
         self.ref = ref_engine if ref_engine is not None else UNetEngine(arch, None, device, batch, height, width, n_ref, seq_len,
                                                                         weights=self.wts)
         self.groups, self.eps = self.cfg["norm_num_groups"], self.cfg["norm_eps"]
         g16 = lambda k: sd[k].detach().to(self.dev, F16).contiguous()             # noqa: E731
         self.resnets = {r.prefix: ResnetBlockTrain(sd, r.prefix, self.groups, self.eps, device) for r in arch.resnets}
         self.temb_proj = {r.prefix: (g16(f"{r.prefix}.time_emb_proj.weight"), g16(f"{r.prefix}.time_emb_proj.bias")) for r in arch.resnets}
-        self.xfs = {a.prefix: Transformer2DTrain(sd, a, self.groups, device)
+        self.trainable = trainable
+        self.xfs = {a.prefix: Transformer2DTrain(sd, a, self.groups, device, trainable)
                     for blk in arch.down + [arch.mid] + arch.up for a in blk.attns if a is not None}
         self.samplers = {}
         for blk in arch.down + arch.up:
@@ -160,9 +165,11 @@ class UNetTrainer:
         """The batch on the device in the dtypes the step consumes (host -> device copies happen only here)."""
         dev = self.dev
         f = lambda k: batch[k].to(dev, F32).contiguous()                             # noqa: E731
-        return dict(latents=f("latents"), noise=f("noise"), ref_latents=f("ref_latents"), ref_noise=f("ref_noise"), mask=f("mask"),
-                    timesteps=batch["timesteps"].to(dev).long(), text=batch["text"].to(dev, F16).contiguous(),
-                    prev_text=batch["prev_text"].to(dev, F16).contiguous())
+        out = dict(latents=f("latents"), noise=f("noise"), mask=f("mask"), timesteps=batch["timesteps"].to(dev).long(),
+                   text=batch["text"].to(dev, F16).contiguous())
+        if "ref_latents" in batch:                                                   # absent in stage-1 batches (no prior frames)
+            out.update(ref_latents=f("ref_latents"), ref_noise=f("ref_noise"), prev_text=batch["prev_text"].to(dev, F16).contiguous())
+        return out
 
     def _step_device(self, inp: Dict[str, torch.Tensor], use_refs) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
         """The whole step on device-resident inputs (no host <-> device traffic unless grad_scale is "auto"): reference passes,
@@ -176,8 +183,8 @@ class UNetTrainer:
             self.ref.set_inputs(self._add_noise(inp["ref_latents"][i], inp["ref_noise"], ti), ti.float(), inp["prev_text"][i])
             self.ref.forward(harvest_slot=slot)
         n_used = len(use_refs)
-        ctx16 = {}
-        for key, buf in self.ref.ctx.items():                                        # [B, R*hw_k, C] -> the used slots, flattened
+        ctx16 = {} if n_used else None                                               # no frame: image_hidden_states=None (stage 1)
+        for key, buf in (self.ref.ctx.items() if n_used else ()):                    # [B, R*hw_k, C] -> the used slots, flattened
             n = buf.shape[1] // self.R
             ctx16[key] = buf[:, : n_used * n].reshape(B * n_used * n, buf.shape[2]).contiguous()
         text16 = inp["text"].reshape(B * inp["text"].shape[1], -1)
@@ -228,13 +235,15 @@ class UNetTrainer:
             return self.train_step_graph(batch, use_refs)
         return st["loss"], st["grads"]
 
-    def set_attn3_parameters(self, named_params: Dict[str, torch.Tensor]) -> None:
-        """Refresh the device copies of the trainable parameters (full state-dict names, `...attn3.to_q.weight` etc.)."""
+    def set_trainable_parameters(self, named_params: Dict[str, torch.Tensor]) -> None:
+        """Refresh the device copies of the trainable parameters (full state-dict names, `...attn3.to_q.weight` etc.), in place."""
         for prefix, xf in self.xfs.items():
-            p = f"{prefix}.transformer_blocks.0.attn3."
+            p = f"{prefix}.transformer_blocks.0.{self.trainable}."
             sub = {k[len(p):]: v for k, v in named_params.items() if k.startswith(p)}
             if sub:
-                xf.blk.set_attn3(sub)
+                xf.blk.set_trainable(sub)
+
+    set_attn3_parameters = set_trainable_parameters          # round-1 name
 
     def forward_main(self, noisy: torch.Tensor, t: torch.Tensor, text16: torch.Tensor, ctx16: Dict[str, torch.Tensor]) -> torch.Tensor:
         """Main pass (unet_2d_condition.py:338-485 in consume mode) keeping the tape for backward_main.  noisy fp32 NCHW
@@ -257,7 +266,7 @@ class UNetTrainer:
 
         def xf(spec, x):
             tape.append(("xf", spec.prefix))
-            return self.xfs[spec.prefix].forward(x, text16, ctx16[spec.feature_key], B)
+            return self.xfs[spec.prefix].forward(x, text16, None if ctx16 is None else ctx16[spec.feature_key], B)
 
         h = _e(B * H * W, boc0, dev=dev, dtype=F32)
         ops.conv_in(noisy, wts.w_conv_in, wts.b_conv_in, h.view(B, H, W, boc0))

@@ -63,8 +63,12 @@ class TransformerBlockTrain:
     """One BasicTransformerBlock (model/attention.py:131-302) in consume mode: attn1 (self), attn2 (text), attn3 (image
     context), GEGLU feed-forward.  `forward` keeps what `backward` needs."""
 
-    def __init__(self, sd: Dict[str, torch.Tensor], prefix: str, heads: int, device):
-        self.dev, self.heads, p = torch.device(device), heads, prefix
+    def __init__(self, sd: Dict[str, torch.Tensor], prefix: str, heads: int, device, trainable: str = "attn3"):
+        """trainable: the module whose five weight gradients `backward` returns — "attn3" (stage 2 / COCO,
+        train_StorySalon_stage2.py:170-177) or "attn1" (stage 1, train_StorySalon_stage1.py:175-179)."""
+        if trainable not in ("attn1", "attn3"):
+            raise NotImplementedError(f"weight gradients are built for attn1 and attn3, not {trainable!r}")
+        self.dev, self.heads, p, self.trainable = torch.device(device), heads, prefix, trainable
         g = lambda k: sd[f"{p}.{k}"].detach().to(self.dev, F16).contiguous()     # noqa: E731
         self.ln = {n: (g(f"{n}.weight"), g(f"{n}.bias")) for n in ("norm1", "norm2", "norm3", "norm4")}
         self.w = {}
@@ -81,9 +85,11 @@ class TransformerBlockTrain:
         self.scale = (self.C // heads) ** -0.5
         self.saved: Optional[dict] = None
 
-    def set_attn3(self, params: Dict[str, torch.Tensor]) -> None:
+    def set_trainable(self, params: Dict[str, torch.Tensor]) -> None:
         """Refresh the device copies of the trainable module after an optimizer step.  `params`: to_q.weight, to_k.weight,
         to_v.weight, to_out.0.weight, to_out.0.bias (any dtype / device)."""
+        a = self.trainable
+
         def put(table, key, value):
             # IN PLACE when the buffer exists: a captured training graph (UNetTrainer.train_step_graph) keeps reading these addresses
             if key in table and table[key].shape == value.shape:
@@ -93,11 +99,13 @@ class TransformerBlockTrain:
 
         cp = lambda t: t.detach().to(self.dev, F16)                                  # noqa: E731
         for m in ("to_q", "to_k", "to_v"):
-            put(self.w, f"attn3.{m}", cp(params[f"{m}.weight"]))
-            put(self.wt, f"attn3.{m}", _t(self.w[f"attn3.{m}"]))
-        put(self.w, "attn3.to_out", cp(params["to_out.0.weight"]))
-        put(self.w, "attn3.b_out", cp(params["to_out.0.bias"]))
-        put(self.wt, "attn3.to_out", _t(self.w["attn3.to_out"]))
+            put(self.w, f"{a}.{m}", cp(params[f"{m}.weight"]))
+            put(self.wt, f"{a}.{m}", _t(self.w[f"{a}.{m}"]))
+        put(self.w, f"{a}.to_out", cp(params["to_out.0.weight"]))
+        put(self.w, f"{a}.b_out", cp(params["to_out.0.bias"]))
+        put(self.wt, f"{a}.to_out", _t(self.w[f"{a}.to_out"]))
+
+    set_attn3 = set_trainable          # round-1 name
 
     # ------------------------------------------------------------------------------------------------ forward
     def _attend(self, name: str, x16: torch.Tensor, kv16: torch.Tensor, B: int) -> dict:
@@ -115,22 +123,29 @@ class TransformerBlockTrain:
         ops.attention_lse(q.view(B, Nq, C), k.view(B, Nk, C), vt, o.view(B, Nq, C), lse, H, self.scale, nk=Nk)
         return dict(q=q, k=k, v=v, o=o, lse=lse, Nq=Nq, Nk=Nk)
 
-    def forward(self, h: torch.Tensor, text16: torch.Tensor, ctx16: torch.Tensor, B: int) -> torch.Tensor:
-        """h fp32 [B*N, C]; text16 fp16 [B*S, 768]; ctx16 fp16 [B*Nc, C] (harvested features).  Returns fp32 [B*N, C]."""
+    def forward(self, h: torch.Tensor, text16: torch.Tensor, ctx16: Optional[torch.Tensor], B: int) -> torch.Tensor:
+        """h fp32 [B*N, C]; text16 fp16 [B*S, 768]; ctx16 fp16 [B*Nc, C] (harvested features) or None = no image context
+        (attention.py:279: the attn3 branch is skipped, stage 1).  Returns fp32 [B*N, C]."""
         C, dev, M = self.C, self.dev, h.shape[0]
         n1 = _e(M, C, dev=dev)
         ops.layernorm(h, *self.ln["norm1"], n1)
         a1 = self._attend("attn1", n1, n1, B)
         h1 = _e(M, C, dev=dev, dtype=F32)
         ops.gemm(a1["o"], self.w["attn1.to_out"], h1, bias=self.w["attn1.b_out"], res1=h)           # :250-262
-        n2, n4 = _e(M, C, dev=dev), _e(M, C, dev=dev)
-        ops.layernorm(h1, *self.ln["norm2"], n2, 1e-5, *self.ln["norm4"], n4)
+        n2, n4, a3 = _e(M, C, dev=dev), None, None
+        if ctx16 is not None:
+            n4 = _e(M, C, dev=dev)
+            ops.layernorm(h1, *self.ln["norm2"], n2, 1e-5, *self.ln["norm4"], n4)
+        else:
+            ops.layernorm(h1, *self.ln["norm2"], n2)
         a2 = self._attend("attn2", n2, text16, B)
-        a3 = self._attend("attn3", n4, ctx16, B)
         t = _e(M, C, dev=dev, dtype=F32)
         ops.gemm(a2["o"], self.w["attn2.to_out"], t, bias=self.w["attn2.b_out"], res1=h1)           # ht :266-277
-        h3 = _e(M, C, dev=dev, dtype=F32)
-        ops.gemm(a3["o"], self.w["attn3.to_out"], h3, bias=self.w["attn3.b_out"], res1=t, res2=h1)  # ht + hi :281-293
+        h3 = t                                                                                      # no image context: :295
+        if ctx16 is not None:
+            a3 = self._attend("attn3", n4, ctx16, B)
+            h3 = _e(M, C, dev=dev, dtype=F32)
+            ops.gemm(a3["o"], self.w["attn3.to_out"], h3, bias=self.w["attn3.b_out"], res1=t, res2=h1)  # ht + hi :281-293
         n3 = _e(M, C, dev=dev)
         ops.layernorm(h3, *self.ln["norm3"], n3)
         ffi = _e(M, 4 * C, dev=dev)
@@ -158,7 +173,8 @@ class TransformerBlockTrain:
         return dq, dkt, dvt
 
     def backward(self, dout: torch.Tensor) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
-        """dout fp32 [M, C] -> (dh fp32 [M, C], {attn3 parameter name: fp32 gradient}); oracle: transformer_block_bwd."""
+        """dout fp32 [M, C] -> (dh fp32 [M, C], {parameter name inside the trainable module: fp32 gradient}); oracle:
+        transformer_block_bwd."""
         s, C, dev = self.saved, self.C, self.dev
         B, M = s["B"], dout.shape[0]
         # feed-forward :298-300
@@ -173,13 +189,18 @@ class TransformerBlockTrain:
         dh3 = _e(M, C, dev=dev, dtype=F32)
         ops.layernorm_bwd(s["h3"], dn3, self.ln["norm3"][0], dh3, res=dout)
         dh3_16 = _cast16(dh3)
-        # image cross-attention (attn3): dgrad + the five weight gradients
-        do3 = _e(M, C, dev=dev)
-        ops.gemm(dh3_16, self.wt["attn3.to_out"], do3)
-        dq3, dk3t, dv3t = self._attend_bwd("attn3", s["a3"], do3, B, need_kv=True)
-        dn4 = _e(M, C, dev=dev)
-        ops.gemm(dq3, self.wt["attn3.to_q"], dn4)
-        grads = self._attn3_wgrads(s, dh3, dh3_16, dq3, dk3t, dv3t, B)
+        grads: Dict[str, torch.Tensor] = {}
+        dn4 = None
+        if s["a3"] is not None:
+            # image cross-attention (attn3): dgrad + (stage 2) the five weight gradients
+            do3 = _e(M, C, dev=dev)
+            ops.gemm(dh3_16, self.wt["attn3.to_out"], do3)
+            want3 = self.trainable == "attn3"
+            dq3, dk3t, dv3t = self._attend_bwd("attn3", s["a3"], do3, B, need_kv=want3)
+            dn4 = _e(M, C, dev=dev)
+            ops.gemm(dq3, self.wt["attn3.to_q"], dn4)
+            if want3:
+                grads = self._attn3_wgrads(s, dh3, dh3_16, dq3, dk3t, dv3t, B)
         # text cross-attention (attn2): only dq matters (text K/V and every attn2 weight are constants)
         do2 = _e(M, C, dev=dev)
         ops.gemm(dh3_16, self.wt["attn2.to_out"], do2)
@@ -188,7 +209,10 @@ class TransformerBlockTrain:
         ops.gemm(dq2, self.wt["attn2.to_q"], dn2)
         # both branches add h1 back: dh1 = 2 dh3 + dLN2 + dLN4 (one kernel: the two LayerNorms share their input)
         dh1 = _e(M, C, dev=dev, dtype=F32)
-        ops.layernorm_bwd(s["h1"], dn2, self.ln["norm2"][0], dh1, dy2=dn4, g2=self.ln["norm4"][0], res=dh3, res_scale=2.0)
+        if dn4 is not None:
+            ops.layernorm_bwd(s["h1"], dn2, self.ln["norm2"][0], dh1, dy2=dn4, g2=self.ln["norm4"][0], res=dh3, res_scale=2.0)
+        else:                                                                       # no image branch: h3 = attn2(LN2(h1)) + h1
+            ops.layernorm_bwd(s["h1"], dn2, self.ln["norm2"][0], dh1, res=dh3)
         dh1_16 = _cast16(dh1)
         # self-attention (attn1)
         do1 = _e(M, C, dev=dev)
@@ -206,7 +230,22 @@ class TransformerBlockTrain:
         ops.gemm(dv1, self.wt["attn1.to_v"], dn1, res1=dn1)
         dh = _e(M, C, dev=dev, dtype=F32)
         ops.layernorm_bwd(s["h"], dn1, self.ln["norm1"][0], dh, res=dh1)
+        if self.trainable == "attn1":
+            grads = self._attn1_wgrads(s, dh1_16, dq1, dk1, dv1)
         return dh, grads
+
+    def _attn1_wgrads(self, s, dh1_16, dq1, dk1, dv1) -> Dict[str, torch.Tensor]:
+        """Stage 1: q, k and v of the self-attention are all projections of n1 = LayerNorm1(h), so with the token-major dq / dk / dv the
+        backward walk already has, dW = d{q,k,v}^T n1; to_out as in _attn3_wgrads."""
+        C, dev = self.C, self.dev
+        f32 = lambda *sh: _e(*sh, dev=dev, dtype=F32)                                # noqa: E731
+        n1_t = _tr(s["n1"])                                                          # [C, M]
+        dh1_t = _tr(dh1_16)
+        g = {"to_q.weight": ops.gemm(_tr(dq1), n1_t, f32(C, C)), "to_k.weight": ops.gemm(_tr(dk1), n1_t, f32(C, C)),
+             "to_v.weight": ops.gemm(_tr(dv1), n1_t, f32(C, C)), "to_out.0.weight": ops.gemm(dh1_t, _tr(s["a1"]["o"]), f32(C, C))}
+        ones = torch.ones(8, dh1_t.shape[1], dtype=F16, device=dev)
+        g["to_out.0.bias"] = ops.gemm(dh1_t, ones, f32(C, 8))[:, 0].contiguous()
+        return g
 
     def _attn3_wgrads(self, s, dh3, dh3_16, dq3, dk3t, dv3t, B) -> Dict[str, torch.Tensor]:
         C, dev = self.C, self.dev

@@ -7,7 +7,8 @@
                                             :304-327   1-3 reference passes -> main pass -> masked MSE -> backward
                                             :328-333   clip_grad_norm_, optimizer.step(), lr_scheduler.step(), zero_grad()
                                             :348-357   checkpoint = the whole pipeline in diffusers folder layout
-(train_COCO.py:283-330 is the same loop with one reference frame).  `Stage2Trainer.step` takes either the raw batch of the
+(train_COCO.py:283-330 is the same loop with one reference frame; train_StorySalon_stage1.py:258-300 is the loop without reference passes
+and with the `attn1` modules trainable: `Stage2Trainer(..., trainable_modules=("attn1",))`).  `Stage2Trainer.step` takes either the raw batch of the
 reference's dataset (images, prompts, masks — encoded here by the HIP AutoencoderKL / CLIPTextModel) or the already-encoded tensors
 (`storygen_amd.synth.synthetic_train_batch`).  Data parallelism: one process per GPU, the attn3 gradients (49.6 M values) averaged
 by ONE RCCL all-reduce per optimizer step (`train.allreduce_gradients`), exactly where accelerate's DDP wrapper would do it.
@@ -39,9 +40,12 @@ class Stage2Trainer:
                  seed: Optional[int] = None):
         """unet: the drop-in UNet2DConditionModel in fp32 on the HIP device (the reference keeps it fp32, :226-235).  height / width are
         latent sizes.  vae / text_encoder / tokenizer are only needed for raw batches (`encode_batch`)."""
-        if tuple(trainable_modules) != ("attn3",):
-            raise NotImplementedError("the HIP backward produces weight gradients for the attn3 modules only (stage 2 / COCO, "
-                                      "train_StorySalon_stage2.py:170-177); stage 1's attn1 training is not built")
+        if tuple(trainable_modules) not in (("attn3",), ("attn1",)):
+            raise NotImplementedError("the HIP backward produces weight gradients for the attn3 modules (stage 2 / COCO, "
+                                      "train_StorySalon_stage2.py:170-177) or the attn1 modules (stage 1, train_StorySalon_stage1.py:175)")
+        self.module = tuple(trainable_modules)[0]
+        if self.module == "attn1":
+            n_ref = 0                                                              # stage 1 has no prior frames (:288 image_hidden_states=None)
         if unet.dtype != torch.float32 or unet.device.type != "cuda":
             raise TypeError("Stage2Trainer: the UNet must be fp32 on the HIP device")
         self.unet, self.vae, self.text_encoder, self.tokenizer = unet, vae, text_encoder, tokenizer
@@ -49,7 +53,7 @@ class Stage2Trainer:
         unet.requires_grad_(False)                                                               # :167-177
         self.named: Dict[str, torch.Tensor] = {}
         for name, p in unet.named_parameters():
-            if ".attn3." in name:
+            if f".{self.module}." in name:
                 p.requires_grad = True
                 self.named[name] = p
         world = torch.distributed.get_world_size() if torch.distributed.is_available() and torch.distributed.is_initialized() else 1
@@ -64,7 +68,7 @@ class Stage2Trainer:
                                           num_training_steps=None if train_steps is None else train_steps * gradient_accumulation_steps)
         self.max_grad_norm, self.accum = max_grad_norm, int(gradient_accumulation_steps)
         self.trainer = UNetTrainer(unet._arch, unet.state_dict(), self.dev, batch_size, height, width, n_ref=n_ref,
-                                   weights=unet._engine_weights())
+                                   weights=unet._engine_weights(), trainable=self.module)
         self.use_graph = use_graph
         self.global_step, self._micro = 0, 0
         self._acc: Optional[Dict[str, torch.Tensor]] = None
@@ -85,17 +89,19 @@ class Stage2Trainer:
         mask = batch["mask"].to(dev, torch.float32)[:, [0]].repeat(1, 4, 1, 1)
         mask = F.interpolate(mask, scale_factor=1 / 8.0, mode="bilinear", align_corners=False)
         latents = self.vae.encode(image).latent_dist.sample(generator) * 0.18215
-        refs = torch.transpose(batch["ref_image"].to(dev), 0, 1)
-        ref_latents = torch.stack([self.vae.encode(r).latent_dist.sample(generator) * 0.18215 for r in refs])
         b = latents.shape[0]
         gdev = generator.device if generator is not None else dev
         noise = torch.randn(latents.shape, generator=generator, device=gdev)
         ref_noise = torch.randn(latents.shape, generator=generator, device=gdev)
         timesteps = torch.randint(0, 1000, (b,), generator=generator, device=gdev)
         text = self.text_encoder(tok(batch["prompt"]).to(dev))[0]
-        prev_text = torch.stack([self.text_encoder(tok(p).to(dev))[0] for p in batch["ref_prompt"]])
-        return dict(latents=latents.float(), ref_latents=ref_latents.float(), noise=noise, ref_noise=ref_noise, timesteps=timesteps, text=text,
-                    prev_text=prev_text, mask=mask)
+        out = dict(latents=latents.float(), noise=noise, timesteps=timesteps, text=text, mask=mask)
+        if self.module == "attn3":                                                  # prior frames and their prompts (:276-288)
+            refs = torch.transpose(batch["ref_image"].to(dev), 0, 1)
+            out["ref_latents"] = torch.stack([self.vae.encode(r).latent_dist.sample(generator) * 0.18215 for r in refs]).float()
+            out["ref_noise"] = ref_noise
+            out["prev_text"] = torch.stack([self.text_encoder(tok(p).to(dev))[0] for p in batch["ref_prompt"]])
+        return out
 
     # ------------------------------------------------------------------------------------------------------- step
     def step(self, batch: dict, use_refs: Optional[Sequence[int]] = None) -> Dict[str, object]:
@@ -103,7 +109,9 @@ class Stage2Trainer:
         Returns {"loss": device scalar tensor, "lr": float, "optimizer_step": bool}."""
         if "image" in batch:
             batch = self.encode_batch(batch)
-        if use_refs is None:
+        if self.module == "attn1":
+            use_refs = ()
+        elif use_refs is None:
             use_refs = use_refs_for(self._rng.uniform(0, 1))
         run = self.trainer.train_step_graph if self.use_graph else self.trainer.train_step
         loss, grads = run(batch, use_refs=tuple(use_refs))
@@ -126,7 +134,7 @@ class Stage2Trainer:
             if self._acc is not None:
                 for a in self._acc.values():
                     a.zero_()
-            self.trainer.set_attn3_parameters(self.named)           # refresh the fp16 operand copies the kernels read
+            self.trainer.set_trainable_parameters(self.named)       # refresh the fp16 operand copies the kernels read
             self.global_step += 1
         return dict(loss=loss, lr=self.lr_scheduler.get_last_lr()[0], optimizer_step=stepped)
 

@@ -277,6 +277,35 @@ def test_training_step_vs_oracle(gpu, use_refs):
     assert max(errs.values()) < 1e-2
 
 
+def test_stage1_training_step_vs_oracle(gpu):
+    """Stage 1 (train_StorySalon_stage1.py:175-179,262-291) on the same 2-level UNet: no reference pass, main pass without image
+    context, the 30 attn1 gradients against oracle.storygen_oracle.train_step(..., (), trainable="attn1") — pinned to the reference's
+    own stage-1 step by tests/golden/tiny_train_stage1.pt."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.arch import build_arch, load_config
+    from storygen_amd.synth import synthetic_state_dict, synthetic_train_batch
+    from storygen_amd.train import UNetTrainer
+    cfg = load_config(dict(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                           up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), cross_attention_dim=768, attention_head_dim=8,
+                           sample_size=128))
+    arch = build_arch(cfg)
+    sd = synthetic_state_dict(arch, 7)
+    batch = {k: v for k, v in synthetic_train_batch(2, 16, 768, 7).items() if k not in ("ref_latents", "ref_noise", "prev_text")}
+    want_loss, want = O.train_step(sd, cfg, batch, (), trainable="attn1")
+    tr = UNetTrainer(arch, sd, gpu, 2, 16, 16, n_ref=0, trainable="attn1")
+    loss, grads = tr.train_step(batch, ())
+    torch.cuda.synchronize()
+    assert abs(float(loss) - float(want_loss)) <= 2e-3 * abs(float(want_loss))
+    assert set(grads) == set(want) and all(".attn1." in k for k in grads)
+    errs = {k: rel(grads[k].cpu(), want[k]) for k in want}
+    print("stage 1, worst gradients:", sorted(errs.items(), key=lambda kv: -kv[1])[:3])
+    assert max(errs.values()) < 1e-2
+    l2, g2 = tr.train_step_graph(batch, ())                       # the captured step returns the same numbers
+    torch.cuda.synchronize()
+    assert abs(float(l2) - float(loss)) <= 1e-5 * abs(float(loss))
+    assert max(rel(g2[k], grads[k]) for k in grads) < 1e-3
+
+
 def test_training_step_graph_replay_matches_eager(gpu):
     """UNetTrainer.train_step_graph — the whole stage-2 step (reference passes, main pass, loss, backward) captured once and
     replayed as one hipGraph — must return the eager step's loss and 80 gradients, also for a NEW batch fed to the captured graph."""

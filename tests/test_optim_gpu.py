@@ -178,6 +178,25 @@ def test_stage2_trainer_8bit_accumulation_and_checkpoint(gpu, tmp_path):
     assert torch.equal(tr2.optimizer.state[i]["code1"], tr.optimizer.state[i]["code1"])
 
 
+def test_stage1_loop_trains_the_attn1_modules(gpu):
+    """train_StorySalon_stage1.py's loop body: Stage2Trainer(trainable_modules=("attn1",)) — no reference frames, attn1 trainable."""
+    from storygen_amd.synth import synthetic_train_batch
+    from storygen_amd.training import Stage2Trainer
+    unet = _small_unet(gpu)
+    before = {n: p.detach().clone() for n, p in unet.named_parameters()}
+    tr = Stage2Trainer(unet, 2, 16, 16, learning_rate=1e-3, use_8bit_adam=True, trainable_modules=("attn1",), use_graph=True)
+    assert len(tr.named) == 5 * 6 and all(".attn1." in n for n in tr.named)
+    batch = {k: v for k, v in synthetic_train_batch(2, 16, 768, 7).items() if k not in ("ref_latents", "ref_noise", "prev_text")}
+    losses = [float(tr.step(batch)["loss"]) for _ in range(3)]
+    print("stage-1 losses on the same batch:", losses)
+    assert losses[2] < losses[0]
+    for n, p in unet.named_parameters():
+        changed = not torch.equal(p.detach(), before[n])
+        assert changed == (".attn1." in n), n
+    with pytest.raises(NotImplementedError):
+        Stage2Trainer(unet, 2, 16, 16, trainable_modules=("attn2",))
+
+
 def test_trained_weights_reach_the_inference_engine(gpu):
     """The optimizer writes the parameters through raw pointers; bumping their autograd version makes the drop-in UNet's staleness tag
     see it, so the next inference forward runs on the new attn3 weights without rebuilding anything."""

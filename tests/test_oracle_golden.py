@@ -167,6 +167,27 @@ def test_oracle_train_step_vs_reference_golden(use_refs):
     assert max(errs.values()) < 1e-4, max(errs.items(), key=lambda kv: kv[1])
 
 
+def test_oracle_stage1_train_step_vs_reference_golden():
+    """Stage 1 (train_StorySalon_stage1.py:171-179,262-291): modules named `*attn1` trainable, no reference pass, main pass with
+    image_hidden_states=None — the oracle's loss and 80 attn1 gradients against the reference's own UNet + autograd
+    (oracle/make_golden_train.py stage1)."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.arch import build_arch
+    from storygen_amd.synth import synthetic_state_dict, synthetic_train_batch
+    gold = _load("tiny_train_stage1")
+    assert gold["trainable"] == "attn1"
+    arch = build_arch(gold["config"])
+    sd = synthetic_state_dict(arch, gold["seed"])
+    batch = synthetic_train_batch(gold["batch"], gold["hw"], arch.config["cross_attention_dim"], gold["seed"])
+    g = gold["cases"]["refs_"]
+    loss, grads = O.train_step(sd, arch.config, batch, (), trainable="attn1")
+    assert abs(float(loss) - g["loss"]) <= 1e-5 * abs(g["loss"])
+    assert set(grads) == set(g["grads"]) and all(".attn1." in k for k in grads)
+    for k, e in g["grads"].items():
+        assert rel_l2(grads[k].flatten()[e["idx"]], e["values"]) < 1e-4, k
+        assert abs(float(grads[k].double().norm()) - e["l2"]) <= 1e-4 * e["l2"], k
+
+
 def test_clip_text_oracle_matches_transformers_golden():
     """oracle/encoders_oracle.py::clip_text_forward against the outputs transformers' CLIPTextModel produced on the same (fp16-rounded)
     weights — the fixture oracle/make_golden_encoders.py wrote; that script also checks a 768-wide, 12-head configuration."""

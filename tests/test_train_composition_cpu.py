@@ -118,6 +118,63 @@ def test_training_step_composition_vs_oracle(cpu_ops, use_refs):
     assert max(errs.values()) < 2e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
 
 
+def test_stage1_block_composition_attn1_gradients_without_image_context(cpu_ops):
+    """Stage 1 (train_StorySalon_stage1.py:175-179,288): the block runs without image context (attn3 skipped) and returns the five
+    attn1 weight gradients — against torch autograd through the oracle's block."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.train_blocks import TransformerBlockTrain
+    from test_backward_gpu import _block_sd
+    C, heads, Bn, N, S = 64, 2, 2, 24, 13
+    sd = _block_sd(C, 96, 3)
+    g = torch.Generator().manual_seed(2)
+    h, text, dout = _r(g, Bn, N, C), _r(g, Bn, S, 96), _r(g, Bn, N, C)
+    names = [f"b.attn1.{k}" for k in ("to_q.weight", "to_k.weight", "to_v.weight", "to_out.0.weight", "to_out.0.bias")]
+    params = {k: (v.clone().requires_grad_(True) if k in names else v) for k, v in sd.items()}
+    hin = h.clone().requires_grad_(True)
+    want_out, _ = O.transformer_block(params, "b", hin, text, None, heads)
+    want = torch.autograd.grad(want_out, [hin] + [params[k] for k in names], dout)
+    blk = TransformerBlockTrain(sd, "b", heads, "cpu", trainable="attn1")
+    out = blk.forward(h.reshape(Bn * N, C).contiguous(), text.half().reshape(Bn * S, 96).contiguous(), None, Bn)
+    assert rel_l2(out.view(Bn, N, C), want_out.detach()) < 3e-3
+    dh, grads = blk.backward(dout.reshape(Bn * N, C).contiguous())
+    assert rel_l2(dh.view(Bn, N, C), want[0]) < 1e-2
+    assert set(grads) == {k[len("b.attn1."):] for k in names}
+    for k, w in zip(names, want[1:]):
+        assert rel_l2(grads[k[len("b.attn1."):]], w) < 1e-2, k
+    with pytest.raises(NotImplementedError):
+        TransformerBlockTrain(sd, "b", heads, "cpu", trainable="attn2")
+
+
+def test_stage1_training_step_composition_vs_oracle(cpu_ops):
+    """UNetTrainer(trainable="attn1").train_step(batch, use_refs=()) — no reference pass, no image context — against
+    oracle.storygen_oracle.train_step(..., (), trainable="attn1"), itself pinned to the reference's stage-1 step
+    (tests/golden/tiny_train_stage1.pt)."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.arch import build_arch, load_config
+    from storygen_amd.synth import synthetic_state_dict, synthetic_train_batch
+    from storygen_amd.train import UNetTrainer
+    cfg = load_config(dict(block_out_channels=(32, 64), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                           up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), cross_attention_dim=48, attention_head_dim=2,
+                           norm_num_groups=8, sample_size=64))
+    arch = build_arch(cfg)
+    sd = synthetic_state_dict(arch, 7)
+    Bn, hw = 2, 8
+    batch = {k: v for k, v in synthetic_train_batch(Bn, hw, 48, 7).items() if k not in ("ref_latents", "ref_noise", "prev_text")}
+    want_loss, want = O.train_step(sd, cfg, batch, (), trainable="attn1")
+    tr = UNetTrainer(arch, sd, "cpu", Bn, hw, hw, n_ref=0, trainable="attn1")
+    loss, grads = tr.train_step(batch, ())
+    assert abs(float(loss) - float(want_loss)) <= 5e-3 * abs(float(want_loss))
+    assert set(grads) == set(want) and all(".attn1." in k for k in grads) and len(grads) == 5 * len(arch.feature_keys)
+    errs = {k: rel_l2(grads[k], want[k]) for k in want}
+    assert max(errs.values()) < 2e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    # the refresh after an optimizer step goes to the attn1 operand copies, in place
+    name = next(iter(grads))
+    blk = tr.xfs[name.split(".transformer_blocks.")[0]].blk
+    before = blk.w["attn1.to_q"].data_ptr()
+    tr.set_trainable_parameters({k: torch.zeros_like(sd[k]) for k in grads})
+    assert blk.w["attn1.to_q"].data_ptr() == before and float(blk.w["attn1.to_q"].abs().max()) == 0.0
+
+
 def test_main_pass_autograd_function_routes_gradients_to_the_attn3_parameters(cpu_ops):
     """storygen_amd.train.MainPassFunction — what the drop-in model's forward uses under autograd: a plain torch loss on
     its output, loss.backward(), and the attn3 leaves must receive the oracle's gradients; nothing else gets one."""

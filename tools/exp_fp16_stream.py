@@ -30,8 +30,8 @@ def main():
     inputs = synthetic_inputs(1, R, hw, hw, gold["seed"], arch.config["cross_attention_dim"])
     want = gold["stages"]["multi-image-condition"]["latents"]
     out = {}
-    for flag in (False, True):
-        engine.FP16_BLOCK_STREAM = flag
+    for name, blk, res in (("fp32_stream", False, False), ("fp16_block_stream", True, False), ("fp16_whole_stream", True, True)):
+        engine.FP16_BLOCK_STREAM, engine.FP16_RESNET_STREAM = blk, res
         smp = StoryGenSampler(arch, sd, dev, 1, hw, hw, R)
         smp.prepare(inputs, gold["n_steps"], "multi-image-condition", *gold["guidance"])
         trace = []
@@ -46,7 +46,7 @@ def main():
         for _ in range(20):
             smp.step()
         torch.cuda.synchronize()
-        out["fp16_block_stream" if flag else "fp32_stream"] = dict(err_step_1=errs[0], err_step_10=errs[9], err_step_25=errs[24], err_step_50=errs[49],
+        out[name] = dict(err_step_1=errs[0], err_step_10=errs[9], err_step_25=errs[24], err_step_50=errs[49],
                                                                    err_max=max(errs), ms_per_step=round((time.perf_counter() - t0) / 20 * 1e3, 3))
         del smp
         torch.cuda.empty_cache()
