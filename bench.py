@@ -238,8 +238,6 @@ def main():
     ap.add_argument("--spread", type=int, default=-1, help="A/B: placement of the ring-refill DMA instructions (sg_debug_set_spread)")
     ap.add_argument("--conv-patch", action="store_true",
                     help="A/B: eligible 3x3 convolutions through the LDS-resident-input-patch kernel (experiment, default off)")
-    ap.add_argument("--fp16-block-stream", action="store_true",
-                    help="A/B (changes results, never the contract line): fp16 residual stream inside the transformer blocks")
     ap.add_argument("--no-gn-epilogue", action="store_true", help="A/B: every GroupNorm makes its own statistics pass")
     ap.add_argument("--fp16-block-stream", action="store_true",
                     help="A/B (changes results, never the contract line): fp16 residual stream inside the transformer blocks")

@@ -369,3 +369,13 @@ def test_ref_ahead_needs_graph_and_overlap():
     for kw in (dict(use_graph=False), dict(overlap=False), dict(ref_ahead=0)):
         with pytest.raises(ValueError):
             StoryGenSampler(arch, None, "cpu", ref_ahead=kw.pop("ref_ahead", 2), weights=object(), **kw)
+
+
+def test_bench_argument_parser_builds():
+    """`python bench.py --help` must exit 0: a duplicated add_argument (it happened) would break every driver run before any GPU work."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-500:]
+    assert "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
