@@ -92,7 +92,7 @@ class Stage2Trainer:
         b = latents.shape[0]
         gdev = generator.device if generator is not None else dev
         noise = torch.randn(latents.shape, generator=generator, device=gdev)
-        ref_noise = torch.randn(latents.shape, generator=generator, device=gdev)
+        ref_noise = torch.randn(latents.shape, generator=generator, device=gdev) if self.module == "attn3" else None   # stage 1 draws none (:277)
         timesteps = torch.randint(0, 1000, (b,), generator=generator, device=gdev)
         text = self.text_encoder(tok(batch["prompt"]).to(dev))[0]
         out = dict(latents=latents.float(), noise=noise, timesteps=timesteps, text=text, mask=mask)

@@ -197,6 +197,41 @@ def test_stage1_loop_trains_the_attn1_modules(gpu):
         Stage2Trainer(unet, 2, 16, 16, trainable_modules=("attn2",))
 
 
+def test_stage2_trainer_raw_dataset_batch_through_the_hip_encoders(gpu):
+    """The reference loop's own per-step plumbing (train_StorySalon_stage2.py:265-302): a raw dataset batch — images, text/face mask,
+    prompts, 3 prior frames with their prompts — goes through the HIP AutoencoderKL and CLIPTextModel inside Stage2Trainer.step."""
+    from types import SimpleNamespace
+    from storygen_amd.model import AutoencoderKL, CLIPTextModel
+    from storygen_amd.training import Stage2Trainer
+
+    class Tok:
+        model_max_length = 77
+
+        def __call__(self, prompt, truncation=None, padding=None, max_length=None, return_tensors=None):
+            prompts = [prompt] if isinstance(prompt, str) else list(prompt)
+            ids = torch.stack([torch.randint(1, 999, (77,), generator=torch.Generator().manual_seed(len(p))) for p in prompts])
+            return SimpleNamespace(input_ids=ids)
+
+    unet = _small_unet(gpu)
+    vae = AutoencoderKL(block_out_channels=(64, 64, 128, 128), down_block_types=("DownEncoderBlock2D",) * 4,
+                        up_block_types=("UpDecoderBlock2D",) * 4, layers_per_block=1, seed=4).to(gpu, torch.float16)
+    clip = CLIPTextModel(dict(vocab_size=1000, hidden_size=768, intermediate_size=1024, num_hidden_layers=2, num_attention_heads=12), seed=5)
+    clip = clip.to(gpu, torch.float16)
+    tr = Stage2Trainer(unet, 2, 16, 16, learning_rate=1e-4, use_8bit_adam=True, use_graph=False, vae=vae, text_encoder=clip, tokenizer=Tok(), seed=1)
+    g = torch.Generator().manual_seed(0)
+    raw = dict(image=torch.rand(2, 3, 128, 128, generator=g), mask=(torch.rand(2, 3, 128, 128, generator=g) > 0.7).float(),
+               prompt=["a cat", "a small dog"], ref_image=torch.rand(2, 3, 3, 128, 128, generator=g),
+               ref_prompt=[["one", "two"], ["three", "four"], ["five", "six"]])
+    enc = tr.encode_batch(raw, generator=torch.Generator().manual_seed(3))
+    assert tuple(enc["latents"].shape) == (2, 4, 16, 16) and tuple(enc["ref_latents"].shape) == (3, 2, 4, 16, 16)
+    assert tuple(enc["text"].shape) == (2, 77, 768) and tuple(enc["prev_text"].shape) == (3, 2, 77, 768) and tuple(enc["mask"].shape) == (2, 4, 16, 16)
+    assert all(bool(torch.isfinite(v.float()).all()) for v in enc.values())
+    before = {n: p.detach().clone() for n, p in tr.named.items()}
+    out = tr.step(raw)
+    assert out["optimizer_step"] and bool(torch.isfinite(out["loss"]).all()) and 0.0 < float(out["loss"]) < 10.0
+    assert all(not torch.equal(p.detach(), before[n]) for n, p in tr.named.items())
+
+
 def test_trained_weights_reach_the_inference_engine(gpu):
     """The optimizer writes the parameters through raw pointers; bumping their autograd version makes the drop-in UNet's staleness tag
     see it, so the next inference forward runs on the new attn3 weights without rebuilding anything."""
