@@ -9,6 +9,8 @@ fixed random index sample.  As a self-check the restatement oracle.storygen_orac
 Usage:  python oracle/make_golden_train.py            (build container only; writes tests/golden/tiny_train.pt)
         python oracle/make_golden_train.py stage1     (train_StorySalon_stage1.py:171-179,262-291: modules named `*attn1` trainable, no
                                                        reference pass, image_hidden_states=None; writes tests/golden/tiny_train_stage1.pt)
+        python oracle/make_golden_train.py coco       (train_COCO.py:286-316: three frames, all at noise level ref_t, unmasked loss;
+                                                       writes tests/golden/tiny_train_coco.pt)
 """
 from __future__ import annotations
 
@@ -36,16 +38,18 @@ def rel_l2(a, b):
     return float((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-30))
 
 
-def main(stage1: bool = False):
+def main(stage1: bool = False, coco: bool = False):
     cfg = load_config(TINY_CONFIG)
     arch = build_arch(cfg)
     seed, b, hw = 5, 2, 64            # the reference's consume path needs a 64..94 latent
     sd = synthetic_state_dict(arch, seed)
     batch = synthetic_train_batch(b, hw, cfg["cross_attention_dim"], seed)
     target = "attn1" if stage1 else "attn3"
-    out = dict(case="tiny_train_stage1" if stage1 else "tiny_train", config=cfg, seed=seed, batch=b, hw=hw, trainable=target,
+    if coco:
+        batch["mask"] = torch.zeros_like(batch["mask"])                                   # train_COCO.py:315: plain MSE
+    out = dict(case="tiny_train_stage1" if stage1 else ("tiny_train_coco" if coco else "tiny_train"), config=cfg, seed=seed, batch=b, hw=hw, trainable=target,
                made_by="oracle/make_golden_train.py", cases={})
-    for use_refs in (((),) if stage1 else ((0, 1, 2), (2,))):
+    for use_refs in (((),) if stage1 else (((0, 1, 2),) if coco else ((0, 1, 2), (2,)))):
         unet = build_reference_unet(cfg, sd)
         unet.requires_grad_(False)                                                        # :166-168
         for name, module in unet.named_modules():                                         # :170-175
@@ -60,8 +64,9 @@ def main(stage1: bool = False):
         noisy = O.ddpm_add_noise(sched, batch["latents"], batch["noise"], t)
         feats = []
         for i in use_refs:
-            x = O.ddpm_add_noise(sched, batch["ref_latents"][i], batch["ref_noise"], ref_t * (3 - i))
-            feats.append(unet(x, ref_t * (3 - i), encoder_hidden_states=batch["prev_text"][i], return_dict=False)[1])
+            ti = ref_t if coco else ref_t * (3 - i)                                       # train_COCO.py:303-304 vs stage 2 :311
+            x = O.ddpm_add_noise(sched, batch["ref_latents"][i], batch["ref_noise"], ti)
+            feats.append(unet(x, ti, encoder_hidden_states=batch["prev_text"][i], return_dict=False)[1])
         ctx = {k: torch.cat([f[k] for f in feats], dim=1) for k in feats[0]} if feats else None
         pred = unet(noisy, t, encoder_hidden_states=batch["text"], image_hidden_states=ctx, return_dict=False)[0]
         loss = F.mse_loss(pred.float() * (1.0 - batch["mask"]), batch["noise"].float() * (1 - batch["mask"]), reduction="mean")
@@ -69,7 +74,7 @@ def main(stage1: bool = False):
         grads = {n: p.grad.detach().clone() for n, p in unet.named_parameters() if p.requires_grad}
         assert all(k.endswith(O.trainable_suffixes(target)) for k in grads) and len(grads) == 5 * len(arch.feature_keys)
         print(f"reference train step refs={use_refs}: loss {float(loss):.6f}, {len(grads)} grads, {time.time() - t0:.1f}s", flush=True)
-        o_loss, o_grads = O.train_step(sd, cfg, batch, use_refs, trainable=target)
+        o_loss, o_grads = O.train_step(sd, cfg, batch, use_refs, trainable=target, ref_levels="coco" if coco else "stage2")
         errs = [abs(float(o_loss) - float(loss)) / abs(float(loss))] + [rel_l2(o_grads[k], grads[k]) for k in grads]
         print(f"restatement vs reference: max rel err {max(errs):.2e}", flush=True)
         assert max(errs) < 1e-4, errs
@@ -86,4 +91,4 @@ def main(stage1: bool = False):
 
 if __name__ == "__main__":
     torch.set_num_threads(os.cpu_count() or 1)
-    main(stage1=len(sys.argv) > 1 and sys.argv[1] == "stage1")
+    main(stage1=len(sys.argv) > 1 and sys.argv[1] == "stage1", coco=len(sys.argv) > 1 and sys.argv[1] == "coco")

@@ -320,14 +320,18 @@ def ddpm_add_noise(sched: DDIM, x: Tensor, noise: Tensor, t: Tensor) -> Tensor:
     return a.sqrt() * x + (1 - a).sqrt() * noise
 
 
-def train_step(sd: SD, cfg: dict, batch: Dict[str, Tensor], use_refs=(0, 1, 2), trainable: str = "attn3") -> Tuple[Tensor, Dict[str, Tensor]]:
+def train_step(sd: SD, cfg: dict, batch: Dict[str, Tensor], use_refs=(0, 1, 2), trainable: str = "attn3",
+               ref_levels: str = "stage2") -> Tuple[Tensor, Dict[str, Tensor]]:
     """Loss and attn3 gradients of one stage-2 training step, train_StorySalon_stage2.py:291-327 after its CLIP / VAE
     plumbing: `batch` holds latents [b,4,h,w], ref_latents [3,b,4,h,w], noise, ref_noise, timesteps [b] (int64), text
     [b,77,c], prev_text [3,b,77,c] and the already 1/8-downsampled mask [b,4,h,w] (:268-270).  `use_refs` replaces the
     random draw of :306-310 (p < 0.3 -> (0,1,2); 0.3 <= p < 0.6 -> (1,2); else (2,)).  The reference-frame noise level
     is ref_t * (3 - i) with the literal 3 of :311, whatever the number of frames used.
     Stage 1 (train_StorySalon_stage1.py:262-291) is the same step with use_refs=() — no reference pass, the main pass runs with
-    image_hidden_states=None — and trainable="attn1"."""
+    image_hidden_states=None — and trainable="attn1".  train_COCO.py:286-316 is the stage-2 step with all three frames, every
+    frame at the noise level ref_t (ref_levels="coco": no `* (3 - i)`, :303-304) and an unmasked loss (pass a zero mask, :315)."""
+    if ref_levels not in ("stage2", "coco"):
+        raise ValueError(ref_levels)
     suffixes = trainable_suffixes(trainable)
     params = {k: (v.detach().clone().requires_grad_(True) if k.endswith(suffixes) else v) for k, v in sd.items()}
     sched = DDIM()
@@ -336,7 +340,7 @@ def train_step(sd: SD, cfg: dict, batch: Dict[str, Tensor], use_refs=(0, 1, 2), 
     noisy = ddpm_add_noise(sched, batch["latents"], batch["noise"], t)                    # :303
     feats = []
     for i in use_refs:                                                                    # :309-314
-        ti = ref_t * (3 - i)
+        ti = ref_t * (3 - i) if ref_levels == "stage2" else ref_t
         x = ddpm_add_noise(sched, batch["ref_latents"][i], batch["ref_noise"], ti)
         feats.append(unet_forward(params, cfg, x, ti, batch["prev_text"][i], None)[1])
     ctx = {k: torch.cat([f[k] for f in feats], dim=1) for k in feats[0]} if feats else None   # :316-318 (stage 1: None, :288)

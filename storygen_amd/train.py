@@ -92,6 +92,7 @@ class UNetTrainer:
         self.resnets = {r.prefix: ResnetBlockTrain(sd, r.prefix, self.groups, self.eps, device) for r in arch.resnets}
         self.temb_proj = {r.prefix: (g16(f"{r.prefix}.time_emb_proj.weight"), g16(f"{r.prefix}.time_emb_proj.bias")) for r in arch.resnets}
         self.trainable = trainable
+        self.ref_levels = "stage2"      # noise level of reference frame i: ref_t * (3 - i) (stage 2, :311) or ref_t for all ("coco", train_COCO.py:303)
         self.xfs = {a.prefix: Transformer2DTrain(sd, a, self.groups, device, trainable)
                     for blk in arch.down + [arch.mid] + arch.up for a in blk.attns if a is not None}
         self.samplers = {}
@@ -179,7 +180,7 @@ class UNetTrainer:
         ref_t = torch.div(t, 10, rounding_mode="floor")                              # (timesteps / 10).long(), :297-300
         # ---- reference passes: features of the frames used, harvested into context slots 0..len(use_refs)-1
         for slot, i in enumerate(use_refs):                                          # :309-314
-            ti = ref_t * (3 - i)
+            ti = ref_t * (3 - i) if self.ref_levels == "stage2" else ref_t
             self.ref.set_inputs(self._add_noise(inp["ref_latents"][i], inp["ref_noise"], ti), ti.float(), inp["prev_text"][i])
             self.ref.forward(harvest_slot=slot)
         n_used = len(use_refs)

@@ -7,8 +7,9 @@
                                             :304-327   1-3 reference passes -> main pass -> masked MSE -> backward
                                             :328-333   clip_grad_norm_, optimizer.step(), lr_scheduler.step(), zero_grad()
                                             :348-357   checkpoint = the whole pipeline in diffusers folder layout
-(train_COCO.py:283-330 is the same loop with one reference frame; train_StorySalon_stage1.py:258-300 is the loop without reference passes
-and with the `attn1` modules trainable: `Stage2Trainer(..., trainable_modules=("attn1",))`).  `Stage2Trainer.step` takes either the raw batch of the
+(train_COCO.py:286-330 is the same loop with all three frames at one noise level and an unmasked loss: `variant="coco"`;
+train_StorySalon_stage1.py:258-300 is the loop without reference passes and with the `attn1` modules trainable:
+`Stage2Trainer(..., trainable_modules=("attn1",))`).  `Stage2Trainer.step` takes either the raw batch of the
 reference's dataset (images, prompts, masks — encoded here by the HIP AutoencoderKL / CLIPTextModel) or the already-encoded tensors
 (`storygen_amd.synth.synthetic_train_batch`).  Data parallelism: one process per GPU, the attn3 gradients (49.6 M values) averaged
 by ONE RCCL all-reduce per optimizer step (`train.allreduce_gradients`), exactly where accelerate's DDP wrapper would do it.
@@ -37,9 +38,13 @@ class Stage2Trainer:
                  use_8bit_adam: bool = True, max_grad_norm: float = 1.0, lr_scheduler: str = "constant", lr_warmup_steps: int = 0,
                  train_steps: Optional[int] = None, gradient_accumulation_steps: int = 1, scale_lr: bool = False,
                  trainable_modules: Sequence[str] = ("attn3",), use_graph: bool = True, vae=None, text_encoder=None, tokenizer=None,
-                 seed: Optional[int] = None):
+                 seed: Optional[int] = None, variant: str = "storysalon"):
         """unet: the drop-in UNet2DConditionModel in fp32 on the HIP device (the reference keeps it fp32, :226-235).  height / width are
-        latent sizes.  vae / text_encoder / tokenizer are only needed for raw batches (`encode_batch`)."""
+        latent sizes.  vae / text_encoder / tokenizer are only needed for raw batches (`encode_batch`).  variant="coco" =
+        train_COCO.py:286-316: always the three frames, each at noise level ref_t (no `* (3 - i)`), loss without the mask."""
+        if variant not in ("storysalon", "coco"):
+            raise ValueError(f"variant must be 'storysalon' or 'coco', got {variant!r}")
+        self.variant = variant
         if tuple(trainable_modules) not in (("attn3",), ("attn1",)):
             raise NotImplementedError("the HIP backward produces weight gradients for the attn3 modules (stage 2 / COCO, "
                                       "train_StorySalon_stage2.py:170-177) or the attn1 modules (stage 1, train_StorySalon_stage1.py:175)")
@@ -69,6 +74,8 @@ class Stage2Trainer:
         self.max_grad_norm, self.accum = max_grad_norm, int(gradient_accumulation_steps)
         self.trainer = UNetTrainer(unet._arch, unet.state_dict(), self.dev, batch_size, height, width, n_ref=n_ref,
                                    weights=unet._engine_weights(), trainable=self.module)
+        if variant == "coco":
+            self.trainer.ref_levels = "coco"
         self.use_graph = use_graph
         self.global_step, self._micro = 0, 0
         self._acc: Optional[Dict[str, torch.Tensor]] = None
@@ -111,6 +118,9 @@ class Stage2Trainer:
             batch = self.encode_batch(batch)
         if self.module == "attn1":
             use_refs = ()
+        elif self.variant == "coco":
+            use_refs = (0, 1, 2)                                                       # train_COCO.py:301: every frame, every step
+            batch = dict(batch, mask=torch.zeros_like(batch["mask"]))                  # :315: unmasked MSE
         elif use_refs is None:
             use_refs = use_refs_for(self._rng.uniform(0, 1))
         run = self.trainer.train_step_graph if self.use_graph else self.trainer.train_step

@@ -232,6 +232,29 @@ def test_stage2_trainer_raw_dataset_batch_through_the_hip_encoders(gpu):
     assert all(not torch.equal(p.detach(), before[n]) for n, p in tr.named.items())
 
 
+def test_coco_variant_of_the_loop(gpu):
+    """train_COCO.py:286-316 through Stage2Trainer(variant="coco"): loss and gradients of its first step equal the oracle's COCO rule
+    (pinned to the reference by tests/golden/tiny_train_coco.pt) — in particular they differ from the stage-2 rule on the same batch."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.arch import build_arch, load_config
+    from storygen_amd.synth import synthetic_state_dict, synthetic_train_batch
+    from storygen_amd.training import Stage2Trainer
+    cfg = load_config(dict(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                           up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), cross_attention_dim=768, attention_head_dim=8, sample_size=128))
+    sd = synthetic_state_dict(build_arch(cfg), 7)
+    batch = synthetic_train_batch(2, 16, 768, 7)
+    zero_mask = dict(batch, mask=torch.zeros_like(batch["mask"]))
+    want_loss, want = O.train_step(sd, cfg, zero_mask, (0, 1, 2), ref_levels="coco")
+    tr = Stage2Trainer(_small_unet(gpu), 2, 16, 16, learning_rate=1e-4, use_8bit_adam=False, use_graph=False, variant="coco")
+    _, grads = tr.trainer.train_step(zero_mask, (0, 1, 2))
+    errs = {k: rel_l2(grads[k].cpu(), want[k]) for k in want}
+    assert max(errs.values()) < 1e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+    out = tr.step(batch)                                            # the driver zeroes the mask and uses every frame itself
+    assert abs(float(out["loss"]) - float(want_loss)) <= 2e-3 * abs(float(want_loss))
+    with pytest.raises(ValueError):
+        Stage2Trainer(_small_unet(gpu), 2, 16, 16, variant="imagenet")
+
+
 def test_trained_weights_reach_the_inference_engine(gpu):
     """The optimizer writes the parameters through raw pointers; bumping their autograd version makes the drop-in UNet's staleness tag
     see it, so the next inference forward runs on the new attn3 weights without rebuilding anything."""

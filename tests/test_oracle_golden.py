@@ -188,6 +188,25 @@ def test_oracle_stage1_train_step_vs_reference_golden():
         assert abs(float(grads[k].double().norm()) - e["l2"]) <= 1e-4 * e["l2"], k
 
 
+def test_oracle_coco_train_step_vs_reference_golden():
+    """train_COCO.py:286-316 (three frames at one noise level, unmasked loss): oracle vs the reference's own UNet + autograd."""
+    if os.environ.get("SG_SLOW_TESTS") != "1":
+        pytest.skip("~40 s of CPU; set SG_SLOW_TESTS=1 (oracle/make_golden_train.py coco ran the same comparison when it wrote the fixture)")
+    from oracle import storygen_oracle as O
+    from storygen_amd.arch import build_arch
+    from storygen_amd.synth import synthetic_state_dict, synthetic_train_batch
+    gold = _load("tiny_train_coco")
+    arch = build_arch(gold["config"])
+    sd = synthetic_state_dict(arch, gold["seed"])
+    batch = synthetic_train_batch(gold["batch"], gold["hw"], arch.config["cross_attention_dim"], gold["seed"])
+    batch["mask"] = torch.zeros_like(batch["mask"])
+    g = gold["cases"]["refs_012"]
+    loss, grads = O.train_step(sd, arch.config, batch, (0, 1, 2), ref_levels="coco")
+    assert abs(float(loss) - g["loss"]) <= 1e-5 * abs(g["loss"])
+    for k, e in g["grads"].items():
+        assert rel_l2(grads[k].flatten()[e["idx"]], e["values"]) < 1e-4, k
+
+
 def test_clip_text_oracle_matches_transformers_golden():
     """oracle/encoders_oracle.py::clip_text_forward against the outputs transformers' CLIPTextModel produced on the same (fp16-rounded)
     weights — the fixture oracle/make_golden_encoders.py wrote; that script also checks a 768-wide, 12-head configuration."""

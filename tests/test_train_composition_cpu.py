@@ -175,6 +175,30 @@ def test_stage1_training_step_composition_vs_oracle(cpu_ops):
     assert blk.w["attn1.to_q"].data_ptr() == before and float(blk.w["attn1.to_q"].abs().max()) == 0.0
 
 
+def test_coco_training_step_composition_vs_oracle(cpu_ops):
+    """train_COCO.py:286-316 — every frame at noise level ref_t, unmasked loss — through UNetTrainer.ref_levels = "coco"."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.arch import build_arch, load_config
+    from storygen_amd.synth import synthetic_state_dict, synthetic_train_batch
+    from storygen_amd.train import UNetTrainer
+    cfg = load_config(dict(block_out_channels=(32, 64), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                           up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), cross_attention_dim=48, attention_head_dim=2,
+                           norm_num_groups=8, sample_size=64))
+    arch = build_arch(cfg)
+    sd = synthetic_state_dict(arch, 7)
+    Bn, hw = 2, 8
+    batch = synthetic_train_batch(Bn, hw, 48, 7)
+    batch["mask"] = torch.zeros_like(batch["mask"])
+    want_loss, want = O.train_step(sd, cfg, batch, (0, 1, 2), ref_levels="coco")
+    other_loss, _ = O.train_step(sd, cfg, batch, (0, 1, 2))
+    assert abs(float(want_loss) - float(other_loss)) > 1e-4 * abs(float(want_loss))        # the two rules really differ
+    tr = UNetTrainer(arch, sd, "cpu", Bn, hw, hw, n_ref=3, ref_engine=_OracleRefEngine(sd, cfg, arch, Bn, 3, hw, hw))
+    tr.ref_levels = "coco"
+    loss, grads = tr.train_step(batch, (0, 1, 2))
+    assert abs(float(loss) - float(want_loss)) <= 5e-3 * abs(float(want_loss))
+    assert max(rel_l2(grads[k], want[k]) for k in want) < 2e-2
+
+
 def test_main_pass_autograd_function_routes_gradients_to_the_attn3_parameters(cpu_ops):
     """storygen_amd.train.MainPassFunction — what the drop-in model's forward uses under autograd: a plain torch loss on
     its output, loss.backward(), and the attn3 leaves must receive the oracle's gradients; nothing else gets one."""
