@@ -283,25 +283,26 @@ class UNet2DConditionModel(nn.Module):
             eng = self._engines[key] = UNetEngine(self._arch, None, self.device, B, H, W, R, S, weights=wts)
         return eng
 
-    def _forward_train(self, sample, timestep, encoder_hidden_states, image_hidden_states, return_dict):
-        """Main pass under autograd: gradients for the attn3 parameters through storygen_amd.train.MainPassFunction."""
+    def _forward_train(self, sample, timestep, encoder_hidden_states, image_hidden_states, return_dict, module: str = "attn3"):
+        """Main pass under autograd: gradients for the parameters of the trainable module (`attn3` with image context — stage 2 / COCO;
+        `attn1` without — stage 1) through storygen_amd.train.MainPassFunction."""
         from ..train import MainPassFunction, UNetTrainer
         B, _, H, W = sample.shape
         shapes = feature_shapes(self._arch, H, W)
         k0 = self._arch.feature_keys[0]
-        R = image_hidden_states[k0].shape[1] // shapes[k0][0]
-        key = (B, H, W, R)
+        R = 0 if image_hidden_states is None else image_hidden_states[k0].shape[1] // shapes[k0][0]
+        key = (B, H, W, R, module)
         tr = self._trainers.get(key)                     # kept apart from the inference engines' LRU
         if tr is None:
             self._trainers.clear()
             tr = self._trainers[key] = UNetTrainer(self._arch, self.state_dict(), self.device, B, H, W, n_ref=R,
                                                   ref_engine=object(),      # reference passes go through forward(None)
-                                                  weights=self._engine_weights())
+                                                  weights=self._engine_weights(), trainable=module)
         t = timestep if torch.is_tensor(timestep) else torch.tensor([timestep])
         t = t.to(self.device, torch.float32).reshape(-1)
         t = t.expand(B) if t.numel() == 1 else t
         named = [(n, p) for n, p in self.named_parameters() if p.requires_grad]
-        keys = list(shapes)
+        keys = list(shapes) if image_hidden_states is not None else []
         feats = [image_hidden_states[k].to(self.device, torch.float16).reshape(-1, shapes[k][1]).contiguous() for k in keys]
         text16 = encoder_hidden_states.to(self.device, torch.float16).reshape(-1, encoder_hidden_states.shape[-1]).contiguous()
         pred = MainPassFunction.apply(tr, [n for n, _ in named], keys, sample.to(self.device, torch.float32).contiguous(), t, text16,
@@ -321,15 +322,18 @@ class UNet2DConditionModel(nn.Module):
             raise RuntimeError("the HIP UNet has no CPU path: move the model to a HIP device (model.to('cuda'))")
         training = torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters())
         if training:
-            other = [n for n, p in self.named_parameters() if p.requires_grad and ".attn3." not in n]
-            if other:
-                raise NotImplementedError(f"only the attn3 modules are trainable on the HIP path (stage 2, "
-                                          f"train_StorySalon_stage2.py:170-177); also trainable here: {other[:3]} ...")
-            if image_hidden_states is not None:
-                return self._forward_train(sample, timestep, encoder_hidden_states, image_hidden_states, return_dict)
-            # harvest pass: attn3 is not evaluated, so no gradient reaches a trainable parameter through it
-            with torch.no_grad():
-                return self.forward(sample, timestep, encoder_hidden_states, None, return_dict=return_dict)
+            mods = {("attn1" if ".attn1." in n else "attn3" if ".attn3." in n else n) for n, p in self.named_parameters() if p.requires_grad}
+            if mods == {"attn3"}:                       # stage 2 / COCO, train_StorySalon_stage2.py:170-177
+                if image_hidden_states is not None:
+                    return self._forward_train(sample, timestep, encoder_hidden_states, image_hidden_states, return_dict, "attn3")
+                # harvest pass: attn3 is not evaluated, so no gradient reaches a trainable parameter through it
+                with torch.no_grad():
+                    return self.forward(sample, timestep, encoder_hidden_states, None, return_dict=return_dict)
+            if mods == {"attn1"} and image_hidden_states is None:      # stage 1, train_StorySalon_stage1.py:175-179,288
+                return self._forward_train(sample, timestep, encoder_hidden_states, None, return_dict, "attn1")
+            raise NotImplementedError("the HIP backward covers: the attn3 modules trainable (stage 2, train_StorySalon_stage2.py:170-177) or the "
+                                      "attn1 modules trainable with image_hidden_states=None (stage 1, train_StorySalon_stage1.py:175,288); "
+                                      f"trainable here: {sorted(mods)[:3]}, image context: {image_hidden_states is not None}")
         B, _, H, W = sample.shape
         S = encoder_hidden_states.shape[1]
         arch = self._arch

@@ -394,8 +394,9 @@ def allreduce_gradients(grads: Dict[str, torch.Tensor], average: bool = True) ->
 
 
 class MainPassFunction(torch.autograd.Function):
-    """epsilon = UNet(sample, t, text, features) as an autograd node whose only differentiable inputs are the attn3
-    parameters (train_StorySalon_stage2.py:170-177): what `accelerator.backward(loss)` needs from the drop-in model.
+    """epsilon = UNet(sample, t, text, features) as an autograd node whose only differentiable inputs are the parameters of the
+    trainer's trainable module (attn3: train_StorySalon_stage2.py:170-177; attn1 with no features: stage 1): what
+    `accelerator.backward(loss)` needs from the drop-in model.
 
     apply(trainer, names, ctx_keys, noisy, t, text16, *features, *params): `features` are the len(ctx_keys) context
     tensors (fp16 [B*R*hw_k, C_k]), `params` the len(names) attn3 parameters under their state-dict names.  The sample,
@@ -405,8 +406,8 @@ class MainPassFunction(torch.autograd.Function):
     def forward(ctx, trainer, names, ctx_keys, noisy, t, text16, *tensors):
         nk = len(ctx_keys)
         feats, params = tensors[:nk], tensors[nk:]
-        trainer.set_attn3_parameters(dict(zip(names, params)))
-        pred = trainer.forward_main(noisy, t, text16, dict(zip(ctx_keys, feats)))
+        trainer.set_trainable_parameters(dict(zip(names, params)))
+        pred = trainer.forward_main(noisy, t, text16, dict(zip(ctx_keys, feats)) if nk else None)      # no features: stage 1
         ctx.trainer, ctx.names, ctx.n_feat = trainer, names, nk
         ctx.meta = [(p.dtype, p.device) for p in params]
         return pred

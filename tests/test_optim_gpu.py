@@ -255,6 +255,62 @@ def test_coco_variant_of_the_loop(gpu):
         Stage2Trainer(_small_unet(gpu), 2, 16, 16, variant="imagenet")
 
 
+@pytest.mark.parametrize("stage", [2, 1])
+def test_dropin_unet_under_autograd_as_the_training_scripts_drive_it(gpu, stage):
+    """The reference's own loop, unmodified in shape, on the drop-in module: freeze everything, un-freeze the modules
+    whose name ends with attn3 (stage 2, train_StorySalon_stage2.py:167-177) or attn1 (stage 1, train_StorySalon_stage1.py:171-179), call
+    `unet(...)` for the reference frames and the main pass (:309-322 / :288), `loss.backward()`, torch.optim.AdamW.step().  The
+    gradients that reach `p.grad` must be the oracle's."""
+    import torch.nn.functional as F
+    from oracle import storygen_oracle as O
+    from storygen_amd.arch import build_arch, load_config
+    from storygen_amd.synth import synthetic_state_dict, synthetic_train_batch
+    cfg = load_config(dict(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                           up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), cross_attention_dim=768, attention_head_dim=8, sample_size=128))
+    sd = synthetic_state_dict(build_arch(cfg), 7)
+    batch = synthetic_train_batch(2, 16, 768, 7)
+    target = "attn3" if stage == 2 else "attn1"
+    use_refs = (0, 1, 2) if stage == 2 else ()
+    want_loss, want = O.train_step(sd, cfg, batch, use_refs, trainable=target)
+    unet = _small_unet(gpu)
+    unet.requires_grad_(False)
+    for name, module in unet.named_modules():
+        if name.endswith(target):
+            for p in module.parameters():
+                p.requires_grad = True
+    trainable = {n: p for n, p in unet.named_parameters() if p.requires_grad}
+    assert set(trainable) == set(want)
+    opt = torch.optim.AdamW(list(trainable.values()), lr=1e-4)
+    sched = O.DDIM()
+    t = batch["timesteps"].long()
+    ref_t = (batch["timesteps"] / 10).long()
+    g = lambda x: x.to(gpu)                                                            # noqa: E731
+
+    def loss_of():
+        ctx = None
+        if stage == 2:
+            feats = []
+            for i in use_refs:
+                ti = ref_t * (3 - i)
+                x = O.ddpm_add_noise(sched, batch["ref_latents"][i], batch["ref_noise"], ti)
+                feats.append(unet(g(x), g(ti), encoder_hidden_states=g(batch["prev_text"][i]), return_dict=False)[1])
+            ctx = {k: torch.cat([f[k] for f in feats], dim=1) for k in feats[0]}
+        noisy = O.ddpm_add_noise(sched, batch["latents"], batch["noise"], t)
+        pred = unet(g(noisy), g(t), encoder_hidden_states=g(batch["text"]), image_hidden_states=ctx, return_dict=False)[0]
+        keep = 1.0 - g(batch["mask"])
+        return F.mse_loss(pred.float() * keep, g(batch["noise"]).float() * keep, reduction="mean")
+
+    loss = loss_of()
+    loss.backward()
+    assert abs(float(loss.detach()) - float(want_loss)) <= 2e-3 * abs(float(want_loss))
+    errs = {n: rel_l2(p.grad.cpu(), want[n]) for n, p in trainable.items()}
+    print(f"stage {stage}: loss {float(loss.detach()):.5f} (oracle {float(want_loss):.5f}); worst gradient {max(errs.values()):.2e}")
+    assert max(errs.values()) < 1e-2 and all(p.grad is None for n, p in unet.named_parameters() if n not in trainable)
+    opt.step()
+    opt.zero_grad()
+    assert abs(float(loss_of().detach()) - float(loss.detach())) > 1e-6                                 # the next call runs on the updated weights
+
+
 def test_trained_weights_reach_the_inference_engine(gpu):
     """The optimizer writes the parameters through raw pointers; bumping their autograd version makes the drop-in UNet's staleness tag
     see it, so the next inference forward runs on the new attn3 weights without rebuilding anything."""

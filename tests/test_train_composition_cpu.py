@@ -237,3 +237,31 @@ def test_main_pass_autograd_function_routes_gradients_to_the_attn3_parameters(cp
     assert abs(float(loss.detach()) - float(want_loss)) <= 5e-3 * abs(float(want_loss))
     errs = {n: rel_l2(p.grad, want[n]) for n, p in zip(names, params)}
     assert max(errs.values()) < 2e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
+
+
+def test_main_pass_autograd_function_stage1_routes_gradients_to_attn1(cpu_ops):
+    """Stage 1 through the same autograd node: no features, attn1 leaves (train_StorySalon_stage1.py:175-179,288-291)."""
+    from oracle import storygen_oracle as O
+    from storygen_amd.arch import build_arch, load_config
+    from storygen_amd.synth import synthetic_state_dict, synthetic_train_batch
+    from storygen_amd.train import MainPassFunction, UNetTrainer
+    cfg = load_config(dict(block_out_channels=(32, 64), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                           up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), cross_attention_dim=48, attention_head_dim=2,
+                           norm_num_groups=8, sample_size=64))
+    arch = build_arch(cfg)
+    sd = synthetic_state_dict(arch, 9)
+    Bn, hw = 2, 8
+    batch = synthetic_train_batch(Bn, hw, 48, 9)
+    want_loss, want = O.train_step(sd, cfg, batch, (), trainable="attn1")
+    tr = UNetTrainer(arch, sd, "cpu", Bn, hw, hw, n_ref=0, trainable="attn1")
+    t = batch["timesteps"].long()
+    noisy = O.ddpm_add_noise(O.DDIM(), batch["latents"], batch["noise"], t)
+    names = sorted(k for k in sd if k.endswith(O.trainable_suffixes("attn1")))
+    params = [sd[k].clone().requires_grad_(True) for k in names]
+    pred = MainPassFunction.apply(tr, names, [], noisy.contiguous(), t.float(), batch["text"].half().reshape(-1, 48).contiguous(), *params)
+    keep = 1.0 - batch["mask"]
+    loss = F.mse_loss(pred * keep, batch["noise"] * keep)
+    loss.backward()
+    assert abs(float(loss.detach()) - float(want_loss)) <= 5e-3 * abs(float(want_loss))
+    errs = {n: rel_l2(p.grad, want[n]) for n, p in zip(names, params)}
+    assert max(errs.values()) < 2e-2, sorted(errs.items(), key=lambda kv: -kv[1])[:3]
