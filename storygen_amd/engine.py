@@ -164,6 +164,19 @@ class EngineWeights:
                 for name, val in self._pack_attn3(sd, xf).items():
                     getattr(xf, name).copy_(val)
 
+    def _pack_attn1(self, sd, xf: "_Xf") -> Dict[str, torch.Tensor]:
+        t = f"{xf.spec.prefix}.transformer_blocks.0"
+        g = lambda k: self._w(sd, k)  # noqa: E731
+        return {"w_qk1": torch.cat([g(f"{t}.attn1.to_q.weight"), g(f"{t}.attn1.to_k.weight")], 0), "w_v1": g(f"{t}.attn1.to_v.weight"),
+                "w_o1": g(f"{t}.attn1.to_out.0.weight"), "b_o1": g(f"{t}.attn1.to_out.0.bias")}
+
+    def refresh_attn1_(self, sd, prefixes=None):
+        """Stage-1 training changes only the attn1 modules (train_StorySalon_stage1.py:175-179): the same in-place re-pack for them."""
+        for p, xf in self.xfs.items():
+            if prefixes is None or p in prefixes:
+                for name, val in self._pack_attn1(sd, xf).items():
+                    getattr(xf, name).copy_(val)
+
     def reload_(self, sd):
         """Re-pack the whole checkpoint into the existing tensors (any parameter may have changed)."""
         fresh = EngineWeights.__new__(EngineWeights)

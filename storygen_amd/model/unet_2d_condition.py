@@ -266,6 +266,9 @@ class UNet2DConditionModel(nn.Module):
             if all(".attn3." in n for n in changed):
                 prefixes = {n.split(".transformer_blocks.")[0] for n in changed}
                 self._weights.refresh_attn3_(self.state_dict(), prefixes)
+            elif all(".attn1." in n for n in changed):                       # stage 1
+                prefixes = {n.split(".transformer_blocks.")[0] for n in changed}
+                self._weights.refresh_attn1_(self.state_dict(), prefixes)
             else:
                 self._weights.reload_(self.state_dict())
                 self._trainers.clear()             # the trainer keeps its own repacked copies of the frozen layers

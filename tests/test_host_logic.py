@@ -379,3 +379,68 @@ def test_bench_argument_parser_builds():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--help"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr[-500:]
     assert "--gpus" in r.stdout and "--steps" in r.stdout and "--warmup" in r.stdout
+
+
+def _all_tensors(obj, prefix=""):
+    """Every tensor held by an EngineWeights (recursively through dicts / tuples / the per-layer records), with a path name."""
+    import torch as _t
+    from storygen_amd.engine import _Resnet, _Xf
+    if _t.is_tensor(obj):
+        yield prefix, obj
+    elif isinstance(obj, dict):
+        for k, v in obj.items():
+            yield from _all_tensors(v, f"{prefix}.{k}")
+    elif isinstance(obj, (tuple, list)):
+        for i, v in enumerate(obj):
+            yield from _all_tensors(v, f"{prefix}[{i}]")
+    elif isinstance(obj, (_Resnet, _Xf)):
+        for k in obj.__slots__:
+            if k != "spec" and getattr(obj, k, None) is not None:
+                yield from _all_tensors(getattr(obj, k), f"{prefix}.{k}")
+
+
+@pytest.mark.parametrize("module", ["attn1", "attn3"])
+def test_in_place_refresh_of_the_trainable_module_equals_a_fresh_repack(module):
+    """EngineWeights.refresh_attn{1,3}_ (what the drop-in UNet calls after an optimizer step of stage 1 / stage 2): after changing every
+    parameter of that module, the refreshed weights equal a fresh re-pack of the whole checkpoint, tensor for tensor, and no tensor was
+    re-allocated (captured hipGraphs hold their addresses).  Pure packing logic: runs on the CPU device."""
+    from storygen_amd.arch import build_arch, load_config
+    from storygen_amd.engine import EngineWeights
+    from storygen_amd.synth import synthetic_state_dict
+    cfg = load_config(dict(block_out_channels=(32, 64), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                           up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), cross_attention_dim=48, attention_head_dim=2,
+                           norm_num_groups=8, sample_size=64))
+    arch = build_arch(cfg)
+    sd = synthetic_state_dict(arch, 3)
+    w = EngineWeights(arch, sd, "cpu")
+    ptrs = {n: t.data_ptr() for n, t in _all_tensors(w.__dict__)}
+    g = torch.Generator().manual_seed(1)
+    sd2 = {k: (v + 0.05 * torch.randn(v.shape, generator=g) if f".{module}." in k else v) for k, v in sd.items()}
+    assert sum(f".{module}." in k for k in sd2) == 5 * len(arch.feature_keys)
+    getattr(w, f"refresh_{module}_")(sd2)
+    fresh = dict(_all_tensors(EngineWeights(arch, sd2, "cpu").__dict__))
+    mine = dict(_all_tensors(w.__dict__))
+    assert set(mine) == set(fresh)
+    for n, t in mine.items():
+        assert torch.equal(t, fresh[n]), n
+        assert t.data_ptr() == ptrs[n], n
+
+
+def test_dropin_unet_tag_routes_attn1_changes_to_the_in_place_refresh():
+    from storygen_amd.model import UNet2DConditionModel
+    cfg = dict(block_out_channels=(32, 64), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+               up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), cross_attention_dim=48, attention_head_dim=2, norm_num_groups=8, sample_size=64)
+    unet = UNet2DConditionModel.from_config(cfg)
+    w = unet._engine_weights()
+    calls = []
+    w.refresh_attn1_ = lambda sd, prefixes=None: calls.append(("attn1", sorted(prefixes)))
+    w.reload_ = lambda sd: calls.append(("reload", None))
+    with torch.no_grad():
+        for n, p in unet.named_parameters():
+            if ".attn1." in n and n.startswith("mid_block"):
+                p.add_(1.0)
+    assert unet._engine_weights() is w and calls == [("attn1", ["mid_block.attentions.0"])]
+    with torch.no_grad():
+        next(p for n, p in unet.named_parameters() if "conv_in" in n).add_(1.0)
+    unet._engine_weights()
+    assert calls[-1] == ("reload", None)
