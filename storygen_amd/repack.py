@@ -35,3 +35,19 @@ def interleave_geglu(w: torch.Tensor, b: Optional[torch.Tensor]) -> Tuple[torch.
     if b is not None:
         bi = torch.stack([b[:inner].reshape(inner // 32, 32), b[inner:].reshape(inner // 32, 32)], dim=1).reshape(-1).contiguous()
     return wi, bi
+
+
+def fold_layernorm(w: torch.Tensor, b: Optional[torch.Tensor], gamma: torch.Tensor, beta: torch.Tensor
+                   ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Weights of `LayerNorm(gamma, beta)` followed by `Linear(w [N,K], b)` for evaluation as ONE GEMM on the raw input plus a rank-1
+    epilogue (tools/next_round/README.md item 1; not used by the engine yet):
+
+        LN(x) w^T + b  =  rstd * (x w'^T)  -  rstd * mu * c  +  d        mu, rstd = row statistics of x
+
+    Returns (w' = gamma (.) w rounded to fp16, c [N] fp32 = row sums of the ROUNDED w' — the correction must cancel what the MFMA
+    actually multiplies —, d [N] fp32 = w beta + b)."""
+    w32, g32, be32 = w.float(), gamma.float(), beta.float()
+    wf = (w32 * g32[None]).to(torch.float16)
+    c = wf.float().sum(dim=1)
+    d = w32 @ be32 + (0.0 if b is None else b.float())
+    return wf, c, d

@@ -444,3 +444,23 @@ def test_dropin_unet_tag_routes_attn1_changes_to_the_in_place_refresh():
         next(p for n, p in unet.named_parameters() if "conv_in" in n).add_(1.0)
     unet._engine_weights()
     assert calls[-1] == ("reload", None)
+
+
+def test_layernorm_fold_is_the_same_linear_map():
+    """repack.fold_layernorm (preparation for folding LayerNorm into the following GEMM's epilogue): the folded form on fp16 operands stays
+    within ~1.5x of the current two-step fp16 path's distance from fp32, also when the row mean is several standard deviations."""
+    from storygen_amd.repack import fold_layernorm
+    g = torch.Generator().manual_seed(0)
+    M, K, N = 256, 320, 96
+    W, b = torch.randn(N, K, generator=g) / K ** 0.5, torch.randn(N, generator=g) * 0.1
+    gamma, beta = 1.0 + 0.2 * torch.randn(K, generator=g), 0.1 * torch.randn(K, generator=g)
+    for offset in (0.0, 3.0):
+        x = torch.randn(M, K, generator=g) + offset
+        ref = F.layer_norm(x, (K,), gamma, beta, 1e-5) @ W.t() + b
+        cur = F.layer_norm(x, (K,), gamma, beta, 1e-5).half().float() @ W.half().float().t() + b
+        wf, c, d = fold_layernorm(W, b, gamma, beta)
+        mu, rstd = x.mean(1, keepdim=True), (x.var(1, unbiased=False, keepdim=True) + 1e-5).rsqrt()
+        fold = rstd * (x.half().float() @ wf.float().t()) - rstd * mu * c[None] + d[None]
+        e_cur = float((cur - ref).norm() / ref.norm())
+        e_fold = float((fold - ref).norm() / ref.norm())
+        assert e_fold < 1e-3 * (1.0 + offset) and e_fold < 2.0 * (1.0 + offset) * e_cur, (offset, e_cur, e_fold)
