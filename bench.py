@@ -235,9 +235,6 @@ def main():
     ap.add_argument("--fp8-attention", action="store_true",
                     help="BASELINE configs[4]'s attention path: head-dim-40 image / self attention on the e4m3 MFMA kernel (with "
                          "--config5-shape; results differ from the fp16 path by fp8 rounding, so never the contract line)")
-    ap.add_argument("--spread", type=int, default=-1, help="A/B: placement of the ring-refill DMA instructions (sg_debug_set_spread)")
-    ap.add_argument("--conv-patch", action="store_true",
-                    help="A/B: eligible 3x3 convolutions through the LDS-resident-input-patch kernel (experiment, default off)")
     ap.add_argument("--no-gn-epilogue", action="store_true", help="A/B: every GroupNorm makes its own statistics pass")
     ap.add_argument("--fp16-block-stream", action="store_true",
                     help="A/B (changes results, never the contract line): fp16 residual stream inside the transformer blocks")
@@ -282,15 +279,9 @@ def main():
     from storygen_amd.arch import SD15_CONFIG, build_arch
     from storygen_amd.sampler import StoryGenSampler, gather_latents
     from storygen_amd.synth import synthetic_inputs, synthetic_state_dict
-    if args.conv_patch:
-        from storygen_amd import ops
-        ops.debug_set_conv_patch(True)
     if os.environ.get("SG_DEV_OPTIONS") == "1":          # A/B runs of development options (tools/next_round/*.sh): never the default
         from storygen_amd import ops
         print("development options:", ops.apply_env_options(), file=sys.stderr)
-    if args.spread >= 0:
-        from storygen_amd import ops
-        ops.debug_set_spread(args.spread)
     if args.no_gemm_pairs:
         from storygen_amd import engine as _engine
         _engine.PAIR_GEMMS = False
@@ -362,7 +353,7 @@ def main():
                        "hipgraph": not args.no_graph, "dedup_identical_reference_samples": not args.no_dedup,
                        "overlap_ref_pass_of_next_step": sampler.overlap, "ref_ahead": G, "warmup_run": warmup_run,
                        "split_graphs": sampler.split, "stream_priority": sampler.stream_priority,
-                       "conv_lds_patch": args.conv_patch, "paired_gemm_launches": not args.no_gemm_pairs,
+                       "paired_gemm_launches": not args.no_gemm_pairs,
                        "groupnorm_stats_from_epilogues": not args.no_gn_epilogue, "fp16_block_stream": args.fp16_block_stream},
             "tflop_per_step_as_written": round(step_tflop, 3),
             "final_allgather_ms": round(gather_ms, 3), "latents_gathered": int(final.shape[0]), "latents_finite": finite,

@@ -90,7 +90,7 @@ typedef struct sg_gemm_desc {
     int32_t        split_k;           /* 0 = auto, 1 = none, >1 = forced */
     int32_t        tile_m, tile_n;    /* 0, 0 = library heuristic; else one of 256x128, 128x128, 256x64, 128x64, 64x128,
                                          64x64 (a tuning hint: results are identical up to fp32 summation order) */
-    int32_t        tile_waves;        /* 0 = default (64x64 per wave); 4 with 256x128 / 2 with 128x128 = 128x64 per wave */
+    int32_t        tile_waves;        /* 0, or the tile's wave count (64x64 per wave: (tile_m/64)*(tile_n/64)); anything else is rejected */
     const void*    res1; int64_t ldr1;   /* fp16, or fp32 with SG_F_RES1_F32 */
     const void*    res2; int64_t ldr2;   /* fp16, or fp32 with SG_F_RES2_F32 */
     void*          workspace; size_t workspace_bytes;
@@ -465,20 +465,21 @@ int sg_debug_mfma_f8_32x32x64(const void* a, const void* b, float* out, int32_t 
  * optionally disable the LDS-DMA pipelined kernel (no_pipe = 1), so the parity tests can cover every code path.
  * Process-global; not for production use. */
 int sg_debug_set_tile(int32_t bm, int32_t bn, int32_t no_pipe);
+/* Host-side self-test of the multiply-shift divisors the GEMM / conv prologues use instead of integer division (made per launch
+ * from tile counts, image sizes, channel chunks): returns the number of mismatches against n / d over a sweep (0 = correct). */
+int sg_debug_fastdiv_selftest(void);
 /* Mainloop anatomy (development): the same launch as sg_gemm_f16 / sg_conv3x3_nhwc_f16, through an instrumented instantiation of
  * the pipelined kernel that stamps s_memtime around the phases of every 64-deep slab.  prof: 10 uint64 per wave,
  * [block][wave][10] = {slabs, vmcnt wait, barrier, first fragment reads + k-step 0, k-step 1 up to the DMA issue, DMA issue, rest
  * of the slab, prologue, epilogue, total} in shader cycles; prof_bytes >= blocks * waves * 80.  tools/anatomy.py prints it. */
+/* Only in a library built with SG_BUILD_EXPERIMENTS (python -m storygen_amd.build --experiments); the product library carries no
+ * instrumented kernels and answers SG_EINVAL. */
 int sg_debug_gemm_anatomy(const sg_gemm_desc* d, void* prof, size_t prof_bytes, sg_stream_t stream);
 int sg_debug_conv_anatomy(const sg_conv3x3_desc* d, void* prof, size_t prof_bytes, sg_stream_t stream);
 /* Development options — kernel-variant selectors for the tuning / anatomy tools and the parity tests.  Process-global; the
  * library never reads the environment (storygen_amd/ops.py maps the SG_* variables of its tools onto this call).  name / value:
  *   "tile_m", "tile_n"   force a GEMM / conv tile (same effect as sg_debug_set_tile)      "no_pipe", "no_split"  1 = disable
- *   "stages"             LDS ring depth of the pipelined kernel: 0 = default (3), 2, 4     "fat"       1 = 128x64-per-wave tiles
- *   "no_nmajor", "late_issue", "no_frag_prefetch"                                          mainloop schedule switches
- *   "spread"             placement of the ring-refill DMA instructions: 0 one block after k-step 0 (default), 1 a third before
- *                        each of k-steps 1-3, 2 behind every MFMA of k-steps 1-3 — bit-identical results
- *   "conv_patch"         1 = eligible 3x3 convolutions through the LDS-resident-input-patch kernel (default 0: equal in time)
+ *   "no_nmajor"          1 = M-major tile order everywhere
  *   "attn_sub2", "attn_prio", "attn_d80" (0..2), "attn_d160" (0..3)                        attention instantiation selectors
  *   "gn_no_fused", "gn_wide", "gn_fused_max"                                               GroupNorm kernel selection
  *   "reset"              every option back to its default */

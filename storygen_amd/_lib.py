@@ -200,6 +200,7 @@ SIGNATURES = {
     "sg_debug_mfma_32x32x16": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "sg_debug_mfma_f8_32x32x64": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]),
     "sg_debug_set_tile": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "sg_debug_fastdiv_selftest": (C.c_int, []),
     "sg_debug_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
     "sg_debug_gemm_anatomy": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "sg_debug_conv_anatomy": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p]),

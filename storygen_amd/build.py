@@ -1,6 +1,9 @@
 """Builds libstorygen_hip.so (hand-written gfx950 kernels + C ABI) in-tree with hipcc.
 
-    python -m storygen_amd.build [--force]
+    python -m storygen_amd.build [--force] [--experiments]
+
+--experiments (or SG_BUILD_EXPERIMENTS=1) adds the instrumented kernel instantiations behind sg_debug_gemm_anatomy /
+sg_debug_conv_anatomy (tools/anatomy.py); the product library is built without them.
 
 hipcc cross-compiles for gfx950 without a GPU.  The shared object lands in storygen_amd/lib/ (git-ignored,
 but shipped to the GPU box by gpurun) and is what storygen_amd/_lib.py dlopens.
@@ -18,6 +21,7 @@ PKG = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libstorygen_hip.so")
+LIB_EXP = os.path.join(LIBDIR, "libstorygen_hip_exp.so")      # --experiments: a SEPARATE library that only tools/anatomy.py loads
 SOURCES = ["gemm_conv.hip", "attention.hip", "attention_f8.hip", "norm.hip", "misc.hip", "backward.hip", "attention_bwd.hip", "encoders.hip", "optim.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-Rpass-analysis=kernel-resource-usage"]          # remarks only: parsed into lib/kernel_resources.json
@@ -87,16 +91,21 @@ def needs_build() -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
-    if not force and not needs_build():
+def build(force: bool = False, verbose: bool = True, experiments: bool = False) -> str:
+    experiments = experiments or os.environ.get("SG_BUILD_EXPERIMENTS") == "1"
+    if not force and not experiments and not needs_build():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)
     hipcc = _hipcc()
+    exp_flags = ["-DSG_BUILD_EXPERIMENTS=1"] if experiments else []
+    objdir = os.path.join(LIBDIR, "exp") if experiments else LIBDIR
+    os.makedirs(objdir, exist_ok=True)
+    out_lib = LIB_EXP if experiments else LIB
     objs = []
     procs = []
     for src in SOURCES:
-        obj = os.path.join(LIBDIR, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
+        cmd = [hipcc, *FLAGS, *exp_flags, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
@@ -109,19 +118,19 @@ def build(force: bool = False, verbose: bool = True) -> str:
         rest = _parse_resource_remarks(out, src, resources)
         if verbose and rest.strip():
             print(rest)
-    with open(RESOURCES, "w") as f:
+    with open(RESOURCES + (".exp" if experiments else ""), "w") as f:
         json.dump(resources, f, indent=1, sort_keys=True)
     # a kernel with a private segment either spills or keeps an array in memory: both are order-of-magnitude cliffs on this
     # hardware (the D = 160 attention instantiation once ran 6x slower that way) — refuse to ship one silently
     bad = {k: v["scratch_bytes_per_lane"] for k, v in resources.items() if v["scratch_bytes_per_lane"]}
     if bad and os.environ.get("SG_ALLOW_SCRATCH") != "1":
         raise RuntimeError(f"kernels using scratch memory (set SG_ALLOW_SCRATCH=1 to build anyway): {bad}")
-    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB]
+    cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out_lib]
     if verbose:
         print(" ".join(cmd), flush=True)
     subprocess.run(cmd, check=True)
-    return LIB
+    return out_lib
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    print(build(force="--force" in sys.argv, experiments="--experiments" in sys.argv))

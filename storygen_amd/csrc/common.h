@@ -37,11 +37,7 @@ static inline int sg_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 struct SgOptions {
     int tile_m = 0, tile_n = 0;        // force a GEMM / conv tile (0, 0 = heuristic / caller's hint)
     int no_pipe = 0, no_split = 0;     // register-staged kernel only / no automatic split-K
-    int stages = 0;                    // LDS ring depth of the pipelined kernel: 0 = default (3), 2, 4 (tiles <= 128x128)
-    int no_nmajor = 0, late_issue = 1, no_frag_prefetch = 0, fat = 0;
-    int spread = 0;                    // placement of the ring-refill DMA instructions (mma_pipe_body SPREAD)
-    int conv_patch = 0;                // LDS-resident-input-patch convolution kernel
-    int pingpong = 0;                  // mma_pp_kernel: two wave groups alternate compute / load on even / odd K slabs
+    int no_nmajor = 0;                 // M-major tile order everywhere
     int attn_sub2 = 0, attn_prio = 0, attn_d80 = 1, attn_d160 = 3;
     int gn_no_fused = 0, gn_wide = 1;
     long gn_fused_max = -1;            // -1 = the kernel's default threshold

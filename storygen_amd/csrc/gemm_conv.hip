@@ -5,32 +5,57 @@
 // from the NHWC input (optional nearest-2x upsample and stride 2 folded into the index).
 //
 // Structure (CDNA4-first, see /opt/skills/guides/cdna_hip_programming.md §5):
-//   * every wave owns a 64x64 output sub-tile = 2x2 accumulators of v_mfma_f32_32x32x16_f16 (one 16-byte fragment
-//     per lane per operand per MFMA, 1 KiB of LDS reads per MFMA); a workgroup is a WGM x WGN grid of such waves
-//     (256x128, 128x128, 256x64, 128x64, 64x128 or 64x64 tiles), chosen per problem so that the 1024 SIMDs of the chip stay busy.
-//   * pipelined kernel (the fast path): K is walked in 64-deep slabs through S=3 LDS stages filled by LDS-DMA
+//   * every wave owns a 64x64 output sub-tile = 2x2 accumulators of v_mfma_f32_32x32x16_f16; a workgroup is a WGM x WGN grid of
+//     such waves (256x128, 128x128, 256x64, 128x64, 64x128 or 64x64 tiles), chosen per problem so that the chip stays busy.
+//   * pipelined kernel (the fast path): K is walked in 64-deep slabs through a 3-stage LDS ring filled by LDS-DMA
 //     (global_load_lds, 16 B per lane, no VGPR staging), counted vmcnt waits and ONE raw s_barrier per slab.
 //   * LDS rows are 128 B (64 halves); the 16-byte chunk c of row r lives at slot c ^ ((r>>1)&7): conflict-free for
-//     the ds_read_b128 fragment reads (a 16-lane service group touches 16 distinct 16-B slots of the 256-B bank row).
-//     LDS-DMA writes lane l of a wave to (wave-uniform base + 16 l), so the swizzle is applied on the SOURCE side
-//     (the lane that owns slot s of row r fetches logical chunk s ^ ((r>>1)&7)) and again on the reads.
+//     the ds_read_b128 fragment reads.  LDS-DMA writes lane l of a wave to (wave-uniform base + 16 l), so the swizzle is
+//     applied on the SOURCE side (the lane that owns slot s of row r fetches logical chunk s ^ ((r>>1)&7)) and again on the reads.
+//   * the accumulators are computed TRANSPOSED (the weight fragment is the MFMA's A operand, the activation fragment its B
+//     operand): a lane then holds, for ONE output row, 4 consecutive output columns per register quad; one v_permlane32_swap per
+//     register pair turns that into 8 consecutive columns per lane, so bias / residual loads and the output stores are direct
+//     16-byte accesses from registers — no LDS staging, no barrier after the mainloop (round 3; the LDS-staged, banded epilogue it
+//     replaces cost 9-17 k cycles per workgroup, profiles/r02d_mainloop_anatomy.txt).  The residual of the tile is requested
+//     during the LAST K slab, so its HBM latency runs under that slab's MFMAs.
 //   * generic kernel (fallback): register-staged double buffer with zero-fill predicates, for K % 64 != 0 or an
 //     unpadded convolution input.
-//   * the fp32 tile is staged through LDS for the epilogue so that bias / residual / output accesses are 16-byte,
-//     row-contiguous; epilogue math is fp32; outputs and residuals may be fp16 or fp32 (the UNet's residual stream
-//     is kept in fp32, MFMA operands in fp16).
-//   * block ids are remapped so that consecutive tiles (same A row panel) run on the same XCD / L2.
+//   * block ids are remapped so that consecutive tiles (same operand panel) run on the same XCD / L2; index arithmetic of the
+//     prologue uses host-made multiply-shift divisors (no integer division on the device).
 //   * small-M layers (16x16 / 8x8 latent levels at batch 3) are split along K into fp32 partial tiles; a second kernel
 //     reduces them in slice order and applies the epilogue (deterministic, no atomics).  An in-launch reduction by the
 //     last-arriving slice (agent-scope release / acquire + ticket counter) was built and measured in round 2: the release
 //     fence behind 64 KB of freshly written partials costs more (+8..13 us per launch) than the kernel boundary it removes.
+// Round-2 mainloop experiments (4-/2-stage rings, spread DMA issue, ping-pong wave groups, LDS-resident conv patches, fat
+// waves) were measured neutral or slower and are no longer part of the library; `git log` has them.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
 constexpr int BK = 64;
 constexpr int MAX_AUTO_SPLIT = 16;
+
+// n / d for any 32-bit n by multiply-high and shifts (Granlund-Montgomery; made on the host by make_fastdiv)
+struct FastDiv { unsigned mul, sh1, sh2; };
+
+__host__ __device__ __forceinline__ unsigned fd_div(unsigned n, FastDiv f) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const unsigned t = __umulhi(n, f.mul);
+#else
+    const unsigned t = (unsigned)(((unsigned long long)n * f.mul) >> 32);
+#endif
+    return (t + ((n - t) >> f.sh1)) >> f.sh2;
+}
+
+FastDiv make_fastdiv(unsigned d) {
+    if (d <= 1) return FastDiv{0u, 0u, 0u};
+    unsigned l = 0;
+    while ((1ull << l) < d) ++l;
+    const unsigned long long m = (((1ull << l) - d) << 32) / d + 1;
+    return FastDiv{(unsigned)m, 1u, l - 1};
+}
 
 struct MmaParams {
     const f16* A; long lda;
@@ -48,256 +73,237 @@ struct MmaParams {
     const void* res2; long ldr2;
     // decomposition
     float* ws; int splits; int kt_per_split; int tiles_m, tiles_n;
-    float* stats; int stats_batch_rows;   // optional GroupNorm partial statistics of the output (tile_epilogue), else nullptr
-    unsigned long long* prof;   // PROF instantiations only (sg_debug_*_anatomy): per-wave cycle totals of the mainloop phases
+    float* stats; int stats_batch_rows;   // optional GroupNorm partial statistics of the output (epi_finish), else nullptr
+    unsigned long long* prof;   // SG_BUILD_EXPERIMENTS (sg_debug_*_anatomy): per-wave cycle totals of the mainloop phases
     int n_major;   // tile order: 1 = consecutive ids walk M first (tiles sharing a weight panel stay on one XCD / L2)
+    FastDiv fd_splits, fd_tiles_m, fd_tiles_n, fd_hw, fd_wo, fd_rpb, fd_cpt;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
 
-__device__ __forceinline__ void add_res8(const void* res, long ld, bool f32, int gm, int gn, float (&v)[8]) {
-    if (f32) {
-        const float* r = reinterpret_cast<const float*>(res) + (long)gm * ld + gn;
-        const float4 a = *reinterpret_cast<const float4*>(r), b = *reinterpret_cast<const float4*>(r + 4);
-        v[0] += a.x; v[1] += a.y; v[2] += a.z; v[3] += a.w; v[4] += b.x; v[5] += b.y; v[6] += b.z; v[7] += b.w;
-    } else {
-        H8 r; r.u = ldg16(reinterpret_cast<const f16*>(res) + (long)gm * ld + gn);
-#pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)r.h[j];
-    }
+// logical block id -> (m0, n0, K slice z).  logical id = tile * splits + slice: the K slices of a tile are consecutive ids
+// (one XCD, see xcd_remap)
+__device__ __forceinline__ void decode_block(const MmaParams& p, int BM, int BN, int& m0, int& n0, int& z) {
+    const unsigned lid2 = (unsigned)xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.splits);
+    const unsigned lid = fd_div(lid2, p.fd_splits);
+    z = (int)(lid2 - lid * p.splits);
+    unsigned tm, tn;
+    if (p.n_major) { tn = fd_div(lid, p.fd_tiles_m); tm = lid - tn * p.tiles_m; }
+    else { tm = fd_div(lid, p.fd_tiles_n); tn = lid - tm * p.tiles_n; }
+    m0 = (int)tm * BM;
+    n0 = (int)tn * BN;
 }
 
-__device__ __forceinline__ void store_out8(const MmaParams& p, int gm, int gn, const float (&v)[8]) {
+// ------------------------------------------------------------------------------------------------------------
+// Epilogue.  acc[i][j] = mfma(W fragment, A fragment) is the TRANSPOSED product: register r of lane (l31, hi) is
+//   output row    i*32 + l31                      (of the wave's 64x64 sub-tile)
+//   output column j*32 + 8*(r>>2) + 4*hi + (r&3)
+// i.e. every register quad is 4 consecutive columns of one row: ONE ds_write_b128 into a row-major fp32 image.  Each wave
+// transposes its own sub-tile through its own 17 KB of LDS (row pitch 68 floats: the quad writes of 8 consecutive rows cover the
+// 32 banks exactly) — no barrier between the waves — and reads it back as 16 "row quads": instruction k gives lane l the 4
+// consecutive columns 4 (l & 15) of row 4 k + (l >> 4), so that every global access of the epilogue is 4 rows x 256 contiguous
+// bytes per wave instruction (the first version of this round kept one row per lane: no LDS, but 32 cache lines per
+// instruction — the stores and residual loads then cost what the barriers of the old banded epilogue had).
+constexpr int EPI_PITCH = 68;                         // floats per staged row
+constexpr int EPI_WAVE_BYTES = 64 * EPI_PITCH * 4;    // 17408
+
+// The additive term that needs HBM (an fp32 res1 of the fused linear epilogue: the UNet's residual stream) is requested early —
+// during the last K slab — into registers, in the row-quad layout (16 B per item).  rowq = first row of the wave's sub-tile
+// + (lane >> 4), colq = first column + 4 (lane & 15).  Rows / columns beyond the problem are clamped, not predicated: 16
+// unconditional loads issue back to back (a branch per load makes the compiler wait for each one where it is issued).
+__device__ __forceinline__ bool epi_prefetches(const MmaParams& p) {
+    return p.res1 != nullptr && (p.flags & SG_F_RES1_F32) && p.splits == 1 && p.mode == SG_EPI_LINEAR;
+}
+
+struct EpiPre { float4 res[16]; uint2 bias; };
+
+__device__ __forceinline__ void epi_prefetch(const MmaParams& p, int rowq, int colq, EpiPre& pf) {
+    float4 (&pre)[16] = pf.res;
+    if (p.bias && p.splits == 1 && p.mode == SG_EPI_LINEAR) pf.bias = *reinterpret_cast<const uint2*>(p.bias + min(colq, p.N - 4));
+    if (!epi_prefetches(p)) return;
+    const float* r = reinterpret_cast<const float*>(p.res1) + min(colq, p.N - 4);
+    const int mlast = p.M - 1;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) pre[k] = *reinterpret_cast<const float4*>(r + (long)min(rowq + 4 * k, mlast) * p.ldr1);
+}
+
+union H4 { uint2 u; f16 h[4]; };
+
+__device__ __forceinline__ void store_out4(const MmaParams& p, int gm, int gn, const float (&v)[4]) {
     const bool f32 = p.flags & SG_F_OUT_F32;
-    if (f32) {
-        float* o = reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn;
-        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
-        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
-    }
+    if (f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn) = make_float4(v[0], v[1], v[2], v[3]);
     if (!f32 || p.C2) {
-        H8 o;
+        H4 o;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) o.h[j] = (f16)v[j];
-        if (!f32) stg16(reinterpret_cast<f16*>(p.C) + (long)gm * p.ldc + gn, o.u);
-        if (p.C2) stg16(p.C2 + (long)gm * p.ldc2 + gn, o.u);
+        for (int e = 0; e < 4; ++e) o.h[e] = (f16)v[e];
+        if (!f32) *reinterpret_cast<uint2*>(reinterpret_cast<f16*>(p.C) + (long)gm * p.ldc + gn) = o.u;
+        if (p.C2) *reinterpret_cast<uint2*>(p.C2 + (long)gm * p.ldc2 + gn) = o.u;
     }
 }
 
-__device__ __forceinline__ void epi_linear8(const MmaParams& p, int gm, int gn, float (&v)[8]) {
-    if (p.bias) {
-        H8 b; b.u = ldg16(p.bias + gn);
+// Everything after the last MFMA.  NW waves as a WGM x WGN grid, this wave at (wm, wn); m0 / n0 = the workgroup's tile origin.
+// One workgroup barrier (the LDS ring is dead once every wave has left the last slab), then each wave works alone; a second
+// barrier only when GroupNorm statistics are requested (to add up the WGM wave rows).
+template <int WGM, int WGN>
+__device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x16 (&acc)[2][2], EpiPre& pf,
+                                           int m0, int n0, int z, int wave, int wm, int wn, int lane) {
+    constexpr int BN = 64 * WGN, NW = WGM * WGN, NT = 64 * NW;
+    const int l31 = lane & 31, hi = lane >> 5, lr = lane >> 4, lc = lane & 15;
+    float* stg = reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES);
+    float4 (&pre)[16] = pf.res;
+    // the ring is dead once every wave has issued its last fragment reads (each wave's own reads were waited for by its MFMAs).
+    // Raw s_barrier: __syncthreads() would also drain vmcnt, i.e. wait for the prefetched residual before the transpose starts.
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int j = 0; j < 8; ++j) v[j] += (float)b.h[j];
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+                *reinterpret_cast<float4*>(stg + (i * 32 + l31) * EPI_PITCH + j * 32 + 8 * g + 4 * hi) =
+                    make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+    // same-wave LDS write -> read: in-order within the wave, the compiler's lgkmcnt wait covers it
+    const int rowq = m0 + wm * 64 + lr, colq = n0 + wn * 64 + 4 * lc;
+    if (p.mode == SG_EPI_GEGLU && p.splits == 1) {
+        // interleaved layout (groups of 64 rows of W: 32 value rows then the 32 matching gate rows): the wave's columns 0..31 are
+        // values, 32..63 the gates of the SAME 32 outputs.  Lane l: row 8 k + (l >> 3), values 4 (l & 7) .. +3.
+        const int gr = lane >> 3, gc = (lane & 7) * 4;
+        const int gv = n0 + wn * 64 + gc;                         // interleaved column of the 4 values; gates at gv + 32
+        if (gv >= p.N) return;
+        float bv[4] = {0, 0, 0, 0}, bg[4] = {0, 0, 0, 0};
+        if (p.bias) {
+            H4 a, b;
+            a.u = *reinterpret_cast<const uint2*>(p.bias + gv); b.u = *reinterpret_cast<const uint2*>(p.bias + gv + 32);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { bv[e] = (float)a.h[e]; bg[e] = (float)b.h[e]; }
+        }
+        const int go = (gv >> 6) * 32 + (gv & 31);                // interleaved column -> output column
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int row = 8 * k + gr, gm = m0 + wm * 64 + row;
+            const float4 a = *reinterpret_cast<const float4*>(stg + row * EPI_PITCH + gc);
+            const float4 b = *reinterpret_cast<const float4*>(stg + row * EPI_PITCH + 32 + gc);
+            if (gm >= p.M) continue;
+            const float o[4] = {(a.x + bv[0]) * gelu_erf_f(b.x + bg[0]), (a.y + bv[1]) * gelu_erf_f(b.y + bg[1]),
+                                (a.z + bv[2]) * gelu_erf_f(b.z + bg[2]), (a.w + bv[3]) * gelu_erf_f(b.w + bg[3])};
+            store_out4(p, gm, go, o);
+        }
+        return;
     }
+    const bool col_ok = colq < p.N;
+    if (p.splits > 1) {   // raw fp32 partial tile; the epilogue happens in splitk_reduce_kernel
+        float* wsz = p.ws + (size_t)z * p.M * p.N + colq;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const int row = 4 * k + lr, gm = rowq + 4 * k;
+            const float4 v = *reinterpret_cast<const float4*>(stg + row * EPI_PITCH + 4 * lc);
+            if (gm < p.M && col_ok) *reinterpret_cast<float4*>(wsz + (size_t)gm * p.N) = v;
+        }
+        return;
+    }
+    // ---- fused linear epilogue: bias, temb row-bias, residuals (fp32 res1 prefetched), outputs, optional GroupNorm statistics.
+    // Phases, not a per-row loop: all loads of a term are issued together (clamped addresses, no predicate), so the epilogue pays
+    // one memory round trip per term instead of one per row quad.
+    const bool want_stats = p.stats != nullptr;
+    const bool r1f32 = p.flags & SG_F_RES1_F32, r2f32 = p.flags & SG_F_RES2_F32;
+    // (a2 + h) + (a3 + h): the same tensor as both residuals is read once
+    const bool res2_same = p.res2 != nullptr && p.res2 == p.res1 && p.ldr2 == p.ldr1 && r1f32 == r2f32;
+    const int cq = min(colq, p.N - 4), mlast = p.M - 1;
+    float v[16][4];
+    {
+        float bias4[4] = {0, 0, 0, 0};
+        if (p.bias) {
+            H4 b; b.u = pf.bias;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias4[e] = (float)b.h[e];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const float4 a = *reinterpret_cast<const float4*>(stg + (4 * k + lr) * EPI_PITCH + 4 * lc);
+            v[k][0] = a.x + bias4[0]; v[k][1] = a.y + bias4[1]; v[k][2] = a.z + bias4[2]; v[k][3] = a.w + bias4[3];
+        }
+    }
+    auto add_f32 = [&](const float* base, long ld) __attribute__((always_inline)) {
+        float4 t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = *reinterpret_cast<const float4*>(base + (long)min(rowq + 4 * k, mlast) * ld + cq);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { v[k][0] += t[k].x; v[k][1] += t[k].y; v[k][2] += t[k].z; v[k][3] += t[k].w; }
+    };
+    auto add_f16 = [&](const f16* base, long ld) __attribute__((always_inline)) {
+        uint2 t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = *reinterpret_cast<const uint2*>(base + (long)min(rowq + 4 * k, mlast) * ld + cq);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            H4 h; h.u = t[k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[k][e] += (float)h.h[e];
+        }
+    };
     if (p.rowbias) {
-        const float* rb = p.rowbias + (long)(gm / p.rows_per_batch) * p.rowbias_ld + gn;
-        const float4 r0 = *reinterpret_cast<const float4*>(rb), r1 = *reinterpret_cast<const float4*>(rb + 4);
-        v[0] += r0.x; v[1] += r0.y; v[2] += r0.z; v[3] += r0.w;
-        v[4] += r1.x; v[5] += r1.y; v[6] += r1.z; v[7] += r1.w;
+        float4 t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            t[k] = *reinterpret_cast<const float4*>(p.rowbias + (long)fd_div((unsigned)min(rowq + 4 * k, mlast), p.fd_rpb) * p.rowbias_ld + cq);
+#pragma unroll
+        for (int k = 0; k < 16; ++k) { v[k][0] += t[k].x; v[k][1] += t[k].y; v[k][2] += t[k].z; v[k][3] += t[k].w; }
     }
-    if (p.res1) add_res8(p.res1, p.ldr1, p.flags & SG_F_RES1_F32, gm, gn, v);
-    if (p.res2) add_res8(p.res2, p.ldr2, p.flags & SG_F_RES2_F32, gm, gn, v);
-    store_out8(p, gm, gn, v);
-}
-
-// val/gate: 8 consecutive interleaved-layout columns starting at global column gv (value) and gv+32 (gate).
-__device__ __forceinline__ void epi_geglu8(const MmaParams& p, int gm, int gv, float (&val)[8], float (&gate)[8]) {
-    if (p.bias) {
-        H8 bv, bg; bv.u = ldg16(p.bias + gv); bg.u = ldg16(p.bias + gv + 32);
+    if (p.res1) {
+        if (r1f32) {
+            const float w = res2_same ? 2.f : 1.f;       // x + r + r == x + 2 r up to one rounding of the fp32 stream
 #pragma unroll
-        for (int j = 0; j < 8; ++j) { val[j] += (float)bv.h[j]; gate[j] += (float)bg.h[j]; }
+            for (int k = 0; k < 16; ++k) {
+                v[k][0] = fmaf(w, pre[k].x, v[k][0]); v[k][1] = fmaf(w, pre[k].y, v[k][1]);
+                v[k][2] = fmaf(w, pre[k].z, v[k][2]); v[k][3] = fmaf(w, pre[k].w, v[k][3]);
+            }
+        } else {
+            add_f16(reinterpret_cast<const f16*>(p.res1), p.ldr1);
+            if (res2_same) add_f16(reinterpret_cast<const f16*>(p.res1), p.ldr1);
+        }
     }
-    float o[8];
+    if (p.res2 && !res2_same) {
+        if (r2f32) add_f32(reinterpret_cast<const float*>(p.res2), p.ldr2);
+        else add_f16(reinterpret_cast<const f16*>(p.res2), p.ldr2);
+    }
+    float cs[4] = {0, 0, 0, 0}, cq2[4] = {0, 0, 0, 0};
 #pragma unroll
-    for (int j = 0; j < 8; ++j) o[j] = val[j] * gelu_erf_f(gate[j]);
-    store_out8(p, gm, (gv >> 6) * 32 + (gv & 31), o);   // interleaved column -> output column
-}
-
-// Shared tail of both mainloops: split-K partial store, or LDS-staged fused epilogue with 16-byte accesses.
-// Must be entered by all threads after a barrier that ends all LDS reads of the mainloop.  Wave (wm, wn) of the
-// WGM x WGN grid holds TM x TN 32x32 accumulators of its (BM/WGM) x (BN/WGN) sub-tile.
-// DUAL (mma_pp_kernel): the workgroup is TWO groups of WGM x WGN waves that each hold a partial accumulator of the same tile
-// (even / odd K slabs); a band is staged by group 0 and then added to by group 1, and all 2 x 64 WGM WGN threads consume it.
-template <int BM, int BN, int WGM, int WGN, bool DUAL = false>
-__device__ __forceinline__ void tile_epilogue(const MmaParams& p, char* smem, f32x16 (&acc)[BM / WGM / 32][BN / WGN / 32],
-                                              int m0, int n0, int z) {
-    constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 32, TN = WN / 32, NWG = WGM * WGN, NT = (DUAL ? 128 : 64) * NWG;
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int group = DUAL ? wave / NWG : 0, wv = DUAL ? wave - group * NWG : wave;
-    const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
-    // one 32-row band of every wave row -> sC [WGM*32][BN] fp32 (DUAL: group 0 stores, group 1 adds); ends with a barrier
-    auto stage_band = [&](int ip, bool first) __attribute__((always_inline)) {
-        float* sC = reinterpret_cast<float*>(smem);
-        if (!first) __syncthreads();   // previous band fully consumed
-        if (group == 0) {
+    for (int k = 0; k < 16; ++k) {
+        const int gm = rowq + 4 * k;
+        if (gm < p.M && col_ok) {
+            store_out4(p, gm, colq, v[k]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int n = wn * WN + j * 32 + l31;
+            for (int e = 0; e < 4; ++e) { cs[e] += v[k][e]; cq2[e] = fmaf(v[k][e], v[k][e], cq2[e]); }
+        }
+    }
+    if (want_stats) {
+        // GroupNorm statistics as an epilogue: per-(row tile, channel) sums of the FINAL fp32 values (bias / temb / residual
+        // included, before the fp16 rounding).  A lane holds 16 rows of its 4 columns; the 4 lane groups (l >> 4) are added by two
+        // exchanges, the WGM wave rows through LDS in fixed order: deterministic, no atomics.
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sC[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * BN + n] = acc[ip][j][r];
+        for (int e = 0; e < 4; ++e) {
+            cs[e] += __shfl_xor(cs[e], 16, 64); cq2[e] += __shfl_xor(cq2[e], 16, 64);
+            cs[e] += __shfl_xor(cs[e], 32, 64); cq2[e] += __shfl_xor(cq2[e], 32, 64);
+        }
+        float* sred = reinterpret_cast<float*>(smem + NW * EPI_WAVE_BYTES);         // [WGM][BN][2], behind the staging regions
+        if (lr == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sred[((wm * BN) + wn * 64 + 4 * lc + e) * 2 + 0] = cs[e];
+                sred[((wm * BN) + wn * 64 + 4 * lc + e) * 2 + 1] = cq2[e];
             }
         }
         __syncthreads();
-        if constexpr (DUAL) {
-            if (group == 1) {
+        for (int idx = threadIdx.x; idx < BN * 2; idx += NT) {
+            const int plane = idx / BN, col = idx - plane * BN;
+            const int gn = n0 + col;
+            if (gn < p.N) {
+                float s = 0.f;
 #pragma unroll
-                for (int j = 0; j < TN; ++j) {
-                    const int n = wn * WN + j * 32 + l31;
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) sC[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi) * BN + n] += acc[ip][j][r];
-                }
+                for (int w = 0; w < WGM; ++w) s += sred[(w * BN + col) * 2 + plane];
+                p.stats[((size_t)(m0 / (64 * WGM)) * 2 + plane) * p.N + gn] = s;
             }
-            __syncthreads();
-        }
-    };
-    if constexpr (DUAL) {
-        if (p.splits > 1) {   // merged partial tile -> workspace, 32 bytes per thread and item
-            float* wsz = p.ws + (size_t)z * p.M * p.N;
-            constexpr int NCHs = BN / 8, BRs = WGM * 32;
-#pragma unroll
-            for (int ip = 0; ip < TM; ++ip) {
-                stage_band(ip, ip == 0);
-                const float* sC = reinterpret_cast<const float*>(smem);
-                for (int idx = t; idx < BRs * NCHs; idx += NT) {
-                    const int lr = idx / NCHs, ch = idx - lr * NCHs;
-                    const int gm = m0 + (lr >> 5) * WM + ip * 32 + (lr & 31), gn = n0 + ch * 8;
-                    if (gm >= p.M || gn >= p.N) continue;
-                    float* dst = wsz + (size_t)gm * p.N + gn;
-                    *reinterpret_cast<float4*>(dst) = *reinterpret_cast<const float4*>(sC + lr * BN + ch * 8);
-                    *reinterpret_cast<float4*>(dst + 4) = *reinterpret_cast<const float4*>(sC + lr * BN + ch * 8 + 4);
-                }
-            }
-            return;
-        }
-    }
-    if (p.splits > 1) {   // raw fp32 partial tile; the epilogue happens in splitk_reduce_kernel
-        float* wsz = p.ws + (size_t)z * p.M * p.N;
-#pragma unroll
-        for (int i = 0; i < TM; ++i)
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const int gn = n0 + wn * WN + j * 32 + l31;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int gm = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * hi;
-                    if (gm < p.M && gn < p.N) wsz[(size_t)gm * p.N + gn] = acc[i][j][r];
-                }
-            }
-        return;
-    }
-    // ---- fused epilogue through LDS, one 32-row band of every wave's sub-tile at a time (TM passes): the staging
-    // buffer is [WGM*32][BN] fp32 = BM*BN*4/TM bytes, so the epilogue never needs more LDS than the mainloop ring and
-    // small rings (S = 2) leave room for a second workgroup of another kernel on the same CU.
-    float* sC = reinterpret_cast<float*>(smem);
-    constexpr int BR = WGM * 32;   // rows staged per pass
-    if (p.mode == SG_EPI_LINEAR) {
-        // every thread owns IT = 4 (row, 8-column chunk) items per band (BR * BN/8 / NT == 4 for every tile shape).  The
-        // additive epilogue terms (bias, temb row-bias, residuals) do not depend on the accumulators, so their global
-        // loads are issued BEFORE the band is staged: the HBM latency overlaps the LDS round trip instead of following it.
-        constexpr int NCH = BN / 8, IT = BR * NCH / NT;
-        static_assert(IT * NT == BR * NCH, "items per thread must be integral");
-        static_assert(NT % NCH == 0 && 64 % NCH == 0, "a thread's items share one column chunk");
-        const bool want_stats = p.stats != nullptr;
-        float cs[8] = {0, 0, 0, 0, 0, 0, 0, 0}, cq[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-#pragma unroll
-        for (int ip = 0; ip < TM; ++ip) {
-            float add[IT][8];
-            int gmv[IT], gnv[IT];
-#pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                const int idx = t + it * NT;
-                const int lr = idx / NCH, ch = idx - lr * NCH;
-                gmv[it] = m0 + (lr >> 5) * WM + ip * 32 + (lr & 31);
-                gnv[it] = n0 + ch * 8;
-#pragma unroll
-                for (int j = 0; j < 8; ++j) add[it][j] = 0.f;
-                if (gmv[it] < p.M && gnv[it] < p.N) {
-                    if (p.bias) {
-                        H8 b; b.u = ldg16(p.bias + gnv[it]);
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) add[it][j] += (float)b.h[j];
-                    }
-                    if (p.rowbias) {
-                        const float* rb = p.rowbias + (long)(gmv[it] / p.rows_per_batch) * p.rowbias_ld + gnv[it];
-                        const float4 r0 = *reinterpret_cast<const float4*>(rb), r1 = *reinterpret_cast<const float4*>(rb + 4);
-                        add[it][0] += r0.x; add[it][1] += r0.y; add[it][2] += r0.z; add[it][3] += r0.w;
-                        add[it][4] += r1.x; add[it][5] += r1.y; add[it][6] += r1.z; add[it][7] += r1.w;
-                    }
-                    if (p.res1) add_res8(p.res1, p.ldr1, p.flags & SG_F_RES1_F32, gmv[it], gnv[it], add[it]);
-                    if (p.res2) add_res8(p.res2, p.ldr2, p.flags & SG_F_RES2_F32, gmv[it], gnv[it], add[it]);
-                }
-            }
-            stage_band(ip, ip == 0);
-#pragma unroll
-            for (int it = 0; it < IT; ++it) {
-                if (gmv[it] >= p.M || gnv[it] >= p.N) continue;
-                const int idx = t + it * NT;
-                const int lr = idx / NCH, ch = idx - lr * NCH;
-                const float4 v0 = *reinterpret_cast<const float4*>(sC + lr * BN + ch * 8);
-                const float4 v1 = *reinterpret_cast<const float4*>(sC + lr * BN + ch * 8 + 4);
-                float v[8] = {v0.x + add[it][0], v0.y + add[it][1], v0.z + add[it][2], v0.w + add[it][3],
-                              v1.x + add[it][4], v1.y + add[it][5], v1.z + add[it][6], v1.w + add[it][7]};
-                store_out8(p, gmv[it], gnv[it], v);
-                if (want_stats) {
-#pragma unroll
-                    for (int j = 0; j < 8; ++j) { cs[j] += v[j]; cq[j] = fmaf(v[j], v[j], cq[j]); }
-                }
-            }
-        }
-        if (want_stats) {
-            // GroupNorm statistics as an epilogue: per-(row tile, channel) sums of the FINAL fp32 values (bias / temb / residual
-            // included, before the fp16 rounding).  A thread's items all sit in column chunk t % NCH (NT % NCH == 0), so: lanes
-            // with equal lane % NCH -> one lane (shuffles), waves -> LDS -> fixed-order sum: deterministic, no atomics.
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-#pragma unroll
-                for (int o = 32; o >= NCH; o >>= 1) {
-                    cs[j] += __shfl_xor(cs[j], o, 64);
-                    cq[j] += __shfl_xor(cq[j], o, 64);
-                }
-            }
-            __syncthreads();                    // the last band's LDS reads are done: sC can be reused
-            float* sred = reinterpret_cast<float*>(smem);            // [wave][NCH][16]
-            if (lane < NCH) {
-#pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    sred[(wave * NCH + lane) * 16 + j] = cs[j];
-                    sred[(wave * NCH + lane) * 16 + 8 + j] = cq[j];
-                }
-            }
-            __syncthreads();
-            if (t < NCH * 2) {                   // thread (plane = t / NCH, ch = t % NCH): 8 consecutive columns of one plane
-                const int plane = t / NCH, ch = t - plane * NCH;
-                const int gn = n0 + ch * 8;
-                if (gn < p.N) {
-                    float a[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                    for (int w = 0; w < NT / 64; ++w)
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) a[j] += sred[(w * NCH + ch) * 16 + plane * 8 + j];
-                    float* dst = p.stats + ((size_t)(m0 / BM) * 2 + plane) * p.N + gn;
-                    *reinterpret_cast<float4*>(dst) = make_float4(a[0], a[1], a[2], a[3]);
-                    *reinterpret_cast<float4*>(dst + 4) = make_float4(a[4], a[5], a[6], a[7]);
-                }
-            }
-        }
-        return;
-    }
-    // GEGLU: bias only (tiny, cached); one band at a time
-#pragma unroll
-    for (int ip = 0; ip < TM; ++ip) {
-        stage_band(ip, ip == 0);
-        constexpr int OCH = BN / 16;
-        for (int idx = t; idx < BR * OCH; idx += NT) {
-            const int lr = idx / OCH, j = idx - lr * OCH;
-            const int vcol = (j >> 2) * 64 + (j & 3) * 8;
-            const int gm = m0 + (lr >> 5) * WM + ip * 32 + (lr & 31), gv = n0 + vcol;
-            if (gm >= p.M || gv >= p.N) continue;
-            const float* sp = sC + lr * BN + vcol;
-            const float4 a0 = *reinterpret_cast<const float4*>(sp), a1 = *reinterpret_cast<const float4*>(sp + 4);
-            const float4 g0 = *reinterpret_cast<const float4*>(sp + 32), g1 = *reinterpret_cast<const float4*>(sp + 36);
-            float val[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-            float gate[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-            epi_geglu8(p, gm, gv, val, gate);
         }
     }
 }
@@ -307,19 +313,17 @@ __device__ __forceinline__ void tile_epilogue(const MmaParams& p, char* smem, f3
 template <int BM, int BN, bool CONV>
 __global__ __launch_bounds__(256) void mma_kernel(const MmaParams p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    static_assert(TM == 2 && TN == 2, "epi_finish works on 64x64 wave tiles");
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int EPI_BYTES = 2 * 32 * BN * 4;   // one 32-row band per wave-row (tile_epilogue)
+    constexpr int EPI_BYTES = 4 * EPI_WAVE_BYTES + 2 * BN * 2 * 4;   // staging regions + statistics scratch of epi_finish
     constexpr int SMEM = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, hi = lane >> 5;
-    // logical id = tile * splits + slice: the K slices of a tile are consecutive ids (one XCD, see xcd_remap)
-    const int lid2 = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.splits);
-    const int lid = lid2 / p.splits, z = lid2 - lid * p.splits;
-    const int m0 = (p.n_major ? lid % p.tiles_m : lid / p.tiles_n) * BM;
-    const int n0 = (p.n_major ? lid / p.tiles_m : lid % p.tiles_n) * BN;
+    int m0, n0, z;
+    decode_block(p, BM, BN, m0, n0, z);
     const int kt0 = z * p.kt_per_split;
     const int kt1 = min(p.KT, kt0 + p.kt_per_split);
 
@@ -419,21 +423,24 @@ __global__ __launch_bounds__(256) void mma_kernel(const MmaParams p) {
             for (int i = 0; i < TM; ++i)
 #pragma unroll
                 for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[j], af[i], acc[i][j], 0, 0, 0);   // transposed product: see epi_finish
         }
         if (more) store_lds(buf ^ 1);
         __syncthreads();
     }
-    tile_epilogue<BM, BN, 2, 2>(p, smem, acc, m0, n0, z);
+    EpiPre pre;
+    epi_prefetch(p, m0 + wm * WM + (lane >> 4), n0 + wn * WN + 4 * (lane & 15), pre);
+    __syncthreads();
+    epi_finish<2, 2>(p, smem, acc, pre, m0, n0, z, wave, wm, wn, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------
-// Pipelined kernel: WGM x WGN waves of 64x64, S LDS stages filled by LDS-DMA.  Requires loads that need no
+// Pipelined kernel: WGM x WGN waves of 64x64, 3 LDS stages filled by LDS-DMA.  Requires loads that need no
 // predicate: rows beyond M / N are clamped to the last valid row (their results are discarded by the epilogue);
 // K % 64 == 0; for the convolution the input has a one-pixel zero border ([B, H+2, W+2, C]), so every tap of every
 // output pixel reads valid memory and padding costs nothing.
-// Slab t+S-1 is issued right after the barrier that (a) publishes slab t (every wave waited for its own DMA with a
-// counted vmcnt first) and (b) retires every wave's reads of slab t-1, whose stage it overwrites.
+// Slab t+2 is issued behind the first k-step of slab t, i.e. after the barrier that (a) publishes slab t (every wave waited
+// for its own DMA with a counted vmcnt first) and (b) retires every wave's reads of slab t-1, whose stage it overwrites.
 __device__ __forceinline__ void glds16(const f16* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
@@ -444,21 +451,19 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int WGM, int WGN, int S, int WTM = 2, int WTN = 2>
+constexpr int S = 3;   // LDS ring depth (2 and 4 were measured in round 2: DESIGN.md 5.2)
+
+template <int WGM, int WGN>
 constexpr int pipe_smem_bytes() {
-    constexpr int STAGE = (32 * WTM * WGM + 32 * WTN * WGN) * 128, EPI = WGM * 32 * (32 * WTN * WGN) * 4;
-    return S * STAGE > EPI ? S * STAGE : EPI;
+    constexpr int ring = S * (64 * WGM + 64 * WGN) * 128, epi = WGM * WGN * EPI_WAVE_BYTES + WGM * 64 * WGN * 2 * 4;
+    return ring > epi ? ring : epi;
 }
 
-// SPREAD: how the LDS-DMA instructions of the slab two ahead are placed among the 16 MFMAs of the current slab.  0: all of them
-// between k-step 0 and k-step 1 (the matrix pipe drains while 6-16 DMA instructions are issued: ~400-550 of ~1400-2000 cycles
-// per slab, tools/anatomy.py); 1: a third each in front of k-steps 1, 2, 3; 2: one or two behind every MFMA of k-steps 1-3, order
-// pinned with sched_barrier.
-template <int WGM, int WGN, int S, bool CONV, bool LATE, bool PREF, int WTM = 2, int WTN = 2, bool PROF = false, int SPREAD = 0>
+template <int WGM, int WGN, bool CONV, bool PROF = false>
 __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
-    // PROF: s_memtime stamps around the phases of every slab, summed per wave (sg_debug_gemm_anatomy / _conv_anatomy):
-    // [0] slabs [1] vmcnt wait [2] barrier [3] first fragment reads + k-step 0 [4] k-step 1 up to the DMA issue [5] DMA issue
-    // [6] rest of the slab [7] prologue (entry -> loop) [8] epilogue (loop end -> exit)
+    // PROF (SG_BUILD_EXPERIMENTS): s_memtime stamps around the phases of every slab, summed per wave (sg_debug_gemm_anatomy /
+    // _conv_anatomy): [0] slabs [1] vmcnt wait [2] barrier [3] first fragment reads + k-step 0 [4] k-step 1 up to the DMA issue
+    // [5] DMA issue [6] rest of the slab [7] prologue (entry -> loop) [8] epilogue (loop end -> exit)
     unsigned long long pf_acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
     unsigned long long pf_t = 0, pf_entry = 0;
     auto stamp = [&](int slot) __attribute__((always_inline)) {
@@ -469,27 +474,20 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         }
     };
     if constexpr (PROF) pf_entry = pf_t = __builtin_readcyclecounter();
-    // every wave owns a (32 WTM) x (32 WTN) output sub-tile.  2 x 2 needs 1 KiB of LDS fragment reads per MFMA, which at
-    // full MFMA rate is the whole LDS read bandwidth of the CU (8 waves x 32 B/clk); "fat" 4 x 2 waves (128 x 64, 128
-    // accumulator registers, one wave per SIMD) need 0.75 KiB per MFMA and half as many waves for the same tile.
+    constexpr int WTM = 2, WTN = 2;
     constexpr int NW = WGM * WGN, WM = 32 * WTM, WN = 32 * WTN, BM = WM * WGM, BN = WN * WGN;
     constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW), LPT = A_IT + B_IT;   // LDS-DMA instructions / lane / slab
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int EPI_BYTES = WGM * 32 * BN * 4;   // one 32-row band per wave-row (tile_epilogue)
-    constexpr int SMEM = (S * STAGE > EPI_BYTES) ? S * STAGE : EPI_BYTES;
     constexpr int ISTR = NW * 1024;   // LDS bytes covered by one DMA instruction of the whole workgroup (8 rows / wave)
-    static_assert(S >= 2 && S <= 4 && (S - 2) * LPT < 64, "2 to 4 stages; vmcnt is a 6-bit counter");
+    static_assert((S - 2) * LPT < 64, "vmcnt is a 6-bit counter");
     static_assert(S * STAGE <= 160 * 1024, "the ring must fit the 160 KB of LDS");
-    static_assert(SMEM == pipe_smem_bytes<WGM, WGN, S, WTM, WTN>(), "LDS size of the wrappers");
+    static_assert(S * STAGE == pipe_smem_bytes<WGM, WGN>(), "the ring covers the epilogue's staging regions for every tile shape");
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, hi = lane >> 5;
-    // logical id = tile * splits + slice: the K slices of a tile are consecutive ids (one XCD, see xcd_remap)
-    const int lid2 = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.splits);
-    const int lid = lid2 / p.splits, z = lid2 - lid * p.splits;
-    const int m0 = (p.n_major ? lid % p.tiles_m : lid / p.tiles_n) * BM;
-    const int n0 = (p.n_major ? lid / p.tiles_m : lid % p.tiles_n) * BN;
+    int m0, n0, z;
+    decode_block(p, BM, BN, m0, n0, z);
     const int kt0 = z * p.kt_per_split;
     const int nt = min(p.KT, kt0 + p.kt_per_split) - kt0;
 
@@ -499,6 +497,22 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     // source row (oy-1+ky)>>1 is not affine in ky, one of three precomputed row / column offsets picked by (ky, kx).
     const int srow = wave * 8 + (lane >> 3);
     const int wp = p.Wd + 2;
+    // the weight side first: its offsets need no division, so the first DMA instructions leave before the pixel arithmetic
+    unsigned w_off[B_IT];
+#pragma unroll
+    for (int i = 0; i < B_IT; ++i) {
+        const int row = srow + 8 * NW * i;
+        const int lc = (lane & 7) ^ ((row >> 1) & 7);
+        w_off[i] = (unsigned)((long)min(n0 + row, p.N - 1) * p.ldw + lc * 8);
+    }
+    auto issue_w = [&](int kt, int stage) __attribute__((always_inline)) {
+        char* sB = smem + stage * STAGE + A_BYTES + wave * 1024;
+        const f16* Wt = p.W + kt * BK;
+#pragma unroll
+        for (int i = 0; i < B_IT; ++i) glds16(Wt + w_off[i], sB + i * ISTR);
+    };
+    if (nt > 0) issue_w(kt0, 0);
+
     unsigned a_off[A_IT];                       // offset of the row (GEMM) / of tap (0, 0) (conv)
     unsigned a_par[A_IT];                       // conv with upsampling: parity bits of (oy - 1, ox - 1)
 #pragma unroll
@@ -508,8 +522,8 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         const int gm = min(m0 + row, p.M - 1);
         if constexpr (CONV) {
             const int hw = p.Ho * p.Wo;
-            const int b = gm / hw, rem = gm - b * hw;
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
+            const int b = (int)fd_div((unsigned)gm, p.fd_hw), rem = gm - b * hw;
+            const int oy = (int)fd_div((unsigned)rem, p.fd_wo), ox = rem - oy * p.Wo;
             const long img = (long)b * (p.H + 2) * wp;
             // padded input pixel of tap (ky, kx): row ((oy*stride - 1 + ky) >> ups) + 1, column likewise
             if (!p.ups) {
@@ -525,32 +539,21 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
             a_par[i] = 0;
         }
     }
-    unsigned w_off[B_IT];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-        const int row = srow + 8 * NW * i;
-        const int lc = (lane & 7) ^ ((row >> 1) & 7);
-        w_off[i] = (unsigned)((long)min(n0 + row, p.N - 1) * p.ldw + lc * 8);
-    }
 
-    // part / nparts: only the loads whose index (A loads first, then W loads) is congruent to `part` modulo `nparts` (all: 0, 1)
-    auto issue = [&](int kt, int stage, int part = 0, int nparts = 1) __attribute__((always_inline)) {
+    auto issue_a = [&](int kt, int stage) __attribute__((always_inline)) {
         char* sA = smem + stage * STAGE + wave * 1024;
-        char* sB = sA + A_BYTES;
         if constexpr (CONV) {
-            const int tap = kt / p.cpt, cc = kt - tap * p.cpt;
-            const int ky = tap / 3, kx = tap - ky * 3;
+            const int tap = (int)fd_div((unsigned)kt, p.fd_cpt), cc = kt - tap * p.cpt;
+            const int ky = (tap * 11) >> 5, kx = tap - ky * 3;           // tap / 3 for tap < 9
             if (!p.ups) {
                 const f16* At = p.A + ((long)(ky * wp + kx) * p.lda + cc * BK);
 #pragma unroll
-                for (int i = 0; i < A_IT; ++i)
-                    if (i % nparts == part) glds16(At + a_off[i], sA + i * ISTR);
+                for (int i = 0; i < A_IT; ++i) glds16(At + a_off[i], sA + i * ISTR);
             } else {
                 const f16* At = p.A + cc * BK;
                 const unsigned rs = (unsigned)(wp * (int)p.lda), cs = (unsigned)p.lda;     // < 2^24 (validated on the host)
 #pragma unroll
                 for (int i = 0; i < A_IT; ++i) {
-                    if (i % nparts != part) continue;
                     const unsigned dy = ((unsigned)ky + (a_par[i] & 1u)) >> 1, dx = ((unsigned)kx + (a_par[i] >> 1)) >> 1;
                     glds16(At + (a_off[i] + __umul24(dy, rs) + __umul24(dx, cs)), sA + i * ISTR);
                 }
@@ -558,14 +561,11 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         } else {
             const f16* At = p.A + kt * BK;
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i)
-                if (i % nparts == part) glds16(At + a_off[i], sA + i * ISTR);
+            for (int i = 0; i < A_IT; ++i) glds16(At + a_off[i], sA + i * ISTR);
         }
-        const f16* Wt = p.W + kt * BK;
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i)
-            if ((A_IT + i) % nparts == part) glds16(Wt + w_off[i], sB + i * ISTR);
     };
+    if (nt > 0) issue_a(kt0, 0);
+    if (nt > 1) { issue_a(kt0 + 1, 1); issue_w(kt0 + 1, 1); }
 
     f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -574,32 +574,26 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         for (int j = 0; j < WTN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-#pragma unroll
-    for (int s = 0; s < S - 1; ++s)
-        if (s < nt) issue(kt0 + s, s);
+    EpiPre pre;
+    const int rowq = m0 + wm * WM + (lane >> 4), colq = n0 + wn * WN + 4 * (lane & 15);
 
     int stage = 0;
     stamp(7);
-    for (int it = 0; it < nt; ++it) {
-        // up to S - 2 younger slabs stay in flight while we wait for slab `it` (fewer at the very end)
-        if (S >= 4 && it + 2 < nt) wait_vmcnt<(S >= 4 ? 2 : 0) * LPT>();
-        else if (S >= 3 && it + 1 < nt) wait_vmcnt<(S >= 3 ? 1 : 0) * LPT>();
-        else wait_vmcnt<0>();
+    // one K slab; LAST = the final slab of this block (no refill: the residual of the epilogue is requested under its MFMAs instead)
+    auto slab = [&](int it, auto last_tag) __attribute__((always_inline)) {
+        constexpr bool LAST = decltype(last_tag)::value;
+        // one younger slab stays in flight while we wait for slab `it` (none at the very end)
+        if constexpr (LAST) wait_vmcnt<0>();
+        else wait_vmcnt<LPT>();
         stamp(1);
         __builtin_amdgcn_s_barrier();
         stamp(2);
-        if (!LATE && it + S - 1 < nt) {         // refill right behind the barrier
-            int st = stage + S - 1;
-            if (st >= S) st -= S;
-            issue(kt0 + it + S - 1, st);
-        }
         const char* sA = smem + stage * STAGE;
         const char* sB = sA + A_BYTES;
         // fragment reads run one k-step ahead of the MFMAs that consume them (two register sets), so that only the first
         // read of a slab exposes LDS latency; the other three hide behind the previous k-step's four MFMAs
         f16x8 af[2][WTM], bf[2][WTN];
-        auto load_frags = [&](int buf, int ks) {
+        auto load_frags = [&](int buf, int ks) __attribute__((always_inline)) {
 #pragma unroll
             for (int i = 0; i < WTM; ++i)
                 af[buf][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WM + i * 32 + l31, ks * 2 + hi));
@@ -610,39 +604,36 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         load_frags(0, 0);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            if (PREF) { if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1); }
-            else if (ks > 0) load_frags(ks & 1, ks);
-            // the refill of the ring (slab it+S-1 into the stage every wave has just left) is issued behind the first
-            // k-step's fragment reads rather than between the barrier and them: its address arithmetic then overlaps
-            // matrix work instead of delaying it
-            int st = stage + S - 1;
-            if (st >= S) st -= S;
-            const bool refill = LATE && it + S - 1 < nt;
-            if (SPREAD == 0 && ks == 1 && refill) {
+            if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
+            if (ks == 1) {
+                // the refill of the ring (slab it+2 into the stage every wave has just left) is issued behind the first
+                // k-step's fragment reads: its address arithmetic then overlaps matrix work instead of delaying it
                 stamp(4);
-                issue(kt0 + it + S - 1, st);
+                if constexpr (LAST) {
+                    epi_prefetch(p, rowq, colq, pre);
+                } else if (it + S - 1 < nt) {
+                    int st = stage + S - 1;
+                    if (st >= S) st -= S;
+                    issue_a(kt0 + it + S - 1, st);
+                    issue_w(kt0 + it + S - 1, st);
+                }
                 stamp(5);
             }
-            if (SPREAD == 1 && ks >= 1 && refill) issue(kt0 + it + S - 1, st, ks - 1, 3);
 #pragma unroll
             for (int i = 0; i < WTM; ++i)
 #pragma unroll
-                for (int j = 0; j < WTN; ++j) {
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
-                    if (SPREAD == 2 && ks >= 1) {
-                        __builtin_amdgcn_sched_barrier(0);
-                        if (refill) issue(kt0 + it + S - 1, st, (ks - 1) * WTM * WTN + i * WTN + j, 3 * WTM * WTN);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                }
+                for (int j = 0; j < WTN; ++j)   // transposed product (weight fragment = A operand): see epi_finish
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0);
             if (ks == 0) stamp(3);
         }
         if (++stage == S) stage = 0;
         stamp(6);
         if constexpr (PROF) pf_acc[0] += 1;
-    }
-    __syncthreads();   // every wave is done reading the stages before the epilogue reuses LDS
-    tile_epilogue<BM, BN, WGM, WGN>(p, smem, acc, m0, n0, z);
+    };
+    for (int it = 0; it + 1 < nt; ++it) slab(it, std::false_type{});
+    if (nt > 0) slab(nt - 1, std::true_type{});
+    if (nt <= 0) epi_prefetch(p, rowq, colq, pre);
+    epi_finish<WGM, WGN>(p, smem, acc, pre, m0, n0, z, wave, wm, wn, lane);
     if constexpr (PROF) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(8);
@@ -655,179 +646,19 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     }
 }
 
-template <int WGM, int WGN, bool CONV, int SPREAD>
-__global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_prof_kernel(const MmaParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN, 3>()];
-    mma_pipe_body<WGM, WGN, 3, CONV, true, true, 2, 2, true, SPREAD>(p, smem);
-}
-
-template <int WGM, int WGN, bool CONV, int SPREAD>
-__global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_spread_kernel(const MmaParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN, 3>()];
-    mma_pipe_body<WGM, WGN, 3, CONV, true, true, 2, 2, false, SPREAD>(p, smem);
-}
-
-// ------------------------------------------------------------------------------------------------------------
-// Ping-pong variant of the pipelined kernel (round 2; the answer to tools/anatomy.py's finding that the phases of a slab ADD
-// because all waves of a workgroup move in lock step).  The workgroup is TWO groups of WGM x WGN waves working on the SAME
-// output tile: group 0 accumulates the even K slabs, group 1 the odd ones, each from its own 2-stage LDS ring filled by its own
-// waves.  Every interval between two workgroup barriers one group computes a slab (fragment reads + 16 MFMAs per wave) while the
-// other issues the LDS-DMA of its slab after next and waits for its next one — each SIMD hosts one wave of either group, so
-// DMA issue, vmcnt wait and barrier latency of one group run beside the matrix work of the other.  The two partial accumulators
-// are added in the LDS-staged epilogue (tile_epilogue<..., DUAL>).  Same loads, one more fp32 addition per output: results agree
-// with mma_pipe_kernel to fp32 summation order.
-// Protocol of group g (its slab i is K slab 2 i + g; n_g slabs; stage = i & 1), identical barrier count for both groups:
-//   prologue: issue slab 0 and slab 1; group 0 waits for slab 0.
-//   interval k = 0 .. nt-1:  s_barrier;
-//       k % 2 == g : compute slab i = k / 2                      (landed: waited for in interval k-1, published by this barrier)
-//       else       : i' = (k + 1) / 2 = the slab computed next;  issue slab i'+1 (if >= 2: its stage held slab i'-1, computed in
-//                    interval k-1, before this barrier), then wait until slab i' has landed (leaving slab i'+1 in flight).
 template <int WGM, int WGN, bool CONV>
-__global__ __launch_bounds__(128 * WGM * WGN) void mma_pp_kernel(const MmaParams p) {
-    constexpr int NW = WGM * WGN, WM = 64, WN = 64, BM = WM * WGM, BN = WN * WGN;
-    constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW), LPT = A_IT + B_IT;   // LDS-DMA instructions / lane / slab (one group)
-    constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int EPI_BYTES = WGM * 32 * BN * 4;
-    constexpr int SMEM = (4 * STAGE > EPI_BYTES) ? 4 * STAGE : EPI_BYTES;
-    constexpr int ISTR = NW * 1024;
-    static_assert(4 * STAGE <= 160 * 1024, "two 2-stage rings must fit the 160 KB of LDS");
-    static_assert(LPT < 64, "vmcnt is a 6-bit counter");
-    __shared__ __attribute__((aligned(16))) char smem[SMEM];
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int g = wave / NW, wv = wave - g * NW;               // group, wave within the group
-    const int wm = wv / WGN, wn = wv % WGN, l31 = lane & 31, hi = lane >> 5;
-    const int lid2 = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.splits);
-    const int lid = lid2 / p.splits, z = lid2 - lid * p.splits;
-    const int m0 = (p.n_major ? lid % p.tiles_m : lid / p.tiles_n) * BM;
-    const int n0 = (p.n_major ? lid / p.tiles_m : lid % p.tiles_n) * BN;
-    const int kt0 = z * p.kt_per_split;
-    const int nt = min(p.KT, kt0 + p.kt_per_split) - kt0;      // K slabs of this block
-    const int ng = (nt - g + 1) >> 1;                           // ... of this group: slabs kt0 + 2 i + g
-    char* const ring = smem + g * 2 * STAGE;
-
-    const int srow = wv * 8 + (lane >> 3);
-    const int wp = p.Wd + 2;
-    unsigned a_off[A_IT], a_par[A_IT];
-#pragma unroll
-    for (int i = 0; i < A_IT; ++i) {
-        const int row = srow + 8 * NW * i;
-        const int lc = (lane & 7) ^ ((row >> 1) & 7);
-        const int gm = min(m0 + row, p.M - 1);
-        if constexpr (CONV) {
-            const int hw = p.Ho * p.Wo;
-            const int b = gm / hw, rem = gm - b * hw;
-            const int oy = rem / p.Wo, ox = rem - oy * p.Wo;
-            const long img = (long)b * (p.H + 2) * wp;
-            if (!p.ups) {
-                a_off[i] = (unsigned)((img + (long)(oy * p.stride) * wp + ox * p.stride) * p.lda + lc * 8);
-                a_par[i] = 0;
-            } else {
-                a_off[i] = (unsigned)((img + (long)(((oy - 1) >> 1) + 1) * wp + ((ox - 1) >> 1) + 1) * p.lda + lc * 8);
-                a_par[i] = (unsigned)(((oy - 1) & 1) | (((ox - 1) & 1) << 1));
-            }
-        } else {
-            a_off[i] = (unsigned)((long)gm * p.lda + lc * 8);
-            a_par[i] = 0;
-        }
-    }
-    unsigned w_off[B_IT];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-        const int row = srow + 8 * NW * i;
-        const int lc = (lane & 7) ^ ((row >> 1) & 7);
-        w_off[i] = (unsigned)((long)min(n0 + row, p.N - 1) * p.ldw + lc * 8);
-    }
-    auto issue = [&](int i) __attribute__((always_inline)) {   // this group's slab i -> stage i & 1
-        const int kt = kt0 + 2 * i + g;
-        char* sA = ring + (i & 1) * STAGE + wv * 1024;
-        char* sB = sA + A_BYTES;
-        if constexpr (CONV) {
-            const int tap = kt / p.cpt, cc = kt - tap * p.cpt;
-            const int ky = tap / 3, kx = tap - ky * 3;
-            if (!p.ups) {
-                const f16* At = p.A + ((long)(ky * wp + kx) * p.lda + cc * BK);
-#pragma unroll
-                for (int j = 0; j < A_IT; ++j) glds16(At + a_off[j], sA + j * ISTR);
-            } else {
-                const f16* At = p.A + cc * BK;
-                const unsigned rs = (unsigned)(wp * (int)p.lda), cs = (unsigned)p.lda;
-#pragma unroll
-                for (int j = 0; j < A_IT; ++j) {
-                    const unsigned dy = ((unsigned)ky + (a_par[j] & 1u)) >> 1, dx = ((unsigned)kx + (a_par[j] >> 1)) >> 1;
-                    glds16(At + (a_off[j] + __umul24(dy, rs) + __umul24(dx, cs)), sA + j * ISTR);
-                }
-            }
-        } else {
-            const f16* At = p.A + kt * BK;
-#pragma unroll
-            for (int j = 0; j < A_IT; ++j) glds16(At + a_off[j], sA + j * ISTR);
-        }
-        const f16* Wt = p.W + kt * BK;
-#pragma unroll
-        for (int j = 0; j < B_IT; ++j) glds16(Wt + w_off[j], sB + j * ISTR);
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    if (ng > 0) issue(0);
-    if (ng > 1) issue(1);
-    if (g == 0) {
-        if (ng > 1) wait_vmcnt<LPT>();
-        else wait_vmcnt<0>();
-    }
-#pragma unroll 1
-    for (int k = 0; k < nt; ++k) {
-        __builtin_amdgcn_s_barrier();
-        if ((k & 1) == g) {
-            const int i = k >> 1;
-            const char* sA = ring + (i & 1) * STAGE;
-            const char* sB = sA + A_BYTES;
-            f16x8 af[2][2], bf[2][2];
-            auto load_frags = [&](int buf, int ks) __attribute__((always_inline)) {
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    af[buf][u] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WM + u * 32 + l31, ks * 2 + hi));
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    bf[buf][u] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WN + u * 32 + l31, ks * 2 + hi));
-            };
-            load_frags(0, 0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
-#pragma unroll
-                for (int u = 0; u < 2; ++u)
-#pragma unroll
-                    for (int v = 0; v < 2; ++v)
-                        acc[u][v] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][u], bf[ks & 1][v], acc[u][v], 0, 0, 0);
-            }
-        } else {
-            const int in = (k + 1) >> 1;                       // the slab this group computes in the next interval
-            if (in < ng) {
-                const bool more = in + 1 < ng;
-                if (more && in + 1 >= 2) issue(in + 1);
-                if (more) wait_vmcnt<LPT>();
-                else wait_vmcnt<0>();
-            }
-        }
-    }
-    __syncthreads();   // every wave is done reading its ring before the epilogue reuses LDS
-    tile_epilogue<BM, BN, WGM, WGN, true>(p, smem, acc, m0, n0, z);
-}
-
-template <int WGM, int WGN, int S, bool CONV, bool LATE, bool PREF, int WTM = 2, int WTN = 2>
 __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN, S, WTM, WTN>()];
-    mma_pipe_body<WGM, WGN, S, CONV, LATE, PREF, WTM, WTN>(p, smem);
+    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN>()];
+    mma_pipe_body<WGM, WGN, CONV>(p, smem);
 }
+
+#ifdef SG_BUILD_EXPERIMENTS
+template <int WGM, int WGN, bool CONV>
+__global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_prof_kernel(const MmaParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN>()];
+    mma_pipe_body<WGM, WGN, CONV, true>(p, smem);
+}
+#endif
 
 // Two independent GEMMs in ONE launch (blockIdx.y selects the problem; blocks beyond a problem's grid exit): the q|k and V^T
 // projections of one LayerNorm output, the text / image query projections, the attn3 K and V^T projections of a finished
@@ -838,12 +669,77 @@ struct MmaPair { MmaParams p0, p1; };
 
 template <int WGM, int WGN>
 __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_pair_kernel(const MmaPair pp) {
-    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN, 3>()];
+    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN>()];
     if (blockIdx.y == 0) {
-        if ((int)blockIdx.x < pp.p0.tiles_m * pp.p0.tiles_n * pp.p0.splits) mma_pipe_body<WGM, WGN, 3, false, true, true>(pp.p0, smem);
+        if ((int)blockIdx.x < pp.p0.tiles_m * pp.p0.tiles_n * pp.p0.splits) mma_pipe_body<WGM, WGN, false>(pp.p0, smem);
     } else {
-        if ((int)blockIdx.x < pp.p1.tiles_m * pp.p1.tiles_n * pp.p1.splits) mma_pipe_body<WGM, WGN, 3, false, true, true>(pp.p1, smem);
+        if ((int)blockIdx.x < pp.p1.tiles_m * pp.p1.tiles_n * pp.p1.splits) mma_pipe_body<WGM, WGN, false>(pp.p1, smem);
     }
+}
+
+// ---- second pass of a split-K launch: partial tiles -> epilogue (8 consecutive columns per thread)
+__device__ __forceinline__ void add8(float (&v)[8], const uint4& a, const uint4& b, bool f32) {
+    if (f32) {
+        v[0] += __uint_as_float(a.x); v[1] += __uint_as_float(a.y); v[2] += __uint_as_float(a.z); v[3] += __uint_as_float(a.w);
+        v[4] += __uint_as_float(b.x); v[5] += __uint_as_float(b.y); v[6] += __uint_as_float(b.z); v[7] += __uint_as_float(b.w);
+    } else {
+        H8 h; h.u = a;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] += (float)h.h[e];
+    }
+}
+
+__device__ __forceinline__ void store_out8(const MmaParams& p, int gm, int gn, const float (&v)[8]) {
+    const bool f32 = p.flags & SG_F_OUT_F32;
+    if (f32) {
+        float* o = reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn;
+        *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+        *reinterpret_cast<float4*>(o + 4) = make_float4(v[4], v[5], v[6], v[7]);
+    }
+    if (!f32 || p.C2) {
+        H8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o.h[e] = (f16)v[e];
+        if (!f32) stg16(reinterpret_cast<f16*>(p.C) + (long)gm * p.ldc + gn, o.u);
+        if (p.C2) stg16(p.C2 + (long)gm * p.ldc2 + gn, o.u);
+    }
+}
+
+__device__ __forceinline__ void add_res8(const void* res, long ld, bool f32, int gm, int gn, float (&v)[8]) {
+    if (f32) {
+        const float* r = reinterpret_cast<const float*>(res) + (long)gm * ld + gn;
+        add8(v, ldg16(r), ldg16(r + 4), true);
+    } else {
+        add8(v, ldg16(reinterpret_cast<const f16*>(res) + (long)gm * ld + gn), make_uint4(0, 0, 0, 0), false);
+    }
+}
+
+__device__ __forceinline__ void epi_linear8(const MmaParams& p, int gm, int gn, float (&v)[8]) {
+    if (p.bias) {
+        H8 b; b.u = ldg16(p.bias + gn);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] += (float)b.h[j];
+    }
+    if (p.rowbias) {
+        const float* rb = p.rowbias + (long)fd_div((unsigned)gm, p.fd_rpb) * p.rowbias_ld + gn;
+        add8(v, ldg16(rb), ldg16(rb + 4), true);
+    }
+    if (p.res1) add_res8(p.res1, p.ldr1, p.flags & SG_F_RES1_F32, gm, gn, v);
+    if (p.res2) add_res8(p.res2, p.ldr2, p.flags & SG_F_RES2_F32, gm, gn, v);
+    store_out8(p, gm, gn, v);
+}
+
+// val/gate: 8 consecutive interleaved-layout columns starting at global column gv (value) and gv+32 (gate).
+__device__ __forceinline__ void epi_geglu8(const MmaParams& p, int gm, int gv, float (&val)[8], float (&gate)[8]) {
+    if (p.bias) {
+        H8 bv, bg; bv.u = ldg16(p.bias + gv); bg.u = ldg16(p.bias + gv + 32);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { val[j] += (float)bv.h[j]; gate[j] += (float)bg.h[j]; }
+    }
+    float o[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = val[j] * gelu_erf_f(gate[j]);
+    store_out8(p, gm, (gv >> 6) * 32 + (gv & 31), o);   // interleaved column -> output column
 }
 
 __global__ __launch_bounds__(256) void splitk_reduce_kernel(const MmaParams p) {
@@ -910,179 +806,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const MmaParams p) {
     }
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// 3x3 convolution (stride 1, zero-bordered input) with the INPUT PATCH RESIDENT IN LDS.
-//
-// The implicit-GEMM kernel above gathers the A tile of every (tap, channel chunk) slab from global memory: each input
-// pixel of a tile crosses the CU's vector L1 nine times.  Every convolution of the step is bound by exactly that per-CU
-// operand feed, so this kernel moves fewer bytes per FLOP instead: a tile is BM consecutive output
-// pixels = BM / W whole image rows (W | BM), whose 3x3 footprint is ONE contiguous range of (BM / W + 2) (W + 2)
-// padded input pixels.  For each 64-channel chunk that patch is brought into LDS once (LDS-DMA, double-buffered:
-// the patch of chunk c + 1 lands while the nine taps of chunk c are consumed) and the MFMA A fragments of tap (ky, kx) are
-// read from it at a pixel offset of ky (W + 2) + kx.  Only the weights stream per slab (S = 3 ring, as above).
-// A-side L1 traffic drops from 9 BM x 128 B to (BM / W + 2)(W + 2) x 128 B per chunk (x 5.8 at 256 x 64-pixel rows).
-// K order = (channel chunk, tap); split-K splits whole chunks.  LDS pixel rows are 128 B with the same XOR swizzle
-// (slot = chunk ^ ((pixel >> 1) & 7), applied on the DMA source side and on the reads).
-// vmcnt bookkeeping: every iteration issues ONE group after its barrier — the weight slab two iterations ahead plus, at
-// taps 0..6 of every chunk but the last, PT pieces (1 KiB each) of the next patch — and iteration `it` needs everything
-// up to group it - 2, i.e. it may leave exactly |group it - 1| loads outstanding; group sizes are the same in every wave
-// (surplus pieces copy a valid pixel into a scrap KiB), so the counts are compile-time constants per tap position.
-template <int WGM, int WGN>
-struct PatchGeom {
-    static constexpr int NW = WGM * WGN, BM = 64 * WGM, BN = 64 * WGN;
-    static constexpr int B_IT = BN / (8 * NW);
-    static constexpr int NPIECES_MAX = ((BM / 64 + 2) * 66 + 7) / 8;              // W <= 64: the largest patch, in 8-pixel pieces
-    static constexpr int PP = (NPIECES_MAX + NW - 1) / NW;                         // pieces per wave per chunk
-    static constexpr int PT = (PP + 6) / 7;                                        // pieces per wave per tap (taps 0..6)
-    static constexpr int PATCH_BYTES = NPIECES_MAX * 1024;
-    static constexpr int W_STAGE = BN * 128, S = 3;
-    static constexpr int SCRAP = 2 * PATCH_BYTES + S * W_STAGE;
-    static constexpr int EPI_BYTES = WGM * 32 * BN * 4;
-    static constexpr int SMEM = (SCRAP + 1024 > EPI_BYTES) ? SCRAP + 1024 : EPI_BYTES;
-    static_assert(SMEM <= 160 * 1024, "patch buffers + weight ring must fit the 160 KB of LDS");
-    static_assert(B_IT + PT < 32, "vmcnt is a 6-bit counter");
-};
-
-template <int WGM, int WGN>
-__global__ __launch_bounds__(64 * WGM * WGN) void conv_patch_kernel(const MmaParams p) {
-    using G = PatchGeom<WGM, WGN>;
-    constexpr int NW = G::NW, BM = G::BM, BN = G::BN, B_IT = G::B_IT, PT = G::PT, S = G::S;
-    constexpr int ISTR = NW * 1024;
-    __shared__ __attribute__((aligned(16))) char smem[G::SMEM];
-    char* const wring = smem + 2 * G::PATCH_BYTES;
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int wm = wave / WGN, wn = wave % WGN, l31 = lane & 31, hi = lane >> 5;
-    const int lid2 = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n * p.splits);
-    const int lid = lid2 / p.splits, z = lid2 - lid * p.splits;
-    const int m0 = (p.n_major ? lid % p.tiles_m : lid / p.tiles_n) * BM;
-    const int n0 = (p.n_major ? lid / p.tiles_m : lid % p.tiles_n) * BN;
-    const int cps = p.kt_per_split / 9;                       // channel chunks per K slice
-    const int c0 = z * cps, nch = min(p.cpt, c0 + cps) - c0;  // this block's chunks [c0, c0 + nch)
-    const int nt = nch * 9;
-
-    // geometry: tile = rows [y0, y0 + BM / Wd) of image b; patch = padded rows [y0, y0 + BM / Wd + 2), all Wd + 2 columns
-    const int Wd = p.Wd, wp = Wd + 2, hw = p.Ho * p.Wo;
-    const int b = m0 / hw, y0 = (m0 - b * hw) / Wd;
-    const int np = (BM / Wd + 2) * wp, npieces = (np + 7) >> 3;
-    const unsigned pix0 = (unsigned)((b * (p.H + 2) + y0) * wp);          // first padded pixel of the patch
-
-    // weight-slab staging (as in mma_pipe_kernel): tile row srow + 8 NW i, LDS slot lane & 7, source-side swizzle
-    const int srow = wave * 8 + (lane >> 3);
-    unsigned w_off[B_IT];
-#pragma unroll
-    for (int i = 0; i < B_IT; ++i) {
-        const int row = srow + 8 * NW * i;
-        const int lc = (lane & 7) ^ ((row >> 1) & 7);
-        w_off[i] = (unsigned)((long)min(n0 + row, p.N - 1) * p.ldw + lc * 8);
-    }
-    // A fragments: patch pixel of tap (0, 0) for this lane's row of each 32-row MFMA tile
-    int q0[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int m = wm * 64 + i * 32 + l31;
-        const int r = m / Wd;
-        q0[i] = r * wp + (m - r * Wd);
-    }
-
-    auto issue_w = [&](int it) {                               // weight slab of iteration `it` (chunk-major K order)
-        const int ci = it / 9, wt = it - ci * 9;               // scalar arithmetic (wave-uniform)
-        char* sB = wring + (it % S) * G::W_STAGE + wave * 1024;
-        const f16* Wt = p.W + (wt * p.cpt + c0 + ci) * BK;
-#pragma unroll
-        for (int i = 0; i < B_IT; ++i) glds16(Wt + w_off[i], sB + i * ISTR);
-    };
-    auto issue_piece = [&](int chunk, int j) {                 // piece j of this wave of the patch of chunk `chunk` (relative)
-        const int g = j * NW + wave;                           // wave-uniform piece id
-        const int pix = min(g * 8 + (lane >> 3), np - 1);
-        const int lc = (lane & 7) ^ ((pix >> 1) & 7);
-        const f16* src = p.A + ((size_t)(pix0 + pix) * p.lda + (c0 + chunk) * BK + lc * 8);
-        char* dst = (g < npieces) ? smem + (chunk & 1) * G::PATCH_BYTES + g * 1024 : smem + G::SCRAP;
-        glds16(src, dst);
-    };
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    // prologue: whole patch of chunk 0, weight slabs 0 and 1
-#pragma unroll 1
-    for (int j = 0; j < 7 * PT; ++j) issue_piece(0, j);
-    issue_w(0);
-    if (nt > 1) issue_w(1);
-
-    // one rolled loop over the slabs (a 9-way unrolled tap loop hoists nine sets of fragment addresses: > 256 VGPRs);
-    // (ch, tap, ky, kx, stage) are wave-uniform counters kept in SGPRs
-    int ch = 0, tap = 0, ky = 0, kx = 0, stage = 0;
-#pragma unroll 1
-    for (int it = 0; it < nt; ++it) {
-        const bool more = ch + 1 < nch;                        // a next chunk exists: its patch is prefetched during this one
-        // leave exactly the previous iteration's group in flight (see header)
-        if (it + 1 >= nt) wait_vmcnt<0>();
-        else if (tap == 0 || tap == 8 || !more) wait_vmcnt<B_IT>();
-        else wait_vmcnt<B_IT + PT>();
-        __builtin_amdgcn_s_barrier();
-        const char* pbuf = smem + (ch & 1) * G::PATCH_BYTES;
-        const char* sB = wring + stage * G::W_STAGE;
-        const int toff = ky * wp + kx;
-        int abase[2], aswz[2];
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int q = q0[i] + toff;
-            abase[i] = q * 128;
-            aswz[i] = (q >> 1) & 7;
-        }
-        f16x8 af[2][2], bf[2][2];
-        auto load_frags = [&](int buf, int ks) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-                af[buf][i] = *reinterpret_cast<const f16x8*>(pbuf + abase[i] + (((ks * 2 + hi) ^ aswz[i]) << 4));
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-                bf[buf][j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * 64 + j * 32 + l31, ks * 2 + hi));
-        };
-        load_frags(0, 0);
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-            if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
-            if (ks == 1) {                                     // this iteration's group, behind the first MFMAs
-                if (it + 2 < nt) issue_w(it + 2);
-                if (tap < 7 && more) {
-#pragma unroll
-                    for (int j = 0; j < PT; ++j) issue_piece(ch + 1, tap * PT + j);
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ks & 1][i], bf[ks & 1][j], acc[i][j], 0, 0, 0);
-        }
-        if (++stage == S) stage = 0;
-        if (++kx == 3) { kx = 0; ++ky; }
-        if (++tap == 9) { tap = 0; ky = 0; ++ch; }
-    }
-    __syncthreads();
-    tile_epilogue<BM, BN, WGM, WGN>(p, smem, acc, m0, n0, z);
-}
-
 // ------------------------------------------------------------------------------------------------ host side
-struct Plan { int bm, bn, splits, fat; };
+struct Plan { int bm, bn, splits; };
 
 // Development options: storygen_amd/csrc/common.h SgOptions (set through sg_debug_set_option; never from the environment).
-// conv_patch is OFF by default: measured on MI355X (round 2, tools/exp_feed.py) conv_patch_kernel ties the gathering kernel on
-// every convolution of the step (47.2 vs 47.2 us at 64x64 320->320) although it moves 2-3x fewer bytes through the L1 — which is
-// what showed that the mainloop is not bound by operand bytes.
 struct TuneView {
     SgOptions& o = sg_options();
-    int& bm = o.tile_m; int& bn = o.tile_n; int& no_pipe = o.no_pipe; int& no_split = o.no_split; int& stages = o.stages;
-    int& no_nmajor = o.no_nmajor; int& late_issue = o.late_issue; int& no_frag_prefetch = o.no_frag_prefetch; int& fat = o.fat;
-    int& conv_patch = o.conv_patch; int& spread = o.spread; int& pingpong = o.pingpong;
+    int& bm = o.tile_m; int& bn = o.tile_n; int& no_pipe = o.no_pipe; int& no_split = o.no_split; int& no_nmajor = o.no_nmajor;
 };
 static const TuneView g_tune;
 
@@ -1092,23 +822,18 @@ static const TuneView g_tune;
 //   t_mfma = (waves per SIMD) x slabs x 512                                  — 16 MFMAs of 32 cycles per 64-deep slab,
 // plus a fixed prologue/epilogue.  Splitting K does not add operand bytes but multiplies the CUs that share them,
 // which is what small-M layers need; it costs a second launch that re-reads the fp32 partial tiles.
-// patch_w > 0: plan for conv_patch_kernel on an image of width patch_w and hw pixels per image (tiles are whole rows; the A
-// side streams (bm / w + 2)(w + 2) pixels per 64-channel chunk instead of 9 bm; K is split in whole chunks of 9 slabs).
-Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool pipe, int hint_bm, int hint_bn, int hint_waves,
-                 int patch_w = 0, int patch_hw = 0) {
+Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool pipe, int hint_bm, int hint_bn) {
     static const int cand_pipe[6][2] = {{256, 128}, {128, 128}, {256, 64}, {128, 64}, {64, 128}, {64, 64}};
-    static const int cand_gen[3][2] = {{128, 128}, {128, 64}, {64, 64}};
+    static const int cand_gen[1][2] = {{128, 128}};      // the register-staged kernel is a cold path: one tile shape
     static const int split_opts[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
-    const int ncand = pipe ? 6 : 3;
+    const int ncand = pipe ? 6 : 1;
     const double CUS = 256.0, BW = pipe ? 18.5 : 12.0;
-    Plan best{64, 64, 1, 0};
+    Plan best{64, 64, 1};
     double best_cost = 1e300;
     for (int ci = 0; ci < ncand; ++ci) {
         const int bm = pipe ? cand_pipe[ci][0] : cand_gen[ci][0], bn = pipe ? cand_pipe[ci][1] : cand_gen[ci][1];
-        if (g_tune.bm && (bm != g_tune.bm || bn != g_tune.bn)) continue;
-        if (!g_tune.bm && hint_bm && (bm != hint_bm || bn != hint_bn)) continue;
-        if (patch_w && (bm % patch_w || patch_hw % bm)) continue;
-        const double a_rows = patch_w ? (bm / patch_w + 2) * (patch_w + 2) / 9.0 : bm;    // A rows streamed per 64-deep slab
+        if (pipe && g_tune.bm && (bm != g_tune.bm || bn != g_tune.bn)) continue;
+        if (pipe && !g_tune.bm && hint_bm && (bm != hint_bm || bn != hint_bn)) continue;
         const long tiles = (long)sg_cdiv(M, bm) * sg_cdiv(N, bn);
         const double waves_per_block = pipe ? (bm / 64) * (bn / 64) : 4.0;
         const double mfma_per_slab = pipe ? 512.0 : 512.0 * (bm / 64.0) * (bn / 64.0) / 4.0;
@@ -1116,65 +841,31 @@ Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool p
             if (force_split > 0 && s != force_split) continue;
             if (force_split <= 0 && s > 1 && (s > max_ws_split || KT / s < 2 || g_tune.no_split)) continue;
             if (s > KT) continue;
-            if (patch_w && s > KT / 9) continue;
             const double blocks = (double)tiles * s;
-            const double slabs = patch_w ? 9.0 * sg_cdiv(KT / 9, s) : sg_cdiv(KT, s);
+            const double slabs = sg_cdiv(KT, s);
             const double blocks_per_cu = sg_cdiv((long)blocks, (long)CUS);
-            const double t_bw = blocks_per_cu * slabs * (a_rows + bn) * 128.0 / BW;
+            const double t_bw = blocks_per_cu * slabs * (bm + bn) * 128.0 / BW;
             const double waves_per_simd = sg_cdiv((long)(blocks * waves_per_block), (long)(CUS * 4));
             const double t_mfma = waves_per_simd * slabs * mfma_per_slab;
             double cost = (t_bw > t_mfma ? t_bw : t_mfma) + 2500.0 + blocks_per_cu * (bm * bn / 16.0);
             if (s > 1) cost += 5000.0 + (double)M * N * 4.0 * (s + 1) / 1500.0;   // second launch + partial tiles
-            if (cost < best_cost) { best_cost = cost; best = Plan{bm, bn, s, 0}; }
+            if (cost < best_cost) { best_cost = cost; best = Plan{bm, bn, s}; }
         }
     }
-    if (best_cost == 1e300) {
-        if (patch_w) return Plan{0, 0, 0, 0};                 // no eligible tile: the caller falls back to the gathering kernel
-        best = Plan{64, 64, force_split > KT ? KT : (force_split > 0 ? force_split : 1), 0};
-    }
-    // "fat" waves (128 x 64 per wave): 256x128 with 4 waves, 128x128 with 2 — on request (tile_waves hint) or SG_FAT=1
-    const bool can_fat = pipe && ((best.bm == 256 && best.bn == 128) || (best.bm == 128 && best.bn == 128));
-    const int fat_waves = best.bm == 256 ? 4 : 2;
-    if (can_fat && (hint_waves == fat_waves || (hint_waves == 0 && g_tune.fat))) best.fat = 1;
+    if (best_cost == 1e300) best = Plan{64, 64, force_split > KT ? KT : (force_split > 0 ? force_split : 1)};
     return best;
 }
 
 template <int WGM, int WGN, bool CONV>
-void launch_pipe_fat(const MmaParams& p, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV, true, true, 4, 2>), grid, dim3(64 * WGM * WGN), 0, st, p);
-}
-
-template <int WGM, int WGN, bool CONV>
-void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st, int stages) {
-    const bool late = g_tune.late_issue != 0, pref = g_tune.no_frag_prefetch == 0;
+void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st) {
     const dim3 block(64 * WGM * WGN);
+#ifdef SG_BUILD_EXPERIMENTS
     if (p.prof) {
-        if (g_tune.spread == 2) hipLaunchKernelGGL((mma_pipe_prof_kernel<WGM, WGN, CONV, 2>), grid, block, 0, st, p);
-        else if (g_tune.spread == 1) hipLaunchKernelGGL((mma_pipe_prof_kernel<WGM, WGN, CONV, 1>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((mma_pipe_prof_kernel<WGM, WGN, CONV, 0>), grid, block, 0, st, p);
+        hipLaunchKernelGGL((mma_pipe_prof_kernel<WGM, WGN, CONV>), grid, block, 0, st, p);
         return;
     }
-    if constexpr ((WGM + WGN) * 64 * 128 * 4 <= 160 * 1024) {      // the two 2-stage rings fit: every tile but 256 x 128
-        if (g_tune.pingpong) {
-            hipLaunchKernelGGL((mma_pp_kernel<WGM, WGN, CONV>), grid, dim3(128 * WGM * WGN), 0, st, p);
-            return;
-        }
-    }
-    if (g_tune.spread && stages == 3) {
-        if (g_tune.spread == 2) hipLaunchKernelGGL((mma_pipe_spread_kernel<WGM, WGN, CONV, 2>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((mma_pipe_spread_kernel<WGM, WGN, CONV, 1>), grid, block, 0, st, p);
-        return;
-    }
-    if constexpr ((WGM + WGN) * 64 * 128 * 4 <= 128 * 1024) {   // 4-deep ring where it fits (tiles up to 128 x 128)
-        if (stages == 4) {
-            hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 4, CONV, true, true>), grid, block, 0, st, p);
-            return;
-        }
-    }
-    if (stages == 2) hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 2, CONV, false, true>), grid, block, 0, st, p);
-    else if (late && pref) hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV, true, true>), grid, block, 0, st, p);
-    else if (late) hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV, true, false>), grid, block, 0, st, p);
-    else hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, 3, CONV, false, true>), grid, block, 0, st, p);
+#endif
+    hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, CONV>), grid, block, 0, st, p);
 }
 
 thread_local unsigned long long* g_prof = nullptr;     // set by sg_debug_*_anatomy around one launch
@@ -1196,14 +887,14 @@ int check_stats(MmaParams& p, int bm, const char* name) {
 // Decomposition of one problem: tile shape, K split, tile order; fills the corresponding fields of p.  `pipe` = the LDS-DMA
 // kernel applies (no load needs a predicate: K % 64 == 0; conv input zero-bordered), else the register-staged kernel.
 template <bool CONV>
-int plan_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_waves, void* ws, size_t ws_bytes, const char* name,
+int plan_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws, size_t ws_bytes, const char* name,
              Plan& pl, bool& pipe) {
     p.KT = sg_cdiv(p.K, BK);
     p.prof = g_prof;
     pipe = (p.K % BK == 0) && (!CONV || p.padded) && !g_tune.no_pipe;
     const size_t per_split = (size_t)p.M * p.N * 4;
     const int max_ws_split = ws ? (int)(ws_bytes / per_split > 64 ? 64 : ws_bytes / per_split) : 1;
-    pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, pipe, hint_bm, hint_bn, hint_waves);
+    pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, pipe, hint_bm, hint_bn);
     if (pl.splits > 1) {
         const size_t need = per_split * pl.splits;
         if (ws == nullptr || ws_bytes < need)
@@ -1221,10 +912,18 @@ int plan_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_w
     const double a_bytes = CONV ? 2.0 * p.M * (p.K / 9) * (p.stride == 1 && !p.ups ? 1.0 : (p.ups ? 0.25 : 4.0)) : 2.0 * p.M * p.K;
     const double w_bytes = 2.0 * p.N * p.K;
     p.n_major = (w_bytes > a_bytes && !g_tune.no_nmajor) ? 1 : 0;
+    p.fd_splits = make_fastdiv((unsigned)p.splits);
+    p.fd_tiles_m = make_fastdiv((unsigned)p.tiles_m);
+    p.fd_tiles_n = make_fastdiv((unsigned)p.tiles_n);
+    p.fd_rpb = make_fastdiv((unsigned)(p.rows_per_batch > 0 ? p.rows_per_batch : 1));
+    if (CONV) {
+        p.fd_hw = make_fastdiv((unsigned)(p.Ho * p.Wo));
+        p.fd_wo = make_fastdiv((unsigned)p.Wo);
+        p.fd_cpt = make_fastdiv((unsigned)p.cpt);
+    }
     return check_stats(p, pl.bm, name);
 }
 
-// second pass of a split-K launch: partial tiles -> epilogue
 int launch_reduce(const MmaParams& p, hipStream_t st) {
     if (p.splits <= 1) return SG_OK;
     const long items = (long)p.M * (p.N / (p.mode == SG_EPI_GEGLU ? 16 : 8));
@@ -1234,85 +933,27 @@ int launch_reduce(const MmaParams& p, hipStream_t st) {
     return SG_OK;
 }
 
-template <int WGM, int WGN>
-void launch_patch(const MmaParams& p, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((conv_patch_kernel<WGM, WGN>), grid, dim3(64 * WGM * WGN), 0, st, p);
-}
-
-// conv_patch_kernel when the problem allows it (stride 1, no upsampling, zero-bordered input, image width <= 64 dividing a tile
-// that divides the image).  Returns 1 if launched, 0 if not applicable, < 0 on error.
-int try_launch_conv_patch(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws, size_t ws_bytes, hipStream_t st,
-                          const char* name) {
-    if (!g_tune.conv_patch || g_tune.no_pipe || !p.padded || p.stride != 1 || p.ups || p.Wd > 64 || p.Wd < 4) return 0;
-    p.KT = 9 * p.cpt;
-    const size_t per_split = (size_t)p.M * p.N * 4;
-    const int max_ws_split = ws ? (int)(ws_bytes / per_split > 64 ? 64 : ws_bytes / per_split) : 1;
-    Plan pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, true, hint_bm, hint_bn, 0, p.Wd, p.Ho * p.Wo);
-    if (pl.bm == 0) return 0;
-    const int cps = sg_cdiv(p.cpt, pl.splits);                // whole channel chunks per slice
-    pl.splits = sg_cdiv(p.cpt, cps);
-    if (pl.splits > 1 && (ws == nullptr || ws_bytes < per_split * pl.splits)) {
-        if (force_split > 1) return sg_set_error(SG_EINVAL, "%s: split_k=%d does not fit the workspace", name, pl.splits);
-        return 0;
-    }
-    p.ws = reinterpret_cast<float*>(ws);
-    p.splits = pl.splits;
-    p.kt_per_split = 9 * cps;
-    p.tiles_m = p.M / pl.bm;
-    p.tiles_n = sg_cdiv(p.N, pl.bn);
-    const double a_bytes = 2.0 * p.M * (p.K / 9), w_bytes = 2.0 * p.N * p.K;
-    p.n_major = (w_bytes > a_bytes && !g_tune.no_nmajor) ? 1 : 0;
-    if (int rc = check_stats(p, pl.bm, name)) return rc;
-    if (g_stats_query) {
-        g_query_rows = p.stats ? pl.bm : 0;
-        return 1;
-    }
-    dim3 grid(p.tiles_m * p.tiles_n * pl.splits);
-    if (pl.bm == 256 && pl.bn == 128) launch_patch<4, 2>(p, grid, st);
-    else if (pl.bm == 128 && pl.bn == 128) launch_patch<2, 2>(p, grid, st);
-    else if (pl.bm == 256 && pl.bn == 64) launch_patch<4, 1>(p, grid, st);
-    else if (pl.bm == 128 && pl.bn == 64) launch_patch<2, 1>(p, grid, st);
-    else if (pl.bm == 64 && pl.bn == 128) launch_patch<1, 2>(p, grid, st);
-    else launch_patch<1, 1>(p, grid, st);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) return sg_set_error(SG_ELAUNCH, "%s: %s", name, hipGetErrorString(e));
-    if (int rc = launch_reduce(p, st)) return rc;
-    return 1;
-}
-
 template <bool CONV>
-int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_waves, void* ws, size_t ws_bytes, hipStream_t st, const char* name) {
-    if constexpr (CONV) {
-        if (hint_waves == 0) {
-            const int rc = try_launch_conv_patch(p, force_split, hint_bm, hint_bn, ws, ws_bytes, st, name);
-            if (rc != 0) return rc < 0 ? rc : SG_OK;
-        }
-    }
+int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws, size_t ws_bytes, hipStream_t st, const char* name) {
     Plan pl;
     bool pipe;
-    if (int rc = plan_mma<CONV>(p, force_split, hint_bm, hint_bn, hint_waves, ws, ws_bytes, name, pl, pipe)) return rc;
+    if (int rc = plan_mma<CONV>(p, force_split, hint_bm, hint_bn, ws, ws_bytes, name, pl, pipe)) return rc;
     if (g_stats_query) {
         g_query_rows = p.stats ? pl.bm : 0;
         return SG_OK;
     }
     dim3 grid(p.tiles_m * p.tiles_n * pl.splits);
-    // ring depth: 3 stages (deeper prefetch) unless overridden; SG_STAGES=2 halves... see DESIGN.md §5.2
-    const int stages = (g_tune.stages == 2 || g_tune.stages == 4) ? g_tune.stages : 3;
-    if (pipe && pl.fat) {
-        if (pl.bm == 256) launch_pipe_fat<2, 2, CONV>(p, grid, st);
-        else launch_pipe_fat<1, 2, CONV>(p, grid, st);
-    } else if (pipe) {
-        if (pl.bm == 256 && pl.bn == 128) launch_pipe<4, 2, CONV>(p, grid, st, stages);
-        else if (pl.bm == 128 && pl.bn == 128) launch_pipe<2, 2, CONV>(p, grid, st, stages);
-        else if (pl.bm == 256 && pl.bn == 64) launch_pipe<4, 1, CONV>(p, grid, st, stages);
-        else if (pl.bm == 128 && pl.bn == 64) launch_pipe<2, 1, CONV>(p, grid, st, stages);
-        else if (pl.bm == 64 && pl.bn == 128) launch_pipe<1, 2, CONV>(p, grid, st, stages);
-        else launch_pipe<1, 1, CONV>(p, grid, st, stages);
+    if (pipe) {
+        if (pl.bm == 256 && pl.bn == 128) launch_pipe<4, 2, CONV>(p, grid, st);
+        else if (pl.bm == 128 && pl.bn == 128) launch_pipe<2, 2, CONV>(p, grid, st);
+        else if (pl.bm == 256 && pl.bn == 64) launch_pipe<4, 1, CONV>(p, grid, st);
+        else if (pl.bm == 128 && pl.bn == 64) launch_pipe<2, 1, CONV>(p, grid, st);
+        else if (pl.bm == 64 && pl.bn == 128) launch_pipe<1, 2, CONV>(p, grid, st);
+        else launch_pipe<1, 1, CONV>(p, grid, st);
     } else {
         dim3 block(256);
         if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((mma_kernel<128, 128, CONV>), grid, block, 0, st, p);
-        else if (pl.bm == 128 && pl.bn == 64) hipLaunchKernelGGL((mma_kernel<128, 64, CONV>), grid, block, 0, st, p);
-        else hipLaunchKernelGGL((mma_kernel<64, 64, CONV>), grid, block, 0, st, p);
+        else return sg_set_error(SG_EINVAL, "%s: internal: the register-staged kernel has only the 128x128 tile", name);
     }
     SG_CHECK_LAUNCH(name);
     return launch_reduce(p, st);
@@ -1329,8 +970,8 @@ int check_out_res(const char* who, int flags, const void* C, int64_t ldc, const 
 }
 
 int check_tile_hint(const char* who, int bm, int bn, int waves) {
-    if (waves != 0 && !((bm == 256 && bn == 128 && (waves == 4 || waves == 8)) || (bm == 128 && bn == 128 && (waves == 2 || waves == 4))))
-        return sg_set_error(SG_EINVAL, "%s: tile_waves=%d is not available for tile %dx%d", who, waves, bm, bn);
+    if (waves != 0 && waves != (bm / 64) * (bn / 64))
+        return sg_set_error(SG_EINVAL, "%s: tile_waves=%d is not available for tile %dx%d (64x64 per wave only)", who, waves, bm, bn);
     if (bm == 0 && bn == 0) return SG_OK;
     static const int ok[6][2] = {{256, 128}, {128, 128}, {256, 64}, {128, 64}, {64, 128}, {64, 64}};
     for (auto& t : ok)
@@ -1396,7 +1037,7 @@ void launch_pair(const MmaPair& pp, dim3 grid, hipStream_t st) {
 extern "C" int sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream) {
     MmaParams p;
     if (int rc = gemm_params(d, p, "sg_gemm_f16")) return rc;
-    return launch_mma<false>(p, d->split_k, d->tile_m, d->tile_n, d->tile_waves, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_gemm_f16");
+    return launch_mma<false>(p, d->split_k, d->tile_m, d->tile_n, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_gemm_f16");
 }
 
 extern "C" int sg_gemm_pair_f16(const sg_gemm_desc* d0, const sg_gemm_desc* d1, sg_stream_t stream) {
@@ -1410,12 +1051,12 @@ extern "C" int sg_gemm_pair_f16(const sg_gemm_desc* d0, const sg_gemm_desc* d1, 
     hipStream_t st = (hipStream_t)stream;
     Plan pl0, pl1;
     bool pipe0, pipe1;
-    if (int rc = plan_mma<false>(pp.p0, d0->split_k, d0->tile_m, d0->tile_n, 0, d0->workspace, d0->workspace_bytes, "sg_gemm_pair_f16[0]", pl0, pipe0)) return rc;
+    if (int rc = plan_mma<false>(pp.p0, d0->split_k, d0->tile_m, d0->tile_n, d0->workspace, d0->workspace_bytes, "sg_gemm_pair_f16[0]", pl0, pipe0)) return rc;
     // one kernel instantiation serves both problems: the second one is planned on the first one's tile shape
-    if (int rc = plan_mma<false>(pp.p1, d1->split_k, pl0.bm, pl0.bn, 0, d1->workspace, d1->workspace_bytes, "sg_gemm_pair_f16[1]", pl1, pipe1)) return rc;
+    if (int rc = plan_mma<false>(pp.p1, d1->split_k, pl0.bm, pl0.bn, d1->workspace, d1->workspace_bytes, "sg_gemm_pair_f16[1]", pl1, pipe1)) return rc;
     if (!pipe0 || !pipe1 || pl1.bm != pl0.bm || pl1.bn != pl0.bn) {        // not pairable (K % 64, forced tile): two launches
-        if (int rc = launch_mma<false>(pp.p0, d0->split_k, d0->tile_m, d0->tile_n, d0->tile_waves, d0->workspace, d0->workspace_bytes, st, "sg_gemm_pair_f16[0]")) return rc;
-        return launch_mma<false>(pp.p1, d1->split_k, d1->tile_m, d1->tile_n, d1->tile_waves, d1->workspace, d1->workspace_bytes, st, "sg_gemm_pair_f16[1]");
+        if (int rc = launch_mma<false>(pp.p0, d0->split_k, d0->tile_m, d0->tile_n, d0->workspace, d0->workspace_bytes, st, "sg_gemm_pair_f16[0]")) return rc;
+        return launch_mma<false>(pp.p1, d1->split_k, d1->tile_m, d1->tile_n, d1->workspace, d1->workspace_bytes, st, "sg_gemm_pair_f16[1]");
     }
     const int g0 = pp.p0.tiles_m * pp.p0.tiles_n * pp.p0.splits, g1 = pp.p1.tiles_m * pp.p1.tiles_n * pp.p1.splits;
     // grid.x is a multiple of 8 so that block (x, 1) sits on XCD x % 8 like block (x, 0): xcd_remap keeps its meaning
@@ -1466,7 +1107,7 @@ extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream)
     SG_REQUIRE(!d->stats || sg_aligned16(d->stats), "sg_conv3x3: stats alignment");
     p.stats = d->stats; p.stats_batch_rows = Ho * Wo;
     if (int rc = check_tile_hint("sg_conv3x3", d->tile_m, d->tile_n, d->tile_waves)) return rc;
-    return launch_mma<true>(p, d->split_k, d->tile_m, d->tile_n, d->tile_waves, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_conv3x3_nhwc_f16");
+    return launch_mma<true>(p, d->split_k, d->tile_m, d->tile_n, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_conv3x3_nhwc_f16");
 }
 
 // Would a launch with this descriptor emit epilogue statistics, and with which tile height?  (Plans the launch exactly as
@@ -1490,26 +1131,50 @@ extern "C" int sg_conv3x3_stats_tile_rows(const sg_conv3x3_desc* d) {
 
 // ------------------------------------------------------------------------------------------------ diagnostics
 // Mainloop anatomy: the same launch as sg_gemm_f16 / sg_conv3x3_nhwc_f16 through the instrumented instantiation of the pipelined
-// kernel; prof receives 10 uint64 per wave ([block][wave][10], see mma_pipe_body).  Needs the LDS-DMA path, no fat waves, S = 3.
+// kernel; prof receives 10 uint64 per wave ([block][wave][10], see mma_pipe_body).  Only in a library built with
+// SG_BUILD_EXPERIMENTS=1 (python -m storygen_amd.build --experiments); the product library answers SG_EINVAL.
 extern "C" int sg_debug_gemm_anatomy(const sg_gemm_desc* d, void* prof, size_t prof_bytes, sg_stream_t stream) {
+#ifdef SG_BUILD_EXPERIMENTS
     SG_REQUIRE(d && prof && prof_bytes >= (size_t)8 * 10 * 8 * 65536 / 64, "sg_debug_gemm_anatomy: need a profile buffer (>= 80 B per wave)");
     g_prof = reinterpret_cast<unsigned long long*>(prof);
     const int rc = sg_gemm_f16(d, stream);
     g_prof = nullptr;
     return rc;
+#else
+    (void)d; (void)prof; (void)prof_bytes; (void)stream;
+    return sg_set_error(SG_EINVAL, "sg_debug_gemm_anatomy: this library was built without SG_BUILD_EXPERIMENTS");
+#endif
 }
 
 extern "C" int sg_debug_conv_anatomy(const sg_conv3x3_desc* d, void* prof, size_t prof_bytes, sg_stream_t stream) {
+#ifdef SG_BUILD_EXPERIMENTS
     SG_REQUIRE(d && prof && prof_bytes >= (size_t)8 * 10 * 8 * 65536 / 64, "sg_debug_conv_anatomy: need a profile buffer (>= 80 B per wave)");
     g_prof = reinterpret_cast<unsigned long long*>(prof);
     const int rc = sg_conv3x3_nhwc_f16(d, stream);
     g_prof = nullptr;
     return rc;
+#else
+    (void)d; (void)prof; (void)prof_bytes; (void)stream;
+    return sg_set_error(SG_EINVAL, "sg_debug_conv_anatomy: this library was built without SG_BUILD_EXPERIMENTS");
+#endif
 }
 
 extern "C" int sg_debug_set_tile(int32_t bm, int32_t bn, int32_t no_pipe) {
     g_tune.bm = bm; g_tune.bn = bn; g_tune.no_pipe = no_pipe;
     return SG_OK;
+}
+
+// host-side check of the multiply-shift divisors (tests/test_abi.py): returns the number of mismatches over a sweep
+extern "C" int sg_debug_fastdiv_selftest(void) {
+    int bad = 0;
+    const unsigned ds[] = {1, 2, 3, 5, 7, 9, 10, 20, 40, 45, 64, 96, 144, 1024, 2304, 4096, 9216, 36864, 65535, 65536, 1000003};
+    for (unsigned d : ds) {
+        const FastDiv f = make_fastdiv(d);
+        for (unsigned long long n = 0; n < (1ull << 32); n += 65521ull) bad += fd_div((unsigned)n, f) != (unsigned)n / d;
+        for (unsigned n = 0; n < 200000; ++n) bad += fd_div(n, f) != n / d;
+        bad += fd_div(0xFFFFFFFFu, f) != 0xFFFFFFFFu / d;
+    }
+    return bad;
 }
 
 namespace {

@@ -16,9 +16,7 @@ extern "C" int sg_debug_set_option(const char* name, int64_t value) {
     SgOptions& o = sg_options();
     struct Entry { const char* n; int* p; };
     const Entry table[] = {{"tile_m", &o.tile_m}, {"tile_n", &o.tile_n}, {"no_pipe", &o.no_pipe}, {"no_split", &o.no_split},
-                           {"stages", &o.stages}, {"no_nmajor", &o.no_nmajor}, {"late_issue", &o.late_issue},
-                           {"no_frag_prefetch", &o.no_frag_prefetch}, {"fat", &o.fat}, {"spread", &o.spread},
-                           {"conv_patch", &o.conv_patch}, {"pingpong", &o.pingpong}, {"attn_sub2", &o.attn_sub2}, {"attn_prio", &o.attn_prio},
+                           {"no_nmajor", &o.no_nmajor}, {"attn_sub2", &o.attn_sub2}, {"attn_prio", &o.attn_prio},
                            {"attn_d80", &o.attn_d80}, {"attn_d160", &o.attn_d160}, {"gn_no_fused", &o.gn_no_fused},
                            {"gn_wide", &o.gn_wide}};
     for (const Entry& e : table)

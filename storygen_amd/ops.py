@@ -817,18 +817,9 @@ def debug_set_option(name: str, value: int) -> None:
     check(lib.sg_debug_set_option(name.encode(), int(value)), "sg_debug_set_option")
 
 
-def debug_set_spread(mode: int) -> None:
-    debug_set_option("spread", mode)
-
-
-def debug_set_conv_patch(enable: bool = True) -> None:
-    debug_set_option("conv_patch", int(enable))
-
-
 # The development tools (tools/*.py, tests) historically selected kernel variants through SG_* environment variables.  The
 # library no longer reads the environment: this maps the variables onto sg_debug_set_option, and only when a tool asks for it.
-_ENV_OPTIONS = {"SG_STAGES": "stages", "SG_NO_NMAJOR": "no_nmajor", "SG_LATE_ISSUE": "late_issue", "SG_NO_FRAG_PREFETCH": "no_frag_prefetch",
-                "SG_FAT": "fat", "SG_NO_PIPE": "no_pipe", "SG_NO_SPLIT": "no_split", "SG_SPREAD": "spread", "SG_CONV_PATCH": "conv_patch", "SG_PINGPONG": "pingpong",
+_ENV_OPTIONS = {"SG_NO_NMAJOR": "no_nmajor", "SG_NO_PIPE": "no_pipe", "SG_NO_SPLIT": "no_split",
                 "SG_ATTN_SUB2": "attn_sub2", "SG_ATTN_PRIO": "attn_prio", "SG_ATTN_D80": "attn_d80", "SG_ATTN_D160": "attn_d160",
                 "SG_NO_GN_FUSED": "gn_no_fused", "SG_GN_WIDE": "gn_wide", "SG_GN_FUSED_MAX": "gn_fused_max"}
 

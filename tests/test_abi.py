@@ -89,6 +89,12 @@ def test_version_and_error_string(lib):
     assert isinstance(lib.sg_last_error(), bytes)
 
 
+def test_multiply_shift_divisors_are_exact(lib):
+    """The GEMM / conv prologues divide by tile counts, image sizes and channel chunks with host-made multiply-shift constants
+    (gemm_conv.hip make_fastdiv / fd_div, the same code on host and device): exact for every 32-bit numerator."""
+    assert lib.sg_debug_fastdiv_selftest() == 0
+
+
 def test_host_validation_rejects_before_launch(lib):
     """Every entry point validates on the host first: these calls return SG_EINVAL / SG_EUNSUP without touching a
     device (so they work on a GPU-less box) and leave a message in sg_last_error()."""
@@ -199,5 +205,5 @@ def test_library_never_reads_the_environment():
         with open(path) as f:
             assert "getenv" not in f.read(), path
     lib = _lib.load()
-    assert lib.sg_debug_set_option(b"spread", 1) == 0 and lib.sg_debug_set_option(b"reset", 0) == 0
+    assert lib.sg_debug_set_option(b"no_split", 1) == 0 and lib.sg_debug_set_option(b"reset", 0) == 0
     assert lib.sg_debug_set_option(b"no_such_option", 1) != 0

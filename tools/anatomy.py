@@ -17,6 +17,11 @@ import sys
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from storygen_amd import _lib, build  # noqa: E402
+
+if not os.path.exists(build.LIB_EXP):
+    sys.exit("tools/anatomy.py needs the experiments library: python -m storygen_amd.build --experiments")
+_lib.LIB_PATH = build.LIB_EXP       # the instrumented instantiations live in a separate library (never the product's)
 from storygen_amd import ops  # noqa: E402
 
 ops.apply_env_options()      # SG_* development variables -> sg_debug_set_option
@@ -73,6 +78,13 @@ def main():
         out = torch.empty(M, N, dtype=torch.float16, device=dev)
         for tile in [(256, 128), (256, 64), (128, 128), (128, 64), (64, 64)]:
             report(f"gemm M{M} N{N} K{K}", tile, 0, lambda t: ops.gemm(a, w, out, split_k=1, workspace=ws, tile=t))
+    # the residual-stream projections (attention.py:262,277): fp32 output + fp32 residual + bias
+    for (M, N, K) in [(12288, 320, 320), (16384, 320, 320), (3072, 640, 640)]:
+        a = torch.randn(M, K, device=dev).half()
+        w = (torch.randn(N, K, device=dev) / K ** 0.5).half()
+        out, res, bias = torch.empty(M, N, device=dev), torch.randn(M, N, device=dev), torch.randn(N, device=dev).half()
+        for tile in [(256, 64), (128, 128), (128, 64), (64, 64)]:
+            report(f"gemm+res32 M{M} N{N} K{K}", tile, 0, lambda t: ops.gemm(a, w, out, bias=bias, res1=res, split_k=1, workspace=ws, tile=t))
 
 
 if __name__ == "__main__":

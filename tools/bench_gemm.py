@@ -11,11 +11,8 @@ from storygen_amd import ops  # noqa: E402
 ops.apply_env_options()      # SG_* development variables -> sg_debug_set_option
 
 dev = torch.device("cuda:0")
-TILES = [(0, 0, False), (256, 128, False), (128, 128, False), (256, 64, False), (128, 64, False), (64, 128, False), (64, 64, False), (128, 128, True),
-         (128, 64, True)]
-
-
-FAT = [(256, 128, 4), (128, 128, 2)]     # 128x64-per-wave variants
+TILES = [(0, 0, False), (256, 128, False), (128, 128, False), (256, 64, False), (128, 64, False), (64, 128, False), (64, 64, False), (128, 128, True)]
+FAT = []
 
 
 def timeit(fn, n=20):
