@@ -96,6 +96,17 @@ typedef struct sg_gemm_desc {
     void*          workspace; size_t workspace_bytes;
     float*         stats;             /* optional: GroupNorm partial statistics of the output, see below (NULL = none) */
     int32_t        stats_batch_rows;  /* rows of C per image (B*HW rows = B images); tiles must not straddle images */
+    /* LayerNorm folded into the GEMM that consumes it (BasicTransformerBlock norm1..norm4 -> to_q / to_k / to_v / ff.net.0,
+     * model/attention.py:250,268,283,298), see "LayerNorm fold" below.  ln_mode 0 = none. */
+    int32_t        ln_mode;           /* 1: rows of A are the normalised tokens; 2: rows of W are (the V^T = W_v X^T product) */
+    int32_t        ln_parts;          /* K / 64 */
+    float          ln_eps;
+    const float*   ln_stats;          /* [tokens][P][2] fp32, P = ln_parts rounded up to even: per token and 64-channel block (sum, M2
+                                         about the block mean); the padding block of an odd ln_parts is never used */
+    const float*   ln_c;              /* fp32 [N] (mode 1) / [M] (mode 2):  c_n = sum_k (gamma (.) W)_nk  of the fp16-rounded folded weight */
+    const float*   ln_d;              /* fp32 [N] / [M]:  d_n = sum_k beta_k W_nk (+ bias_n) */
+    float*         ln_stats_out;      /* producer side: write the partials of THIS output, [M][P][2] with P = N/64 rounded up to even
+                                         (NULL = none; needs N % 64 == 0) */
 } sg_gemm_desc;
 
 int    sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream);
@@ -109,6 +120,15 @@ int    sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream);
  * or 0 when that launch cannot emit statistics (split-K, GEGLU, a tile that does not divide the image) — in which case a launch
  * with `stats` set fails with SG_EINVAL.  Size: (M / T) * 2 * N floats. */
 int    sg_gemm_stats_tile_rows(const sg_gemm_desc* d);
+/* LayerNorm fold.  Instead of a LayerNorm launch between two GEMMs, the producer of the stream tensor x (proj_in, attn1.to_out,
+ * attn2/3.to_out) also writes x's fp16 copy (C2) and, through ln_stats_out, per token and 64-channel block the sum and the M2
+ * (sum of squared deviations from the block mean) of its FINAL fp32 values; the consumer runs on the raw copy with the weight
+ * W' = gamma (.) W (rounded to fp16 once) and its epilogue evaluates
+ *     LN(x) W^T + b  =  rstd_t (x W'^T - mean_t c) + d
+ * with mean_t / rstd_t merged from the partials (Chan's parallel formula: every block is centred on its own mean first, so no
+ * cancellation against the token mean; eps inside the square root as torch.nn.LayerNorm).  GEGLU applies it to values and gates
+ * before the gate activation.  A GEMM with ln_mode never splits K.  Results equal the unfused LayerNorm -> GEMM up to the fp16
+ * rounding of x and W' instead of LN(x) and W (tests/test_kernels_gpu.py::test_gemm_layernorm_fold). */
 /* Two independent GEMMs in ONE launch (same results as two sg_gemm_f16 calls): the pairs of projections that share an
  * activation operand and are each too small to fill the chip — attn1.to_q|to_k with attn1.to_v (model/attention.py:250-262 via
  * CrossAttention), attn2.to_q with attn3.to_q (:266-276,281-290), attn3.to_k with attn3.to_v of a harvested context.  The two

@@ -30,6 +30,8 @@ class GemmDesc(C.Structure):
         ("res2", C.c_void_p), ("ldr2", C.c_int64),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("stats", C.c_void_p), ("stats_batch_rows", C.c_int32),
+        ("ln_mode", C.c_int32), ("ln_parts", C.c_int32), ("ln_eps", C.c_float),
+        ("ln_stats", C.c_void_p), ("ln_c", C.c_void_p), ("ln_d", C.c_void_p), ("ln_stats_out", C.c_void_p),
     ]
 
 

@@ -74,6 +74,10 @@ struct MmaParams {
     // decomposition
     float* ws; int splits; int kt_per_split; int tiles_m, tiles_n;
     float* stats; int stats_batch_rows;   // optional GroupNorm partial statistics of the output (epi_finish), else nullptr
+    // LayerNorm folded into this GEMM (sg_gemm_desc.ln_*): consumer side = per-token (mean, M2) partials of the raw operand,
+    // c / d vectors of the folded weight; producer side = where to write the partials of THIS output
+    const float* ln_stats; int ln_parts; const float* ln_c; const float* ln_d; int ln_mode; float ln_eps;
+    float* ln_out;
     unsigned long long* prof;   // SG_BUILD_EXPERIMENTS (sg_debug_*_anatomy): per-wave cycle totals of the mainloop phases
     int n_major;   // tile order: 1 = consecutive ids walk M first (tiles sharing a weight panel stay on one XCD / L2)
     FastDiv fd_splits, fd_tiles_m, fd_tiles_n, fd_hw, fd_wo, fd_rpb, fd_cpt;
@@ -105,26 +109,64 @@ __device__ __forceinline__ void decode_block(const MmaParams& p, int BM, int BN,
 // bytes per wave instruction (the first version of this round kept one row per lane: no LDS, but 32 cache lines per
 // instruction — the stores and residual loads then cost what the barriers of the old banded epilogue had).
 constexpr int EPI_PITCH = 68;                         // floats per staged row
-constexpr int EPI_WAVE_BYTES = 64 * EPI_PITCH * 4;    // 17408
+constexpr int EPI_XTR = 64 * EPI_PITCH;               // float offset of a wave's 1 KB extra area: [0,128) LayerNorm coefficients,
+                                                      // [128,256) its 64 columns x 2 planes of GroupNorm statistics (or more LN rows)
+constexpr int EPI_WAVE_BYTES = 64 * EPI_PITCH * 4 + 1024;    // 18432
 
-// The additive term that needs HBM (an fp32 res1 of the fused linear epilogue: the UNet's residual stream) is requested early —
-// during the last K slab — into registers, in the row-quad layout (16 B per item).  rowq = first row of the wave's sub-tile
-// + (lane >> 4), colq = first column + 4 (lane & 15).  Rows / columns beyond the problem are clamped, not predicated: 16
-// unconditional loads issue back to back (a branch per load makes the compiler wait for each one where it is issued).
+constexpr int LN_MAX_PARTS = 20;      // 64-column blocks per token: C <= 1280
+// Prefetched epilogue operands (native clang vectors, not HIP's float4 class: as members of a struct, or as HIP vector classes,
+// the arrays were demoted to scratch memory): pre[k] = row quad k of the fp32 residual, pbias = bias of the lane's 4 columns.
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+#define EPI_PRE_DECL f32x4 pre_f[16]; u32x2 pre_bias
+#define EPI_PRE_ARGS pre_f, pre_bias
+#define EPI_PRE_PARAMS f32x4 (&pre)[16], u32x2& pbias
+
+// Everything the fused linear epilogue needs from memory that does not depend on the accumulators is requested early — during the
+// last K slab — into registers: the fp32 residual (the UNet's residual stream) in the row-quad layout (16 B per item; rowq = first
+// row of the wave's sub-tile + (lane >> 4), colq = first column + 4 (lane & 15)) and the bias.  Rows / columns beyond the problem
+// are clamped, not predicated: unconditional loads issue back to back (a branch per load makes the compiler wait for each one
+// where it is issued).
 __device__ __forceinline__ bool epi_prefetches(const MmaParams& p) {
     return p.res1 != nullptr && (p.flags & SG_F_RES1_F32) && p.splits == 1 && p.mode == SG_EPI_LINEAR;
 }
 
-struct EpiPre { float4 res[16]; uint2 bias; };
-
-__device__ __forceinline__ void epi_prefetch(const MmaParams& p, int rowq, int colq, EpiPre& pf) {
-    float4 (&pre)[16] = pf.res;
-    if (p.bias && p.splits == 1 && p.mode == SG_EPI_LINEAR) pf.bias = *reinterpret_cast<const uint2*>(p.bias + min(colq, p.N - 4));
+__device__ __forceinline__ void epi_prefetch(const MmaParams& p, int m0, int n0, int wm, int wn, int lane, EPI_PRE_PARAMS) {
+    if (p.splits > 1 || p.mode != SG_EPI_LINEAR) return;
+    const int rowq = m0 + wm * 64 + (lane >> 4), cq = min(n0 + wn * 64 + 4 * (lane & 15), p.N - 4);
+    if (p.bias) pbias = *reinterpret_cast<const u32x2*>(p.bias + cq);
     if (!epi_prefetches(p)) return;
-    const float* r = reinterpret_cast<const float*>(p.res1) + min(colq, p.N - 4);
+    const float* r = reinterpret_cast<const float*>(p.res1) + cq;
     const int mlast = p.M - 1;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) pre[k] = *reinterpret_cast<const float4*>(r + (long)min(rowq + 4 * k, mlast) * p.ldr1);
+    for (int k = 0; k < 16; ++k) pre[k] = *reinterpret_cast<const f32x4*>(r + (long)min(rowq + 4 * k, mlast) * p.ldr1);
+}
+
+// LayerNorm fold (consumer side).  The GEMM ran on the RAW fp16 activations x with W' = gamma (.) W, so
+//   LN(x) W^T + b = rstd (x W'^T - mean c) + d,   c_n = sum_k W'_nk,  d_n = sum_k beta_k W_nk + b_n
+// (ln_mode 1: tokens are the rows of this GEMM; ln_mode 2 — the transposed V^T = W_v X^T product — tokens are its columns and
+// c / d are per row).  The producer of x wrote, per token and 64-column block, (sum, M2 about the block mean): merged here with
+// Chan's formula, so nothing cancels against the row mean.  Returns (mean * rstd, rstd) of one token.  The table holds an even
+// number of blocks per token (whole 16-byte loads); these loads are issued after the mainloop (a folded GEMM replaces a whole
+// LayerNorm launch: one exposed L2 round trip is a small price, and holding 40 more registers across the last slab is not).
+__device__ __forceinline__ float2 ln_token_coeffs(const MmaParams& p, int token) {
+    const int pairs = (p.ln_parts + 1) >> 1;
+    const f32x4* s = reinterpret_cast<const f32x4*>(p.ln_stats) + (long)token * pairs;
+    f32x4 t[LN_MAX_PARTS / 2];
+#pragma unroll
+    for (int q = 0; q < LN_MAX_PARTS / 2; ++q) t[q] = s[min(q, pairs - 1)];
+    float tot = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_MAX_PARTS; ++q) tot += q < p.ln_parts ? ((q & 1) ? t[q >> 1].z : t[q >> 1].x) : 0.f;
+    const float n = 64.f * (float)p.ln_parts, mean = tot / n;
+    float m2 = 0.f;
+#pragma unroll
+    for (int q = 0; q < LN_MAX_PARTS; ++q) {
+        const float sq = (q & 1) ? t[q >> 1].z : t[q >> 1].x, mq = (q & 1) ? t[q >> 1].w : t[q >> 1].y;
+        const float dm = sq * (1.f / 64.f) - mean;
+        m2 += q < p.ln_parts ? fmaf(64.f * dm, dm, mq) : 0.f;
+    }
+    const float r = rsqrtf(m2 / n + p.ln_eps);
+    return make_float2(mean * r, r);
 }
 
 union H4 { uint2 u; f16 h[4]; };
@@ -145,12 +187,12 @@ __device__ __forceinline__ void store_out4(const MmaParams& p, int gm, int gn, c
 // One workgroup barrier (the LDS ring is dead once every wave has left the last slab), then each wave works alone; a second
 // barrier only when GroupNorm statistics are requested (to add up the WGM wave rows).
 template <int WGM, int WGN>
-__device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x16 (&acc)[2][2], EpiPre& pf,
+__device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x16 (&acc)[2][2], EPI_PRE_PARAMS,
                                            int m0, int n0, int z, int wave, int wm, int wn, int lane) {
     constexpr int BN = 64 * WGN, NW = WGM * WGN, NT = 64 * NW;
+    const int lnm = p.ln_mode;
     const int l31 = lane & 31, hi = lane >> 5, lr = lane >> 4, lc = lane & 15;
     float* stg = reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES);
-    float4 (&pre)[16] = pf.res;
     // the ring is dead once every wave has issued its last fragment reads (each wave's own reads were waited for by its MFMAs).
     // Raw s_barrier: __syncthreads() would also drain vmcnt, i.e. wait for the prefetched residual before the transpose starts.
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -165,6 +207,15 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
                     make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
     // same-wave LDS write -> read: in-order within the wave, the compiler's lgkmcnt wait covers it
     const int rowq = m0 + wm * 64 + lr, colq = n0 + wn * 64 + 4 * lc;
+    float* xtr = stg + EPI_XTR;
+    if (lnm) {               // lane l: coefficients of token row (mode 1) / token column (mode 2) l of this wave's sub-tile
+        *reinterpret_cast<float2*>(xtr + 2 * lane) =
+            ln_token_coeffs(p, lnm == 1 ? min(m0 + wm * 64 + lane, p.M - 1) : min(n0 + wn * 64 + lane, p.N - 1));
+        if (lnm == 2) {      // ... and c / d of row l
+            const int rr = min(m0 + wm * 64 + lane, p.M - 1);
+            *reinterpret_cast<float2*>(xtr + 128 + 2 * lane) = make_float2(p.ln_c[rr], p.ln_d[rr]);
+        }
+    }
     if (p.mode == SG_EPI_GEGLU && p.splits == 1) {
         // interleaved layout (groups of 64 rows of W: 32 value rows then the 32 matching gate rows): the wave's columns 0..31 are
         // values, 32..63 the gates of the SAME 32 outputs.  Lane l: row 8 k + (l >> 3), values 4 (l & 7) .. +3.
@@ -179,14 +230,26 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
             for (int e = 0; e < 4; ++e) { bv[e] = (float)a.h[e]; bg[e] = (float)b.h[e]; }
         }
         const int go = (gv >> 6) * 32 + (gv & 31);                // interleaved column -> output column
+        float cv[4] = {0, 0, 0, 0}, cg[4] = {0, 0, 0, 0};
+        if (lnm == 1) {      // folded LayerNorm: value / gate = rstd (acc - mean c) + d  (d carries the bias)
+            const f32x4 a = *reinterpret_cast<const f32x4*>(p.ln_c + gv), b = *reinterpret_cast<const f32x4*>(p.ln_c + gv + 32);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(p.ln_d + gv), d = *reinterpret_cast<const f32x4*>(p.ln_d + gv + 32);
+            cv[0] = a.x; cv[1] = a.y; cv[2] = a.z; cv[3] = a.w; cg[0] = b.x; cg[1] = b.y; cg[2] = b.z; cg[3] = b.w;
+            bv[0] += c.x; bv[1] += c.y; bv[2] += c.z; bv[3] += c.w; bg[0] += d.x; bg[1] += d.y; bg[2] += d.z; bg[3] += d.w;
+        }
 #pragma unroll
         for (int k = 0; k < 8; ++k) {
             const int row = 8 * k + gr, gm = m0 + wm * 64 + row;
             const float4 a = *reinterpret_cast<const float4*>(stg + row * EPI_PITCH + gc);
             const float4 b = *reinterpret_cast<const float4*>(stg + row * EPI_PITCH + 32 + gc);
+            float2 mr = make_float2(0.f, 1.f);
+            if (lnm == 1) mr = *reinterpret_cast<const float2*>(xtr + 2 * row);
             if (gm >= p.M) continue;
-            const float o[4] = {(a.x + bv[0]) * gelu_erf_f(b.x + bg[0]), (a.y + bv[1]) * gelu_erf_f(b.y + bg[1]),
-                                (a.z + bv[2]) * gelu_erf_f(b.z + bg[2]), (a.w + bv[3]) * gelu_erf_f(b.w + bg[3])};
+            const float va[4] = {a.x, a.y, a.z, a.w}, ga[4] = {b.x, b.y, b.z, b.w};
+            float o[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                o[e] = (fmaf(mr.y, va[e], bv[e]) - mr.x * cv[e]) * gelu_erf_f(fmaf(mr.y, ga[e], bg[e]) - mr.x * cg[e]);
             store_out4(p, gm, go, o);
         }
         return;
@@ -214,14 +277,40 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
     {
         float bias4[4] = {0, 0, 0, 0};
         if (p.bias) {
-            H4 b; b.u = pf.bias;
+            H4 b; b.u = make_uint2(pbias.x, pbias.y);
 #pragma unroll
             for (int e = 0; e < 4; ++e) bias4[e] = (float)b.h[e];
         }
+        if (lnm == 1) {           // rows are tokens: per-row (mean rstd, rstd), per-column c / d
+            const f32x4 lc4 = *reinterpret_cast<const f32x4*>(p.ln_c + cq), ld4 = *reinterpret_cast<const f32x4*>(p.ln_d + cq);
+            const float c4[4] = {lc4.x, lc4.y, lc4.z, lc4.w};
+            const float d4[4] = {ld4.x + bias4[0], ld4.y + bias4[1], ld4.z + bias4[2], ld4.w + bias4[3]};
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const float4 a = *reinterpret_cast<const float4*>(stg + (4 * k + lr) * EPI_PITCH + 4 * lc);
-            v[k][0] = a.x + bias4[0]; v[k][1] = a.y + bias4[1]; v[k][2] = a.z + bias4[2]; v[k][3] = a.w + bias4[3];
+            for (int k = 0; k < 16; ++k) {
+                const float4 a = *reinterpret_cast<const float4*>(stg + (4 * k + lr) * EPI_PITCH + 4 * lc);
+                const float2 mr = *reinterpret_cast<const float2*>(xtr + 2 * (4 * k + lr));
+                const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[k][e] = fmaf(mr.y, av[e], d4[e]) - mr.x * c4[e];
+            }
+        } else if (lnm == 2) {    // columns are tokens (V^T = W_v X^T): per-column (mean rstd, rstd), per-row c / d
+            float mrx[4], mry[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float2 t = *reinterpret_cast<const float2*>(xtr + 2 * (4 * lc + e)); mrx[e] = t.x; mry[e] = t.y; }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float4 a = *reinterpret_cast<const float4*>(stg + (4 * k + lr) * EPI_PITCH + 4 * lc);
+                const float2 cd = *reinterpret_cast<const float2*>(xtr + 128 + 2 * (4 * k + lr));
+                const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[k][e] = fmaf(mry[e], av[e], cd.y + bias4[e]) - mrx[e] * cd.x;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const float4 a = *reinterpret_cast<const float4*>(stg + (4 * k + lr) * EPI_PITCH + 4 * lc);
+                v[k][0] = a.x + bias4[0]; v[k][1] = a.y + bias4[1]; v[k][2] = a.z + bias4[2]; v[k][3] = a.w + bias4[3];
+            }
         }
     }
     auto add_f32 = [&](const float* base, long ld) __attribute__((always_inline)) {
@@ -277,6 +366,30 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
             for (int e = 0; e < 4; ++e) { cs[e] += v[k][e]; cq2[e] = fmaf(v[k][e], v[k][e], cq2[e]); }
         }
     }
+    if (p.ln_out) {
+        // LayerNorm fold, producer side: per token (row) and per 64-column block (this wave's columns) the sum and the M2 about the
+        // block mean of the FINAL fp32 values.  The wave puts them back into its staging image and lane l reads row l whole
+        // (16 x 16 B, conflict-free at this pitch): 64 adds + 64 fmas per lane, no cross-lane traffic, fixed order.
+#pragma unroll
+        for (int k = 0; k < 16; ++k)
+            *reinterpret_cast<float4*>(stg + (4 * k + lr) * EPI_PITCH + 4 * lc) = make_float4(v[k][0], v[k][1], v[k][2], v[k][3]);
+        float4 rv[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) rv[q] = *reinterpret_cast<const float4*>(stg + lane * EPI_PITCH + 4 * q);
+        float sum = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sum += (rv[q].x + rv[q].y) + (rv[q].z + rv[q].w);
+        const float mean = sum * (1.f / 64.f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const float a = rv[q].x - mean, b = rv[q].y - mean, c = rv[q].z - mean, d = rv[q].w - mean;
+            m2 = fmaf(a, a, m2); m2 = fmaf(b, b, m2); m2 = fmaf(c, c, m2); m2 = fmaf(d, d, m2);
+        }
+        const int gm = m0 + wm * 64 + lane;
+        if (gm < p.M && n0 + wn * 64 < p.N)
+            *reinterpret_cast<float2*>(p.ln_out + ((size_t)gm * (((p.N >> 6) + 1) & ~1) + ((n0 >> 6) + wn)) * 2) = make_float2(sum, m2);
+    }
     if (want_stats) {
         // GroupNorm statistics as an epilogue: per-(row tile, channel) sums of the FINAL fp32 values (bias / temb / residual
         // included, before the fp16 rounding).  A lane holds 16 rows of its 4 columns; the 4 lane groups (l >> 4) are added by two
@@ -286,12 +399,12 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
             cs[e] += __shfl_xor(cs[e], 16, 64); cq2[e] += __shfl_xor(cq2[e], 16, 64);
             cs[e] += __shfl_xor(cs[e], 32, 64); cq2[e] += __shfl_xor(cq2[e], 32, 64);
         }
-        float* sred = reinterpret_cast<float*>(smem + NW * EPI_WAVE_BYTES);         // [WGM][BN][2], behind the staging regions
+        // every wave parks its 64 columns x 2 planes in the second half of its own extra area
         if (lr == 0) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                sred[((wm * BN) + wn * 64 + 4 * lc + e) * 2 + 0] = cs[e];
-                sred[((wm * BN) + wn * 64 + 4 * lc + e) * 2 + 1] = cq2[e];
+                xtr[128 + (4 * lc + e) * 2 + 0] = cs[e];
+                xtr[128 + (4 * lc + e) * 2 + 1] = cq2[e];
             }
         }
         __syncthreads();
@@ -301,7 +414,8 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
             if (gn < p.N) {
                 float s = 0.f;
 #pragma unroll
-                for (int w = 0; w < WGM; ++w) s += sred[(w * BN + col) * 2 + plane];
+                for (int w = 0; w < WGM; ++w)
+                    s += reinterpret_cast<const float*>(smem + (w * WGN + (col >> 6)) * EPI_WAVE_BYTES)[EPI_XTR + 128 + (col & 63) * 2 + plane];
                 p.stats[((size_t)(m0 / (64 * WGM)) * 2 + plane) * p.N + gn] = s;
             }
         }
@@ -316,7 +430,7 @@ __global__ __launch_bounds__(256) void mma_kernel(const MmaParams p) {
     static_assert(TM == 2 && TN == 2, "epi_finish works on 64x64 wave tiles");
     constexpr int A_IT = BM / 32, B_IT = BN / 32;
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
-    constexpr int EPI_BYTES = 4 * EPI_WAVE_BYTES + 2 * BN * 2 * 4;   // staging regions + statistics scratch of epi_finish
+    constexpr int EPI_BYTES = 4 * EPI_WAVE_BYTES;   // staging regions (+ 1 KB of scratch each) of epi_finish
     constexpr int SMEM = (2 * STAGE > EPI_BYTES) ? 2 * STAGE : EPI_BYTES;
     __shared__ __attribute__((aligned(16))) char smem[SMEM];
 
@@ -428,10 +542,10 @@ __global__ __launch_bounds__(256) void mma_kernel(const MmaParams p) {
         if (more) store_lds(buf ^ 1);
         __syncthreads();
     }
-    EpiPre pre;
-    epi_prefetch(p, m0 + wm * WM + (lane >> 4), n0 + wn * WN + 4 * (lane & 15), pre);
+    EPI_PRE_DECL;
+    epi_prefetch(p, m0, n0, wm, wn, lane, EPI_PRE_ARGS);
     __syncthreads();
-    epi_finish<2, 2>(p, smem, acc, pre, m0, n0, z, wave, wm, wn, lane);
+    epi_finish<2, 2>(p, smem, acc, EPI_PRE_ARGS, m0, n0, z, wave, wm, wn, lane);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -455,7 +569,7 @@ constexpr int S = 3;   // LDS ring depth (2 and 4 were measured in round 2: DESI
 
 template <int WGM, int WGN>
 constexpr int pipe_smem_bytes() {
-    constexpr int ring = S * (64 * WGM + 64 * WGN) * 128, epi = WGM * WGN * EPI_WAVE_BYTES + WGM * 64 * WGN * 2 * 4;
+    constexpr int ring = S * (64 * WGM + 64 * WGN) * 128, epi = WGM * WGN * EPI_WAVE_BYTES;
     return ring > epi ? ring : epi;
 }
 
@@ -574,8 +688,7 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         for (int j = 0; j < WTN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    EpiPre pre;
-    const int rowq = m0 + wm * WM + (lane >> 4), colq = n0 + wn * WN + 4 * (lane & 15);
+    EPI_PRE_DECL;
 
     int stage = 0;
     stamp(7);
@@ -610,7 +723,7 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
                 // k-step's fragment reads: its address arithmetic then overlaps matrix work instead of delaying it
                 stamp(4);
                 if constexpr (LAST) {
-                    epi_prefetch(p, rowq, colq, pre);
+                    epi_prefetch(p, m0, n0, wm, wn, lane, EPI_PRE_ARGS);
                 } else if (it + S - 1 < nt) {
                     int st = stage + S - 1;
                     if (st >= S) st -= S;
@@ -632,8 +745,8 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     };
     for (int it = 0; it + 1 < nt; ++it) slab(it, std::false_type{});
     if (nt > 0) slab(nt - 1, std::true_type{});
-    if (nt <= 0) epi_prefetch(p, rowq, colq, pre);
-    epi_finish<WGM, WGN>(p, smem, acc, pre, m0, n0, z, wave, wm, wn, lane);
+    if (nt <= 0) epi_prefetch(p, m0, n0, wm, wn, lane, EPI_PRE_ARGS);
+    epi_finish<WGM, WGN>(p, smem, acc, EPI_PRE_ARGS, m0, n0, z, wave, wm, wn, lane);
     if constexpr (PROF) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(8);
@@ -727,6 +840,18 @@ __device__ __forceinline__ void epi_linear8(const MmaParams& p, int gm, int gn, 
     if (p.res1) add_res8(p.res1, p.ldr1, p.flags & SG_F_RES1_F32, gm, gn, v);
     if (p.res2) add_res8(p.res2, p.ldr2, p.flags & SG_F_RES2_F32, gm, gn, v);
     store_out8(p, gm, gn, v);
+    if (p.ln_out) {
+        // LayerNorm fold, producer side (see epi_finish): the 8 threads of a 64-column block (consecutive lanes, same row: N % 64
+        // == 0) add their sums with three exchanges, then their squared deviations from the block mean
+        float s = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+        s += __shfl_xor(s, 1, 64); s += __shfl_xor(s, 2, 64); s += __shfl_xor(s, 4, 64);
+        const float mean = s * (1.f / 64.f);
+        float m2 = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = v[j] - mean; m2 = fmaf(d, d, m2); }
+        m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64);
+        if ((gn & 63) == 0) *reinterpret_cast<float2*>(p.ln_out + ((size_t)gm * (((p.N >> 6) + 1) & ~1) + (gn >> 6)) * 2) = make_float2(s, m2);
+    }
 }
 
 // val/gate: 8 consecutive interleaved-layout columns starting at global column gv (value) and gv+32 (gate).
@@ -952,6 +1077,7 @@ int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws
         else launch_pipe<1, 1, CONV>(p, grid, st);
     } else {
         dim3 block(256);
+        if (p.ln_mode) return sg_set_error(SG_EINVAL, "%s: a folded LayerNorm needs the LDS-DMA kernel (K %% 64 == 0)", name);
         if (pl.bm == 128 && pl.bn == 128) hipLaunchKernelGGL((mma_kernel<128, 128, CONV>), grid, block, 0, st, p);
         else return sg_set_error(SG_EINVAL, "%s: internal: the register-staged kernel has only the 128x128 tile", name);
     }
@@ -1025,6 +1151,23 @@ int gemm_params(const sg_gemm_desc* d, MmaParams& p, const char* who) {
     p.res2 = d->res2; p.ldr2 = d->ldr2;
     SG_REQUIRE(!d->stats || (sg_aligned16(d->stats) && d->stats_batch_rows > 0), "%s: stats alignment / stats_batch_rows", who);
     p.stats = d->stats; p.stats_batch_rows = d->stats_batch_rows;
+    SG_REQUIRE(d->ln_mode >= 0 && d->ln_mode <= 2, "%s: ln_mode must be 0, 1 or 2", who);
+    if (d->ln_mode) {
+        SG_REQUIRE(d->ln_stats && d->ln_c && d->ln_d, "%s: ln_mode needs ln_stats, ln_c and ln_d", who);
+        SG_REQUIRE(d->ln_parts >= 1 && d->ln_parts <= LN_MAX_PARTS && d->K == 64 * d->ln_parts,
+                   "%s: ln_parts (%d) must be K / 64 (K = %d) and at most %d", who, d->ln_parts, d->K, LN_MAX_PARTS);
+        SG_REQUIRE(sg_aligned16(d->ln_c) && sg_aligned16(d->ln_d) && sg_aligned16(d->ln_stats), "%s: ln_c / ln_d / ln_stats alignment", who);
+        SG_REQUIRE(d->split_k <= 1, "%s: a GEMM with a folded LayerNorm does not split K (its epilogue is not linear in the partials)", who);
+        SG_REQUIRE(!d->stats && !d->rowbias && !d->res1 && !d->res2, "%s: ln_mode excludes stats, rowbias and residuals", who);
+        SG_REQUIRE(d->ln_mode == 1 || d->epilogue == SG_EPI_LINEAR, "%s: ln_mode 2 needs the linear epilogue", who);
+        SG_REQUIRE(d->ln_eps > 0.f, "%s: ln_eps must be positive", who);
+    }
+    if (d->ln_stats_out) {
+        SG_REQUIRE(d->epilogue == SG_EPI_LINEAR && d->N % 64 == 0 && sg_aligned16(d->ln_stats_out),
+                   "%s: ln_stats_out needs the linear epilogue, N %% 64 == 0 and a 16-byte aligned buffer", who);
+    }
+    p.ln_stats = d->ln_stats; p.ln_parts = d->ln_parts; p.ln_c = d->ln_c; p.ln_d = d->ln_d; p.ln_mode = d->ln_mode; p.ln_eps = d->ln_eps;
+    p.ln_out = d->ln_stats_out;
     return check_tile_hint(who, d->tile_m, d->tile_n, d->tile_waves);
 }
 
@@ -1037,7 +1180,7 @@ void launch_pair(const MmaPair& pp, dim3 grid, hipStream_t st) {
 extern "C" int sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream) {
     MmaParams p;
     if (int rc = gemm_params(d, p, "sg_gemm_f16")) return rc;
-    return launch_mma<false>(p, d->split_k, d->tile_m, d->tile_n, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_gemm_f16");
+    return launch_mma<false>(p, d->ln_mode ? 1 : d->split_k, d->tile_m, d->tile_n, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_gemm_f16");
 }
 
 extern "C" int sg_gemm_pair_f16(const sg_gemm_desc* d0, const sg_gemm_desc* d1, sg_stream_t stream) {
@@ -1051,12 +1194,13 @@ extern "C" int sg_gemm_pair_f16(const sg_gemm_desc* d0, const sg_gemm_desc* d1, 
     hipStream_t st = (hipStream_t)stream;
     Plan pl0, pl1;
     bool pipe0, pipe1;
-    if (int rc = plan_mma<false>(pp.p0, d0->split_k, d0->tile_m, d0->tile_n, d0->workspace, d0->workspace_bytes, "sg_gemm_pair_f16[0]", pl0, pipe0)) return rc;
+    const int sk0 = d0->ln_mode ? 1 : d0->split_k, sk1 = d1->ln_mode ? 1 : d1->split_k;
+    if (int rc = plan_mma<false>(pp.p0, sk0, d0->tile_m, d0->tile_n, d0->workspace, d0->workspace_bytes, "sg_gemm_pair_f16[0]", pl0, pipe0)) return rc;
     // one kernel instantiation serves both problems: the second one is planned on the first one's tile shape
-    if (int rc = plan_mma<false>(pp.p1, d1->split_k, pl0.bm, pl0.bn, d1->workspace, d1->workspace_bytes, "sg_gemm_pair_f16[1]", pl1, pipe1)) return rc;
+    if (int rc = plan_mma<false>(pp.p1, sk1, pl0.bm, pl0.bn, d1->workspace, d1->workspace_bytes, "sg_gemm_pair_f16[1]", pl1, pipe1)) return rc;
     if (!pipe0 || !pipe1 || pl1.bm != pl0.bm || pl1.bn != pl0.bn) {        // not pairable (K % 64, forced tile): two launches
-        if (int rc = launch_mma<false>(pp.p0, d0->split_k, d0->tile_m, d0->tile_n, d0->workspace, d0->workspace_bytes, st, "sg_gemm_pair_f16[0]")) return rc;
-        return launch_mma<false>(pp.p1, d1->split_k, d1->tile_m, d1->tile_n, d1->workspace, d1->workspace_bytes, st, "sg_gemm_pair_f16[1]");
+        if (int rc = launch_mma<false>(pp.p0, sk0, d0->tile_m, d0->tile_n, d0->workspace, d0->workspace_bytes, st, "sg_gemm_pair_f16[0]")) return rc;
+        return launch_mma<false>(pp.p1, sk1, d1->tile_m, d1->tile_n, d1->workspace, d1->workspace_bytes, st, "sg_gemm_pair_f16[1]");
     }
     const int g0 = pp.p0.tiles_m * pp.p0.tiles_n * pp.p0.splits, g1 = pp.p1.tiles_m * pp.p1.tiles_n * pp.p1.splits;
     // grid.x is a multiple of 8 so that block (x, 1) sits on XCD x % 8 like block (x, 0): xcd_remap keeps its meaning

@@ -33,7 +33,7 @@ import torch
 
 from . import ops
 from .arch import BlockSpec, ResnetSpec, UNetArch, XfSpec, feature_shapes
-from .repack import conv1x1_nk, conv3x3_krsc, conv_in_kn, interleave_geglu
+from .repack import conv1x1_nk, conv3x3_krsc, conv_in_kn, fold_layernorm, interleave_geglu
 
 F16 = torch.float16
 GN_EPILOGUE_STATS = True   # GroupNorm statistics from the producing conv / GEMM epilogues (False = every GroupNorm makes its own pass)
@@ -43,6 +43,12 @@ GN_EPILOGUE_STATS = True   # GroupNorm statistics from the producing conv / GEMM
 FP16_BLOCK_STREAM = False
 FP16_RESNET_STREAM = False   # same experiment for the rest of the stream: resnet / transformer / shortcut outputs and the skip-concat buffers
 PAIR_GEMMS = True     # q|k + V^T, q2 + q3, k3 + v3^T as one launch each (sg_gemm_pair_f16); False = two launches (A/B switch)
+# LayerNorm folded into the GEMM that consumes it (round 3; model/attention.py:250,268,283,298): the producers of h0 / h1 / h3 also
+# write the raw fp16 copy and per-token partial statistics, the q|k / V^T / q2 / q3 / GEGLU projections run on the raw copy with
+# gamma-scaled weights and normalise in their epilogues (sg_gemm_desc.ln_*).  No LayerNorm launch is left in a pass (-94 launches
+# per step).  False = the separate layernorm kernel (A/B switch).
+LN_FOLD = True
+LN_EPS = 1e-5         # torch.nn.LayerNorm default, as the reference constructs norm1..norm4 (model/attention.py:213-233)
 
 
 def _pair(first, second):
@@ -59,7 +65,10 @@ class _Resnet:
 
 class _Xf:
     __slots__ = ("spec", "ng", "nb", "w_in", "b_in", "w_out", "b_out", "ln", "w_qk1", "w_v1", "w_o1", "b_o1", "w_q2", "w_k2",
-                 "w_v2", "w_o2", "b_o2", "w_q3", "w_k3", "w_v3", "w_o3", "b_o3", "w_o23", "b_o23", "w_ff1", "b_ff1", "w_ff2", "b_ff2")
+                 "w_v2", "w_o2", "b_o2", "w_q3", "w_k3", "w_v3", "w_o3", "b_o3", "w_o23", "b_o23", "w_ff1", "b_ff1", "w_ff2", "b_ff2",
+                 # LayerNorm-folded copies (repack.fold_layernorm): weight gamma (.) W in fp16, c / d in fp32
+                 "w_qk1f", "c_qk1", "d_qk1", "w_v1f", "c_v1", "d_v1", "w_q2f", "c_q2", "d_q2", "w_q3f", "c_q3", "d_q3",
+                 "w_ff1f", "c_ff1", "d_ff1")
 
 
 class EngineWeights:
@@ -136,6 +145,8 @@ class EngineWeights:
                 o.b_o23 = (sd[f"{t}.attn2.to_out.0.bias"].float() + sd[f"{t}.attn3.to_out.0.bias"].float()).to(dev, F16)
                 o.w_ff1, o.b_ff1 = interleave_geglu(g(f"{t}.ff.net.0.proj.weight"), g(f"{t}.ff.net.0.proj.bias"))
                 o.w_ff2, o.b_ff2 = g(f"{t}.ff.net.2.weight"), g(f"{t}.ff.net.2.bias")
+                for name, val in self._pack_folds(o).items():
+                    setattr(o, name, val)
                 self.xfs[p] = o
         self.samplers = {}
         for blk in arch.down + arch.up:
@@ -145,6 +156,19 @@ class EngineWeights:
         self.gn_out = (g("conv_norm_out.weight"), g("conv_norm_out.bias"))
         self.w_conv_out = conv3x3_krsc(g("conv_out.weight"))
         self.b_conv_out = g("conv_out.bias")
+
+    @staticmethod
+    def _pack_folds(xf: "_Xf", which=("qk1", "v1", "q2", "q3", "ff1")) -> Dict[str, torch.Tensor]:
+        """LayerNorm-folded operand copies of the projections that follow norm1 (q|k, v), norm2 (q2), norm4 (q3) and norm3 (GEGLU):
+        W' = gamma (.) W in fp16, c = row sums of W', d = W beta (+ bias)."""
+        src = {"qk1": (xf.w_qk1, None, "norm1"), "v1": (xf.w_v1, None, "norm1"), "q2": (xf.w_q2, None, "norm2"),
+               "q3": (xf.w_q3, None, "norm4"), "ff1": (xf.w_ff1, xf.b_ff1, "norm3")}
+        out = {}
+        for k in which:
+            w, b, n = src[k]
+            wf, c, d = fold_layernorm(w, b, *xf.ln[n])
+            out[f"w_{k}f"], out[f"c_{k}"], out[f"d_{k}"] = wf.contiguous(), c.contiguous(), d.contiguous()
+        return out
 
     # ---- in-place refresh: captured hipGraphs and engines hold the ADDRESSES of the repacked tensors, so new parameter
     # values are copied into the existing storage (same shapes) instead of re-allocating
@@ -163,6 +187,8 @@ class EngineWeights:
             if prefixes is None or p in prefixes:
                 for name, val in self._pack_attn3(sd, xf).items():
                     getattr(xf, name).copy_(val)
+                for name, val in self._pack_folds(xf, ("q3",)).items():
+                    getattr(xf, name).copy_(val)
 
     def _pack_attn1(self, sd, xf: "_Xf") -> Dict[str, torch.Tensor]:
         t = f"{xf.spec.prefix}.transformer_blocks.0"
@@ -175,6 +201,8 @@ class EngineWeights:
         for p, xf in self.xfs.items():
             if prefixes is None or p in prefixes:
                 for name, val in self._pack_attn1(sd, xf).items():
+                    getattr(xf, name).copy_(val)
+                for name, val in self._pack_folds(xf, ("qk1", "v1")).items():
                     getattr(xf, name).copy_(val)
 
     def reload_(self, sd):
@@ -345,7 +373,9 @@ class UNetEngine:
                 **{n: (self._buf(M, C) if FP16_BLOCK_STREAM else f32(M, C)) for n in ("h0", "h1", "h2", "h3")},
                 # fp16 MFMA operands
                 gn=self._buf(M, C), x16=self._buf(M * Cw), c1=self._buf(M, C), h4=self._buf(M, C),
-                ln=self._buf(M, C), ln4=self._buf(M, C), qk=self._buf(M, 2 * C), vt=self._buf(C, M), q=self._buf(M, C),
+                ln=self._buf(M, C), ln4=self._buf(M, C), qk=self._buf(M, 2 * C),
+                # LayerNorm fold: per-token (sum, M2) partials of h0 / h1 / h3 per 64-channel block
+                **{n: torch.zeros(M, (C // 64 + 1) & ~1, 2, dtype=F32, device=self.dev) for n in ("lnst0", "lnst1", "lnst3")}, vt=self._buf(C, M), q=self._buf(M, C),
                 att=self._buf(M, C), q2=self._buf(M, C), att23=self._buf(M, 2 * C), ffi=self._buf(M, 4 * C),
                 kt=self._buf(B * self.Sp, C), vtt=self._buf(C, B * self.Sp),
                 ki=self._buf(self.ctx_rows * self.R * self.hw[l], C) if self.R else None,
@@ -522,18 +552,27 @@ class UNetEngine:
         ops.groupnorm(x.unflatten(0, (B, hw)), xf.ng, xf.nb, L["gn"].unflatten(0, (B, hw)), self.groups, 1e-6, False,
                       self.ws_gn, pstats=self._pstats_of(x))                              # :99 (eps 1e-6, :55)
         h0 = L["h0"]
-        ops.gemm(L["gn"], xf.w_in, h0, bias=xf.b_in, workspace=ws)                        # proj_in :101
+        fold = LN_FOLD and C % 64 == 0 and C // 64 <= 20
+        # with the fold, the producer of a stream tensor also writes its raw fp16 copy and the LayerNorm partials of its rows
+        raw = lambda t, buf: t if t.dtype == F16 else buf                                 # noqa: E731  (fp16 stream: it IS the copy)
+        prod = lambda t, buf, st: dict(out2=None if t.dtype == F16 else buf, ln_out=st) if fold else {}   # noqa: E731
+        h0r, h1r = raw(h0, L["ln"]), raw(L["h1"], L["ln4"])
+        ops.gemm(L["gn"], xf.w_in, h0, bias=xf.b_in, workspace=ws, **prod(h0, L["ln"], L["lnst0"]))   # proj_in :101
         # --- self-attention :250-262
-        ops.layernorm(h0, *xf.ln["norm1"], L["ln"])
         qk, vt = L["qk"], L["vt"]
         wp = self.ws_pair
         # q|k (token-major) and V^T = Wv . X^T (the attention kernel's operand layout): two GEMMs on one LayerNorm output, one launch
-        _pair(((L["ln"], xf.w_qk1, qk), dict(workspace=ws)), ((xf.w_v1, L["ln"], vt), dict(workspace=wp)))
+        if fold:
+            _pair(((h0r, xf.w_qk1f, qk), dict(ln=(1, L["lnst0"], xf.c_qk1, xf.d_qk1, LN_EPS))),
+                  ((xf.w_v1f, h0r, vt), dict(ln=(2, L["lnst0"], xf.c_v1, xf.d_v1, LN_EPS))))
+        else:
+            ops.layernorm(h0, *xf.ln["norm1"], L["ln"])
+            _pair(((L["ln"], xf.w_qk1, qk), dict(workspace=ws)), ((xf.w_v1, L["ln"], vt), dict(workspace=wp)))
         qk3 = qk.view(B, hw, 2 * C)
         att = L["att"]
         self._attention(qk3[:, :, :C], qk3[:, :, C:], vt.view(C, B, hw).permute(1, 0, 2), att.view(B, hw, C), heads, scale)
         h1 = L["h1"]
-        ops.gemm(att, xf.w_o1, h1, bias=xf.b_o1, res1=h0, workspace=ws)
+        ops.gemm(att, xf.w_o1, h1, bias=xf.b_o1, res1=h0, workspace=ws, **prod(h1, L["ln4"], L["lnst1"]))
         if harvest is not None:                                                           # feature :263, written in place
             h1b = h1.view(B, hw, C)
             for plan in (harvest if isinstance(harvest, (list, tuple)) else (harvest,)):
@@ -548,7 +587,9 @@ class UNetEngine:
             if stop_after_harvest:
                 return
         # --- text cross-attention :266-277 (norm2) and image cross-attention :281-291 (norm4) share statistics
-        if consume:
+        if fold:
+            pass
+        elif consume:
             ops.layernorm(h1, *xf.ln["norm2"], L["ln"], 1e-5, *xf.ln["norm4"], L["ln4"])
         else:
             ops.layernorm(h1, *xf.ln["norm2"], L["ln"])
@@ -560,7 +601,11 @@ class UNetEngine:
             a2v, a3v = att23[:, :C].unflatten(0, (B, hw)), att23[:, C:].unflatten(0, (B, hw))
             # both query projections in one launch (norm2 / norm4 outputs of the same statistics), then the two attentions side by side
             q2, q3buf = L["q2"], L["q"]
-            _pair(((L["ln"], xf.w_q2, q2), dict(workspace=ws)), ((L["ln4"], xf.w_q3, q3buf), dict(workspace=wp)))
+            if fold:
+                _pair(((h1r, xf.w_q2f, q2), dict(ln=(1, L["lnst1"], xf.c_q2, xf.d_q2, LN_EPS))),
+                      ((h1r, xf.w_q3f, q3buf), dict(ln=(1, L["lnst1"], xf.c_q3, xf.d_q3, LN_EPS))))
+            else:
+                _pair(((L["ln"], xf.w_q2, q2), dict(workspace=ws)), ((L["ln4"], xf.w_q3, q3buf), dict(workspace=wp)))
             forked = self._fork()
             if forked:
                 with torch.cuda.stream(self.side):
@@ -585,15 +630,22 @@ class UNetEngine:
             if forked:
                 self._join()
             h3 = L["h3"]
-            ops.gemm(att23, xf.w_o23, h3, bias=xf.b_o23, res1=h1, res2=h1, workspace=ws)  # (a2 + h) + (a3 + h)
+            ops.gemm(att23, xf.w_o23, h3, bias=xf.b_o23, res1=h1, res2=h1, workspace=ws,  # (a2 + h) + (a3 + h)
+                     **prod(h3, L["ln"], L["lnst3"]))
         else:
-            ops.gemm(L["ln"], xf.w_q2, L["q"], workspace=ws)
+            if fold:
+                ops.gemm(h1r, xf.w_q2f, L["q"], ln=(1, L["lnst1"], xf.c_q2, xf.d_q2, LN_EPS))
+            else:
+                ops.gemm(L["ln"], xf.w_q2, L["q"], workspace=ws)
             ops.attention(L["q"].view(B, hw, C), kt3, vtt3, att.view(B, hw, C), heads, scale, nk=S)
             h3 = L["h2"]
-            ops.gemm(att, xf.w_o2, h3, bias=xf.b_o2, res1=h1, workspace=ws)               # :277,295
+            ops.gemm(att, xf.w_o2, h3, bias=xf.b_o2, res1=h1, workspace=ws, **prod(h3, L["ln"], L["lnst3"]))   # :277,295
         # --- feed-forward :298-300
-        ops.layernorm(h3, *xf.ln["norm3"], L["ln"])
-        ops.gemm(L["ln"], xf.w_ff1, L["ffi"], bias=xf.b_ff1, epilogue=ops.EPI_GEGLU, workspace=ws)
+        if fold:
+            ops.gemm(raw(h3, L["ln"]), xf.w_ff1f, L["ffi"], epilogue=ops.EPI_GEGLU, ln=(1, L["lnst3"], xf.c_ff1, xf.d_ff1, LN_EPS))
+        else:
+            ops.layernorm(h3, *xf.ln["norm3"], L["ln"])
+            ops.gemm(L["ln"], xf.w_ff1, L["ffi"], bias=xf.b_ff1, epilogue=ops.EPI_GEGLU, workspace=ws)
         ops.gemm(L["ffi"], xf.w_ff2, L["h4"], bias=xf.b_ff2, res1=h3, workspace=ws)       # fp16: only feeds proj_out
         kwo = dict(bias=xf.b_out, res1=x, workspace=ws)                                   # proj_out + residual :121-123
         site = xf.spec.prefix + ".proj_out"

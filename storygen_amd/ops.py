@@ -143,9 +143,13 @@ def _gemm_desc(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Opt
                rowbias: Optional[torch.Tensor] = None, rows_per_batch: int = 1, res1: Optional[torch.Tensor] = None,
                res2: Optional[torch.Tensor] = None, epilogue: int = EPI_LINEAR, split_k: int = 0,
                workspace: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
-               tile: Optional[tuple] = None, use_table: bool = True, stats: Optional[tuple] = None):
+               tile: Optional[tuple] = None, use_table: bool = True, stats: Optional[tuple] = None,
+               ln: Optional[tuple] = None, ln_out: Optional[torch.Tensor] = None):
     """Builds the sg_gemm_desc of one problem; returns (desc, flops, shape string).  stats = (fp32 buffer, rows per image): the
-    epilogue also writes the GroupNorm partial statistics of the output (sg_gemm_desc.stats)."""
+    epilogue also writes the GroupNorm partial statistics of the output (sg_gemm_desc.stats).
+    ln = (mode, stats [tokens, K/64 rounded up to even, 2] fp32, c fp32, d fp32, eps): LayerNorm folded into this GEMM (sg_gemm_desc.ln_*: mode 1 =
+    the rows of `a` are the normalised tokens, 2 = the rows of `w` are); ln_out = fp32 [M, N/64 rounded up to even, 2]: also write the LayerNorm
+    partials of THIS output (sg_gemm_desc.ln_stats_out)."""
     _f16(a, "a"), _f16(w, "w")
     flags = F_OUT_F32 if _act(out, "out") else 0
     M, K = a.shape
@@ -183,7 +187,22 @@ def _gemm_desc(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Opt
     if stats is not None:
         _f32(stats[0], "stats")
         d.stats, d.stats_batch_rows = stats[0].data_ptr(), int(stats[1])
+    if ln is not None:
+        mode, lst, lc, ld_, eps = ln
+        _f32(lst, "ln stats"), _f32(lc, "ln c"), _f32(ld_, "ln d")
+        tokens = M if mode == 1 else N
+        if tuple(lst.shape) != (tokens, (K // 64 + 1) & ~1, 2) or not lst.is_contiguous() or lc.numel() != (N if mode == 1 else M) or ld_.numel() != lc.numel():
+            raise ValueError(f"gemm: ln operands do not match mode {mode}, {tokens} tokens, K = {K}")
+        d.ln_mode, d.ln_parts, d.ln_eps = int(mode), K // 64, float(eps)
+        d.ln_stats, d.ln_c, d.ln_d = lst.data_ptr(), lc.data_ptr(), ld_.data_ptr()
+    if ln_out is not None:
+        _f32(ln_out, "ln_out")
+        if ln_out.numel() != M * ((N // 64 + 1) & ~1) * 2 or not ln_out.is_contiguous():
+            raise ValueError(f"gemm: ln_out must hold [{M}, {(N // 64 + 1) & ~1}, 2] floats (N / 64 blocks rounded up to even)")
+        d.ln_stats_out = ln_out.data_ptr()
     sig = f"g:{M}:{N}:{K}:{epilogue}:{flags}:{int(bias is not None)}{int(rowbias is not None)}{int(res1 is not None)}{int(res2 is not None)}{int(out2 is not None)}"
+    if ln is not None:
+        sig += f":ln{ln[0]}"
     if use_table or tile is not None:
         _apply_tile(d, tile, split_k, sig)
     if TUNE_SINK is not None and use_table:

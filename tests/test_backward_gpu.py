@@ -328,3 +328,40 @@ def test_training_step_graph_replay_matches_eager(gpu):
         assert abs(float(loss) - wl) <= 1e-6 * abs(wl)
         assert max(rel(grads[k], wg[k]) for k in wg) < 1e-6
     assert len(tr._graphs) == 1
+
+
+def test_training_step_at_baseline_config4_size_vs_reference_golden(gpu):
+    """BASELINE config 4 AT ITS OWN SIZE: SD-1.5 UNet, 64x64 latent, batch 4, reference frames (0, 1, 2) — loss and all 80 attn3
+    gradients of UNetTrainer.train_step_graph (the whole step as one hipGraph, loss scaling included) against the gradients the
+    REFERENCE's own UNet + torch.autograd produced on CPU fp32 (tests/golden/sd15_train_bs4.pt, oracle/make_golden_train_sd15.py).
+    Here the backward attention sees Nq 4096 x Nk 12 288 at D = 40 — the regime round 2 never compared with anything.
+    Bars: loss 2e-3; every gradient 1e-2 (L2 norm, the 512-entry index sample, and the full tensor for the 9 stored ones)."""
+    import os
+    from storygen_amd.arch import build_arch
+    from storygen_amd.synth import synthetic_state_dict, synthetic_train_batch
+    from storygen_amd.train import UNetTrainer
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sd15_train_bs4.pt")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated")
+    gold = torch.load(path, weights_only=False)
+    arch = build_arch(gold["config"])
+    sd = synthetic_state_dict(arch, gold["seed"])
+    B, hw = gold["batch"], gold["hw"]
+    batch = synthetic_train_batch(B, hw, arch.config["cross_attention_dim"], gold["seed"])
+    tr = UNetTrainer(arch, sd, gpu, B, hw, hw, n_ref=3)
+    loss, grads = tr.train_step_graph(batch, tuple(gold["use_refs"]))
+    torch.cuda.synchronize()
+    print(f"config 4 size: loss {float(loss):.6f} vs reference {gold['loss']:.6f}; gradient scale {tr.last_grad_scale:g}")
+    assert abs(float(loss) - gold["loss"]) <= 2e-3 * abs(gold["loss"])
+    assert set(grads) == set(gold["grads"])
+    errs, nfull = {}, 0
+    for k, e in gold["grads"].items():
+        g = grads[k].float().cpu()
+        assert tuple(g.shape) == tuple(e["shape"]) and torch.isfinite(g).all(), k
+        errs[k] = max(abs(float(g.double().norm()) - e["l2"]) / e["l2"], rel(g.flatten()[e["idx"]], e["values"]))
+        if "full" in e:
+            errs[k] = max(errs[k], rel(g, e["full"]))
+            nfull += 1
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:4]
+    print("worst gradients:", [(k.replace("transformer_blocks.0.", ""), f"{v:.2e}") for k, v in worst], f"({nfull} compared in full)")
+    assert nfull >= 8 and max(errs.values()) < 1e-2

@@ -116,6 +116,58 @@ def test_tile_waves_hint_is_validated(gpu):
         ops.gemm(a, w, out, tile=(128, 128, 2))
 
 
+@pytest.mark.parametrize("M,C,split", [(4096, 320, 1), (1000, 640, 1), (768, 1280, 4), (192, 1280, 0), (64, 64, 1)])
+def test_gemm_layernorm_fold(gpu, M, C, split):
+    """LayerNorm folded into the consuming GEMM (sg_gemm_desc.ln_*; model/attention.py:250,268,283,298): a producer GEMM writes the
+    fp32 stream x, its fp16 copy and the per-token (sum, M2) partials per 64-channel block (fused epilogue or split-K reduce); the
+    consumers run on the raw copy with gamma-scaled weights and normalise in their epilogues — rows-are-tokens (q | k), the
+    transposed V^T product (columns are tokens) and GEGLU.  Reference: torch LayerNorm -> Linear in fp32 on the fp32 stream.
+    The stream carries a large common offset (|mean| = 3 sigma) so a cancellation in the fold would show."""
+    from storygen_amd import ops
+    from storygen_amd.repack import fold_layernorm, interleave_geglu
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=gpu)
+    a0, w0 = rnd((M, C), gpu, 1.0, 1), rnd((C, C), gpu, C ** -0.5, 2)
+    res = rnd((M, C), gpu, 1.0, 3, torch.float32) + 3.0
+    x = torch.empty(M, C, dtype=torch.float32, device=gpu)
+    x16 = torch.empty(M, C, dtype=torch.float16, device=gpu)
+    P = C // 64
+    st = torch.full((M, (P + 1) & ~1, 2), float("nan"), dtype=torch.float32, device=gpu)      # padded to an even number of blocks
+    ops.gemm(a0, w0, x, bias=rnd((C,), gpu, 1.0, 4), res1=res, out2=x16, ln_out=st, split_k=split, workspace=ws)
+    blocks = x.view(M, P, 64).double()
+    check(st[:, :P, 0], blocks.sum(-1), "block sums", l2=1e-6, mx=1e-4)
+    check(st[:, :P, 1], ((blocks - blocks.mean(-1, keepdim=True)) ** 2).sum(-1), "block M2", l2=1e-5, mx=1e-3)
+    st[:, P:] = 0.0                                                                          # the padding block is loaded, never used
+    gamma, beta = rnd((C,), gpu, 0.3, 5) + 1.0, rnd((C,), gpu, 0.3, 6)
+    ln = F.layer_norm(x, (C,), gamma.float(), beta.float(), 1e-5)
+    # rows are tokens: a q | k style projection with a bias
+    wq, bq = rnd((2 * C, C), gpu, C ** -0.5, 7), rnd((2 * C,), gpu, 1.0, 8)
+    wf, c, d = fold_layernorm(wq, bq, gamma, beta)
+    out = torch.full((M, 2 * C), float("nan"), dtype=torch.float16, device=gpu)
+    ops.gemm(x16, wf, out, ln=(1, st, c, d, 1e-5))
+    check(out, ln @ wq.float().t() + bq.float(), "LayerNorm fold, rows = tokens", l2=1.5e-3, mx=2e-2)
+    # columns are tokens: V^T = W_v LN(x)^T
+    wv = rnd((C, C), gpu, C ** -0.5, 9)
+    wvf, cv, dv = fold_layernorm(wv, None, gamma, beta)
+    Mp = (M + 7) & ~7
+    vt = torch.full((C, Mp), float("nan"), dtype=torch.float16, device=gpu)[:, :M]
+    ops.gemm(wvf, x16, vt, ln=(2, st, cv, dv, 1e-5))
+    check(vt, wv.float() @ ln.t(), "LayerNorm fold, columns = tokens", l2=1.5e-3, mx=2e-2)
+    # GEGLU on the folded LayerNorm
+    wg, bg = rnd((8 * C, C), gpu, C ** -0.5, 10), rnd((8 * C,), gpu, 1.0, 11)
+    wi, bi = interleave_geglu(wg, bg)
+    wif, ci, di = fold_layernorm(wi, bi, gamma, beta)
+    og = torch.full((M, 4 * C), float("nan"), dtype=torch.float16, device=gpu)
+    ops.gemm(x16, wif, og, epilogue=ops.EPI_GEGLU, ln=(1, st, ci, di, 1e-5))
+    val, gate = (ln @ wg.float().t() + bg.float()).chunk(2, dim=-1)
+    check(og, val * F.gelu(gate), "LayerNorm fold + GEGLU", l2=2e-3, mx=3e-2)
+    # both consumers of one LayerNorm in one launch
+    o1, o2 = torch.empty_like(out), torch.empty_like(vt)
+    ops.gemm_pair(((x16, wf, o1), dict(ln=(1, st, c, d, 1e-5))), ((wvf, x16, o2), dict(ln=(2, st, cv, dv, 1e-5))))
+    assert torch.equal(o1, out) and torch.equal(o2, vt)
+    with pytest.raises(RuntimeError, match="split"):
+        ops.gemm(x16, wf, out, ln=(1, st, c, d, 1e-5), split_k=2, workspace=ws)
+
+
 def test_gemm_strided_views(gpu):
     """lda/ldc/ldr larger than the logical widths: operands are column slices of wider buffers."""
     from storygen_amd import ops

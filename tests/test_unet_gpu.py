@@ -356,58 +356,70 @@ def test_two_samples_per_gpu_vs_oracle_32x32(gpu, sd15, stage):
     assert max(errs + per_sample) <= TOL_LATENT
 
 
-def test_config5_shape_runs_96x96_r5(gpu, sd15):
-    """BASELINE config 5's shape (768x768 = 96x96 latent, 5 prior frames; 46 080 context tokens at the first level) through the
-    fp16 path: block-index feature keying lets the loop run where the reference's height heuristic cannot.  No CPU
-    oracle at this size (minutes per pass): the check is that a deduplicated step and an as-written step agree and stay finite."""
+def _config5_golden():
+    path = os.path.join(GOLDEN, "sd15_96_r5.pt")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated (oracle/make_golden_config5.py)")
+    gold = torch.load(path, weights_only=False)
+    assert gold["hw"] == 96 and gold["n_ref"] == 5 and len(gold["latents"]) >= 2
+    return gold
+
+
+def test_config5_fp16_path_vs_oracle_golden_96x96_r5(gpu, sd15):
+    """BASELINE config 5's shape (768x768 = 96x96 latent, 5 prior frames; 46 080 context tokens at the first level) through the fp16
+    path, against the latents of the oracle's loop at that shape (tests/golden/sd15_96_r5.pt: oracle.storygen_oracle with
+    block-index feature keys — the reference's own height heuristic cannot run 96x96; the restatement is pinned to the
+    reference at 64x64).  Default schedule (graph + dedup + overlap); bar: the north-star's 1e-3 after every stored step, and the
+    as-written schedule (no dedup) agrees."""
     from storygen_amd.engine import EngineWeights
     from storygen_amd.sampler import StoryGenSampler
     from storygen_amd.synth import synthetic_inputs
+    gold = _config5_golden()
     arch, sd = sd15
-    inputs = synthetic_inputs(1, 5, 96, 96, 21, arch.config["cross_attention_dim"])
+    assert gold["seed_weights"] == 0
+    inputs = synthetic_inputs(1, 5, 96, 96, gold["seed_inputs"], arch.config["cross_attention_dim"])
     wts = EngineWeights(arch, sd, gpu)
-    outs = []
-    for dedup in (True, False):
-        smp = StoryGenSampler(arch, None, gpu, 1, 96, 96, 5, use_graph=False, dedup=dedup, weights=wts)
-        smp.prepare(inputs, 50, "multi-image-condition", 7.5, 3.5)
-        outs.append(smp.run(max_steps=1).clone().cpu())
-        del smp
-        torch.cuda.empty_cache()
-    assert torch.isfinite(outs[0]).all() and torch.isfinite(outs[1]).all()
-    err = rel_l2(outs[0], outs[1])
-    print(f"96x96 R=5: dedup vs as-written rel-L2 {err:.2e}")
-    assert err <= TOL_LATENT
+    n = len(gold["latents"])
+    smp = StoryGenSampler(arch, None, gpu, 1, 96, 96, 5, weights=wts)
+    smp.prepare(inputs, gold["n_steps"], gold["stage"], *gold["guidance"])
+    trace = []
+    smp.run(max_steps=n, trace=trace)
+    torch.cuda.synchronize()
+    errs = [rel_l2(a.cpu(), b) for a, b in zip(trace, gold["latents"])]
+    print(f"config 5 shape, fp16 path vs oracle, steps 1..{n}:", [f"{e:.2e}" for e in errs])
+    assert len(errs) == n and max(errs) <= TOL_LATENT, errs
+    first = trace[0].clone().cpu()
+    del smp
+    torch.cuda.empty_cache()
+    smp = StoryGenSampler(arch, None, gpu, 1, 96, 96, 5, use_graph=False, dedup=False, weights=wts)
+    smp.prepare(inputs, gold["n_steps"], gold["stage"], *gold["guidance"])
+    aw = smp.run(max_steps=1).clone().cpu()
+    assert rel_l2(aw, gold["latents"][0]) <= TOL_LATENT and rel_l2(aw, first) <= TOL_LATENT
 
 
-def test_config5_fp8_attention_vs_fp16_96x96_r5(gpu, sd15):
+def test_config5_fp8_attention_vs_oracle_golden_96x96_r5(gpu, sd15):
     """BASELINE config 5 as named: 768x768 (96x96 latent), 5 prior frames, the head-dim-40 image / self attention on the fp8
-    (e4m3) MFMA path.  There is no fp8 reference (the reference has no fp8 path at all): parity is stated against this
-    framework's own fp16 path — itself pinned to the reference at 64x64 — on the same inputs.  Bound: e4m3 rounding of Q, K, V, P
-    (3 mantissa bits) moves the attention outputs by 3-6e-2 (tests/test_kernels_gpu.py::test_attention_fp8_d40), the predicted
-    noise of a whole UNet pass by <= 5e-2 (measured 1.4e-2) and, through the DDIM coefficients of the 50-step schedule, the
-    latents by <= 1e-2 after two steps (measured 4.0e-3 / 5.2e-3 after steps 1 / 2: the deviation accumulates with the steps)."""
+    (e4m3) MFMA path — deviation stated AGAINST THE ORACLE at steps 1, 2 and the last stored step (10 when the golden holds ten).
+    e4m3 keeps 3 mantissa bits of Q, K, V and P: the attention outputs move by 3-6e-2 (test_attention_fp8_d40), the predicted noise
+    of a pass by ~1.4e-2, and through the DDIM coefficients the latents by a few 1e-3 per step early in the schedule.  This is
+    OUTSIDE the north-star's 1e-3 (which the fp16 path meets, test above): the fp8 path is the throughput option BASELINE config 5
+    names, with the bound asserted here — 1.5e-2 over the first ten steps — and written in DESIGN.md 2."""
     from storygen_amd.engine import EngineWeights
     from storygen_amd.sampler import StoryGenSampler
     from storygen_amd.synth import synthetic_inputs
+    gold = _config5_golden()
     arch, sd = sd15
-    inputs = synthetic_inputs(1, 5, 96, 96, 21, arch.config["cross_attention_dim"])
-    wts = EngineWeights(arch, sd, gpu)
-    outs, eps = [], []
-    for fp8 in (False, True):
-        smp = StoryGenSampler(arch, None, gpu, 1, 96, 96, 5, weights=wts, fp8_attention=fp8)
-        smp.prepare(inputs, 50, "multi-image-condition", 7.5, 3.5)
-        trace = []
-        smp.run(max_steps=2, trace=trace)
-        torch.cuda.synchronize()
-        outs.append([t.cpu() for t in trace])
-        eps.append(smp.main.eps_out.clone().cpu())
-        del smp
-        torch.cuda.empty_cache()
-    e_lat = [rel_l2(a, b) for a, b in zip(outs[1], outs[0])]
-    e_eps = rel_l2(eps[1], eps[0])
-    print(f"config 5, fp8 vs fp16 attention: latents after steps 1, 2: {[f'{e:.2e}' for e in e_lat]}; last epsilon (batch 3): {e_eps:.2e}")
-    assert all(torch.isfinite(t).all() for t in outs[1])
-    assert max(e_lat) <= 1e-2 and e_eps <= 5e-2
+    inputs = synthetic_inputs(1, 5, 96, 96, gold["seed_inputs"], arch.config["cross_attention_dim"])
+    n = len(gold["latents"])
+    smp = StoryGenSampler(arch, sd, gpu, 1, 96, 96, 5, fp8_attention=True)
+    smp.prepare(inputs, gold["n_steps"], gold["stage"], *gold["guidance"])
+    trace = []
+    smp.run(max_steps=n, trace=trace)
+    torch.cuda.synchronize()
+    errs = [rel_l2(a.cpu(), b) for a, b in zip(trace, gold["latents"])]
+    print(f"config 5, fp8 attention vs oracle, steps 1..{n}:", [f"{e:.2e}" for e in errs])
+    assert all(torch.isfinite(t).all() for t in trace)
+    assert max(errs) <= 1.5e-2, errs
 
 
 def test_bench_multi_gpu_path_over_rccl_with_one_rank(gpu):
