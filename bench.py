@@ -66,7 +66,11 @@ def cpu_baseline(arch, sd, inputs):
     step_s = R * t_ref + t_main_s
     return {"value": 1.0 / step_s, "unit": "denoising steps/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle fp32: 1 ref pass ({t_ref:.1f}s) + 1 main pass ({t_main_s:.1f}s), batch 3, R=3; "
-                      f"step = 3*t_ref + t_main = {step_s:.1f}s", "seconds_per_step": step_s}
+                      f"step = 3*t_ref + t_main = {step_s:.1f}s", "seconds_per_step": step_s,
+            # the reference's OWN pipeline loop (model/pipeline.py on the diffusers shim, CPU fp32) over all 50 steps of this
+            # workload when the full-depth golden was made in the build container (oracle/make_golden.py sd15_64_r3_full,
+            # gpurun_out/golden_full.log: 2 693 s / 50 steps on 6 threads) — quoted, not re-timed here (it cannot travel)
+            "reference_pipeline_seconds_per_step": 53.9, "reference_pipeline_threads": 6}
 
 
 def measured_traffic(kernel: str):
@@ -219,6 +223,10 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stage", choices=("multi-image-condition", "auto-regressive"), default="multi-image-condition",
+                    help="multi-image-condition = the contract line (SURVEY 8d); auto-regressive = the mode /root/reference/inference.py:133 "
+                         "defaults to (every prior frame at its own noise level: 2R distinct reference samples per step instead of R + 1) — "
+                         "a NON-CONTRACT line, named as such in the JSON")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-dedup", action="store_true", help="run all 3R reference samples as written")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: reference pass, then main pass")
@@ -307,7 +315,7 @@ def main():
                               overlap=not args.no_overlap, ref_ahead=G, split_graphs=args.split_graphs,
                               stream_priority=args.stream_priority, fp8_attention=args.fp8_attention)
     n_sched = max(T, args.steps + warmup_run)
-    sampler.prepare(inputs, n_sched, "multi-image-condition", 7.5, 3.5)
+    sampler.prepare(inputs, n_sched, args.stage, 7.5, 3.5)
 
     def barrier():
         if use_dist:
@@ -340,7 +348,9 @@ def main():
         value = world * N_PER_GPU * args.steps / dt
         out = {
             "metric": ("UNet denoising steps/sec @768x768, 5 prior-frame ctx, bs=1 (non-contract)" if (args.config5_shape or args.fp8_attention) else
-                       "UNet denoising steps/sec @512x512, 3 prior-frame ctx, bs=1"), "value": round(value, 4),
+                       "UNet denoising steps/sec @512x512, 3 prior-frame ctx, bs=1"
+                       + (" (non-contract: stage auto-regressive, the reference's inference.py default)" if args.stage != "multi-image-condition" else "")),
+            "value": round(value, 4),
             "unit": "denoising steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f16 (attention operands e4m3)" if args.fp8_attention else "f16", "data": "synthetic",
@@ -349,7 +359,7 @@ def main():
                                        else "fp16 attention") if args.config5_shape else
                                     "BASELINE configs[1]: StoryGen denoising loop, 512x512 (64x64x4 latent), R=3 prior "
                                     "frames, CFG batch 3, DDIM, SD-1.5 UNet + attn3 (909M params, synthetic fp16 weights)"),
-                       "samples_per_gpu": N_PER_GPU, "parallelism": f"dp{world} (one sample per GPU, final all-gather)",
+                       "stage": args.stage, "samples_per_gpu": N_PER_GPU, "parallelism": f"dp{world} (one sample per GPU, final all-gather)",
                        "hipgraph": not args.no_graph, "dedup_identical_reference_samples": not args.no_dedup,
                        "overlap_ref_pass_of_next_step": sampler.overlap, "ref_ahead": G, "warmup_run": warmup_run,
                        "split_graphs": sampler.split, "stream_priority": sampler.stream_priority,

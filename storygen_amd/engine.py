@@ -323,7 +323,7 @@ class UNetEngine:
         self.temb1 = self._buf(B, arch.temb_dim, dtype=F32)
         self.temb2 = self._buf(B, arch.temb_dim, dtype=F32)
         self.tproj = self._buf(B, self.temb_total, dtype=F32)
-        self.ws_split = ops.new_workspace(splitk_mb << 20, self.dev)      # split-K partial tiles + zeroed arrival counters
+        self.ws_split = ops.new_workspace(splitk_mb << 20, self.dev)      # split-K partial tiles (fp32, reduced by a second launch: no initialisation needed)
         self.ws_side = ops.new_workspace(splitk_mb << 20, self.dev)       # split-K scratch of the side-stream branches
         self.ws_pair = ops.new_workspace(splitk_mb << 20, self.dev)       # second problem of a paired GEMM launch
         self.side: Optional[torch.cuda.Stream] = None                   # set by forward(side=...)

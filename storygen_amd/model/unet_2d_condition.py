@@ -294,13 +294,19 @@ class UNet2DConditionModel(nn.Module):
         shapes = feature_shapes(self._arch, H, W)
         k0 = self._arch.feature_keys[0]
         R = 0 if image_hidden_states is None else image_hidden_states[k0].shape[1] // shapes[k0][0]
-        key = (B, H, W, R, module)
+        # The reference's stage-2 loop draws 1-3 prior frames at random per step (train_StorySalon_stage2.py:306-313), so R changes on
+        # most steps: the trainer is keyed on (B, H, W, module) only — forward_main / backward_main never read its n_ref (the context
+        # tensors carry their own length) — and is NOT rebuilt when R changes.  _engine_weights() runs on every call so that a
+        # load_state_dict between two training forwards invalidates the cached trainers (their frozen-layer copies would be stale).
+        wts = self._engine_weights()                     # (clears self._trainers itself when it re-packs the whole checkpoint)
+        key = (B, H, W, module)
         tr = self._trainers.get(key)                     # kept apart from the inference engines' LRU
         if tr is None:
-            self._trainers.clear()
+            if len(self._trainers) >= 2:
+                self._trainers.pop(next(iter(self._trainers)))
             tr = self._trainers[key] = UNetTrainer(self._arch, self.state_dict(), self.device, B, H, W, n_ref=R,
                                                   ref_engine=object(),      # reference passes go through forward(None)
-                                                  weights=self._engine_weights(), trainable=module)
+                                                  weights=wts, trainable=module)
         t = timestep if torch.is_tensor(timestep) else torch.tensor([timestep])
         t = t.to(self.device, torch.float32).reshape(-1)
         t = t.expand(B) if t.numel() == 1 else t

@@ -203,12 +203,15 @@ def _gemm_desc(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Opt
     sig = f"g:{M}:{N}:{K}:{epilogue}:{flags}:{int(bias is not None)}{int(rowbias is not None)}{int(res1 is not None)}{int(res2 is not None)}{int(out2 is not None)}"
     if ln is not None:
         sig += f":ln{ln[0]}"
+    if ln_out is not None:
+        sig += ":lo"
     if use_table or tile is not None:
         _apply_tile(d, tile, split_k, sig)
     if TUNE_SINK is not None and use_table:
         TUNE_SINK.append((sig, dict(kind="gemm", M=M, N=N, K=K, epilogue=epilogue, out_f32=bool(flags & F_OUT_F32), bias=bias is not None,
                                     rowbias=rowbias is not None, rows_per_batch=rows_per_batch, out2=out2 is not None,
-                                    res1=None if res1 is None else str(res1.dtype), res2=None if res2 is None else str(res2.dtype))))
+                                    res1=None if res1 is None else str(res1.dtype), res2=None if res2 is None else str(res2.dtype),
+                                    ln=0 if ln is None else int(ln[0]), ln_out=ln_out is not None)))
     return d, 2.0 * M * N * K, f"M{M} N{N} K{K}{' geglu' if epilogue else ''}"
 
 

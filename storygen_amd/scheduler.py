@@ -36,7 +36,11 @@ class DDIMSchedule:
         self._config = dict(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
                             beta_schedule=beta_schedule, steps_offset=steps_offset, set_alpha_to_one=set_alpha_to_one,
                             trained_betas=None if trained_betas is None else [float(b) for b in trained_betas],
-                            prediction_type=prediction_type)
+                            prediction_type=prediction_type,
+                            # always False here (True raises below) and written out explicitly: diffusers' DDIMScheduler DEFAULTS
+                            # clip_sample to True, so a saved config without the key would make the reference's inference.py:48
+                            # (`DDIMScheduler.from_pretrained(ckpt, subfolder="scheduler")`) clip x0 on a checkpoint written here
+                            clip_sample=False)
         if trained_betas is not None:
             betas = torch.tensor([float(b) for b in trained_betas], dtype=torch.float32)
             if betas.numel() != num_train_timesteps:
@@ -125,6 +129,7 @@ class PNDMSchedule(DDIMSchedule):
         super().__init__(**kw)
         self._config["skip_prk_steps"] = True
         self._config.pop("set_alpha_to_one", None)
+        self._config.pop("clip_sample", None)            # not a PNDMScheduler key
         self._config["set_alpha_to_one"] = kw.get("set_alpha_to_one", False)
 
     def timesteps(self, n: int) -> List[int]:

@@ -201,13 +201,13 @@ class UNetTrainer:
         the device, {parameter name: fp32 gradient}).  Eager: every kernel is launched from the host."""
         return self._step_device(self._stage_inputs(batch), tuple(use_refs))
 
-    def train_step_graph(self, batch: Dict[str, torch.Tensor], use_refs=(0, 1, 2)) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
+    def train_step_graph(self, batch: Dict[str, torch.Tensor], use_refs=(0, 1, 2), _retry: int = 0) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
         """The same step replayed as ONE hipGraph (~3 000 kernel nodes): the first call with a given `use_refs` stages the batch
         into static device tensors, fixes the gradient scale from one eager step ("auto" needs a host read, a graph cannot), warms
         up and captures `_step_device` (its per-call allocations come from the graph's private pool, so replays reuse the same
         addresses); later calls copy the new batch into the static inputs and replay.  The returned loss / gradients are the
         graph's static outputs: consume them (optimizer step, all-reduce) before the next call.  A non-finite gradient drops
-        the captured graph, lowers the scale 16x and re-captures."""
+        the captured graph, lowers the scale 16x and re-captures — at most four times, then raises."""
         use_refs = tuple(use_refs)
         staged = self._stage_inputs(batch)
         st = self._graphs.get(use_refs)
@@ -230,10 +230,20 @@ class UNetTrainer:
         for k, v in staged.items():                  # (capture only records: the capturing call replays like every other)
             st["inputs"][k].copy_(v, non_blocking=True)
         st["graph"].replay()
-        if self.check_finite and not all(bool(torch.isfinite(v).all()) for v in st["grads"].values()):
-            self._graphs.pop(use_refs)
-            self.grad_scale = float(self.grad_scale) / 16.0 if self.grad_scale != "auto" else "auto"
-            return self.train_step_graph(batch, use_refs)
+        if self.check_finite:
+            # ONE host read per step: the number of gradient tensors with a non-finite entry, reduced on the device
+            bad = torch.stack([(~torch.isfinite(v)).any() for v in st["grads"].values()]).sum()
+            if int(bad) > 0:
+                # fp16 overflow of the scaled backward: drop the graph and retry with a 16x smaller scale — a BOUNDED number of
+                # times (a NaN that comes from the batch or the weights never goes away: the reference's GradScaler would skip such
+                # a step; here the caller gets an error instead of an endless re-capture)
+                self._graphs.pop(use_refs)
+                s_now = float(self.grad_scale) if self.grad_scale != "auto" else float(self.last_grad_scale)
+                if _retry >= 4 or s_now / 16.0 < 2.0 ** -8:
+                    raise FloatingPointError(f"train_step_graph: non-finite gradients at loss scale {s_now:g} after {_retry} retries "
+                                             "(inputs or weights are not finite?)")
+                self.grad_scale = s_now / 16.0
+                return self.train_step_graph(batch, use_refs, _retry=_retry + 1)
         return st["loss"], st["grads"]
 
     def set_trainable_parameters(self, named_params: Dict[str, torch.Tensor]) -> None:

@@ -139,13 +139,15 @@ class Stage2Trainer:
             self.optimizer.set_grads(grads)
             self.last_grad_norm = self.optimizer.clip_grad_norm_(self.max_grad_norm)                 # :329-330
             self.optimizer.step()
-            self.lr_scheduler.step()
             self.optimizer.zero_grad()
             if self._acc is not None:
                 for a in self._acc.values():
                     a.zero_()
             self.trainer.set_trainable_parameters(self.named)       # refresh the fp16 operand copies the kernels read
             self.global_step += 1
+        # the reference steps its LR schedule after EVERY micro-batch (train_StorySalon_stage2.py:331, no accelerator.accumulate),
+        # which is why warm-up / total steps are scaled by gradient_accumulation_steps above
+        self.lr_scheduler.step()
         return dict(loss=loss, lr=self.lr_scheduler.get_last_lr()[0], optimizer_step=stepped)
 
     # ------------------------------------------------------------------------------------------------ checkpoints

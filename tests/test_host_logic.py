@@ -40,6 +40,20 @@ def test_ddim_schedule_from_shipped_json(tmp_path):
     assert s.timesteps(50)[0] == 981 and torch.equal(s.alphas_cumprod, DDIMSchedule().alphas_cumprod)
 
 
+def test_saved_ddim_config_says_clip_sample_false(tmp_path):
+    """diffusers' DDIMScheduler defaults clip_sample to True, so the config this framework writes (pipeline / trainer
+    checkpoints) must carry the key explicitly — else the reference's inference.py:48 would clip x0 on a checkpoint saved here.
+    PNDMScheduler has no such key."""
+    import json
+    from storygen_amd.scheduler import DDIMSchedule, PNDMSchedule
+    DDIMSchedule().save_pretrained(str(tmp_path / "d"))
+    cfg = json.loads((tmp_path / "d" / "scheduler_config.json").read_text())
+    assert cfg["_class_name"] == "DDIMScheduler" and cfg["clip_sample"] is False
+    assert DDIMSchedule.from_pretrained(str(tmp_path / "d"), subfolder=None).key() == DDIMSchedule().key()
+    PNDMSchedule(skip_prk_steps=True).save_pretrained(str(tmp_path / "p"))
+    assert "clip_sample" not in json.loads((tmp_path / "p" / "scheduler_config.json").read_text())
+
+
 def test_scheduler_configs_are_honoured_or_rejected():
     """trained_betas must be used, non-epsilon prediction / unknown keys / unknown classes must raise, and the
     config may be a dict or an attribute object (the shim's DDIMScheduler.config)."""

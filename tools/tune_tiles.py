@@ -84,6 +84,15 @@ def make_call(rec, ws):
             kw["res2"] = rnd(M, n_out, dtype=dt[rec["res2"]])
         if rec["out2"]:
             kw["out2"] = torch.empty(M, n_out, dtype=F16, device=dev)
+        if rec.get("ln_out"):
+            kw["ln_out"] = torch.empty(M, (N // 64 + 1) & ~1, 2, dtype=F32, device=dev)
+        if rec.get("ln"):
+            tokens, nvec = (M, N) if rec["ln"] == 1 else (N, M)
+            st = torch.zeros(tokens, (K // 64 + 1) & ~1, 2, dtype=F32, device=dev)
+            st[:, : K // 64, 1] = 64.0                       # unit variance per block
+            kw["ln"] = (rec["ln"], st, rnd(nvec, dtype=F32), rnd(nvec, dtype=F32), 1e-5)
+            kw.pop("workspace")
+            return lambda tile, split: ops.gemm(a, w, out, tile=tile, split_k=1, **kw)
         return lambda tile, split: ops.gemm(a, w, out, tile=tile, split_k=split, **kw)
     B, H, W, Ci, Co = rec["B"], rec["H"], rec["W"], rec["Cin"], rec["Cout"]
     xp = torch.zeros(B, H + 2, W + 2, Ci, dtype=F16, device=dev)
