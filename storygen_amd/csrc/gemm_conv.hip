@@ -13,11 +13,16 @@
 //     the ds_read_b128 fragment reads.  LDS-DMA writes lane l of a wave to (wave-uniform base + 16 l), so the swizzle is
 //     applied on the SOURCE side (the lane that owns slot s of row r fetches logical chunk s ^ ((r>>1)&7)) and again on the reads.
 //   * the accumulators are computed TRANSPOSED (the weight fragment is the MFMA's A operand, the activation fragment its B
-//     operand): a lane then holds, for ONE output row, 4 consecutive output columns per register quad; one v_permlane32_swap per
-//     register pair turns that into 8 consecutive columns per lane, so bias / residual loads and the output stores are direct
-//     16-byte accesses from registers — no LDS staging, no barrier after the mainloop (round 3; the LDS-staged, banded epilogue it
-//     replaces cost 9-17 k cycles per workgroup, profiles/r02d_mainloop_anatomy.txt).  The residual of the tile is requested
-//     during the LAST K slab, so its HBM latency runs under that slab's MFMAs.
+//     operand): every register quad of a lane is then 4 consecutive output columns of ONE row = one ds_write_b128 into a row-major
+//     fp32 image.  Each wave transposes its own 64x64 sub-tile through its own 17 KB of LDS — ONE workgroup barrier after the
+//     mainloop (the ring must be dead), none between the waves — and reads it back as row quads, so that every global access of
+//     the epilogue (bias, fp32 residual, fp32 / fp16 outputs) is 4 rows x 256 contiguous bytes per wave instruction.  All loads of
+//     an epilogue term are issued together (clamped addresses, no predicates): one memory round trip per term; the fp32 residual and
+//     the bias are requested during the LAST K slab, so their HBM latency runs under that slab's MFMAs (round 3; replaces the
+//     banded, LDS-staged epilogue with 2 barriers and one residual round trip per 32-row band).
+//   * LayerNorm folded into the consuming GEMM (round 3; sg_gemm_desc.ln_*): producers also emit the fp16 copy of their output and
+//     per-token (sum, M2) partials per 64-column block; consumers run on the raw copy with gamma-scaled weights and their epilogue
+//     applies rstd (acc - mean c) + d — rows-are-tokens, columns-are-tokens (the transposed V^T product) and GEGLU forms.
 //   * generic kernel (fallback): register-staged double buffer with zero-fill predicates, for K % 64 != 0 or an
 //     unpadded convolution input.
 //   * block ids are remapped so that consecutive tiles (same operand panel) run on the same XCD / L2; index arithmetic of the

@@ -386,9 +386,11 @@ def allreduce_gradients(grads: Dict[str, torch.Tensor], average: bool = True) ->
     (or average) the attn3 gradients over the ranks with ONE all-reduce of one flat fp32 bucket — 80 tensors, 49.6 M
     parameters = 198 MB for SD-1.5: on xGMI's point-to-point ring a single large collective is the per-link-bandwidth
     optimum, and there is nothing to overlap it with (the gradients exist only after the backward walk has reached the
-    first transformer block).  In place; identity when torch.distributed is not initialised."""
+    first transformer block).  In place; identity when torch.distributed is not initialised.  With an initialised group of ONE rank
+    the collective still runs (a no-op reduction over RCCL): that is how the single-GPU box exercises this exact code path
+    (tests/test_optim_gpu.py::test_gradient_allreduce_over_rccl_with_one_rank)."""
     import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return grads
     names = sorted(grads)
     flat = torch.cat([grads[n].reshape(-1).to(torch.float32) for n in names])

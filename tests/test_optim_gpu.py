@@ -325,3 +325,23 @@ def test_trained_weights_reach_the_inference_engine(gpu):
     assert unet._engine_weights() is wts                               # refreshed in place, not rebuilt
     changed = [n for n in unet._weights_tag if unet._weights_tag[n] != tag0[n]]
     assert set(changed) == set(named)
+
+
+def test_gradient_allreduce_over_rccl_with_one_rank(gpu):
+    """The data-parallel gradient exchange of the training loop (storygen_amd.train.allreduce_gradients: ONE flat fp32 bucket, one
+    RCCL all-reduce, average — the DDP of train_StorySalon_stage2.py:222) through the real `nccl` (= RCCL) backend with the one GPU
+    this box has: a world of one rank still builds the bucket, calls the collective and scatters the result back."""
+    import torch.distributed as dist
+    from storygen_amd.train import allreduce_gradients
+    assert not dist.is_initialized()
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29571", rank=0, world_size=1, device_id=torch.device(gpu))
+    try:
+        g = torch.Generator().manual_seed(5)
+        grads = {f"blk{i}.attn3.to_q.weight": torch.randn(320 * (i + 1), 320, generator=g).to(gpu) for i in range(3)}
+        grads["blk0.attn3.to_out.0.bias"] = torch.randn(320, generator=g).to(gpu)
+        want = {k: v.clone() for k, v in grads.items()}
+        out = allreduce_gradients(grads)
+        torch.cuda.synchronize()
+        assert out is grads and all(torch.equal(grads[k], want[k]) for k in want)          # mean over one rank = identity, in place
+    finally:
+        dist.destroy_process_group()

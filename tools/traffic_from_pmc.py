@@ -35,6 +35,19 @@ def load(path, counter):
     return tot, n
 
 
+def by_grid(path, counter):
+    """Counter totals and launch counts per (kernel name, grid size): the grid identifies the shape class of a launch."""
+    tot, n = collections.Counter(), collections.Counter()
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            key = (r["Kernel_Name"].split("(")[0][-60:], r.get("Grid_Size", "?"))
+            tot[key] += float(r["Counter_Value"])
+            n[key] += 1
+    return tot, n
+
+
 def main():
     fpath, wpath, note = sys.argv[1], sys.argv[2], (sys.argv[3] if len(sys.argv) > 3 else "")
     ft, fn = load(fpath, "FETCH_SIZE")
@@ -49,6 +62,13 @@ def main():
         fetch, write = ft[g] / fn[g] * 1024.0, wt[g] / wn[g] * 1024.0
         out["kernels"][g] = {"launches_fetch_pass": fn[g], "launches_write_pass": wn[g], "fetch_size_bytes_raw": round(fetch),
                              "write_size_bytes": round(write), "hbm_bytes_per_launch": round(2 * fetch + write)}
+    # the ten (kernel, grid) classes that move the most bytes over the run: where a traffic reduction would have to come from
+    gf, gn_ = by_grid(fpath, "FETCH_SIZE")
+    gw, _ = by_grid(wpath, "WRITE_SIZE")
+    rows = sorted(((2 * gf[k] + gw.get(k, 0.0)) * 1024.0, k) for k in gf)[::-1][:10]
+    out["top_traffic_classes"] = [{"kernel": k[0], "grid": k[1], "launches": gn_[k], "hbm_mbytes_per_launch": round(b / gn_[k] / 1e6, 2),
+                                   "hbm_gbytes_total": round(b / 1e9, 3)} for b, k in rows]
+    out["total_hbm_gbytes_all_kernels"] = round(sum((2 * gf[k] + gw.get(k, 0.0)) * 1024.0 for k in gf) / 1e9, 3)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     with open(os.path.join(root, "profiles", "traffic.json"), "w") as f:
         json.dump(out, f, indent=1)

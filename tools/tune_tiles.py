@@ -123,8 +123,11 @@ def main():
         call = make_call(e["rec"], ws)
         base = timeit(lambda: call(None, 0))
         best, best_cfg = base, None
+        # split-K: the library's choice (0), none (1), and explicit counts where the K axis is long enough to matter
+        kt = (e["rec"]["K"] if e["rec"]["kind"] == "gemm" else 9 * e["rec"]["Cin"]) // 64
+        splits = (0, 1) if (kt < 8 or e["rec"].get("ln")) else tuple(s for s in (0, 1, 2, 3, 4, 6, 8) if s <= kt // 2)
         for tile in TILES:
-            for split in (0, 1):
+            for split in splits:
                 try:
                     us = timeit(lambda: call(tile, split), n=12)
                 except RuntimeError:
