@@ -42,7 +42,8 @@ def by_grid(path, counter):
         for r in csv.DictReader(f):
             if r["Counter_Name"] != counter:
                 continue
-            key = (r["Kernel_Name"].split("(")[0][-60:], r.get("Grid_Size", "?"))
+            name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+            key = (name.split("(")[0][:70], r.get("Grid_Size", "?"))
             tot[key] += float(r["Counter_Value"])
             n[key] += 1
     return tot, n
