@@ -247,6 +247,7 @@ def main():
     ap.add_argument("--fp16-block-stream", action="store_true",
                     help="A/B (changes results, never the contract line): fp16 residual stream inside the transformer blocks")
     ap.add_argument("--no-gemm-pairs", action="store_true", help="A/B: q|k + V^T, q2 + q3, k3 + v3^T as separate launches")
+    ap.add_argument("--attn-pair", action="store_true", help="A/B: text and image cross-attention of a block in one launch")
     ap.add_argument("--optimizer", choices=("none", "adamw", "adamw8bit"), default="none",
                     help="with --train-step: include the reference's clip_grad_norm_ + optimizer step (storygen_amd.training.Stage2Trainer)")
     ap.add_argument("--train-step", action="store_true",
@@ -296,6 +297,9 @@ def main():
     if args.no_gn_epilogue:
         from storygen_amd import engine as _engine
         _engine.GN_EPILOGUE_STATS = False
+    if args.attn_pair:
+        from storygen_amd import engine as _engine
+        _engine.ATTN_PAIR = True
     if args.fp16_block_stream:
         from storygen_amd import engine as _engine
         _engine.FP16_BLOCK_STREAM = True
@@ -363,7 +367,7 @@ def main():
                        "hipgraph": not args.no_graph, "dedup_identical_reference_samples": not args.no_dedup,
                        "overlap_ref_pass_of_next_step": sampler.overlap, "ref_ahead": G, "warmup_run": warmup_run,
                        "split_graphs": sampler.split, "stream_priority": sampler.stream_priority,
-                       "paired_gemm_launches": not args.no_gemm_pairs,
+                       "paired_gemm_launches": not args.no_gemm_pairs, "paired_text_image_attention": args.attn_pair,
                        "groupnorm_stats_from_epilogues": not args.no_gn_epilogue, "fp16_block_stream": args.fp16_block_stream},
             "tflop_per_step_as_written": round(step_tflop, 3),
             "final_allgather_ms": round(gather_ms, 3), "latents_gathered": int(final.shape[0]), "latents_finite": finite,

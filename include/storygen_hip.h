@@ -115,10 +115,11 @@ int    sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream);
  * with `stats` set, the fused linear epilogue also writes, for every output row tile t (T rows) and column n,
  *     stats[(t*2 + 0)*N + n] = sum over the tile's rows of C[m, n],   stats[(t*2 + 1)*N + n] = sum of C[m, n]^2
  * (final fp32 values: bias, row bias and residuals included, before any fp16 rounding; deterministic, no atomics), which
- * sg_groupnorm_nhwc_f16 accepts instead of its own statistics pass (sg_groupnorm_desc.pstats).  T is the launch's tile height:
- * sg_gemm_stats_tile_rows / sg_conv3x3_stats_tile_rows return it for a descriptor (the plan is a pure function of the descriptor),
- * or 0 when that launch cannot emit statistics (split-K, GEGLU, a tile that does not divide the image) — in which case a launch
- * with `stats` set fails with SG_EINVAL.  Size: (M / T) * 2 * N floats. */
+ * sg_groupnorm_nhwc_f16 accepts instead of its own statistics pass (sg_groupnorm_desc.pstats).  T is the launch's tile height; a
+ * split-K launch writes them from its second (reduction) pass instead, with T = 256, 128 or 64 rows (needs N % 64 == 0).
+ * sg_gemm_stats_tile_rows / sg_conv3x3_stats_tile_rows return T for a descriptor (the plan is a pure function of the descriptor),
+ * or 0 when that launch cannot emit statistics (GEGLU, a tile that does not divide the image, split-K with N % 64 != 0) — in
+ * which case a launch with `stats` set fails with SG_EINVAL.  Size: (M / T) * 2 * N floats (T >= 64). */
 int    sg_gemm_stats_tile_rows(const sg_gemm_desc* d);
 /* LayerNorm fold.  Instead of a LayerNorm launch between two GEMMs, the producer of the stream tensor x (proj_in, attn1.to_out,
  * attn2/3.to_out) also writes x's fp16 copy (C2) and, through ln_stats_out, per token and 64-channel block the sum and the M2
@@ -209,6 +210,12 @@ typedef struct sg_attn_desc {
 } sg_attn_desc;
 
 int sg_attn_fwd_f16(const sg_attn_desc* d, sg_stream_t stream);
+
+/* Two attentions with the same query geometry (B, H, Nq, D) in ONE launch: the text cross-attention (attention.py:271-276) and the
+ * image cross-attention (:285-290) of one BasicTransformerBlock read different K / V^T and write different outputs, but neither
+ * depends on the other, so their workgroups share a grid (the short text problem fills the tail of the long image one).  Results
+ * are bit-identical to two sg_attn_fwd_f16 calls.  Descriptors of different geometry are accepted and run as two launches. */
+int sg_attn_fwd_pair_f16(const sg_attn_desc* d0, const sg_attn_desc* d1, sg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU) over NHWC fp16, fp32 statistics.

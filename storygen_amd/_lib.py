@@ -148,6 +148,7 @@ SIGNATURES = {
     "sg_conv_out_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                   C.c_int32, C.c_int32, C.c_int32, C.c_void_p]),
     "sg_attn_fwd_f16": (C.c_int, [C.POINTER(AttnDesc), C.c_void_p]),
+    "sg_attn_fwd_pair_f16": (C.c_int, [C.POINTER(AttnDesc), C.POINTER(AttnDesc), C.c_void_p]),
     "sg_groupnorm_nhwc_f16": (C.c_int, [C.POINTER(GroupNormDesc), C.c_void_p]),
     "sg_groupnorm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "sg_layernorm_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p,

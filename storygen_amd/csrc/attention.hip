@@ -35,21 +35,22 @@
 using namespace sgattn;
 
 
-static int attn_fwd(const sg_attn_desc* d, float* lse2, sg_stream_t stream) {
-    SG_REQUIRE(d != nullptr, "sg_attn_fwd_f16: null descriptor");
-    SG_REQUIRE(d->q && d->k && d->vt && d->o, "sg_attn_fwd_f16: null q/k/vt/o");
-    SG_REQUIRE(d->B > 0 && d->H > 0 && d->Nq > 0 && d->Nk > 0, "sg_attn_fwd_f16: bad shape");
+// Validates a descriptor and translates it into kernel parameters.
+static int attn_params(const sg_attn_desc* d, AttnParams& p, const char* who) {
+    SG_REQUIRE(d != nullptr, "%s: null descriptor", who);
+    SG_REQUIRE(d->q && d->k && d->vt && d->o, "%s: null q/k/vt/o", who);
+    SG_REQUIRE(d->B > 0 && d->H > 0 && d->Nq > 0 && d->Nk > 0, "%s: bad shape", who);
     if (d->D != 40 && d->D != 80 && d->D != 160)
-        return sg_set_error(SG_EUNSUP, "sg_attn_fwd_f16: head dim %d not in {40, 80, 160}", d->D);
-    SG_REQUIRE(d->kv_batches >= 0 && d->kv_batches <= d->B, "sg_attn_fwd_f16: kv_batches must be in [0, B]");
-    SG_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldvt % 8 == 0 && d->ldo % 4 == 0, "sg_attn_fwd_f16: row strides");
-    SG_REQUIRE(d->bsq % 8 == 0 && d->bsk % 8 == 0 && d->bsvt % 8 == 0 && d->bso % 4 == 0, "sg_attn_fwd_f16: batch strides");
-    SG_REQUIRE(sg_aligned16(d->q) && sg_aligned16(d->k) && sg_aligned16(d->vt) && sg_aligned16(d->o), "sg_attn_fwd_f16: 16-byte alignment");
+        return sg_set_error(SG_EUNSUP, "%s: head dim %d not in {40, 80, 160}", who, d->D);
+    SG_REQUIRE(d->kv_batches >= 0 && d->kv_batches <= d->B, "%s: kv_batches must be in [0, B]", who);
+    SG_REQUIRE(d->ldq % 8 == 0 && d->ldk % 8 == 0 && d->ldvt % 8 == 0 && d->ldo % 4 == 0, "%s: row strides", who);
+    SG_REQUIRE(d->bsq % 8 == 0 && d->bsk % 8 == 0 && d->bsvt % 8 == 0 && d->bso % 4 == 0, "%s: batch strides", who);
+    SG_REQUIRE(sg_aligned16(d->q) && sg_aligned16(d->k) && sg_aligned16(d->vt) && sg_aligned16(d->o), "%s: 16-byte alignment", who);
     const int64_t hd = (int64_t)d->H * d->D;
-    SG_REQUIRE(d->ldq >= hd && d->ldk >= hd && d->ldo >= hd, "sg_attn_fwd_f16: token stride smaller than H*D");
-    SG_REQUIRE(d->ldvt >= ((d->Nk + 7) & ~7), "sg_attn_fwd_f16: ldvt must cover Nk rounded up to 8 keys");
-    SG_REQUIRE((int64_t)d->D * d->ldvt < (1ll << 31), "sg_attn_fwd_f16: VT head slab too large for 32-bit offsets");
-    AttnParams p{};
+    SG_REQUIRE(d->ldq >= hd && d->ldk >= hd && d->ldo >= hd, "%s: token stride smaller than H*D", who);
+    SG_REQUIRE(d->ldvt >= ((d->Nk + 7) & ~7), "%s: ldvt must cover Nk rounded up to 8 keys", who);
+    SG_REQUIRE((int64_t)d->D * d->ldvt < (1ll << 31), "%s: VT head slab too large for 32-bit offsets", who);
+    p = AttnParams{};
     p.q = reinterpret_cast<const f16*>(d->q); p.ldq = d->ldq; p.bsq = d->bsq;
     p.k = reinterpret_cast<const f16*>(d->k); p.ldk = d->ldk; p.bsk = d->bsk;
     p.vt = reinterpret_cast<const f16*>(d->vt); p.ldvt = d->ldvt; p.bsvt = d->bsvt;
@@ -57,6 +58,15 @@ static int attn_fwd(const sg_attn_desc* d, float* lse2, sg_stream_t stream) {
     p.B = d->B; p.H = d->H; p.Nq = d->Nq; p.Nk = d->Nk;
     p.kv_batches = d->kv_batches > 0 ? d->kv_batches : d->B;
     p.scale_log2 = d->scale * 1.44269504088896340736f;
+    return SG_OK;
+}
+
+// 4-wave workgroups with a 3-deep ring when that still gives the chip >= 2 workgroups per CU (a property of the queries only)
+static bool attn_big(const sg_attn_desc* d) { return (long)sg_cdiv(d->Nq, 128) * d->H * d->B >= 512; }
+
+static int attn_fwd(const sg_attn_desc* d, float* lse2, sg_stream_t stream) {
+    AttnParams p;
+    if (int rc = attn_params(d, p, "sg_attn_fwd_f16")) return rc;
     hipStream_t st = (hipStream_t)stream;
     if (lse2) {   // training forward (sg_attn_fwd_lse_f16): the default instantiations with the log-sum-exp rows stored
         p.lse2 = lse2;
@@ -66,9 +76,7 @@ static int attn_fwd(const sg_attn_desc* d, float* lse2, sg_stream_t stream) {
         SG_CHECK_LAUNCH("sg_attn_fwd_lse_f16");
         return SG_OK;
     }
-    // 4-wave workgroups with a 3-deep ring when that still gives the chip >= 2 workgroups per CU, else 2 waves / 2 stages
-    const long wgs4 = (long)sg_cdiv(d->Nq, 128) * d->H * d->B;
-    const bool big = wgs4 >= 512;
+    const bool big = attn_big(d);
     const SgOptions& opt = sg_options();          // development options (sg_debug_set_option), defaults in common.h
     const int sub2 = opt.attn_sub2, prio = opt.attn_prio;
     if (d->D == 40) {
@@ -101,6 +109,32 @@ static int attn_fwd(const sg_attn_desc* d, float* lse2, sg_stream_t stream) {
 }
 
 extern "C" int sg_attn_fwd_f16(const sg_attn_desc* d, sg_stream_t stream) { return attn_fwd(d, nullptr, stream); }
+
+// Two attentions over the same query geometry (B, H, Nq, D) in one launch — the text and the image cross-attention of one
+// BasicTransformerBlock.  The longer key loop is numbered first.  Pairs that the default instantiation table would not serve with
+// one kernel (development options set, different query geometry) are simply launched one after the other.
+extern "C" int sg_attn_fwd_pair_f16(const sg_attn_desc* d0, const sg_attn_desc* d1, sg_stream_t stream) {
+    AttnParams p0, p1;
+    if (int rc = attn_params(d0, p0, "sg_attn_fwd_pair_f16[0]")) return rc;
+    if (int rc = attn_params(d1, p1, "sg_attn_fwd_pair_f16[1]")) return rc;
+    const SgOptions& opt = sg_options();
+    const bool same = d0->D == d1->D && d0->B == d1->B && d0->H == d1->H && d0->Nq == d1->Nq;
+    const bool defaults = !opt.attn_sub2 && !opt.attn_prio && opt.attn_d80 == 1 && opt.attn_d160 == 3;
+    if (!same || !defaults) {
+        if (int rc = attn_fwd(d0, nullptr, stream)) return rc;
+        return attn_fwd(d1, nullptr, stream);
+    }
+    const AttnParams& a = p0.Nk >= p1.Nk ? p0 : p1;
+    const AttnParams& b = p0.Nk >= p1.Nk ? p1 : p0;
+    hipStream_t st = (hipStream_t)stream;
+    if (d0->D == 40) {
+        if (attn_big(d0)) launch_attn_pair<40, 4, 3>(a, b, st);
+        else launch_attn_pair<40, 2, 2>(a, b, st);
+    } else if (d0->D == 80) launch_attn_pair<80, 4, 3>(a, b, st);
+    else launch_attn_pair<160, 4, 3>(a, b, st);
+    SG_CHECK_LAUNCH("sg_attn_fwd_pair_f16");
+    return SG_OK;
+}
 
 extern "C" int sg_attn_fwd_lse_f16(const sg_attn_desc* d, float* lse2, sg_stream_t stream) {
     SG_REQUIRE(lse2 != nullptr, "sg_attn_fwd_lse_f16: null lse2");

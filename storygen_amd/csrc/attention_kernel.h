@@ -33,8 +33,13 @@ __device__ __forceinline__ int kswz(int row) {
     return D == 40 ? 0 : (D == 80 ? ((row >> 3) & 1) : ((row >> 2) & 3));
 }
 
-template <int D, int NW, int S, int SUB = 1, bool PRIO = false, bool LSE = false>
-__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
+// LDS of one workgroup: the S-stage ring of (K tile | VT tile) images
+template <int D, int S, int SUB>
+constexpr int attn_smem_bytes() { return S * SUB * (KVBLK * D * 2 + D * 128) + 16; }
+
+// One workgroup's work: `block` of `nblocks` (the launch's own numbering — a paired launch runs two problems in one grid).
+template <int D, int NW, int S, int SUB, bool PRIO, bool LSE>
+__device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, const int block, const int nblocks) {
     constexpr int DC = D / 8;                   // 16-byte chunks per K row
     constexpr int NDK = (D + 15) / 16;          // MFMA k-steps of S^T (contraction padded to 16)
     constexpr int DT = (D + 31) / 32;           // 32-row tiles of O^T
@@ -49,7 +54,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     static_assert(S == 2 || S == 3, "2 or 3 stages");
     static_assert(SUB == 1 || S == 2, "multi-tile stages use the 2-stage ring (plain vmcnt(0) waits)");
     static_assert((S - 1) * MAXL < 64, "vmcnt is a 6-bit counter");
-    __shared__ __attribute__((aligned(16))) char smem[S * STAGE + 16];
+    static_assert(S * STAGE + 16 == attn_smem_bytes<D, S, SUB>(), "LDS size");
 
     const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -57,7 +62,7 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     // an XCD works on ONE head across all batches at a time — with H = 8 heads, XCD k owns head k.  Its K/V working set
     // is then one head's keys for the distinct K/V batches (2 x 1.9 MB for the main pass's 12 288-key context, where
     // batches 1 and 2 share a row) instead of three different (batch, head) streams that do not fit.
-    const int work = xcd_remap(blockIdx.x, gridDim.x);
+    const int work = xcd_remap(block, nblocks);
     const int bh = work / p.nqb, qb = work - bh * p.nqb;
     const int h = bh / p.B, b = bh - h * p.B;
     const int kvb = b < p.kv_batches ? b : b - (p.B - p.kv_batches);
@@ -318,10 +323,34 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
 }
 
 template <int D, int NW, int S, int SUB = 1, bool PRIO = false, bool LSE = false>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[attn_smem_bytes<D, S, SUB>()];
+    attn_fwd_body<D, NW, S, SUB, PRIO, LSE>(p, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// Two attentions of one transformer block in one grid (text: attention.py:271-276, image: :285-290 — same queries' shape, two
+// K/V sources, two outputs): workgroups [0, na) run problem a (the long one: launched first), the rest problem b, which fills the
+// CUs that a's tail leaves idle.
+template <int D, int NW, int S>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_pair_kernel(const AttnParams a, const AttnParams b, const int na) {
+    __shared__ __attribute__((aligned(16))) char smem[attn_smem_bytes<D, S, 1>()];
+    if ((int)blockIdx.x < na) attn_fwd_body<D, NW, S, 1, false, false>(a, smem, (int)blockIdx.x, na);
+    else attn_fwd_body<D, NW, S, 1, false, false>(b, smem, (int)blockIdx.x - na, (int)gridDim.x - na);
+}
+
+template <int D, int NW, int S, int SUB = 1, bool PRIO = false, bool LSE = false>
 void launch_attn(const AttnParams& p0, hipStream_t st) {
     AttnParams p = p0;
     p.nqb = sg_cdiv(p.Nq, 32 * NW);
     hipLaunchKernelGGL((attn_fwd_kernel<D, NW, S, SUB, PRIO, LSE>), dim3(p.nqb * p.H * p.B), dim3(64 * NW), 0, st, p);
+}
+
+template <int D, int NW, int S>
+void launch_attn_pair(const AttnParams& a0, const AttnParams& b0, hipStream_t st) {
+    AttnParams a = a0, b = b0;
+    a.nqb = sg_cdiv(a.Nq, 32 * NW); b.nqb = sg_cdiv(b.Nq, 32 * NW);
+    const int na = a.nqb * a.H * a.B, nb = b.nqb * b.H * b.B;
+    hipLaunchKernelGGL((attn_fwd_pair_kernel<D, NW, S>), dim3(na + nb), dim3(64 * NW), 0, st, a, b, na);
 }
 
 

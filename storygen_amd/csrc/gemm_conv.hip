@@ -936,6 +936,85 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const MmaParams p) {
     }
 }
 
+// Split-K second pass that also emits the GroupNorm partial statistics of the finished rows (MmaParams::stats, same buffer
+// layout as epi_finish's), so that a split-K producer does not cost its consumer a statistics pass.  One workgroup = 32 RPT rows x
+// 64 columns = one partial: thread (tr = t >> 3, vc = t & 7) owns the 8-column vector vc of rows tr, tr + 32, ... (a wave reads
+// 8 rows x 256 contiguous bytes per split), two rows x two splits in flight.  The 32 thread rows are added through LDS in a fixed
+// order: deterministic, no atomics.  Host contract (check_stats / reduce_stats_rows): linear epilogue, M % (32 RPT) == 0,
+// N % 64 == 0, partials never straddle two images.
+template <int RPT>
+__global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const MmaParams p) {
+    static_assert(RPT % 2 == 0, "two rows per step");
+    __shared__ float s_acc[32][2][64];
+    const int t = threadIdx.x, vc = t & 7, tr = t >> 3;
+    const int nb = p.N >> 6;
+    const int mt = blockIdx.x / nb, nt = blockIdx.x - mt * nb;
+    const int gn = nt * 64 + vc * 8, gm0 = mt * (32 * RPT) + tr;
+    const size_t MN = (size_t)p.M * p.N;
+    const size_t hstep = (size_t)32 * p.N;
+    float s1[8], s2[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
+#pragma unroll 1
+    for (int h0 = 0; h0 < RPT; h0 += 2) {
+        float v[2][8];
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[h][j] = 0.f;
+        const float* s = p.ws + (size_t)(gm0 + 32 * h0) * p.N + gn;
+        for (int z0 = 0; z0 < p.splits; z0 += 2) {      // partial tiles added in split order (bit-identical to the plain kernel)
+            float4 a[2][2], b[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    a[u][h] = b[u][h] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (z0 + u < p.splits) {
+                        const float* src = s + (z0 + u) * MN + h * hstep;
+                        a[u][h] = *reinterpret_cast<const float4*>(src);
+                        b[u][h] = *reinterpret_cast<const float4*>(src + 4);
+                    }
+                }
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    v[h][0] += a[u][h].x; v[h][1] += a[u][h].y; v[h][2] += a[u][h].z; v[h][3] += a[u][h].w;
+                    v[h][4] += b[u][h].x; v[h][5] += b[u][h].y; v[h][6] += b[u][h].z; v[h][7] += b[u][h].w;
+                }
+        }
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            epi_linear8(p, gm0 + 32 * (h0 + h), gn, v[h]);      // bias / temb row / residuals added in place, outputs stored
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { s1[j] += v[h][j]; s2[j] = fmaf(v[h][j], v[h][j], s2[j]); }
+        }
+    }
+    *reinterpret_cast<float4*>(&s_acc[tr][0][vc * 8]) = make_float4(s1[0], s1[1], s1[2], s1[3]);
+    *reinterpret_cast<float4*>(&s_acc[tr][0][vc * 8 + 4]) = make_float4(s1[4], s1[5], s1[6], s1[7]);
+    *reinterpret_cast<float4*>(&s_acc[tr][1][vc * 8]) = make_float4(s2[0], s2[1], s2[2], s2[3]);
+    *reinterpret_cast<float4*>(&s_acc[tr][1][vc * 8 + 4]) = make_float4(s2[4], s2[5], s2[6], s2[7]);
+    __syncthreads();
+    if (t < 128) {
+        const int plane = t >> 6, ch = t & 63;
+        float acc = 0.f;
+#pragma unroll 8
+        for (int r = 0; r < 32; ++r) acc += s_acc[r][plane][ch];
+        p.stats[((size_t)mt * 2 + plane) * p.N + nt * 64 + ch] = acc;
+    }
+}
+
+// Rows per statistics partial of a split-K launch (0 = it cannot emit them): the largest of 256 / 128 / 64 that divides an image
+// and still leaves the second pass ~100 workgroups (fewer, larger partials make the consumer's merge shorter).
+int reduce_stats_rows(const MmaParams& p) {
+    if (p.mode != SG_EPI_LINEAR || p.N % 64 != 0 || p.stats_batch_rows <= 0 || p.M % p.stats_batch_rows != 0) return 0;
+    int best = 0;
+    for (int rows = 64; rows <= 256; rows *= 2)
+        if (p.stats_batch_rows % rows == 0 && (best == 0 || (long)(p.M / rows) * (p.N / 64) >= 96)) best = rows;
+    return best;
+}
+
 // ------------------------------------------------------------------------------------------------ host side
 struct Plan { int bm, bn, splits; };
 
@@ -1002,16 +1081,20 @@ thread_local unsigned long long* g_prof = nullptr;     // set by sg_debug_*_anat
 thread_local int g_query_rows = 0;                     // result of a stats query (rows per partial = the tile height), 0 = none
 thread_local bool g_stats_query = false;               // sg_*_stats_tile_rows: plan only, report eligibility instead of failing
 
-// GroupNorm statistics from the epilogue (MmaParams::stats) need whole tiles inside one image, the fused (non split-K) linear
-// epilogue, and N % 8 == 0.  A launch that was asked for them but cannot deliver fails (the caller asks sg_*_stats_tile_rows first).
+// GroupNorm statistics from the epilogue (MmaParams::stats) need whole tiles inside one image and the linear epilogue; a split-K
+// launch emits them from its second pass.  A launch that was asked for them but cannot deliver fails (the caller asks
+// sg_*_stats_tile_rows first).
 int check_stats(MmaParams& p, int bm, const char* name) {
     if (!p.stats) return SG_OK;
-    const bool ok = p.splits == 1 && p.mode == SG_EPI_LINEAR && p.stats_batch_rows > 0 && p.stats_batch_rows % bm == 0 &&
+    // fused epilogue: one partial per row tile of the launch; split-K: from the second pass (reduce_stats_rows)
+    const int rows = p.splits == 1 ? bm : reduce_stats_rows(p);
+    const bool ok = p.mode == SG_EPI_LINEAR && rows > 0 && p.stats_batch_rows > 0 && p.stats_batch_rows % rows == 0 &&
                     p.M % p.stats_batch_rows == 0;
     if (ok) return SG_OK;
     if (g_stats_query) { p.stats = nullptr; return SG_OK; }
-    return sg_set_error(SG_EINVAL, "%s: epilogue statistics need a %d-row tile that divides the %d rows of an image and no split-K "
-                        "(split %d): query sg_*_stats_tile_rows first", name, bm, p.stats_batch_rows, p.splits);
+    return sg_set_error(SG_EINVAL, "%s: epilogue statistics need the linear epilogue, a %d-row tile that divides the %d rows of an image "
+                        "and, under split-K (here %d), N %% 64 == 0: query sg_*_stats_tile_rows first", name, rows, p.stats_batch_rows,
+                        p.splits);
 }
 
 // Decomposition of one problem: tile shape, K split, tile order; fills the corresponding fields of p.  `pipe` = the LDS-DMA
@@ -1056,6 +1139,15 @@ int plan_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws, 
 
 int launch_reduce(const MmaParams& p, hipStream_t st) {
     if (p.splits <= 1) return SG_OK;
+    if (p.stats) {      // check_stats made sure of the contract
+        const int rows = reduce_stats_rows(p);
+        const dim3 grid((p.M / rows) * (p.N / 64));
+        if (rows == 256) hipLaunchKernelGGL(splitk_reduce_stats_kernel<8>, grid, dim3(256), 0, st, p);
+        else if (rows == 128) hipLaunchKernelGGL(splitk_reduce_stats_kernel<4>, grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL(splitk_reduce_stats_kernel<2>, grid, dim3(256), 0, st, p);
+        SG_CHECK_LAUNCH("splitk_reduce_stats");
+        return SG_OK;
+    }
     const long items = (long)p.M * (p.N / (p.mode == SG_EPI_GEGLU ? 16 : 8));
     const int blocks = (int)min((long)4096, (items + 255) / 256);
     hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, p);
@@ -1069,7 +1161,7 @@ int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws
     bool pipe;
     if (int rc = plan_mma<CONV>(p, force_split, hint_bm, hint_bn, ws, ws_bytes, name, pl, pipe)) return rc;
     if (g_stats_query) {
-        g_query_rows = p.stats ? pl.bm : 0;
+        g_query_rows = p.stats ? (pl.splits > 1 ? reduce_stats_rows(p) : pl.bm) : 0;
         return SG_OK;
     }
     dim3 grid(p.tiles_m * p.tiles_n * pl.splits);

@@ -272,6 +272,9 @@ __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p)
         }
     };
     load_batch();       // the first rows travel while the statistics are being reduced
+    H8 gam, bet;        // ... and so do the affine parameters (requested after the statistics they would cost a second round trip)
+    gam.u = bet.u = make_uint4(0, 0, 0, 0);
+    if (active) { gam.u = ldg16(p.gamma + c0); bet.u = ldg16(p.beta + c0); }
     if (p.ps[0]) {
         // Statistics from the producers' epilogue partials.  Entry e of group g = (channel c of the group, row tile of c's source):
         // n_e rows, S1 = sum x, S2 = sum x^2.  Two passes over the (few hundred) entries, both tree-reduced in a fixed order:
@@ -282,22 +285,37 @@ __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p)
         const int t0 = p.HW / p.ps_rows[0], t1 = p.ps[1] ? p.HW / p.ps_rows[1] : 0;
         const int tmax = t0 > t1 ? t0 : t1;
         const int nent = p.cpg * tmax;
-        auto entry = [&](int e, float& s1, float& s2, float& n) -> bool {
-            const int cl = e / tmax, tile = e - cl * tmax;
-            const int c = grp * p.cpg + cl;
-            const int src = (p.ps[1] && c >= p.ps_c0[1]) ? 1 : 0;
-            const int tiles = src ? t1 : t0;
-            if (tile >= tiles) return false;
-            const float* base = p.ps[src] + ((long)(b * tiles + tile) * 2) * p.ps_nc[src] + (c - p.ps_c0[src]);
-            s1 = base[0]; s2 = base[p.ps_nc[src]]; n = (float)p.ps_rows[src];
-            return true;
+        const int per = (nent + parts - 1) / parts;          // entries per worker thread: part, part + parts, ...
+        const bool worker = part < parts;
+        // The entries travel in chunks of GNW_CH per thread with every load of a chunk in flight at once (clamped addresses, no
+        // predicate on the loads): the prologue costs one memory round trip per chunk and pass instead of one per entry, and a
+        // thread with <= GNW_CH entries (the 64x64 level behind 256-row tiles) keeps them in registers for the second pass.
+        constexpr int GNW_CH = 8;
+        float s1[GNW_CH], s2[GNW_CH], nr[GNW_CH];
+        auto load_chunk = [&](int i0) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < GNW_CH; ++u) {
+                const int e = part + (i0 + u) * parts;
+                const bool inside = worker && e < nent;
+                const int ec = inside ? e : 0;                // entry 0 of a group always exists
+                const int cl = ec / tmax;
+                int tile = ec - cl * tmax;
+                const int c = grp * p.cpg + cl;
+                const int src = (p.ps[1] && c >= p.ps_c0[1]) ? 1 : 0;
+                const int tiles = src ? t1 : t0;
+                const bool valid = inside && tile < tiles;
+                if (tile >= tiles) tile = 0;
+                const float* base = p.ps[src] + ((long)(b * tiles + tile) * 2) * p.ps_nc[src] + (c - p.ps_c0[src]);
+                s1[u] = base[0]; s2[u] = base[p.ps_nc[src]];
+                nr[u] = valid ? (float)p.ps_rows[src] : 0.f;
+            }
         };
         float acc = 0.f;
-        if (part < parts)
-            for (int e = part; e < nent; e += parts) {
-                float s1, s2, n;
-                if (entry(e, s1, s2, n)) acc += s1;
-            }
+        for (int i0 = 0; i0 < per; i0 += GNW_CH) {
+            load_chunk(i0);
+#pragma unroll
+            for (int u = 0; u < GNW_CH; ++u) acc += nr[u] > 0.f ? s1[u] : 0.f;
+        }
         s_ps[t] = acc;
         __syncthreads();
         const float ntot = (float)p.HW * (float)p.cpg;
@@ -309,14 +327,15 @@ __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p)
         __syncthreads();
         const float mean = s_mean[grp];
         acc = 0.f;
-        if (part < parts)
-            for (int e = part; e < nent; e += parts) {
-                float s1, s2, n;
-                if (entry(e, s1, s2, n)) {
-                    const float me = s1 / n, dm = me - mean;
-                    acc += fmaxf(s2 - s1 * me, 0.f) + n * dm * dm;
+        for (int i0 = 0; i0 < per; i0 += GNW_CH) {
+            if (per > GNW_CH) load_chunk(i0);                 // else the only chunk is still in registers
+#pragma unroll
+            for (int u = 0; u < GNW_CH; ++u)
+                if (nr[u] > 0.f) {
+                    const float me = s1[u] / nr[u], dm = me - mean;
+                    acc += fmaxf(s2[u] - s1[u] * me, 0.f) + nr[u] * dm * dm;
                 }
-            }
+        }
         s_pq[t] = acc;
         __syncthreads();
         if (t < p.G) {
@@ -353,14 +372,11 @@ __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p)
     f16* yb = pw ? p.y + ((long)b * (p.HW / pw + 2) * (pw + 2)) * p.ldy : p.y + (long)b * p.HW * p.ldy;
     f16* cb = p.xcopy ? p.xcopy + (long)b * p.HW * p.ldxc : nullptr;
     float sc[8], sh[8];
-    {
-        H8 g, be; g.u = ldg16(p.gamma + c0); be.u = ldg16(p.beta + c0);
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int grp = (c0 + j) / p.cpg;
-            sc[j] = s_rstd[grp] * (float)g.h[j];
-            sh[j] = (float)be.h[j] - s_mean[grp] * sc[j];
-        }
+    for (int j = 0; j < 8; ++j) {
+        const int grp = (c0 + j) / p.cpg;
+        sc[j] = s_rstd[grp] * (float)gam.h[j];
+        sh[j] = (float)bet.h[j] - s_mean[grp] * sc[j];
     }
     while (base < p1) {
 #pragma unroll
@@ -594,14 +610,18 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GnParams p) {
     const long xb = (long)b * p.HW * p.ldx + (long)g * p.cpg;
     const bool f32 = p.x_f32;
     float v[GNF_MAXI][4];
+    f16x4 gm[GNF_MAXI], bt[GNF_MAXI];    // the affine parameters travel with the data, not after the statistics
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < GNF_MAXI; ++i) {
         const int it = t + i * 256;
         v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+        gm[i] = bt[i] = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
         if (it < items) {
             const int px = it / q, c4 = it - px * q;
             const long off = xb + (long)px * p.ldx + c4 * 4;
+            gm[i] = *reinterpret_cast<const f16x4*>(p.gamma + g * p.cpg + c4 * 4);
+            bt[i] = *reinterpret_cast<const f16x4*>(p.beta + g * p.cpg + c4 * 4);
             if (f32) {
                 const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.x) + off);
                 v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
@@ -638,11 +658,10 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GnParams p) {
         if (it < items) {
             const int px = it / q, c4 = it - px * q;
             const int ch = g * p.cpg + c4 * 4;
-            const f16x4 gm = *reinterpret_cast<const f16x4*>(p.gamma + ch), bt = *reinterpret_cast<const f16x4*>(p.beta + ch);
             f16x4 o;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                const float r = (v[i][j] - mean) * rstd * (float)gm[j] + (float)bt[j];
+                const float r = (v[i][j] - mean) * rstd * (float)gm[i][j] + (float)bt[i][j];
                 o[j] = (f16)(p.silu ? silu_f(r) : r);
             }
             long orow = px;

@@ -48,6 +48,10 @@ PAIR_GEMMS = True     # q|k + V^T, q2 + q3, k3 + v3^T as one launch each (sg_gem
 # gamma-scaled weights and normalise in their epilogues (sg_gemm_desc.ln_*).  No LayerNorm launch is left in a pass (-94 launches
 # per step).  False = the separate layernorm kernel (A/B switch).
 LN_FOLD = True
+# Text and image cross-attention of a block in one launch (sg_attn_fwd_pair_f16).  Measured on the contract workload (r3c12: 14.69 /
+# 14.70 ms paired vs 14.62 ms): the text attention already runs on the side stream beside the context K / V^T projections, and one
+# grid after them gives that overlap up — so the default stays two launches (A/B: bench.py --attn-pair).
+ATTN_PAIR = False
 LN_EPS = 1e-5         # torch.nn.LayerNorm default, as the reference constructs norm1..norm4 (model/attention.py:213-233)
 
 
@@ -291,6 +295,7 @@ class UNetEngine:
         self.gn_epilogue_stats = GN_EPILOGUE_STATS
         self._stats_buf: Dict[str, torch.Tensor] = {}
         self._stats_rows: Dict[str, int] = {}
+        self._stats_want: Dict[tuple, bool] = {}
         self._pstats: Dict[int, tuple] = {}           # data_ptr of a produced tensor -> (buffer, rows per partial, channels)
         self.text_cache: Dict[str, torch.Tensor] = {}
         self._alloc(splitk_workspace_mb)
@@ -433,7 +438,7 @@ class UNetEngine:
     def _stats_for(self, site: str, lvl: int, n_out: int, query) -> Optional[torch.Tensor]:
         """The statistics buffer a producer at `site` (output [B*hw[lvl], n_out]) should write, or None.  `query(buf)` -> rows per
         partial of exactly that launch (ops.*_stats_rows); asked once per site (the plan depends only on the shapes)."""
-        if not self.gn_epilogue_stats or not ops.groupnorm_uses_pstats(self.hw[lvl], n_out, self.groups):
+        if not self.gn_epilogue_stats or not self._stats_wanted(lvl, n_out):
             return None
         rows = self._stats_rows.get(site)
         if rows is None:
@@ -443,6 +448,17 @@ class UNetEngine:
             if rows:
                 self._stats_buf[site] = buf
         return self._stats_buf.get(site) if rows else None
+
+    def _stats_wanted(self, lvl: int, n_out: int) -> bool:
+        """Does any GroupNorm that can read a tensor of n_out channels at this level take producer statistics?  Its own width, or the
+        wider channel concats [h | skip] of the up blocks (unet_2d_blocks.py:600-601) — e.g. at 16x16 a 1280-channel GroupNorm is
+        the one-launch kernel, the 2560- and 1920-channel concats are not.  (Statistics nobody reads cost the producer a few
+        shuffles; a consumer that does not use them ignores them.)"""
+        key = (lvl, n_out)
+        if key not in self._stats_want:
+            widths = [n_out] + sorted({r.cin for r in self.arch.resnets if r.cin > n_out})
+            self._stats_want[key] = any(ops.groupnorm_uses_pstats(self.hw[lvl], c, self.groups) for c in widths)
+        return self._stats_want[key]
 
     def _publish(self, out: torch.Tensor, site: str, n_out: int):
         self._pstats[out.data_ptr()] = (self._stats_buf[site], self._stats_rows[site], n_out)
@@ -606,8 +622,13 @@ class UNetEngine:
                       ((h1r, xf.w_q3f, q3buf), dict(ln=(1, L["lnst1"], xf.c_q3, xf.d_q3, LN_EPS))))
             else:
                 _pair(((L["ln"], xf.w_q2, q2), dict(workspace=ws)), ((L["ln4"], xf.w_q3, q3buf), dict(workspace=wp)))
-            forked = self._fork()
-            if forked:
+            # text + image attention as one launch when the image attention is one fp16 launch itself (else the text attention runs
+            # beside the context projections on the side stream)
+            paired = ATTN_PAIR and self.attn3_share is not None and not (self.fp8_attention and C == heads * 40)
+            forked = False if paired else self._fork()
+            if paired:
+                pass
+            elif forked:
                 with torch.cuda.stream(self.side):
                     ops.attention(q2.view(B, hw, C), kt3, vtt3, a2v, heads, scale, nk=S)
             else:
@@ -622,7 +643,9 @@ class UNetEngine:
                 _pair(((c2d, xf.w_k3, ki), dict(workspace=ws)), ((xf.w_v3, c2d, vti), dict(workspace=wp)))   # VT[C, rows*nk]
             ki3, vti3 = ki.view(rows, nk, C), vti.view(C, rows, nk).permute(1, 0, 2)
             q3 = q3buf.view(B, hw, C)
-            if self.attn3_share is not None:      # one launch: batch b reads context row b (b < rows) or b - (B - rows)
+            if paired:
+                ops.attention_pair((q3, ki3, vti3, a3v, None), (q2.view(B, hw, C), kt3, vtt3, a2v, S), heads, scale)
+            elif self.attn3_share is not None:    # one launch: batch b reads context row b (b < rows) or b - (B - rows)
                 self._attention(q3, ki3, vti3, a3v, heads, scale)
             else:
                 for q0, n, c0 in self.attn3_groups:
@@ -704,11 +727,12 @@ class UNetEngine:
         last_xf = [a for blk in self.arch.up for a in blk.attns if a is not None][-1].prefix if harvest_only else None
         tk = dict(text_cache=text_cache)
         arch, text, skips = self.arch, self.text_in, self.skips
-        # --- time embedding :392-398, then all 22 time_emb_proj(silu(emb)) in one GEMV bundle
+        # --- time embedding :392-398, then all 22 time_emb_proj(silu(emb)) in one GEMV bundle.  emb is only ever consumed through
+        # silu (resnet.py time_emb_proj), so the second linear writes silu(emb) once instead of every wave of the bundle redoing it
         ops.timestep_embed(self.t_in, self.freqs, self.temb0, self.cfg["flip_sin_to_cos"])
         ops.linear_rows(self.temb0, self.w_t1, self.b_t1, self.temb1, act_out=True)
-        ops.linear_rows(self.temb1, self.w_t2, self.b_t2, self.temb2)
-        ops.linear_rows(self.temb2, self.w_temb, self.b_temb, self.tproj, act_in=True)
+        ops.linear_rows(self.temb1, self.w_t2, self.b_t2, self.temb2, act_out=True)
+        ops.linear_rows(self.temb2, self.w_temb, self.b_temb, self.tproj)
         # --- conv_in :411
         ops.conv_in(self.x_in, self.w_conv_in, self.b_conv_in, self._img(skips[0], 0))
         h, lvl, si = skips[0], 0, 1

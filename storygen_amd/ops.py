@@ -348,11 +348,7 @@ def conv_out(x: torch.Tensor, w_krsc: torch.Tensor, bias: torch.Tensor, out_nchw
     return out_nchw
 
 
-def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, heads: int, scale: float,
-              nk: Optional[int] = None) -> torch.Tensor:
-    """q [B,Nq,H*D], k [Bk,Nk',H*D] (token- and batch-strided views allowed), vt [Bk,H*D,Nk''] = V transposed (keys
-    contiguous; rows finite up to nk rounded up to 8), out [B,Nq,H*D].  nk = number of valid keys (default k.shape[1]).
-    Bk < B: query batch b uses K/V batch (b if b < Bk else b - (B - Bk))."""
+def _attn_fwd_desc(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, heads: int, scale: float, nk: Optional[int]):
     for n, t in (("q", q), ("k", k), ("vt", vt), ("out", out)):
         _f16(t, n)
         if t.dim() != 3 or t.stride(-1) != 1:
@@ -371,9 +367,27 @@ def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Ten
     d.B, d.H, d.Nq, d.Nk, d.D = B, heads, Nq, Nk, D
     d.kv_batches = Bk
     d.scale = scale
-    with _timed(f"attention_d{D}", 4.0 * B * heads * Nq * Nk * D, f"B{B} H{heads} Nq{Nq} Nk{Nk}"):
+    return d, 4.0 * B * heads * Nq * Nk * D, f"B{B} H{heads} Nq{Nq} Nk{Nk}"
+
+
+def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, heads: int, scale: float,
+              nk: Optional[int] = None) -> torch.Tensor:
+    """q [B,Nq,H*D], k [Bk,Nk',H*D] (token- and batch-strided views allowed), vt [Bk,H*D,Nk''] = V transposed (keys
+    contiguous; rows finite up to nk rounded up to 8), out [B,Nq,H*D].  nk = number of valid keys (default k.shape[1]).
+    Bk < B: query batch b uses K/V batch (b if b < Bk else b - (B - Bk))."""
+    d, flops, shape = _attn_fwd_desc(q, k, vt, out, heads, scale, nk)
+    with _timed(f"attention_d{d.D}", flops, shape):
         check(lib.sg_attn_fwd_f16(C.byref(d), _stream()), "sg_attn_fwd_f16")
     return out
+
+
+def attention_pair(a: tuple, b: tuple, heads: int, scale: float) -> None:
+    """Two attentions of the same query geometry in one launch (sg_attn_fwd_pair_f16): a, b = (q, k, vt, out, nk) as in attention()
+    — the text and the image cross-attention of one transformer block (attention.py:271-276,285-290)."""
+    da, fa, sa = _attn_fwd_desc(a[0], a[1], a[2], a[3], heads, scale, a[4])
+    db, fb, sb = _attn_fwd_desc(b[0], b[1], b[2], b[3], heads, scale, b[4])
+    with _timed(f"attention_d{da.D}", fa + fb, f"{sa} + {sb}"):
+        check(lib.sg_attn_fwd_pair_f16(C.byref(da), C.byref(db), _stream()), "sg_attn_fwd_pair_f16")
 
 
 def attention_f8_bytes(B: int, heads: int, N: int, transposed: bool) -> int:

@@ -265,13 +265,13 @@ class UNetTrainer:
         temb0, temb1, temb2 = (_e(B, n, dev=dev, dtype=F32) for n in (boc0, arch.temb_dim, arch.temb_dim))
         ops.timestep_embed(t.to(dev, F32).contiguous(), wts.freqs, temb0, self.cfg["flip_sin_to_cos"])
         ops.linear_rows(temb0, wts.w_t1, wts.b_t1, temb1, act_out=True)
-        ops.linear_rows(temb1, wts.w_t2, wts.b_t2, temb2)
+        ops.linear_rows(temb1, wts.w_t2, wts.b_t2, temb2, act_out=True)     # emb is only consumed as silu(emb) (resnet.py time_emb_proj)
         tape: List[tuple] = []
         hh, ww = H, W
 
         def resnet(prefix, x):
             w, b = self.temb_proj[prefix]
-            tp = ops.linear_rows(temb2, w, b, _e(B, w.shape[0], dev=dev, dtype=F32), act_in=True)
+            tp = ops.linear_rows(temb2, w, b, _e(B, w.shape[0], dev=dev, dtype=F32))
             tape.append(("resnet", prefix))
             return self.resnets[prefix].forward(x, tp, B, hh, ww)
 

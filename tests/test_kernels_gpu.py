@@ -377,12 +377,66 @@ def test_groupnorm_statistics_from_producer_epilogues(gpu, B, H, W, C1, C2):
         check(outs[0], want, "groupnorm from epilogue statistics")
         check(outs[1], want, "groupnorm, own statistics")
         assert rel_l2(outs[0].float(), outs[1].float()) < 3e-4
-    # split-K cannot emit statistics: the query says so and the launch refuses
-    a3, w3 = rnd((768, 5120), gpu, 1.0, 12), rnd((640, 5120), gpu, 0.01, 13)
-    o3, st3 = torch.empty(768, 640, dtype=torch.float32, device=gpu), torch.zeros(768 // 64 * 2 * 640, dtype=torch.float32, device=gpu)
+    # a launch that cannot emit statistics says so and refuses them: split-K needs N % 64 == 0 (its second pass works on 64-column blocks)
+    a3, w3 = rnd((768, 5120), gpu, 1.0, 12), rnd((72, 5120), gpu, 0.01, 13)
+    o3, st3 = torch.empty(768, 72, dtype=torch.float32, device=gpu), torch.zeros(768 // 64 * 2 * 72, dtype=torch.float32, device=gpu)
     assert ops.gemm_stats_rows(a3, w3, o3, stats=(st3, 256), split_k=4, workspace=ws) == 0
     with pytest.raises(RuntimeError, match="statistics"):
         ops.gemm(a3, w3, o3, stats=(st3, 256), split_k=4, workspace=ws)
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,split", [(2, 32, 32, 640, 640, 3), (3, 16, 16, 1280, 1280, 5), (4, 16, 16, 1280, 640, 2),
+                                               (1, 64, 64, 320, 320, 2)])
+def test_groupnorm_statistics_from_the_split_k_second_pass(gpu, B, H, W, C1, C2, split):
+    """Round 3: a split-K conv / GEMM emits the GroupNorm partials from its reduction pass
+    (splitk_reduce_stats_kernel), so the 32x32 / 16x16 levels stop paying a statistics launch.  (i) the outputs are bit-identical to
+    the plain second pass; (ii) the partials equal torch's per-tile column sums; (iii) GroupNorm fed with them (one source and the
+    [conv | GEMM] channel concat) matches torch and the self-contained statistics."""
+    from storygen_amd import ops
+    HW, M = H * W, B * H * W
+    ws = torch.empty(128 << 20, dtype=torch.uint8, device=gpu)
+    xp = torch.zeros(B, H + 2, W + 2, 128, dtype=torch.float16, device=gpu)
+    xp[:, 1:-1, 1:-1] = rnd((B, H, W, 128), gpu, 1.0, 1)
+    wk, bias, rb = rnd((C1, 3, 3, 128), gpu, 0.04, 2), rnd((C1,), gpu, 1.0, 3), rnd((B, C1), gpu, 1.0, 4, torch.float32)
+    res = rnd((B, H, W, C1), gpu, 1.0, 5, torch.float32) + 2.0
+    cat = torch.empty(M, C1 + C2, dtype=torch.float32, device=gpu)
+    y1, y2 = cat[:, :C1], cat[:, C1:]
+    st1 = torch.full((M // 64 * 2 * C1,), float("nan"), dtype=torch.float32, device=gpu)
+    kw1 = dict(bias=bias, rowbias=rb, res1=res, workspace=ws, x_padded=True, split_k=split)
+    rows1 = ops.conv3x3_stats_rows(xp, wk, y1.view(B, H, W, C1), stats=st1, **kw1)
+    assert rows1 in (64, 128, 256) and HW % rows1 == 0
+    ops.conv3x3(xp, wk, y1.view(B, H, W, C1), stats=st1, **kw1)
+    plain1 = torch.empty(M, C1, dtype=torch.float32, device=gpu)
+    ops.conv3x3(xp, wk, plain1.view(B, H, W, C1), **kw1)
+    a, w2 = rnd((M, 1280), gpu, 1.0, 6), rnd((C2, 1280), gpu, 1280 ** -0.5, 7)
+    st2 = torch.full((M // 64 * 2 * C2,), float("nan"), dtype=torch.float32, device=gpu)
+    kw2 = dict(bias=rnd((C2,), gpu, 1.0, 8), res1=rnd((M, C2), gpu, 1.0, 9, torch.float32), workspace=ws, split_k=split)
+    rows2 = ops.gemm_stats_rows(a, w2, y2, stats=(st2, HW), **kw2)
+    assert rows2 in (64, 128, 256) and HW % rows2 == 0
+    ops.gemm(a, w2, y2, stats=(st2, HW), **kw2)
+    plain2 = torch.empty(M, C2, dtype=torch.float32, device=gpu)
+    ops.gemm(a, w2, plain2, **kw2)
+    torch.cuda.synchronize()
+    assert torch.equal(y1, plain1) and torch.equal(y2, plain2)
+    for y, st, rows, C in ((y1, st1, rows1, C1), (y2, st2, rows2, C2)):
+        got = st[: M // rows * 2 * C].view(M // rows, 2, C)
+        tiles = y.reshape(M // rows, rows, C).double()
+        assert rel_l2(got[:, 0].double(), tiles.sum(1)) < 1e-6 and rel_l2(got[:, 1].double(), (tiles * tiles).sum(1)) < 1e-6
+    wsg = torch.empty(ops.groupnorm_workspace_bytes(B, 32), dtype=torch.uint8, device=gpu)
+    for x, pst in ((y1, [(st1, rows1, C1)]), (cat, [(st1, rows1, C1), (st2, rows2, C2)])):
+        C = x.shape[1]
+        if not ops.groupnorm_uses_pstats(HW, C, 32):
+            continue                                    # e.g. 16x16 x 1280: the one-launch kernel has its own statistics
+        gamma, beta = rnd((C,), gpu, 1.0, 10) + 1.0, rnd((C,), gpu, 1.0, 11)
+        xc = x.contiguous()
+        want = F.silu(F.group_norm(xc.view(B, HW, C).permute(0, 2, 1).float(), 32, gamma.float(), beta.float(), 1e-5)).permute(0, 2, 1)
+        outs = []
+        for p in (pst, None):
+            o = torch.full((B, HW, C), float("nan"), dtype=torch.float16, device=gpu)
+            ops.groupnorm(x.view(B, HW, C), gamma, beta, o, 32, 1e-5, True, wsg, pstats=p)
+            outs.append(o)
+        check(outs[0], want, "groupnorm from second-pass statistics")
+        assert rel_l2(outs[0].float(), outs[1].float()) < 3e-4
 
 
 @pytest.mark.parametrize("tile", [(256, 128), (256, 64), (128, 128), (128, 64), (64, 128), (64, 64)])
@@ -550,6 +604,43 @@ def test_attention_shared_kv_batches(gpu, D, Nq, Nk):
         return t.float().view(t.shape[0], t.shape[1], H, D).transpose(1, 2)
     att = torch.softmax(heads(q) @ heads(k[idx]).transpose(-1, -2) * D ** -0.5, dim=-1) @ heads(v[idx])
     check(out, att.transpose(1, 2).reshape(3, Nq, C), "attention shared kv")
+
+
+@pytest.mark.parametrize("D,Nq,Nk_img,Bk", [(40, 4096, 1024, 2), (40, 1024, 3072, 3), (80, 1024, 640, 2), (160, 256, 768, 3), (160, 64, 192, 2)])
+def test_attention_pair_text_and_image_in_one_launch(gpu, D, Nq, Nk_img, Bk):
+    """sg_attn_fwd_pair_f16: the text (77 keys, one K/V row per query batch) and the image cross-attention
+    (R * HW keys, context rows shared between CFG batches) of one block in one grid — bit-identical to the two separate launches
+    and equal to torch; a pair with different query geometry falls back to two launches."""
+    from storygen_amd import ops
+    H, B, S = 8, 3, 77
+    C = H * D
+    scale = D ** -0.5
+    q2, q3 = rnd((B, Nq, C), gpu, 1.5, seed=1), rnd((B, Nq, C), gpu, 1.5, seed=2)
+    kt, vt_ = rnd((B, 80, C), gpu, 1.5, seed=3), rnd((B, 80, C), gpu, 1.0, seed=4)
+    ki, vi = rnd((Bk, Nk_img, C), gpu, 1.5, seed=5), rnd((Bk, Nk_img, C), gpu, 1.0, seed=6)
+    vtt, vti = _vt(vt_), _vt(vi)
+    both = torch.full((B, Nq, 2 * C), float("nan"), dtype=torch.float16, device=gpu)       # the engine's [a2 | a3] buffer
+    a2, a3 = both[:, :, :C], both[:, :, C:]
+    ops.attention_pair((q3, ki, vti, a3, None), (q2, kt, vtt, a2, S), H, scale)
+    s2, s3 = torch.empty(B, Nq, C, dtype=torch.float16, device=gpu), torch.empty(B, Nq, C, dtype=torch.float16, device=gpu)
+    ops.attention(q2, kt, vtt, s2, H, scale, nk=S)
+    ops.attention(q3, ki, vti, s3, H, scale)
+    torch.cuda.synchronize()
+    assert torch.equal(a2, s2) and torch.equal(a3, s3)
+    idx = [b if b < Bk else b - (B - Bk) for b in range(B)]
+
+    def heads(t):
+        return t.float().view(t.shape[0], t.shape[1], H, D).transpose(1, 2)
+    ref3 = (torch.softmax(heads(q3) @ heads(ki[idx]).transpose(-1, -2) * scale, -1) @ heads(vi[idx])).transpose(1, 2).reshape(B, Nq, C)
+    ref2 = (torch.softmax(heads(q2) @ heads(kt[:, :S]).transpose(-1, -2) * scale, -1) @ heads(vt_[:, :S])).transpose(1, 2).reshape(B, Nq, C)
+    check(a3, ref3, "paired image attention")
+    check(a2, ref2, "paired text attention")
+    # different query counts: served as two launches, same results
+    o2 = torch.full((B, Nq // 2, C), float("nan"), dtype=torch.float16, device=gpu)
+    o3 = torch.full((B, Nq, C), float("nan"), dtype=torch.float16, device=gpu)
+    ops.attention_pair((q3, ki, vti, o3, None), (q2[:, : Nq // 2], kt, vtt, o2, S), H, scale)
+    torch.cuda.synchronize()
+    assert torch.equal(o3, s3) and torch.equal(o2, s2[:, : Nq // 2])
 
 
 @pytest.mark.parametrize("B,HW,C,silu,eps", [(3, 256, 320, True, 1e-5), (2, 64, 1920, True, 1e-5), (1, 100, 2560, False, 1e-6),

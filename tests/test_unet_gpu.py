@@ -247,6 +247,24 @@ def test_graph_replay_matches_eager(gpu, sd15):
     assert torch.equal(outs[0], outs[1])
 
 
+def test_paired_text_image_attention_is_the_same_trajectory(gpu, sd15, monkeypatch):
+    """engine.ATTN_PAIR (text + image cross-attention of every block in one sg_attn_fwd_pair_f16 launch, off by default — DESIGN
+    §5.2b) runs the same arithmetic as the two launches: bit-identical latents after 4 steps."""
+    from storygen_amd import engine
+    from storygen_amd.sampler import StoryGenSampler
+    from storygen_amd.synth import synthetic_inputs
+    arch, sd = sd15
+    inputs = synthetic_inputs(1, 3, 32, 32, 5, arch.config["cross_attention_dim"])
+    outs = []
+    for paired in (False, True):
+        monkeypatch.setattr(engine, "ATTN_PAIR", paired)
+        smp = StoryGenSampler(arch, sd, gpu, 1, 32, 32, 3)
+        smp.prepare(inputs, 4, "multi-image-condition", 7.5, 3.5)
+        outs.append(smp.run().clone())
+        torch.cuda.synchronize()
+    assert torch.equal(outs[0], outs[1])
+
+
 def test_loop_vs_oracle_both_stages_32x32(gpu, sd15):
     """The whole loop (R=2, first 3 steps of the 50-step schedule BASELINE config 2 uses — the 1e-3 latent bar is
     stated for that schedule: a coarser one multiplies the same epsilon error by a larger DDIM coefficient) in both
