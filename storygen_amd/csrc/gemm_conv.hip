@@ -939,12 +939,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const MmaParams p) {
 // Split-K second pass that also emits the GroupNorm partial statistics of the finished rows (MmaParams::stats, same buffer
 // layout as epi_finish's), so that a split-K producer does not cost its consumer a statistics pass.  One workgroup = 32 RPT rows x
 // 64 columns = one partial: thread (tr = t >> 3, vc = t & 7) owns the 8-column vector vc of rows tr, tr + 32, ... (a wave reads
-// 8 rows x 256 contiguous bytes per split), two rows x two splits in flight.  The 32 thread rows are added through LDS in a fixed
+// 8 rows x 256 contiguous bytes per split), up to four rows x two splits in flight.  The 32 thread rows are added through LDS in a fixed
 // order: deterministic, no atomics.  Host contract (check_stats / reduce_stats_rows): linear epilogue, M % (32 RPT) == 0,
 // N % 64 == 0, partials never straddle two images.
 template <int RPT>
 __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const MmaParams p) {
-    static_assert(RPT % 2 == 0, "two rows per step");
+    constexpr int RB = RPT < 4 ? RPT : 4;           // rows of a thread in flight together
+    static_assert(RPT % RB == 0, "whole steps");
     __shared__ float s_acc[32][2][64];
     const int t = threadIdx.x, vc = t & 7, tr = t >> 3;
     const int nb = p.N >> 6;
@@ -956,19 +957,19 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const MmaParam
 #pragma unroll
     for (int j = 0; j < 8; ++j) s1[j] = s2[j] = 0.f;
 #pragma unroll 1
-    for (int h0 = 0; h0 < RPT; h0 += 2) {
-        float v[2][8];
+    for (int h0 = 0; h0 < RPT; h0 += RB) {
+        float v[RB][8];
 #pragma unroll
-        for (int h = 0; h < 2; ++h)
+        for (int h = 0; h < RB; ++h)
 #pragma unroll
             for (int j = 0; j < 8; ++j) v[h][j] = 0.f;
         const float* s = p.ws + (size_t)(gm0 + 32 * h0) * p.N + gn;
         for (int z0 = 0; z0 < p.splits; z0 += 2) {      // partial tiles added in split order (bit-identical to the plain kernel)
-            float4 a[2][2], b[2][2];
+            float4 a[2][RB], b[2][RB];
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < RB; ++h) {
                     a[u][h] = b[u][h] = make_float4(0.f, 0.f, 0.f, 0.f);
                     if (z0 + u < p.splits) {
                         const float* src = s + (z0 + u) * MN + h * hstep;
@@ -979,13 +980,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const MmaParam
 #pragma unroll
             for (int u = 0; u < 2; ++u)
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
+                for (int h = 0; h < RB; ++h) {
                     v[h][0] += a[u][h].x; v[h][1] += a[u][h].y; v[h][2] += a[u][h].z; v[h][3] += a[u][h].w;
                     v[h][4] += b[u][h].x; v[h][5] += b[u][h].y; v[h][6] += b[u][h].z; v[h][7] += b[u][h].w;
                 }
         }
 #pragma unroll
-        for (int h = 0; h < 2; ++h) {
+        for (int h = 0; h < RB; ++h) {
             epi_linear8(p, gm0 + 32 * (h0 + h), gn, v[h]);      // bias / temb row / residuals added in place, outputs stored
 #pragma unroll
             for (int j = 0; j < 8; ++j) { s1[j] += v[h][j]; s2[j] = fmaf(v[h][j], v[h][j], s2[j]); }
@@ -1006,12 +1007,13 @@ __global__ __launch_bounds__(256) void splitk_reduce_stats_kernel(const MmaParam
 }
 
 // Rows per statistics partial of a split-K launch (0 = it cannot emit them): the largest of 256 / 128 / 64 that divides an image
-// and still leaves the second pass ~100 workgroups (fewer, larger partials make the consumer's merge shorter).
+// and still leaves the second pass a workgroup for most CUs (fewer, larger partials make the consumer's merge shorter, but a
+// 120-workgroup second pass measured 14 us against 7 us for the plain one — profiles/r03e_kernel_stats.csv).
 int reduce_stats_rows(const MmaParams& p) {
     if (p.mode != SG_EPI_LINEAR || p.N % 64 != 0 || p.stats_batch_rows <= 0 || p.M % p.stats_batch_rows != 0) return 0;
     int best = 0;
     for (int rows = 64; rows <= 256; rows *= 2)
-        if (p.stats_batch_rows % rows == 0 && (best == 0 || (long)(p.M / rows) * (p.N / 64) >= 96)) best = rows;
+        if (p.stats_batch_rows % rows == 0 && (best == 0 || (long)(p.M / rows) * (p.N / 64) >= 192)) best = rows;
     return best;
 }
 

@@ -276,29 +276,40 @@ __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p)
     gam.u = bet.u = make_uint4(0, 0, 0, 0);
     if (active) { gam.u = ldg16(p.gamma + c0); bet.u = ldg16(p.beta + c0); }
     if (p.ps[0]) {
-        // Statistics from the producers' epilogue partials.  Entry e of group g = (channel c of the group, row tile of c's source):
-        // n_e rows, S1 = sum x, S2 = sum x^2.  Two passes over the (few hundred) entries, both tree-reduced in a fixed order:
-        //   mean = sum_e S1 / N;   M2 = sum_e [ (S2 - S1^2 / n_e) + n_e (S1 / n_e - mean)^2 ]   (Chan et al.: no cancellation
-        //   between the group mean and the sum of squares — each entry is centred on its own mean first)
+        // Statistics from the producers' partials (fused epilogues and split-K second passes).  Entry e of group g = (channel of the
+        // group, row tile of that channel's source): n_e rows, S1 = sum x, S2 = sum x^2.  ONE pass over the (few hundred) entries:
+        //   mean = sum_e S1 / N
+        //   M2   = sum_e [ (S2 - S1^2 / n_e) + n_e (S1 / n_e - K)^2 ] - N (mean - K)^2          (Chan et al. about a pivot K)
+        // with K = the mean of the group's first entry, a sample of the means being merged: every entry is centred on its own mean
+        // first, and what is subtracted at the end is the small (mean - K)^2, so nothing cancels.  A thread's entries (part, part +
+        // parts, ...) travel in chunks of GNW_CH with all loads of a chunk in flight (clamped addresses, no predicate on the loads),
+        // and the index arithmetic is division-free ((e + 0.5) * (1 / tmax) is exact far beyond the 5120 entries a group can have).
         const int parts = GNW_NT / p.G;
         const int grp = t % p.G, part = t / p.G;
         const int t0 = p.HW / p.ps_rows[0], t1 = p.ps[1] ? p.HW / p.ps_rows[1] : 0;
         const int tmax = t0 > t1 ? t0 : t1;
         const int nent = p.cpg * tmax;
-        const int per = (nent + parts - 1) / parts;          // entries per worker thread: part, part + parts, ...
+        const int per = (nent + parts - 1) / parts;
         const bool worker = part < parts;
-        // The entries travel in chunks of GNW_CH per thread with every load of a chunk in flight at once (clamped addresses, no
-        // predicate on the loads): the prologue costs one memory round trip per chunk and pass instead of one per entry, and a
-        // thread with <= GNW_CH entries (the 64x64 level behind 256-row tiles) keeps them in registers for the second pass.
+        const float inv_tmax = 1.0f / (float)tmax;
+        const float rows0 = (float)p.ps_rows[0], rows1 = p.ps[1] ? (float)p.ps_rows[1] : 1.f;
+        const float inv_rows0 = 1.0f / rows0, inv_rows1 = 1.0f / rows1;
+        float K;
+        {
+            const int c = grp * p.cpg;
+            const int src = (p.ps[1] && c >= p.ps_c0[1]) ? 1 : 0;
+            K = p.ps[src][((long)(b * (src ? t1 : t0)) * 2) * p.ps_nc[src] + (c - p.ps_c0[src])] * (src ? inv_rows1 : inv_rows0);
+        }
         constexpr int GNW_CH = 8;
-        float s1[GNW_CH], s2[GNW_CH], nr[GNW_CH];
-        auto load_chunk = [&](int i0) __attribute__((always_inline)) {
+        float a_s = 0.f, a_q = 0.f;
+        for (int i0 = 0; i0 < per; i0 += GNW_CH) {
+            float s1[GNW_CH], s2[GNW_CH], nr[GNW_CH], inr[GNW_CH];
 #pragma unroll
             for (int u = 0; u < GNW_CH; ++u) {
                 const int e = part + (i0 + u) * parts;
                 const bool inside = worker && e < nent;
                 const int ec = inside ? e : 0;                // entry 0 of a group always exists
-                const int cl = ec / tmax;
+                const int cl = (int)(((float)ec + 0.5f) * inv_tmax);
                 int tile = ec - cl * tmax;
                 const int c = grp * p.cpg + cl;
                 const int src = (p.ps[1] && c >= p.ps_c0[1]) ? 1 : 0;
@@ -307,41 +318,26 @@ __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p)
                 if (tile >= tiles) tile = 0;
                 const float* base = p.ps[src] + ((long)(b * tiles + tile) * 2) * p.ps_nc[src] + (c - p.ps_c0[src]);
                 s1[u] = base[0]; s2[u] = base[p.ps_nc[src]];
-                nr[u] = valid ? (float)p.ps_rows[src] : 0.f;
+                nr[u] = valid ? (src ? rows1 : rows0) : 0.f;
+                inr[u] = src ? inv_rows1 : inv_rows0;
             }
-        };
-        float acc = 0.f;
-        for (int i0 = 0; i0 < per; i0 += GNW_CH) {
-            load_chunk(i0);
-#pragma unroll
-            for (int u = 0; u < GNW_CH; ++u) acc += nr[u] > 0.f ? s1[u] : 0.f;
-        }
-        s_ps[t] = acc;
-        __syncthreads();
-        const float ntot = (float)p.HW * (float)p.cpg;
-        if (t < p.G) {
-            float s = 0.f;
-            for (int k = 0; k < parts; ++k) s += s_ps[k * p.G + t];
-            s_mean[t] = s / ntot;
-        }
-        __syncthreads();
-        const float mean = s_mean[grp];
-        acc = 0.f;
-        for (int i0 = 0; i0 < per; i0 += GNW_CH) {
-            if (per > GNW_CH) load_chunk(i0);                 // else the only chunk is still in registers
 #pragma unroll
             for (int u = 0; u < GNW_CH; ++u)
                 if (nr[u] > 0.f) {
-                    const float me = s1[u] / nr[u], dm = me - mean;
-                    acc += fmaxf(s2[u] - s1[u] * me, 0.f) + nr[u] * dm * dm;
+                    const float me = s1[u] * inr[u], dm = me - K;
+                    a_s += s1[u];
+                    a_q += fmaxf(s2[u] - s1[u] * me, 0.f) + nr[u] * dm * dm;
                 }
         }
-        s_pq[t] = acc;
+        s_ps[t] = a_s; s_pq[t] = a_q;
         __syncthreads();
-        if (t < p.G) {
-            float q = 0.f;
-            for (int k = 0; k < parts; ++k) q += s_pq[k * p.G + t];
-            s_rstd[t] = rsqrtf(q / ntot + p.eps);
+        if (t < p.G) {          // t < G: part == 0 and grp == t, so K is this group's pivot
+            float sm = 0.f, q = 0.f;
+            for (int k = 0; k < parts; ++k) { sm += s_ps[k * p.G + t]; q += s_pq[k * p.G + t]; }
+            const float ntot = (float)p.HW * (float)p.cpg;
+            const float mean = sm / ntot, dk = mean - K;
+            s_mean[t] = mean;
+            s_rstd[t] = rsqrtf(fmaxf(q / ntot - dk * dk, 0.f) + p.eps);
         }
         __syncthreads();
     } else
@@ -372,9 +368,10 @@ __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p)
     f16* yb = pw ? p.y + ((long)b * (p.HW / pw + 2) * (pw + 2)) * p.ldy : p.y + (long)b * p.HW * p.ldy;
     f16* cb = p.xcopy ? p.xcopy + (long)b * p.HW * p.ldxc : nullptr;
     float sc[8], sh[8];
+    const float inv_cpg = 1.0f / (float)p.cpg, inv_pw = pw ? 1.0f / (float)pw : 0.f;    // exact quotients for operands < 2^20
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const int grp = (c0 + j) / p.cpg;
+        const int grp = (int)(((float)(c0 + j) + 0.5f) * inv_cpg);
         sc[j] = s_rstd[grp] * (float)gam.h[j];
         sh[j] = (float)bet.h[j] - s_mean[grp] * sc[j];
     }
@@ -391,7 +388,7 @@ __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p)
                     o[j] = p.silu ? silu_f(r) : r;
                 }
                 long orow = px;
-                if (pw) { const int yy = px / pw, xx = px - yy * pw; orow = (long)(yy + 1) * (pw + 2) + xx + 1; }
+                if (pw) { const int yy = (int)(((float)px + 0.5f) * inv_pw), xx = px - yy * pw; orow = (long)(yy + 1) * (pw + 2) + xx + 1; }
                 store8h(yb + orow * p.ldy + c0, o);
             }
         }

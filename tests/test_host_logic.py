@@ -254,6 +254,17 @@ def test_traffic_on_file_was_measured_on_this_build():
     assert t["kernels"]["mma_pipe_kernel (gemm + conv3x3)"]["hbm_bytes_per_launch"] > 0
 
 
+def test_float_reciprocal_quotients_used_by_the_groupnorm_kernels_are_exact():
+    """gn_apply_wide_kernel (storygen_amd/csrc/norm.hip) replaces its integer divisions by (int)((e + 0.5f) * (1.0f / d)) — entry ->
+    (channel, tile), channel -> group, pixel -> image row.  Exact for every operand the kernels can see (e < 2^20, any divisor)."""
+    import numpy as np
+    e = np.arange(0, 1 << 20, dtype=np.int64)
+    ef = e.astype(np.float32) + np.float32(0.5)
+    for d in list(range(1, 130)) + [144, 192, 256, 320, 576, 768, 1024, 2304, 2560, 4096, 9216]:
+        q = (ef * (np.float32(1.0) / np.float32(d))).astype(np.int64)
+        assert np.array_equal(q, e // d), d
+
+
 def test_gather_is_identity_without_process_group():
     from storygen_amd.sampler import gather_latents
     x = torch.randn(1, 4, 8, 8)
