@@ -5,8 +5,10 @@ Only tests/ may import this module; the product (storygen_amd/optim.py) never do
   * `adamw_step`       torch.optim.AdamW's single-tensor update — PINNED: tests/test_optim_host.py checks it against
                        torch.optim.AdamW itself (the class the reference instantiates when use_8bit_adam is false).
   * `clip_coef`        torch.nn.utils.clip_grad_norm_ (accelerate's clip_grad_norm_ after unscaling) — pinned the same way.
-  * `lr_lambda`        diffusers 0.13.1 optimization.get_scheduler's multiplier for the schedule names it offers — PARITY UNPINNED
-                       (diffusers absent); the reference's configs use "constant" (config/*.yml `lr_scheduler: constant`).
+  * `lr_lambda`        diffusers 0.13.1 optimization.get_scheduler's multiplier for the schedule names it offers — diffusers is absent,
+                       but its optimization.py restates transformers.optimization, which is installed: PINNED against transformers'
+                       own schedule functions for all six names (tests/test_optim_host.py).  The reference's configs use "constant"
+                       (config/*.yml `lr_scheduler: constant`).
   * `dynamic_map`, `adamw8bit_step`   block-wise 8-bit AdamW as published for bitsandbytes==0.35.4 (environment.yaml; CUDA-only, not
                        installable here): dynamic-tree code books (signed for the first moment, unsigned for the second), 2048-element
                        blocks with per-block absmax, states de-quantised, updated in fp32 and re-quantised to the nearest code —
@@ -36,7 +38,8 @@ def clip_coef(grads: List[torch.Tensor], max_norm: float) -> float:
     return float(torch.clamp(max_norm / (total + 1e-6), max=1.0))
 
 
-def lr_lambda(name: str, warmup: int = 0, total: Optional[int] = None, cycles: float = 0.5, power: float = 1.0):
+def lr_lambda(name: str, warmup: int = 0, total: Optional[int] = None, cycles: float = 0.5, power: float = 1.0,
+              lr_init: float = 1.0, lr_end: float = 1e-7):
     """step -> multiplier of the base learning rate (diffusers optimization.py, SchedulerType values)."""
     def warm(s):
         return float(s) / float(max(1, warmup))
@@ -57,7 +60,13 @@ def lr_lambda(name: str, warmup: int = 0, total: Optional[int] = None, cycles: f
             return 0.0 if prog >= 1.0 else max(0.0, 0.5 * (1.0 + math.cos(math.pi * ((float(cycles) * prog) % 1.0))))
         return f
     if name == "polynomial":
-        return lambda s: warm(s) if s < warmup else (0.0 if s > total else (1.0 - (s - warmup) / (total - warmup)) ** power)
+        def g(s):
+            if s < warmup:
+                return warm(s)
+            if s > total:
+                return lr_end / lr_init
+            return ((lr_init - lr_end) * (1.0 - (s - warmup) / (total - warmup)) ** power + lr_end) / lr_init
+        return g
     raise ValueError(f"unknown lr scheduler {name!r}")
 
 

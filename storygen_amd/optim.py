@@ -194,7 +194,10 @@ class AdamW8bit(AdamW):
 SCHEDULES = ("constant", "constant_with_warmup", "linear", "cosine", "cosine_with_restarts", "polynomial")
 
 
-def _multiplier(name: str, warmup: int, total: Optional[int], cycles: float, power: float):
+LR_END = 1e-7      # get_polynomial_decay_schedule_with_warmup's default lr_end (get_scheduler does not expose it)
+
+
+def _multiplier(name: str, warmup: int, total: Optional[int], cycles: float, power: float, lr_init: float = 1.0):
     if name not in SCHEDULES:
         raise ValueError(f"{name!r} is not a valid lr scheduler, choose one of {SCHEDULES}")
     if name not in ("constant", "constant_with_warmup") and total is None:
@@ -215,7 +218,10 @@ def _multiplier(name: str, warmup: int, total: Optional[int], cycles: float, pow
             return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(cycles) * 2.0 * prog)))
         if name == "cosine_with_restarts":
             return 0.0 if prog >= 1.0 else max(0.0, 0.5 * (1.0 + math.cos(math.pi * ((float(cycles) * prog) % 1.0))))
-        return 0.0 if s > total else (1.0 - (s - warmup) / (total - warmup)) ** power            # polynomial
+        # polynomial: decays from the optimizer's initial lr to lr_end; LambdaLR multiplies by lr_init again
+        if s > total:
+            return LR_END / lr_init
+        return ((lr_init - LR_END) * (1.0 - (s - warmup) / (total - warmup)) ** power + LR_END) / lr_init
     return f
 
 
@@ -248,11 +254,14 @@ class LambdaLR:
 
 
 def get_scheduler(name: str, optimizer: AdamW, num_warmup_steps: Optional[int] = None, num_training_steps: Optional[int] = None,
-                  num_cycles: float = 0.5, power: float = 1.0) -> LambdaLR:
-    """diffusers.optimization.get_scheduler (train_StorySalon_stage2.py:214-219)."""
+                  num_cycles: int = 1, power: float = 1.0) -> LambdaLR:
+    """diffusers.optimization.get_scheduler (train_StorySalon_stage2.py:214-219).  As there, `num_cycles` reaches only the
+    hard-restart schedule (the cosine schedule keeps its half cycle) and `power` only the polynomial one, whose end value is the
+    library default lr_end = 1e-7 relative to the optimizer's initial learning rate.  The multipliers are pinned against
+    transformers.optimization, whose functions diffusers' optimization.py restates (tests/test_optim_host.py)."""
     name = getattr(name, "value", name)
     if name != "constant" and num_warmup_steps is None:
         raise ValueError(f"{name} requires `num_warmup_steps`, please provide that argument.")
-    if name == "cosine_with_restarts" and num_cycles == 0.5:
-        num_cycles = 1
-    return LambdaLR(optimizer, _multiplier(name, int(num_warmup_steps or 0), num_training_steps, num_cycles, power))
+    cycles = float(num_cycles) if name == "cosine_with_restarts" else 0.5
+    lr_init = float(getattr(optimizer, "defaults", {}).get("lr", optimizer.param_groups[0]["lr"]))
+    return LambdaLR(optimizer, _multiplier(name, int(num_warmup_steps or 0), num_training_steps, cycles, power, lr_init))

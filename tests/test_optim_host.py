@@ -71,6 +71,34 @@ def test_adamw8bit_oracle_tracks_fp32_adamw():
     assert float((p8 - target).norm()) < 0.7 * float(target.norm())
 
 
+def test_lr_schedules_are_pinned_to_transformers_optimization():
+    """diffusers 0.13.1 (absent here) took its schedule functions from transformers.optimization (installed): the oracle's
+    multipliers and the product's get_scheduler reproduce transformers' own LambdaLR trajectories for all six schedule names,
+    including the polynomial schedule's lr_end = 1e-7 floor relative to the initial learning rate."""
+    import transformers.optimization as to
+    from storygen_amd.optim import get_scheduler
+    lr, warm, total = 1e-5, 7, 40          # the reference's learning rate (config/stage2_config.yml)
+    for name, kw in (("constant", {}), ("constant_with_warmup", {}), ("linear", {}), ("cosine", {}),
+                     ("cosine_with_restarts", {"num_cycles": 3}), ("polynomial", {"power": 2.0})):
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.AdamW([p], lr=lr)
+        ref = to.get_scheduler(name, opt, num_warmup_steps=warm, num_training_steps=total, scheduler_specific_kwargs=kw or None)
+
+        class _Opt:
+            defaults = dict(lr=lr)
+            param_groups = [dict(lr=lr)]
+        mine = get_scheduler(name, _Opt(), num_warmup_steps=warm, num_training_steps=total, **kw)
+        cyc = float(kw.get("num_cycles", 0.5))
+        orc = oo.lr_lambda(name, warm, total, cyc, kw.get("power", 1.0), lr_init=lr)
+        for step in range(total + 6):
+            want = ref.get_last_lr()[0]
+            assert mine.get_last_lr()[0] == pytest.approx(want, rel=1e-12, abs=1e-20), (name, step)
+            assert lr * orc(step) == pytest.approx(want, rel=1e-12, abs=1e-20), (name, step)
+            opt.step()
+            ref.step()
+            mine.step()
+
+
 def test_lr_schedules():
     from storygen_amd.optim import _multiplier
     for name in ("constant", "constant_with_warmup", "linear", "cosine", "cosine_with_restarts", "polynomial"):
