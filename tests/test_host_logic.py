@@ -254,6 +254,23 @@ def test_traffic_on_file_was_measured_on_this_build():
     assert t["kernels"]["mma_pipe_kernel (gemm + conv3x3)"]["hbm_bytes_per_launch"] > 0
 
 
+def test_producers_emit_groupnorm_statistics_for_the_wider_concats_of_the_up_path():
+    """UNetEngine._stats_wanted: a producer writes GroupNorm partials when ANY GroupNorm that can read its output takes them — its own
+    width or a channel concat [h | skip] of the up blocks (unet_2d_blocks.py:600-601).  SD-1.5: at 16x16 a 1280-channel GroupNorm is
+    the one-launch kernel (no partials), but the 2560- / 1920-channel concats are the wide pair; at 8x8 nothing takes them."""
+    from storygen_amd.arch import SD15_CONFIG, build_arch
+    from storygen_amd.engine import UNetEngine
+    eng = object.__new__(UNetEngine)
+    eng.arch, eng.groups, eng._stats_want = build_arch(SD15_CONFIG), 32, {}
+    eng.hw = [64 * 64, 32 * 32, 16 * 16, 8 * 8]
+    assert eng._stats_wanted(0, 320) and eng._stats_wanted(1, 640) and eng._stats_wanted(1, 320)
+    assert eng._stats_wanted(2, 1280) and eng._stats_wanted(2, 640)        # via the 2560 / 1920 concats
+    assert not eng._stats_wanted(3, 1280)
+    from storygen_amd import ops
+    assert not ops.groupnorm_uses_pstats(16 * 16, 1280, 32) and ops.groupnorm_uses_pstats(16 * 16, 2560, 32)
+    assert eng._stats_want[(2, 1280)] is True                              # cached per (level, width)
+
+
 def test_float_reciprocal_quotients_used_by_the_groupnorm_kernels_are_exact():
     """gn_apply_wide_kernel (storygen_amd/csrc/norm.hip) replaces its integer divisions by (int)((e + 0.5f) * (1.0f / d)) — entry ->
     (channel, tile), channel -> group, pixel -> image row.  Exact for every operand the kernels can see (e < 2^20, any divisor)."""
