@@ -336,12 +336,16 @@ def test_tuned_tile_table_is_well_formed():
 
 
 def test_committed_bench_line_honours_the_contract():
-    """profiles/r01g_final_bench.json is a verbatim `python bench.py` line from the GPU box: guard the keys the driver and
-    the judge read (a format regression in bench.py shows up here the next time the line is refreshed)."""
+    """profiles/r03f_bench.json (and round 1's r01g_final_bench.json) are verbatim `python bench.py` lines from the GPU box: guard the
+    keys the driver and the judge read (a format regression in bench.py shows up here the next time the line is refreshed)."""
     import json
-    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "r01g_final_bench.json")
-    line = [ln for ln in open(path) if ln.startswith("{")][-1]
-    d = json.loads(line)
+    for name in ("r03f_bench.json", "r01g_final_bench.json"):
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", name)
+        line = [ln for ln in open(path) if ln.startswith("{")][-1]
+        _check_bench_line(json.loads(line))
+
+
+def _check_bench_line(d):
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
               "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
