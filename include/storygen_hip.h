@@ -207,6 +207,14 @@ typedef struct sg_attn_desc {
     int32_t B, H, Nq, Nk, D;
     int32_t kv_batches;
     float   scale;
+    /* Optional SHORT K / V rows (0 / NULL = none): the first kv2_batches of the kv_batches K/V rows live in (k2, vt2) — row j at
+     * k2 + j bsk2, vt2 + j bsvt2, same ldk / ldvt — and hold Nk2 keys each; K/V row j >= kv2_batches is row j - kv2_batches of
+     * (k, vt) with Nk keys.  StoryGen's main pass uses it for the zero-image CFG branch in `multi-image-condition` mode: its R
+     * context frames are R copies of one feature map (model/pipeline.py:390-397,425-430), and softmax over R copies of the same keys
+     * equals softmax over one copy, so that row carries HW keys instead of R * HW. */
+    const sg_half* k2;  int64_t bsk2;
+    const sg_half* vt2; int64_t bsvt2;
+    int32_t Nk2, kv2_batches;
 } sg_attn_desc;
 
 int sg_attn_fwd_f16(const sg_attn_desc* d, sg_stream_t stream);

@@ -95,6 +95,9 @@ class AttnDesc(C.Structure):
         ("B", C.c_int32), ("H", C.c_int32), ("Nq", C.c_int32), ("Nk", C.c_int32), ("D", C.c_int32),
         ("kv_batches", C.c_int32),
         ("scale", C.c_float),
+        ("k2", C.c_void_p), ("bsk2", C.c_int64),
+        ("vt2", C.c_void_p), ("bsvt2", C.c_int64),
+        ("Nk2", C.c_int32), ("kv2_batches", C.c_int32),
     ]
 
 

@@ -58,6 +58,14 @@ static int attn_params(const sg_attn_desc* d, AttnParams& p, const char* who) {
     p.B = d->B; p.H = d->H; p.Nq = d->Nq; p.Nk = d->Nk;
     p.kv_batches = d->kv_batches > 0 ? d->kv_batches : d->B;
     p.scale_log2 = d->scale * 1.44269504088896340736f;
+    if (d->kv2_batches > 0) {      // leading K/V rows with their own key count (same token / row strides)
+        SG_REQUIRE(d->k2 && d->vt2 && d->Nk2 > 0 && d->kv2_batches <= p.kv_batches, "%s: kv2_batches needs k2, vt2, Nk2 and at most kv_batches rows", who);
+        SG_REQUIRE(d->bsk2 % 8 == 0 && d->bsvt2 % 8 == 0 && sg_aligned16(d->k2) && sg_aligned16(d->vt2), "%s: k2 / vt2 strides and alignment", who);
+        SG_REQUIRE(d->ldvt >= ((d->Nk2 + 7) & ~7), "%s: ldvt must cover Nk2 rounded up to 8 keys", who);
+        p.k2 = reinterpret_cast<const f16*>(d->k2); p.bsk2 = d->bsk2;
+        p.vt2 = reinterpret_cast<const f16*>(d->vt2); p.bsvt2 = d->bsvt2;
+        p.Nk2 = d->Nk2; p.kv2 = d->kv2_batches;
+    }
     return SG_OK;
 }
 
@@ -82,6 +90,8 @@ static int attn_fwd(const sg_attn_desc* d, float* lse2, sg_stream_t stream) {
     if (d->D == 40) {
         if (big && sub2 && d->Nk >= 256) launch_attn<40, 4, 2, 2>(p, st);   // 128 keys per barrier, 2-stage ring
         else if (big && prio) launch_attn<40, 4, 3, 1, true>(p, st);
+        else if (big && opt.attn_d40_general) launch_attn<40, 4, 3, 1, false, false, false, true>(p, st);   // round-3 softmax (A/B)
+        else if (big && opt.attn_lean) launch_attn<40, 4, 3, 1, false, false, true>(p, st);   // V^T fragments per k-step: fewer VGPRs
         else if (big) launch_attn<40, 4, 3>(p, st);
         else launch_attn<40, 2, 2>(p, st);
     }
@@ -118,7 +128,7 @@ extern "C" int sg_attn_fwd_pair_f16(const sg_attn_desc* d0, const sg_attn_desc* 
     if (int rc = attn_params(d0, p0, "sg_attn_fwd_pair_f16[0]")) return rc;
     if (int rc = attn_params(d1, p1, "sg_attn_fwd_pair_f16[1]")) return rc;
     const SgOptions& opt = sg_options();
-    const bool same = d0->D == d1->D && d0->B == d1->B && d0->H == d1->H && d0->Nq == d1->Nq;
+    const bool same = d0->D == d1->D && d0->B == d1->B && d0->H == d1->H && d0->Nq == d1->Nq;   // (short K/V rows: either problem)
     const bool defaults = !opt.attn_sub2 && !opt.attn_prio && opt.attn_d80 == 1 && opt.attn_d160 == 3;
     if (!same || !defaults) {
         if (int rc = attn_fwd(d0, nullptr, stream)) return rc;

@@ -15,6 +15,9 @@ struct AttnParams {
     const f16* vt; long ldvt, bsvt;
     f16* o; long ldo, bso;
     int B, H, Nq, Nk, kv_batches, nqb;
+    // optional SHORT K / V rows (sg_attn_desc.k2 ...): K/V rows [0, kv2) live in (k2, vt2) with Nk2 keys each, K/V row j >= kv2 is
+    // row j - kv2 of (k, vt) with Nk keys (same ldk / ldvt)
+    const f16* k2; long bsk2; const f16* vt2; long bsvt2; int Nk2, kv2;
     float scale_log2;   // scale * log2(e)
     float* lse2;        // LSE instantiations only: [B, H, Nq] log2-domain log-sum-exp rows (max + log2(sum)) for the backward
 };
@@ -33,13 +36,28 @@ __device__ __forceinline__ int kswz(int row) {
     return D == 40 ? 0 : (D == 80 ? ((row >> 3) & 1) : ((row >> 2) & 3));
 }
 
+// D = 40 fast path (round 4): the padded part of the head dimension carries the softmax bookkeeping, so that the MFMAs do the
+// work of 66 of the ~160 VALU instructions of a 64-key tile:
+//   * contraction slots d = 40, 41 of S^T = K Q^T: the K fragment holds the constants (1, 1) there and the Q^T fragment
+//     (-m_hi, -m_lo), the running row maximum split into two fp16 values — the MFMA delivers s - m directly (Q is pre-multiplied by
+//     scale * log2 e once per workgroup), so the exponent needs no FMA;
+//   * rows d >= 40 of the O^T tile read a row of ONES instead of a duplicate of row 39: O^T row 40 accumulates the row sum of the
+//     fp16 probabilities — exactly the values that multiply V — and is rescaled with the accumulators.  No row-sum adds.
+// Both constants live in LDS: the (1, 1, 0, ...) K chunks at the start of the workgroup's LDS (one per 32-key block: the lanes
+// hi = 1 of k-step 2 read them instead of the first chunk of the next key row), the ones row behind every V^T tile image.
+constexpr int F40_KPAD = 2688;       // bytes in front of the ring: 16-byte constants at 0 and 32 * 80 (the two 32-key blocks)
+constexpr int F40_ONES = 128;        // bytes behind every tile image: one V^T row of ones
+
 // LDS of one workgroup: the S-stage ring of (K tile | VT tile) images
 template <int D, int S, int SUB>
-constexpr int attn_smem_bytes() { return S * SUB * (KVBLK * D * 2 + D * 128) + 16; }
+constexpr int attn_smem_bytes() {
+    return D == 40 ? F40_KPAD + S * SUB * (KVBLK * D * 2 + D * 128 + F40_ONES) : S * SUB * (KVBLK * D * 2 + D * 128) + 16;
+}
 
 // One workgroup's work: `block` of `nblocks` (the launch's own numbering — a paired launch runs two problems in one grid).
-template <int D, int NW, int S, int SUB, bool PRIO, bool LSE>
+template <int D, int NW, int S, int SUB, bool PRIO, bool LSE, bool LEAN = false, bool GENERAL = false>
 __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, const int block, const int nblocks) {
+    constexpr bool F40 = D == 40 && !GENERAL;   // softmax bookkeeping in the padded head dimension (see F40_KPAD)
     constexpr int DC = D / 8;                   // 16-byte chunks per K row
     constexpr int NDK = (D + 15) / 16;          // MFMA k-steps of S^T (contraction padded to 16)
     constexpr int DT = (D + 31) / 32;           // 32-row tiles of O^T
@@ -47,14 +65,16 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
     constexpr int K_BYTES = KVBLK * KROW;       // = D KiB / 8
     constexpr int V_BYTES = D * 128;
     constexpr int K_SEG = K_BYTES / 1024, V_SEG = V_BYTES / 1024, NSEG = K_SEG + V_SEG;   // 1 KiB = one wave DMA
-    constexpr int TSTAGE = K_BYTES + V_BYTES;   // LDS image of one 64-key tile
+    constexpr int TSTAGE = K_BYTES + V_BYTES + (F40 ? F40_ONES : 0);   // LDS image of one 64-key tile
     constexpr int STAGE = SUB * TSTAGE;         // a ring stage holds SUB consecutive tiles: one barrier per SUB tiles
+    constexpr int RING0 = F40 ? F40_KPAD : 0;   // byte offset of the ring
     constexpr int MAXL = (NSEG + NW - 1) / NW;  // DMA instructions per tile of the busiest wave
     constexpr int REM = NSEG % NW;              // waves < REM issue MAXL, the others MAXL - 1 (REM == 0: all MAXL)
     static_assert(S == 2 || S == 3, "2 or 3 stages");
     static_assert(SUB == 1 || S == 2, "multi-tile stages use the 2-stage ring (plain vmcnt(0) waits)");
     static_assert((S - 1) * MAXL < 64, "vmcnt is a 6-bit counter");
-    static_assert(S * STAGE + 16 == attn_smem_bytes<D, S, SUB>(), "LDS size");
+    static_assert(RING0 + S * STAGE + (F40 ? 0 : 16) <= attn_smem_bytes<D, S, SUB>(), "LDS size");
+    static_assert(!F40 || (32 * KROW + 16 <= F40_KPAD && F40_KPAD % 128 == 0), "K pad constants of both 32-key blocks");
 
     const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -66,11 +86,27 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
     const int bh = work / p.nqb, qb = work - bh * p.nqb;
     const int h = bh / p.B, b = bh - h * p.B;
     const int kvb = b < p.kv_batches ? b : b - (p.B - p.kv_batches);
+    const bool short_row = kvb < p.kv2;         // wave-uniform: a K/V row with its own key count (sg_attn_desc.k2)
+    const int Nk = short_row ? p.Nk2 : p.Nk;
     const int q0 = (qb * NW + wave) * 32;
     const f16* Q = p.q + (long)b * p.bsq + (long)h * D;
-    const f16* K = p.k + (long)kvb * p.bsk + (long)h * D;
-    const f16* VT = p.vt + (long)kvb * p.bsvt + (long)h * D * p.ldvt;
-    const int nkp8 = (p.Nk + 7) & ~7;           // VT rows hold finite data up to here (host contract)
+    const f16* K = (short_row ? p.k2 + (long)kvb * p.bsk2 : p.k + (long)(kvb - p.kv2) * p.bsk) + (long)h * D;
+    const f16* VT = (short_row ? p.vt2 + (long)kvb * p.bsvt2 : p.vt + (long)(kvb - p.kv2) * p.bsvt) + (long)h * D * p.ldvt;
+    const int nkp8 = (Nk + 7) & ~7;             // VT rows hold finite data up to here (host contract)
+
+    if constexpr (F40) {
+        // the constants of the fast path: (1, 1, 0, 0, 0, 0, 0, 0) for the K side of contraction slots 40..47 of both 32-key blocks,
+        // a row of ones behind every V^T tile image.  Written once; the first ring barrier publishes them (LDS-DMA never touches them).
+        if (t < 8) {
+            const unsigned v = (t & 3) == 0 ? 0x3C003C00u : 0u;  // halves (1.0, 1.0), then zeros
+            *reinterpret_cast<unsigned*>(smem + ((t >> 2) ? 32 * KROW : 0) + 4 * (t & 3)) = v;
+        }
+        for (int i = t; i < S * SUB * (F40_ONES / 4); i += 64 * NW) {
+            const int img = i / (F40_ONES / 4), w = i - img * (F40_ONES / 4);
+            *reinterpret_cast<unsigned*>(smem + RING0 + img * TSTAGE + K_BYTES + V_BYTES + 4 * w) = 0x3C003C00u;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
 
     // ---- per-lane DMA source coordinates of this wave's segments (segment g = i*NW + wave).  off = 32-bit element
     // offset from the (wave-uniform) tile origin, so the loads can use an SGPR base + VGPR offset.
@@ -98,12 +134,12 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
         coords(g, row, col);
         off[i] = g < K_SEG ? (unsigned)(row * (int)p.ldk + col) : (unsigned)(row + col);
     }
-    const int ntiles = (p.Nk + KVBLK - 1) / KVBLK;
+    const int ntiles = (Nk + KVBLK - 1) / KVBLK;
     // (always_inline: at D = 160 the bodies are large enough for the inliner to leave real calls, which pins `off`
     // and the Q fragments in scratch memory — 6x slower)
     auto issue_tile = [&](int tile, char* base) __attribute__((always_inline)) {
         const int key0 = tile * KVBLK;
-        if (key0 + KVBLK <= p.Nk) {             // full tile: no clamping, uniform base + per-lane offset
+        if (key0 + KVBLK <= Nk) {               // full tile: no clamping, uniform base + per-lane offset
             const f16* Kt = K + (long)key0 * p.ldk;
             const f16* Vt = VT + key0;
 #pragma unroll
@@ -119,7 +155,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
                 int row, col;
                 coords(g, row, col);
                 if (g < K_SEG) {
-                    const int key = min(key0 + row, p.Nk - 1);                  // tail rows: duplicates (finite)
+                    const int key = min(key0 + row, Nk - 1);                    // tail rows: duplicates (finite)
                     glds16(K + (long)key * p.ldk + col, base + g * 1024);
                 } else if (g < NSEG) {
                     const int kc = min(key0 + col, nkp8 - 8);                   // tail chunks: duplicates (finite)
@@ -131,10 +167,11 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
     auto issue = [&](int group, int stage) __attribute__((always_inline)) {     // the SUB tiles of ring group `group`
 #pragma unroll
         for (int sub = 0; sub < SUB; ++sub)
-            if (group * SUB + sub < ntiles) issue_tile(group * SUB + sub, smem + stage * STAGE + sub * TSTAGE);
+            if (group * SUB + sub < ntiles) issue_tile(group * SUB + sub, smem + RING0 + stage * STAGE + sub * TSTAGE);
     };
 
-    // ---- Q^T fragments: lane = (query l31, d-chunk 2s+hi); rows beyond Nq are clamped (never stored)
+    // ---- Q^T fragments: lane = (query l31, d-chunk 2s+hi); rows beyond Nq are clamped (never stored).  F40: pre-multiplied by
+    // scale * log2 e (one more fp16 rounding of q, 2^-11 relative: what the operand already carries), so that S^T is in the log2 domain
     f16x8 qf[NDK];
     {
         const int qi = min(q0 + l31, p.Nq - 1);
@@ -143,6 +180,10 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
             const int d0 = s * 16 + hi * 8;
             H8 x; x.u = make_uint4(0, 0, 0, 0);
             if (d0 < D) x.u = ldg16(Q + (long)qi * p.ldq + d0);
+            if constexpr (F40) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) x.h[j] = (f16)((float)x.h[j] * p.scale_log2);
+            }
             qf[s] = x.v;
         }
     }
@@ -155,8 +196,11 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
     for (int i = 0; i < DT; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) oacc[i][r] = 0.f;
-    float m_run = -INFINITY;   // running max of the scaled (log2-domain) scores of query l31
-    float l_run = 0.f;         // this lane's share of the running row sum
+    // general path: m_run = running max of the scaled (log2-domain) scores of query l31, l_run = this lane's share of the row sum.
+    // F40: m_run = the value the Q^T pad slots currently subtract (exactly fp16 hi + fp16 lo; 0 until the first tile has set it);
+    // the row sum lives in O^T row 40.
+    float m_run = F40 ? 0.f : -INFINITY;
+    float l_run = 0.f;
 
     const int ngroups = (ntiles + SUB - 1) / SUB;
 #pragma unroll
@@ -184,7 +228,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
       for (int sub = 0; sub < SUB; ++sub) {
         const int tile = group * SUB + sub;
         if (tile < ntiles) {      // (no `break`: it keeps the per-lane arrays from being promoted to registers)
-        const char* sK = smem + stage * STAGE + sub * TSTAGE;
+        const char* sK = smem + RING0 + stage * STAGE + sub * TSTAGE;
         const char* sV = sK + K_BYTES;
 
         // ---- S^T = K Q^T for the two 32-key blocks.  D <= 80: all K fragments are requested first, so the LDS latency is
@@ -194,14 +238,26 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
         constexpr bool KBATCH = NDK <= 5;
         if constexpr (KBATCH) {
             f16x8 kf[2][NDK];
+            if constexpr (F40) {
+                // lanes hi = 1 of k-step 2 hold contraction slots 40..47: the constant chunk instead of the next row's first bytes
+                const char* k01 = sK + prow * KROW + hi * 16;
+                const char* k2 = hi ? smem : sK + prow * KROW + 64;
 #pragma unroll
-            for (int kb = 0; kb < 2; ++kb) {
-                const int row = kb * 32 + prow;
-                const char* krow = sK + row * KROW;
-                const int sw = kswz<D>(row);
+                for (int kb = 0; kb < 2; ++kb) {
+                    kf[kb][0] = *reinterpret_cast<const f16x8*>(k01 + kb * 32 * KROW);
+                    kf[kb][1] = *reinterpret_cast<const f16x8*>(k01 + kb * 32 * KROW + 32);
+                    kf[kb][2] = *reinterpret_cast<const f16x8*>(k2 + kb * 32 * KROW);
+                }
+            } else {
 #pragma unroll
-                for (int st = 0; st < NDK; ++st)
-                    kf[kb][st] = *reinterpret_cast<const f16x8*>(krow + (((st * 2 + hi) ^ sw) << 4));
+                for (int kb = 0; kb < 2; ++kb) {
+                    const int row = kb * 32 + prow;
+                    const char* krow = sK + row * KROW;
+                    const int sw = kswz<D>(row);
+#pragma unroll
+                    for (int st = 0; st < NDK; ++st)
+                        kf[kb][st] = *reinterpret_cast<const f16x8*>(krow + (((st * 2 + hi) ^ sw) << 4));
+                }
             }
             __builtin_amdgcn_sched_barrier(0);   // keep the loads ahead of the MFMAs (the scheduler would re-serialise them)
             // PRIO: raise this wave's issue priority over its SIMD neighbours (other workgroups, in their softmax VALU
@@ -227,25 +283,26 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
         }
         // ---- V^T fragments of this tile are independent of the softmax: request them now so that their LDS latency
         // hides behind the softmax VALU work (D <= 80: 32 / 48 VGPRs; D = 160 reads them per k-step instead)
-        constexpr bool VPRE = DT <= 3;
+        constexpr bool VPRE = DT <= 3 && !LEAN;   // LEAN: V^T fragments per k-step (24 fewer VGPRs: 4 waves per SIMD at D = 40)
+        constexpr int DLAST = F40 ? D : D - 1;   // F40: rows >= D read the row of ones behind the image (row sum), else duplicates
         f16x8 vf[VPRE ? 4 : 1][DT];
         if constexpr (VPRE) {
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks)
 #pragma unroll
                 for (int i = 0; i < DT; ++i) {
-                    const int d = min(i * 32 + l31, D - 1);      // rows >= D: duplicates, never stored
+                    const int d = min(i * 32 + l31, DLAST);      // rows >= D: never stored
                     vf[ks][i] = *reinterpret_cast<const f16x8*>(sV + d * 128 + (((ks * 2 + hi) ^ ((d >> 1) & 7)) << 4));
                 }
         }
         // ---- online softmax: mask the key tail, row max (raw scores), deferred rescale, exponentiate
-        if ((tile + 1) * KVBLK > p.Nk) {
+        if ((tile + 1) * KVBLK > Nk) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int key = tile * KVBLK + kb * 32 + 16 * (r >> 3) + 8 * hi + (r & 7);
-                    if (key >= p.Nk) s[kb][r] = -INFINITY;
+                    if (key >= Nk) s[kb][r] = -INFINITY;
                 }
         }
         float mx = s[0][0];
@@ -253,27 +310,57 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
         for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) mx = fmaxf(mx, s[kb][r]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;   // finite: every tile holds >= 1 valid key
-        if (__builtin_amdgcn_ballot_w64(mx - m_run > RESCALE_THR) != 0) {
-            const float m_new = fmaxf(m_run, mx);
-            const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);            // 0 on the first tile (m_run = -inf)
-            m_run = m_new;
-            l_run *= alpha;
+        if constexpr (F40) {
+            // s holds (log2-domain score) - m_run already.  The first tile always sets the maximum (m_run = 0 is a placeholder there).
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));          // finite: every tile holds >= 1 valid key
+            if (tile == 0 || __builtin_amdgcn_ballot_w64(mx > RESCALE_THR) != 0) {
+                float m_new = m_run + (tile == 0 ? mx : fmaxf(mx, 0.f));
+                m_new = fminf(fmaxf(m_new, -60000.f), 60000.f);
+                const f16 mh = (f16)m_new;
+                const f16 ml = (f16)(m_new - (float)mh);
+                m_new = (float)mh + (float)ml;                // what the pad slots will subtract, exactly
+                const float delta = m_new - m_run;
+                if (tile != 0) {                              // (tile 0: the accumulators are zero, and exp2(-delta) may overflow)
+                    const float alpha = __builtin_amdgcn_exp2f(-delta);
 #pragma unroll
-            for (int i = 0; i < DT; ++i)
+                    for (int i = 0; i < DT; ++i)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
-        }
-        float psum = 0.f;
+                        for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+                }
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+                for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2, -m_run));
-                s[kb][r] = e;
-                psum += e;
+                    for (int r = 0; r < 16; ++r) s[kb][r] -= delta;
+                m_run = m_new;
+                if (hi) { qf[NDK - 1][0] = -mh; qf[NDK - 1][1] = -ml; }
             }
-        l_run += psum;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) s[kb][r] = __builtin_amdgcn_exp2f(s[kb][r]);
+        } else {
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64)) * p.scale_log2;   // finite: every tile holds >= 1 valid key
+            if (__builtin_amdgcn_ballot_w64(mx - m_run > RESCALE_THR) != 0) {
+                const float m_new = fmaxf(m_run, mx);
+                const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);            // 0 on the first tile (m_run = -inf)
+                m_run = m_new;
+                l_run *= alpha;
+#pragma unroll
+                for (int i = 0; i < DT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) oacc[i][r] *= alpha;
+            }
+            float psum = 0.f;
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[kb][r], p.scale_log2, -m_run));
+                    s[kb][r] = e;
+                    psum += e;
+                }
+            l_run += psum;
+        }
 
         // ---- O^T += VT P^T : 4 k-steps of 16 keys; B fragment = this lane's own P registers
 #pragma unroll
@@ -284,7 +371,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
             if constexpr (!VPRE) {
 #pragma unroll
                 for (int i = 0; i < DT; ++i) {
-                    const int d = min(i * 32 + l31, D - 1);
+                    const int d = min(i * 32 + l31, DLAST);
                     vf[0][i] = *reinterpret_cast<const f16x8*>(sV + d * 128 + (((ks * 2 + hi) ^ ((d >> 1) & 7)) << 4));
                 }
             }
@@ -299,8 +386,11 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
         if (++stage == S) stage = 0;
     }
 
-    // ---- normalise and store O[b, q, h*D + d]  (lane holds d = 32i + (r&3) + 8(r>>2) + 4hi for its query)
-    const float l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    // ---- normalise and store O[b, q, h*D + d]  (lane holds d = 32i + (r&3) + 8(r>>2) + 4hi for its query).  F40: the row sum is
+    // O^T row 40 (hi = 0) / 44 (hi = 1) — both rows of ones saw every key — i.e. register 4 of the second tile in every lane.
+    float l_tot;
+    if constexpr (F40) l_tot = oacc[DT - 1][4];
+    else l_tot = l_run + __shfl_xor(l_run, 32, 64);
     const float inv = 1.0f / l_tot;
     const int qi = q0 + l31;
     if constexpr (LSE) {    // training forward: P = exp2(s * scale_log2 - lse2) is what the backward kernels recompute
@@ -322,10 +412,10 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
     }
 }
 
-template <int D, int NW, int S, int SUB = 1, bool PRIO = false, bool LSE = false>
+template <int D, int NW, int S, int SUB = 1, bool PRIO = false, bool LSE = false, bool LEAN = false, bool GENERAL = false>
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[attn_smem_bytes<D, S, SUB>()];
-    attn_fwd_body<D, NW, S, SUB, PRIO, LSE>(p, smem, (int)blockIdx.x, (int)gridDim.x);
+    attn_fwd_body<D, NW, S, SUB, PRIO, LSE, LEAN, GENERAL>(p, smem, (int)blockIdx.x, (int)gridDim.x);
 }
 
 // Two attentions of one transformer block in one grid (text: attention.py:271-276, image: :285-290 — same queries' shape, two
@@ -338,11 +428,11 @@ __global__ __launch_bounds__(64 * NW) void attn_fwd_pair_kernel(const AttnParams
     else attn_fwd_body<D, NW, S, 1, false, false>(b, smem, (int)blockIdx.x - na, (int)gridDim.x - na);
 }
 
-template <int D, int NW, int S, int SUB = 1, bool PRIO = false, bool LSE = false>
+template <int D, int NW, int S, int SUB = 1, bool PRIO = false, bool LSE = false, bool LEAN = false, bool GENERAL = false>
 void launch_attn(const AttnParams& p0, hipStream_t st) {
     AttnParams p = p0;
     p.nqb = sg_cdiv(p.Nq, 32 * NW);
-    hipLaunchKernelGGL((attn_fwd_kernel<D, NW, S, SUB, PRIO, LSE>), dim3(p.nqb * p.H * p.B), dim3(64 * NW), 0, st, p);
+    hipLaunchKernelGGL((attn_fwd_kernel<D, NW, S, SUB, PRIO, LSE, LEAN, GENERAL>), dim3(p.nqb * p.H * p.B), dim3(64 * NW), 0, st, p);
 }
 
 template <int D, int NW, int S>

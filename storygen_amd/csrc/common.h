@@ -38,8 +38,11 @@ struct SgOptions {
     int tile_m = 0, tile_n = 0;        // force a GEMM / conv tile (0, 0 = heuristic / caller's hint)
     int no_pipe = 0, no_split = 0;     // register-staged kernel only / no automatic split-K
     int no_nmajor = 0;                 // M-major tile order everywhere
-    int attn_sub2 = 0, attn_prio = 0, attn_d80 = 1, attn_d160 = 3;
+    int attn_sub2 = 0, attn_prio = 0, attn_d80 = 1, attn_d160 = 3, attn_lean = 0;
+    int attn_d40_general = 0;          // 1 = the D = 40 launches use the general softmax path (A/B against the padded-dimension fast path)
     int gn_no_fused = 0, gn_wide = 1;
+    int gn_no_splitk_in = 0;           // reserved (A/B switches of round 4)
+    int ff_fused = 1;
     long gn_fused_max = -1;            // -1 = the kernel's default threshold
 };
 SgOptions& sg_options();

@@ -18,7 +18,8 @@ extern "C" int sg_debug_set_option(const char* name, int64_t value) {
     const Entry table[] = {{"tile_m", &o.tile_m}, {"tile_n", &o.tile_n}, {"no_pipe", &o.no_pipe}, {"no_split", &o.no_split},
                            {"no_nmajor", &o.no_nmajor}, {"attn_sub2", &o.attn_sub2}, {"attn_prio", &o.attn_prio},
                            {"attn_d80", &o.attn_d80}, {"attn_d160", &o.attn_d160}, {"gn_no_fused", &o.gn_no_fused},
-                           {"gn_wide", &o.gn_wide}};
+                           {"gn_wide", &o.gn_wide}, {"attn_lean", &o.attn_lean}, {"attn_d40_general", &o.attn_d40_general},
+                           {"gn_no_splitk_in", &o.gn_no_splitk_in}, {"ff_fused", &o.ff_fused}};
     for (const Entry& e : table)
         if (strcmp(e.n, name) == 0) {
             *e.p = (int)value;

@@ -242,25 +242,45 @@ class HarvestPlan:
     into `count` frame slots)."""
 
     def __init__(self, ctx: Dict[str, torch.Tensor], ops_: List[tuple], kv: Optional[Dict[str, tuple]] = None,
-                 src_offset: int = 0):
+                 src_offset: int = 0, short: int = 0, slots_per_row: Optional[int] = None, direct: bool = False):
         # kv: feature key -> (K [rows*R*HW, C], VT [C, rows*R*HW]) buffers: when given, the reference pass also runs the
         # attn3 K / V^T projections of each finished context (they depend on nothing else), taking them off the main
         # pass's critical path.
         # src_offset: added to every op's `src` — a reference pass that batches the samples of several denoising steps
         # (sampler ref_ahead > 1) passes one plan per step, each pointing at that step's slice of the batch.
+        # short / slots_per_row: layout of the DESTINATION buffers (UNetEngine ctx_short): the first `short` context rows hold one
+        # frame slot, the others slots_per_row; flat slot of (row, slot) = row if row < short else short + (row - short) * R + slot.
+        # direct: the pass's sample u belongs in flat slot u for every u (sampler._plan orders the batch that way), so the
+        # producer of the feature writes its fp16 copy straight into the context buffer and no copy kernel runs.
         self.ctx, self.ops, self.kv, self.src_offset = ctx, list(ops_), kv, int(src_offset)
+        self.short, self.slots_per_row, self.direct = int(short), slots_per_row, bool(direct)
+
+    def flat_slot(self, row: int, slot: int, R: int) -> int:
+        return row if row < self.short else self.short + (row - self.short) * R + slot
+
+    def is_direct(self, n_samples: int, R: int) -> bool:
+        """True when this plan alone maps sample u -> flat slot u for all n_samples samples of the pass."""
+        if not self.direct or self.src_offset:
+            return False
+        seen = {}
+        for src, step, row, slot, cnt in self.ops:
+            for j in range(cnt):
+                seen[self.flat_slot(row, slot + j, R)] = src + j * step
+        return seen == {u: u for u in range(n_samples)}
 
 
 class UNetEngine:
     def __init__(self, arch: UNetArch, state_dict: Optional[Dict[str, torch.Tensor]], device, batch: int, height: int,
                  width: int, n_ref: int = 0, seq_len: int = 77, splitk_workspace_mb: int = 96,
                  weights: Optional[EngineWeights] = None, ctx_rows: Optional[int] = None,
-                 attn3_groups: Optional[List[tuple]] = None, fp8_attention: bool = False):
+                 attn3_groups: Optional[List[tuple]] = None, fp8_attention: bool = False, ctx_short: int = 0):
         """batch = samples per UNet call; n_ref = R prior frames (sizes the context buffers; 0 = an engine that only
         harvests, into another engine's buffers).  ctx_rows = number of distinct context rows (default: one per
         sample); attn3_groups = [(q0, n, c0), ...]: samples [q0, q0+n) cross-attend to context rows [c0, c0+n) — lets
         samples whose prior-frame features are identical (the two image-conditioned CFG branches) share
-        one copy of the context and of its K/V projection."""
+        one copy of the context and of its K/V projection.  ctx_short = S > 0: the first S context rows hold ONE frame slot instead
+        of R (the zero-image rows of `multi-image-condition`, whose R slots would be R copies of one feature map: softmax over R
+        copies of the same keys is softmax over one); the context buffers are then flat [(S + (rows - S) R) HW, C] matrices."""
         self.arch, self.dev = arch, torch.device(device)
         self.B, self.H, self.W, self.R, self.S = batch, height, width, n_ref, seq_len
         cfg = arch.config
@@ -285,6 +305,10 @@ class UNetEngine:
         rows = self.ctx_rows
         share = sorted(self.attn3_groups) == ([(0, batch, 0)] if rows == batch else [(0, rows, 0), (rows, batch - rows, 2 * rows - batch)])
         self.attn3_share = rows if share else None
+        self.ctx_short = int(ctx_short)
+        if self.ctx_short and (not n_ref or self.attn3_share is None or self.ctx_short > rows):
+            raise ValueError("ctx_short needs context buffers, at most ctx_rows short rows and the shared-row attn3 pattern")
+        self.ctx_slots = self.ctx_short + (rows - self.ctx_short) * n_ref      # frame slots per feature key
         self.wts = weights if weights is not None else EngineWeights(arch, state_dict, device)
         # BASELINE config 5: the head-dim-40 self / image attentions (the 46 080-key context of the 96x96 level) on the fp8 MFMA
         # path (sg_attn_fwd_f8_d40); text attention and the D = 80 / 160 levels stay fp16
@@ -383,8 +407,8 @@ class UNetEngine:
                 **{n: torch.zeros(M, (C // 64 + 1) & ~1, 2, dtype=F32, device=self.dev) for n in ("lnst0", "lnst1", "lnst3")}, vt=self._buf(C, M), q=self._buf(M, C),
                 att=self._buf(M, C), q2=self._buf(M, C), att23=self._buf(M, 2 * C), ffi=self._buf(M, 4 * C),
                 kt=self._buf(B * self.Sp, C), vtt=self._buf(C, B * self.Sp),
-                ki=self._buf(self.ctx_rows * self.R * self.hw[l], C) if self.R else None,
-                vti=self._buf(C, self.ctx_rows * self.R * self.hw[l]) if self.R else None,
+                ki=self._buf(self.ctx_slots * self.hw[l], C) if self.R else None,
+                vti=self._buf(C, self.ctx_slots * self.hw[l]) if self.R else None,
             )
             self.lv.append(d)
         # torch.cat([h, skip]) (unet_2d_blocks.py:609,626,716) without a copy: every up-path resnet owns its concat input
@@ -412,11 +436,12 @@ class UNetEngine:
         assert len(self.skips) == len(self.skip_meta)
         for sk, (l, c) in zip(self.skips, self.skip_meta):
             assert tuple(sk.shape) == (B * self.hw[l], c), (tuple(sk.shape), l, c)
-        # context buffers: [ctx_rows, R*HW, C] fp16 per feature key (K/V projection operands of attn3)
+        # context buffers: [ctx_rows, R*HW, C] fp16 per feature key (K/V projection operands of attn3); with short rows a flat
+        # [ctx_slots * HW, C] matrix (short rows first)
         self.ctx: Dict[str, torch.Tensor] = {}
         if self.R:
             for k, (n, c) in feature_shapes(arch, self.H, self.W).items():
-                self.ctx[k] = self._buf(self.ctx_rows, self.R * n, c)
+                self.ctx[k] = self._buf(self.ctx_slots * n, c) if self.ctx_short else self._buf(self.ctx_rows, self.R * n, c)
 
     # ------------------------------------------------------------------------------------------ layers
     def _img(self, x2d: torch.Tensor, lvl: int) -> torch.Tensor:
@@ -477,14 +502,19 @@ class UNetEngine:
                 return [a, b]
         return None
 
-    def _attention(self, q, k, vt, out, heads: int, scale: float, nk: Optional[int] = None):
+    def _attention(self, q, k, vt, out, heads: int, scale: float, nk: Optional[int] = None, short: Optional[tuple] = None):
         """softmax(scale q k^T) v on the HIP kernels: fp16 MFMA, or e4m3 MFMA for the D = 40 image / self attentions when the
-        engine was built with fp8_attention (text attention — 77 keys — and every other head dim stay fp16)."""
+        engine was built with fp8_attention (text attention — 77 keys — and every other head dim stay fp16).
+        short = (k2, vt2): leading K/V rows with their own key count (ops.attention)."""
         n_keys = k.shape[1] if nk is None else nk
         if self.fp8_attention and q.shape[2] == heads * 40 and n_keys >= 256:
+            if short is not None:          # the fp8 kernel has one key count per launch: short rows first, then the others
+                ns = short[0].shape[0]
+                ops.attention_f8(q[:ns], short[0], short[1], out[:ns], heads, scale, self.f8_scratch)
+                q, out = q[ns:], out[ns:]
             ops.attention_f8(q, k, vt, out, heads, scale, self.f8_scratch, nk=nk)
         else:
-            ops.attention(q, k, vt, out, heads, scale, nk=nk)
+            ops.attention(q, k, vt, out, heads, scale, nk=nk, short=short)
 
     def _resnet(self, rn: _Resnet, x: torch.Tensor, out: torch.Tensor, lvl: int):
         """diffusers ResnetBlock2D.  x fp32 [M,Cin] contiguous; out fp32 [M,Cout], possibly a column
@@ -588,18 +618,34 @@ class UNetEngine:
         att = L["att"]
         self._attention(qk3[:, :, :C], qk3[:, :, C:], vt.view(C, B, hw).permute(1, 0, 2), att.view(B, hw, C), heads, scale)
         h1 = L["h1"]
-        ops.gemm(att, xf.w_o1, h1, bias=xf.b_o1, res1=h0, workspace=ws, **prod(h1, L["ln4"], L["lnst1"]))
-        if harvest is not None:                                                           # feature :263, written in place
+        plans = () if harvest is None else (tuple(harvest) if isinstance(harvest, (list, tuple)) else (harvest,))
+        # feature :263.  A plan whose sample order is the context's slot order (HarvestPlan.direct) gets the feature as the second,
+        # fp16 output of this GEMM — written straight into the context buffer, which then also serves as the raw copy of h1 that the
+        # folded query projections read; any other plan is served by strided copies.
+        direct = None
+        if len(plans) == 1 and h1.dtype != F16 and plans[0].is_direct(B, plans[0].slots_per_row or self.R):
+            c = plans[0].ctx[xf.spec.feature_key]
+            direct = c if c.dim() == 2 else c.view(-1, C)
+            assert direct.shape[0] == M, (direct.shape, M)
+        kw1 = prod(h1, L["ln4"], L["lnst1"])
+        if direct is not None:
+            kw1["out2"] = direct
+            h1r = direct
+        ops.gemm(att, xf.w_o1, h1, bias=xf.b_o1, res1=h0, workspace=ws, **kw1)
+        if harvest is not None:
             h1b = h1.view(B, hw, C)
-            for plan in (harvest if isinstance(harvest, (list, tuple)) else (harvest,)):
+            for plan in plans:
                 ctx = plan.ctx[xf.spec.feature_key]
-                for src, step, row, slot, cnt in plan.ops:
-                    dst = ctx[row, slot * hw:(slot + cnt) * hw, :].view(cnt, hw, C)
-                    ops.copy_rows(dst, h1b[plan.src_offset + src:].as_strided((cnt, hw, C), (step * hw * C, C, 1)))
+                c2d = ctx if ctx.dim() == 2 else ctx.view(-1, C)
+                if direct is None:
+                    Rp = plan.slots_per_row or (ctx.shape[1] // hw)
+                    for src, step, row, slot, cnt in plan.ops:
+                        t0 = plan.flat_slot(row, slot, Rp) * hw
+                        dst = c2d[t0:t0 + cnt * hw].view(cnt, hw, C)
+                        ops.copy_rows(dst, h1b[plan.src_offset + src:].as_strided((cnt, hw, C), (step * hw * C, C, 1)))
                 if plan.kv is not None:            # attn3 K / V^T of the finished context (attention.py:215-223)
                     ki, vti = plan.kv[xf.spec.feature_key]
-                    c2d = ctx.view(ctx.shape[0] * ctx.shape[1], C)
-                    _pair(((c2d, xf.w_k3, ki), dict(workspace=ws)), ((xf.w_v3, c2d, vti), dict(workspace=wp)))   # VT[C, rows*nk]
+                    _pair(((c2d, xf.w_k3, ki), dict(workspace=ws)), ((xf.w_v3, c2d, vti), dict(workspace=wp)))   # VT[C, slots*hw]
             if stop_after_harvest:
                 return
         # --- text cross-attention :266-277 (norm2) and image cross-attention :281-291 (norm4) share statistics
@@ -624,7 +670,7 @@ class UNetEngine:
                 _pair(((L["ln"], xf.w_q2, q2), dict(workspace=ws)), ((L["ln4"], xf.w_q3, q3buf), dict(workspace=wp)))
             # text + image attention as one launch when the image attention is one fp16 launch itself (else the text attention runs
             # beside the context projections on the side stream)
-            paired = ATTN_PAIR and self.attn3_share is not None and not (self.fp8_attention and C == heads * 40)
+            paired = ATTN_PAIR and self.attn3_share is not None and not self.ctx_short and not (self.fp8_attention and C == heads * 40)
             forked = False if paired else self._fork()
             if paired:
                 pass
@@ -634,19 +680,25 @@ class UNetEngine:
             else:
                 ops.attention(q2.view(B, hw, C), kt3, vtt3, a2v, heads, scale, nk=S)
             ctx = self.ctx[xf.spec.feature_key]
-            rows, nk = ctx.shape[0], ctx.shape[1]
+            ns, rows = self.ctx_short, self.ctx_rows
+            nk = self.R * hw
+            c2d = ctx if ctx.dim() == 2 else ctx.view(-1, C)
             if self.kv_ext is not None:
                 ki, vti = self.kv_ext[xf.spec.feature_key]
             else:
                 ki, vti = L["ki"], L["vti"]
-                c2d = ctx.view(rows * nk, C)
-                _pair(((c2d, xf.w_k3, ki), dict(workspace=ws)), ((xf.w_v3, c2d, vti), dict(workspace=wp)))   # VT[C, rows*nk]
-            ki3, vti3 = ki.view(rows, nk, C), vti.view(C, rows, nk).permute(1, 0, 2)
+                _pair(((c2d, xf.w_k3, ki), dict(workspace=ws)), ((xf.w_v3, c2d, vti), dict(workspace=wp)))   # VT[C, slots*hw]
+            # K / V^T rows: `ns` short ones (hw keys) in front of rows - ns long ones (R hw keys)
+            ki3 = ki[ns * hw:].view(rows - ns, nk, C)
+            vti3 = vti[:, ns * hw:].unflatten(1, (rows - ns, nk)).permute(1, 0, 2)
+            short = None
+            if ns:
+                short = (ki[: ns * hw].view(ns, hw, C), vti[:, : ns * hw].unflatten(1, (ns, hw)).permute(1, 0, 2))
             q3 = q3buf.view(B, hw, C)
             if paired:
                 ops.attention_pair((q3, ki3, vti3, a3v, None), (q2.view(B, hw, C), kt3, vtt3, a2v, S), heads, scale)
             elif self.attn3_share is not None:    # one launch: batch b reads context row b (b < rows) or b - (B - rows)
-                self._attention(q3, ki3, vti3, a3v, heads, scale)
+                self._attention(q3, ki3, vti3, a3v, heads, scale, short=short)
             else:
                 for q0, n, c0 in self.attn3_groups:
                     self._attention(q3[q0:q0 + n], ki3[c0:c0 + n], vti3[c0:c0 + n], a3v[q0:q0 + n], heads, scale)
@@ -809,6 +861,8 @@ class UNetEngine:
 
     def features(self, slot: int = 0) -> Dict[str, torch.Tensor]:  # fp16 views
         """The 16 harvested [B, HW, C] features of slot r, as views into the context buffers."""
+        if self.ctx_short:
+            raise ValueError("features(): this engine's context rows have different slot counts (ctx_short)")
         out = {}
         for k, (n, _) in feature_shapes(self.arch, self.H, self.W).items():
             out[k] = self.ctx[k][:, slot * n:(slot + 1) * n, :]

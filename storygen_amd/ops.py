@@ -348,7 +348,8 @@ def conv_out(x: torch.Tensor, w_krsc: torch.Tensor, bias: torch.Tensor, out_nchw
     return out_nchw
 
 
-def _attn_fwd_desc(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, heads: int, scale: float, nk: Optional[int]):
+def _attn_fwd_desc(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, heads: int, scale: float, nk: Optional[int],
+                   short: Optional[tuple] = None):
     for n, t in (("q", q), ("k", k), ("vt", vt), ("out", out)):
         _f16(t, n)
         if t.dim() != 3 or t.stride(-1) != 1:
@@ -367,15 +368,31 @@ def _attn_fwd_desc(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torc
     d.B, d.H, d.Nq, d.Nk, d.D = B, heads, Nq, Nk, D
     d.kv_batches = Bk
     d.scale = scale
-    return d, 4.0 * B * heads * Nq * Nk * D, f"B{B} H{heads} Nq{Nq} Nk{Nk}"
+    keys = [Nk] * B
+    if short is not None:          # leading K/V rows with their own key count (sg_attn_desc.k2 ...)
+        k2, vt2 = short
+        _f16(k2, "k2"), _f16(vt2, "vt2")
+        n2, Nk2 = k2.shape[0], k2.shape[1]
+        if (k2.dim() != 3 or vt2.dim() != 3 or k2.shape[2] != Cq or tuple(vt2.shape[:2]) != (n2, Cq) or vt2.shape[2] < ((Nk2 + 7) & ~7)
+                or k2.stride(-1) != 1 or vt2.stride(-1) != 1 or k2.stride(1) != k.stride(1) or vt2.stride(1) != vt.stride(1)):
+            raise ValueError("attention: short rows must be [n, Nk2, H*D] / [n, H*D, Nk2] views with the token / row strides of k / vt")
+        d.k2, d.bsk2, d.vt2, d.bsvt2 = k2.data_ptr(), k2.stride(0), vt2.data_ptr(), vt2.stride(0)
+        d.Nk2, d.kv2_batches = Nk2, n2
+        d.kv_batches = Bk = Bk + n2
+        keys = [Nk2 if (b if b < Bk else b - (B - Bk)) < n2 else Nk for b in range(B)]
+    if d.kv_batches > B:
+        raise ValueError(f"attention: {d.kv_batches} K/V rows for {B} query batches")
+    shape = f"B{B} H{heads} Nq{Nq} Nk{Nk}" + (f" ({d.kv2_batches}x Nk{d.Nk2})" if short is not None else "")
+    return d, 4.0 * heads * Nq * D * float(sum(keys)), shape
 
 
 def attention(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch.Tensor, heads: int, scale: float,
-              nk: Optional[int] = None) -> torch.Tensor:
+              nk: Optional[int] = None, short: Optional[tuple] = None) -> torch.Tensor:
     """q [B,Nq,H*D], k [Bk,Nk',H*D] (token- and batch-strided views allowed), vt [Bk,H*D,Nk''] = V transposed (keys
     contiguous; rows finite up to nk rounded up to 8), out [B,Nq,H*D].  nk = number of valid keys (default k.shape[1]).
-    Bk < B: query batch b uses K/V batch (b if b < Bk else b - (B - Bk))."""
-    d, flops, shape = _attn_fwd_desc(q, k, vt, out, heads, scale, nk)
+    Bk < B: query batch b uses K/V batch (b if b < Bk else b - (B - Bk)).
+    short = (k2 [n, Nk2, H*D], vt2 [n, H*D, Nk2]): n more K/V rows IN FRONT of k's, with Nk2 keys each (all of them valid)."""
+    d, flops, shape = _attn_fwd_desc(q, k, vt, out, heads, scale, nk, short)
     with _timed(f"attention_d{d.D}", flops, shape):
         check(lib.sg_attn_fwd_f16(C.byref(d), _stream()), "sg_attn_fwd_f16")
     return out
@@ -857,7 +874,7 @@ def debug_set_option(name: str, value: int) -> None:
 # library no longer reads the environment: this maps the variables onto sg_debug_set_option, and only when a tool asks for it.
 _ENV_OPTIONS = {"SG_NO_NMAJOR": "no_nmajor", "SG_NO_PIPE": "no_pipe", "SG_NO_SPLIT": "no_split",
                 "SG_ATTN_SUB2": "attn_sub2", "SG_ATTN_PRIO": "attn_prio", "SG_ATTN_D80": "attn_d80", "SG_ATTN_D160": "attn_d160",
-                "SG_NO_GN_FUSED": "gn_no_fused", "SG_GN_WIDE": "gn_wide", "SG_GN_FUSED_MAX": "gn_fused_max"}
+                "SG_ATTN_LEAN": "attn_lean", "SG_ATTN_D40_GENERAL": "attn_d40_general", "SG_NO_GN_FUSED": "gn_no_fused", "SG_GN_WIDE": "gn_wide", "SG_GN_FUSED_MAX": "gn_fused_max"}
 
 
 def apply_env_options() -> dict:

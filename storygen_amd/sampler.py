@@ -113,42 +113,46 @@ class StoryGenSampler:
     def _plan(self, stage: str, share_zero: bool):
         """Which reference samples are computed and where their features go.
 
-        Returns (kind, frame, sample) per reference-pass sample u, the harvest ops, the number of context rows and
-        the main pass's attn3 groups.  kind 0 = zero-image latent with the uncond embedding, 1 = prior frame `frame`
-        with its prompt.  Main-pass sample order is [uncond/zero-image x N, uncond/frames x N, text/frames x N]
-        (pipeline.py:448-450 with the context rows of :440-443)."""
+        Returns (kind, frame, sample) per reference-pass sample u, the harvest ops (src, src_step, ctx row, first slot, count),
+        the number of context rows, the main pass's attn3 groups and the number of SHORT context rows.  kind 0 = zero-image
+        latent with the uncond embedding, 1 = prior frame `frame` with its prompt.  Main-pass sample order is
+        [uncond/zero-image x N, uncond/frames x N, text/frames x N] (pipeline.py:448-450 with the context rows of :440-443).
+
+        The samples are ordered so that sample u's features belong in context slot u (rows in order, frame slots inside a row): the
+        reference pass then writes its fp16 feature copies straight into the context buffer (engine: HarvestPlan.direct) and no copy
+        kernel runs.  With `share_zero` the zero-image rows are SHORT: as written their R frame slots hold R copies of the same
+        feature map, and softmax over R copies of the same keys equals softmax over one copy, so those rows keep ONE slot and the
+        image cross-attention of the zero-image CFG branch runs over HW keys instead of R * HW (sg_attn_desc.k2)."""
         N, R = self.N, self.R
         units, hops = [], []
+        short = 0
         if self.dedup:
             rows = 2 * N                      # context rows: [zero-image features x N | frame features x N]
             groups = [(0, 2 * N, 0), (2 * N, N, N)]
             if share_zero:
+                short = N
                 for n in range(N):
                     units.append((0, 0, n))
-                    hops.append((n, 0, n, 0, R))                     # one sample -> all R slots of row n
+                    hops.append((n, 0, n, 0, 1))                     # one sample -> the single slot of short row n
             else:
-                for i in range(R):
-                    for n in range(N):
+                for n in range(N):
+                    for i in range(R):
                         units.append((0, i, n))
-                for n in range(N):
-                    hops.append((n, N, n, 0, R))                     # samples n, n+N, ... -> slots 0..R-1 of row n
+                    hops.append((n * R, 1, n, 0, R))                 # samples n R .. n R + R - 1 -> slots 0..R-1 of row n
             base = len(units)
-            for i in range(R):
-                for n in range(N):
-                    units.append((1, i, n))
             for n in range(N):
-                hops.append((base + n, N, N + n, 0, R))
+                for i in range(R):
+                    units.append((1, i, n))
+                hops.append((base + n * R, 1, N + n, 0, R))
         else:
             rows = 3 * N
             groups = [(0, 3 * N, 0)]
-            for i in range(R):                 # pass i = [zero_i | img_i | img_i], exactly as written
-                for kind in (0, 1, 1):
-                    for n in range(N):
-                        units.append((kind, i, n))
-            for j in range(3):
+            for j in range(3):                 # all 3 N R samples of the loop as written (pass i = [zero_i | img_i | img_i]), row-major
                 for n in range(N):
-                    hops.append((j * N + n, 3 * N, j * N + n, 0, R))
-        return units, hops, rows, groups
+                    for i in range(R):
+                        units.append((0 if j == 0 else 1, i, n))
+                    hops.append(((j * N + n) * R, 1, j * N + n, 0, R))
+        return units, hops, rows, groups, short
 
     def _build(self, stage: str, share_zero: bool):
         key = (stage if not share_zero else "shared-zero", self.dedup) if self.dedup else ("as-written", False)
@@ -170,14 +174,14 @@ class StoryGenSampler:
             self.params = torch.zeros(self.n_par, dtype=torch.float32, device=self.dev)
             self.layout, self.graph, self.graphs, self.g_ref, self.g_main = key, None, [], [], []
             return
-        units, hops, rows, groups = self._plan(stage, share_zero)
+        units, hops, rows, groups, short = self._plan(stage, share_zero)
         G = self.G
         self.U0 = len(units)                  # reference samples of ONE step; the reference engine batches G steps of them
         units = units * G                     # unit g*U0 + u = sample u of the g-th step of a group
         self.units, self.U = units, len(units)
         kw = dict(weights=self.weights, fp8_attention=self.fp8_attention)
         self.main = UNetEngine(self.arch, None, self.dev, self.B, self.h, self.w, self.R, self.S, ctx_rows=rows,
-                               attn3_groups=groups, **kw)
+                               attn3_groups=groups, ctx_short=short, **kw)
         self.ref = UNetEngine(self.arch, None, self.dev, self.U, self.h, self.w, 0, self.S, **kw)
         # context sets: the main pass of step k reads set k%2 (only one set without overlap)
         self.ctx_sets = [self.main.ctx]
@@ -185,10 +189,11 @@ class StoryGenSampler:
             for _ in range(2 * G - 1):         # G = 1: sets k%2; G > 1: set = step mod 2G
                 self.ctx_sets.append({k: torch.empty_like(v) for k, v in self.main.ctx.items()})
         # attn3 K / V^T per context set: computed by the reference pass right after each feature is harvested
-        self.kv_sets = [{k: (torch.empty(v.shape[0] * v.shape[1], v.shape[2], dtype=v.dtype, device=self.dev),
-                             torch.empty(v.shape[2], v.shape[0] * v.shape[1], dtype=v.dtype, device=self.dev))
+        self.kv_sets = [{k: (torch.empty(v.numel() // v.shape[-1], v.shape[-1], dtype=v.dtype, device=self.dev),
+                             torch.empty(v.shape[-1], v.numel() // v.shape[-1], dtype=v.dtype, device=self.dev))
                          for k, v in c.items()} for c in self.ctx_sets]
-        self.plans = [HarvestPlan(c, hops, kv, src_offset=(i % G) * self.U0)
+        # G = 1: sample u of the reference pass IS context slot u (_plan) -> its feature copies are written in place (direct)
+        self.plans = [HarvestPlan(c, hops, kv, src_offset=(i % G) * self.U0, short=short, slots_per_row=self.R, direct=(G == 1))
                       for i, (c, kv) in enumerate(zip(self.ctx_sets, self.kv_sets))]
         self.plan = self.plans[0]
         # side streams for the independent branches inside a pass (engine.forward(side=...)).  In overlap mode the

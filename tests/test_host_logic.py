@@ -298,14 +298,23 @@ def test_reference_batch_layout_reproduces_the_as_written_context(N, R, mode):
     from storygen_amd.sampler import StoryGenSampler
     smp = object.__new__(StoryGenSampler)
     smp.N, smp.R, smp.dedup = N, R, mode != "as-written"
-    units, hops, rows, groups = smp._plan("multi-image-condition", mode == "shared-zero")
+    units, hops, rows, groups, short = smp._plan("multi-image-condition", mode == "shared-zero")
     assert len(units) == {"shared-zero": N * (1 + R), "dedup": 2 * N * R, "as-written": 3 * N * R}[mode]
-    ctx = [[None] * R for _ in range(rows)]
+    assert short == (N if mode == "shared-zero" else 0)
+    # short rows (the zero-image rows of shared-zero mode) hold ONE slot: as written their R slots are R copies of one feature map
+    # and softmax over R copies of the same keys is softmax over one copy
+    ctx = [[None] * (1 if row < short else R) for row in range(rows)]
+    slot_of_unit = {}
     for src, step, row, slot, cnt in hops:
         for j in range(cnt):
             assert ctx[row][slot + j] is None, "a context slot is written twice"
             ctx[row][slot + j] = units[src + j * step]
+            slot_of_unit[src + j * step] = (row if row < short else short + (row - short) * R + slot + j)
     assert all(c is not None for r in ctx for c in r), "a context slot is never written"
+    # the reference batch is ordered like the context buffer: sample u belongs in flat slot u (direct harvest, no copy kernel)
+    assert slot_of_unit == {u: u for u in range(len(units))}
+    for row in range(short):
+        ctx[row] = ctx[row] * R
     row_of = {}
     for q0, n, c0 in groups:
         for k in range(n):

@@ -606,6 +606,84 @@ def test_attention_shared_kv_batches(gpu, D, Nq, Nk):
     check(out, att.transpose(1, 2).reshape(3, Nq, C), "attention shared kv")
 
 
+@pytest.mark.parametrize("D,Nq,hw,R", [(40, 4096, 256, 3), (40, 320, 64, 5), (80, 1024, 128, 3), (160, 256, 72, 2)])
+def test_attention_short_kv_rows(gpu, D, Nq, hw, R):
+    """sg_attn_desc.k2 (round 4): query batches [u/zero, u/img, t/img] over K/V rows [zero (hw keys) | frames (R hw keys)] laid out
+    back to back in ONE flat projection output, as the main pass lays them out — against torch on the same rows, and against the
+    as-written form of the zero-image branch (R copies of its hw keys: softmax over R copies of the same keys is softmax over one)."""
+    from storygen_amd import ops
+    H = 8
+    C = H * D
+    T = hw + R * hw
+    q = rnd((3, Nq, C), gpu, 1.5, seed=1)
+    kflat, vflat = rnd((T, C), gpu, 1.5, seed=2), rnd((T, C), gpu, 1.0, seed=3)
+    vt = vflat.t().contiguous()                                        # [C, T]
+    k_s, k_l = kflat[:hw].view(1, hw, C), kflat[hw:].view(1, R * hw, C)
+    vt_s = vt[:, :hw].unflatten(1, (1, hw)).permute(1, 0, 2)
+    vt_l = vt[:, hw:].unflatten(1, (1, R * hw)).permute(1, 0, 2)
+    out = torch.full((3, Nq, C), float("nan"), dtype=torch.float16, device=gpu)
+    ops.attention(q, k_l, vt_l, out, H, D ** -0.5, short=(k_s, vt_s))
+
+    def heads(t):
+        return t.float().view(t.shape[0], t.shape[1], H, D).transpose(1, 2)
+
+    def ref(qq, kk, vv):
+        return (torch.softmax(heads(qq) @ heads(kk).transpose(-1, -2) * D ** -0.5, -1) @ heads(vv)).transpose(1, 2).reshape(qq.shape[0], Nq, C)
+    v_s, v_l = vflat[:hw].view(1, hw, C), vflat[hw:].view(1, R * hw, C)
+    check(out[:1], ref(q[:1], k_s, v_s), "short row")
+    check(out[1:], ref(q[1:], k_l.expand(2, -1, -1), v_l.expand(2, -1, -1)), "long rows")
+    # the as-written zero-image branch: R copies of the same keys
+    rep = torch.full((1, Nq, C), float("nan"), dtype=torch.float16, device=gpu)
+    k_rep, v_rep = k_s.repeat(1, R, 1), v_s.repeat(1, R, 1)
+    ops.attention(q[:1], k_rep, _vt(v_rep), rep, H, D ** -0.5)
+    check(out[:1], rep, "one copy of the keys vs R copies", l2=3e-4, mx=2e-3)
+
+
+@pytest.mark.parametrize("shift", [-40.0, 25.0])
+def test_attention_d40_fast_path_extreme_maxima(gpu, shift):
+    """The D = 40 path keeps the running maximum in two fp16 contraction slots (hi + lo) and starts from a placeholder of 0: rows whose
+    scores are all far below zero (exp2 of the raw first tile underflows) or far above it (the maximum needs both halves), with the
+    maximum moving between tiles, must come out like torch's softmax."""
+    from storygen_amd import ops
+    B, H, Nq, Nk, D = 1, 8, 256, 448, 40
+    C = H * D
+    q, k, v = rnd((B, Nq, C), gpu, 1.0, seed=7), rnd((B, Nk, C), gpu, 1.0, seed=8), rnd((B, Nk, C), gpu, seed=9)
+    qh, kh = q.view(B, Nq, H, D), k.view(B, Nk, H, D)
+    # a common component along one direction shifts every score of a row by `shift` * |row scale| (log2 units: x 1.44 / sqrt(40))
+    qh[..., 0] = 8.0
+    kh[..., 0] = shift
+    kh[0, 200:, :, 0] = shift * 1.5 if shift > 0 else shift * 0.5      # later tiles: higher maximum -> rescale with a large delta
+    out = torch.empty(B, Nq, C, dtype=torch.float16, device=gpu)
+    ops.attention(q, k, _vt(v), out, H, D ** -0.5)
+
+    def heads(t):
+        return t.float().view(B, -1, H, D).transpose(1, 2)
+    ref = (torch.softmax(heads(q) @ heads(k).transpose(-1, -2) * D ** -0.5, -1) @ heads(v)).transpose(1, 2).reshape(B, Nq, C)
+    check(out, ref, "attention extreme maxima", l2=2e-3, mx=6e-3)
+
+
+def test_attention_d40_fast_path_vs_general_path(gpu):
+    """Development switch attn_d40_general: the round-3 softmax (exponent FMA, row-sum adds) and the round-4 fast path (both in the
+    MFMAs) on the same operands."""
+    from storygen_amd import ops
+    B, H, Nq, Nk, D = 2, 8, 4096, 1000, 40
+    C = H * D
+    q, k, v = rnd((B, Nq, C), gpu, 1.5, seed=1), rnd((B, Nk, C), gpu, 1.5, seed=2), rnd((B, Nk, C), gpu, seed=3)
+    outs = []
+    try:
+        for general, lean in ((1, 0), (0, 0), (0, 1)):
+            ops.debug_set_option("attn_d40_general", general)
+            ops.debug_set_option("attn_lean", lean)
+            o = torch.empty(B, Nq, C, dtype=torch.float16, device=gpu)
+            ops.attention(q, k, _vt(v), o, H, D ** -0.5, nk=Nk)
+            outs.append(o)
+    finally:
+        ops.debug_set_option("attn_d40_general", 0)
+        ops.debug_set_option("attn_lean", 0)
+    check(outs[1], outs[0], "fast vs general", l2=5e-4, mx=3e-3)
+    assert torch.equal(outs[1], outs[2]), "the lean instantiation computes the same values in the same order"
+
+
 @pytest.mark.parametrize("D,Nq,Nk_img,Bk", [(40, 4096, 1024, 2), (40, 1024, 3072, 3), (80, 1024, 640, 2), (160, 256, 768, 3), (160, 64, 192, 2)])
 def test_attention_pair_text_and_image_in_one_launch(gpu, D, Nq, Nk_img, Bk):
     """sg_attn_fwd_pair_f16: the text (77 keys, one K/V row per query batch) and the image cross-attention
