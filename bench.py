@@ -127,7 +127,8 @@ def in_situ_roofline(sampler):
     # attention head dims are instantiations of attn_fwd_kernel
     kernels = {}
     for name, f in fam.items():
-        kname = "mma_pipe_kernel (gemm + conv3x3)" if name in ("gemm", "conv3x3") else "attn_fwd_kernel"
+        kname = ("mma_pipe_kernel (gemm + conv3x3)" if name in ("gemm", "conv3x3") else
+                 "ff_fused_kernel" if name == "ff_fused" else "attn_fwd_kernel")
         k = kernels.setdefault(kname, {"launches": 0, "ms": 0.0, "gflop": 0.0})
         for key in k:
             k[key] += f[key]
@@ -248,6 +249,12 @@ def main():
                     help="A/B (changes results, never the contract line): fp16 residual stream inside the transformer blocks")
     ap.add_argument("--no-gemm-pairs", action="store_true", help="A/B: q|k + V^T, q2 + q3, k3 + v3^T as separate launches")
     ap.add_argument("--attn-pair", action="store_true", help="A/B: text and image cross-attention of a block in one launch")
+    ap.add_argument("--no-short-rows", action="store_true",
+                    help="A/B: the zero-image context rows keep R copies of their feature map, as written (default: one copy — softmax over R "
+                         "copies of the same keys equals softmax over one)")
+    ap.add_argument("--no-splitk-in-gn", action="store_true",
+                    help="A/B: split-K convolutions at the 16x16 / 8x8 levels run their own second pass instead of leaving it to the GroupNorm")
+    ap.add_argument("--no-ff-fused", action="store_true", help="A/B: GEGLU feed-forward of the 64x64 level as two GEMM launches")
     ap.add_argument("--optimizer", choices=("none", "adamw", "adamw8bit"), default="none",
                     help="with --train-step: include the reference's clip_grad_norm_ + optimizer step (storygen_amd.training.Stage2Trainer)")
     ap.add_argument("--train-step", action="store_true",
@@ -303,6 +310,12 @@ def main():
     if args.fp16_block_stream:
         from storygen_amd import engine as _engine
         _engine.FP16_BLOCK_STREAM = True
+    if args.no_splitk_in_gn:
+        from storygen_amd import engine as _engine
+        _engine.SPLITK_IN_GN = False
+    if args.no_ff_fused:
+        from storygen_amd import engine as _engine
+        _engine.FF_FUSED = False
 
     hw, n_ref = (96, 5) if args.config5_shape else (HW, R)
     # per-sample GFLOP of one ref / main pass: 64x64 R=3, or 96x96 R=5
@@ -317,7 +330,8 @@ def main():
     warmup_run = -(-args.warmup // G) * G          # the timed window starts on a group boundary
     sampler = StoryGenSampler(arch, sd, dev, N_PER_GPU, hw, hw, n_ref, use_graph=not args.no_graph, dedup=not args.no_dedup,
                               overlap=not args.no_overlap, ref_ahead=G, split_graphs=args.split_graphs,
-                              stream_priority=args.stream_priority, fp8_attention=args.fp8_attention)
+                              stream_priority=args.stream_priority, fp8_attention=args.fp8_attention,
+                              short_rows=not args.no_short_rows)
     n_sched = max(T, args.steps + warmup_run)
     sampler.prepare(inputs, n_sched, args.stage, 7.5, 3.5)
 
@@ -368,7 +382,9 @@ def main():
                        "overlap_ref_pass_of_next_step": sampler.overlap, "ref_ahead": G, "warmup_run": warmup_run,
                        "split_graphs": sampler.split, "stream_priority": sampler.stream_priority,
                        "paired_gemm_launches": not args.no_gemm_pairs, "paired_text_image_attention": args.attn_pair,
-                       "groupnorm_stats_from_epilogues": not args.no_gn_epilogue, "fp16_block_stream": args.fp16_block_stream},
+                       "groupnorm_stats_from_epilogues": not args.no_gn_epilogue, "fp16_block_stream": args.fp16_block_stream,
+                       "short_zero_image_rows": not args.no_short_rows, "splitk_reduce_in_groupnorm": not args.no_splitk_in_gn,
+                       "fused_feed_forward_64x64": not args.no_ff_fused},
             "tflop_per_step_as_written": round(step_tflop, 3),
             "final_allgather_ms": round(gather_ms, 3), "latents_gathered": int(final.shape[0]), "latents_finite": finite,
             "latents_distinct_per_rank": distinct,

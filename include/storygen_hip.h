@@ -169,10 +169,18 @@ typedef struct sg_conv3x3_desc {
     int32_t        tile_m, tile_n, tile_waves;   /* as in sg_gemm_desc */
     void*          workspace; size_t workspace_bytes;   /* sg_gemm_workspace_bytes(B*Ho*Wo, Cout, split_k) */
     float*         stats;             /* optional GroupNorm partial statistics of y, as sg_gemm_desc.stats (image = Ho*Wo rows) */
+    int32_t        defer_reduce;      /* 1: a split-K launch stops after writing its fp32 partial tiles [splits][B*Ho*Wo][Cout] into the
+                                         workspace: bias / rowbias / res1 / y are NOT applied or written — the consumer does it
+                                         (sg_groupnorm_desc.split_*: the one-launch GroupNorm sums the slices in slice order while it
+                                         loads its slab, so conv1 -> norm2 of a ResnetBlock2D at the 16x16 / 8x8 levels costs no
+                                         second pass).  Only valid when sg_conv3x3_planned_splits(d) > 1 (else SG_EINVAL). */
 } sg_conv3x3_desc;
 
 int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream);
 int sg_conv3x3_stats_tile_rows(const sg_conv3x3_desc* d);
+/* Number of K slices sg_conv3x3_nhwc_f16 will use for this descriptor (1 = no split-K; the plan is a pure function of the descriptor
+ * and the development options).  No launch happens.  < 0 on an invalid descriptor. */
+int sg_conv3x3_planned_splits(const sg_conv3x3_desc* d);
 
 /* conv_in: x fp32 NCHW [B, Cin<=8, H, W] -> y NHWC [B,H,W,Cout] (fp16, or fp32 when y_f32), 3x3 pad 1
  * (unet_2d_condition.py:124,411).
@@ -183,6 +191,29 @@ int sg_conv_in_f16(const float* x_nchw, const sg_half* w_kn, const sg_half* bias
  * w: fp16 [Cout, 3, 3, Cin]; bias fp16 [Cout]; Cin % 8 == 0. */
 int sg_conv_out_f16(const sg_half* x, int64_t ldx, const sg_half* w, const sg_half* bias, float* y_nchw,
                     int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, sg_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Fused GEGLU feed-forward of a BasicTransformerBlock (round 4):
+ *   y[m, :] = Linear2( a * gelu(g) ) + b2 + x[m, :],   [a | g] = Linear1( LayerNorm(x[m, :]) ) + b1
+ * Replaces norm3 -> ff.net.0 (GEGLU: Linear(C, 8C), chunk, gelu) -> ff.net.2 (Linear(4C, C)) -> + hidden_states of
+ * model/attention.py:298-300 (FeedForward / GEGLU: :365-393) in ONE launch: the [M, 4C] intermediate is never materialised and the
+ * LayerNorm is evaluated in registers (exact two-pass).  x is the fp32 residual stream; y is fp16 (it only feeds proj_out).
+ * wpack = the weight stream of storygen_amd/repack.ff_fused_pack(gamma (.) W1 interleaved, W1 beta + b1, W2): per 32 hidden units the
+ * byte-for-byte LDS images of the W1 rows (values | gates, K-slab-wise, rows bit-permuted) and of W2's columns, followed by the chunk's
+ * 64 fp32 bias terms (layout: repack.ff_fused_pack's docstring); sg_ff_fused_pack_bytes(C) bytes (0: C not supported).
+ * Built for C = 320 (the 64x64 level, where M = B * 4096 rows give every wave 32 rows of its own); other widths return SG_EUNSUP and
+ * the caller runs the two GEMMs.  GELU uses erf to 1.5e-7 (Abramowitz-Stegun 7.1.26). */
+typedef struct sg_ff_desc {
+    const float*   x;  int64_t ldx;      /* [M, C] fp32 */
+    const void*    wpack; size_t wpack_bytes;
+    const sg_half* b2;                   /* [C] bias of the second linear */
+    sg_half*       y;  int64_t ldy;      /* [M, C] fp16 */
+    int32_t        M, C;
+    float          eps;                  /* LayerNorm eps */
+} sg_ff_desc;
+
+size_t sg_ff_fused_pack_bytes(int32_t C);
+int sg_ff_geglu_fused_f16(const sg_ff_desc* d, sg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Fused attention (flash-style, online softmax in fp32, no mask, no dropout):
@@ -251,9 +282,23 @@ typedef struct sg_groupnorm_desc {
      * pstats[0] == NULL: none (the kernel makes its own pass).  Only the wide variant uses them (sg_groupnorm_uses_pstats). */
     const float* pstats[2];
     int32_t pstats_rows[2], pstats_c0[2], pstats_nc[2];
+    /* x as the UNREDUCED output of a split-K convolution (sg_conv3x3_desc.defer_reduce), one-launch variant only
+     * (sg_groupnorm_is_fused): x[b, p, c] = sum over the split_count fp32 slices split_ws[z][b*HW + p][c] (slice order) + split_bias[c]
+     * + split_rowbias[b][c] + split_res[b*HW + p][c] — the additions of the convolution's own second pass, in its order, so the
+     * values are bit-identical to reduce-then-normalise.  split_out (optional) receives the reduced tensor (fp32, or fp16 when
+     * split_out_f32 = 0; with an fp16 split_out — or none and split_round_f16 = 1 — the normalisation sees the fp16-rounded values,
+     * exactly as if the tensor had been stored and read back).  x / ldx / x_f32 are ignored.  split_ws == NULL: x is a plain tensor. */
+    const float*   split_ws; int32_t split_count;
+    const sg_half* split_bias;
+    const float*   split_rowbias; int64_t split_rowbias_ld;
+    const void*    split_res; int64_t split_ldr; int32_t split_res_f32;
+    void*          split_out; int64_t split_ldo; int32_t split_out_f32;
+    int32_t        split_round_f16;
 } sg_groupnorm_desc;
 
 int sg_groupnorm_nhwc_f16(const sg_groupnorm_desc* d, sg_stream_t stream);
+/* 1 when a GroupNorm of this shape runs as the one-launch kernel (slab of one (batch, group) in registers), else 0 */
+int sg_groupnorm_is_fused(int32_t HW, int32_t C, int32_t groups);
 size_t sg_groupnorm_workspace_bytes(int32_t B, int32_t groups);
 /* 1 if a GroupNorm of this shape would consume producer statistics (the two-launch "wide" variant), 0 if it runs the
  * single-launch register-resident variant, which reads x once anyway: producers then need not emit any. */
@@ -511,6 +556,9 @@ int sg_debug_fastdiv_selftest(void);
  * instrumented kernels and answers SG_EINVAL. */
 int sg_debug_gemm_anatomy(const sg_gemm_desc* d, void* prof, size_t prof_bytes, sg_stream_t stream);
 int sg_debug_conv_anatomy(const sg_conv3x3_desc* d, void* prof, size_t prof_bytes, sg_stream_t stream);
+/* the same for sg_ff_geglu_fused_f16: 8 uint64 per wave ([workgroup][wave][8]: iterations, vmcnt wait, barrier, DMA issue + d1, GEMM1 (+ GEGLU),
+ * GEMM2, prologue, total cycles) */
+int sg_debug_ff_anatomy(const sg_ff_desc* d, void* prof, size_t prof_bytes, sg_stream_t stream);
 /* Development options — kernel-variant selectors for the tuning / anatomy tools and the parity tests.  Process-global; the
  * library never reads the environment (storygen_amd/ops.py maps the SG_* variables of its tools onto this call).  name / value:
  *   "tile_m", "tile_n"   force a GEMM / conv tile (same effect as sg_debug_set_tile)      "no_pipe", "no_split"  1 = disable

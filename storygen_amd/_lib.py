@@ -52,6 +52,7 @@ class ConvDesc(C.Structure):
         ("tile_m", C.c_int32), ("tile_n", C.c_int32), ("tile_waves", C.c_int32),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("stats", C.c_void_p),
+        ("defer_reduce", C.c_int32),
     ]
 
 
@@ -69,6 +70,12 @@ class GroupNormDesc(C.Structure):
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("pstats", C.c_void_p * 2),
         ("pstats_rows", C.c_int32 * 2), ("pstats_c0", C.c_int32 * 2), ("pstats_nc", C.c_int32 * 2),
+        ("split_ws", C.c_void_p), ("split_count", C.c_int32),
+        ("split_bias", C.c_void_p),
+        ("split_rowbias", C.c_void_p), ("split_rowbias_ld", C.c_int64),
+        ("split_res", C.c_void_p), ("split_ldr", C.c_int64), ("split_res_f32", C.c_int32),
+        ("split_out", C.c_void_p), ("split_ldo", C.c_int64), ("split_out_f32", C.c_int32),
+        ("split_round_f16", C.c_int32),
     ]
 
 
@@ -98,6 +105,17 @@ class AttnDesc(C.Structure):
         ("k2", C.c_void_p), ("bsk2", C.c_int64),
         ("vt2", C.c_void_p), ("bsvt2", C.c_int64),
         ("Nk2", C.c_int32), ("kv2_batches", C.c_int32),
+    ]
+
+
+class FfDesc(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64),
+        ("wpack", C.c_void_p), ("wpack_bytes", C.c_size_t),
+        ("b2", C.c_void_p),
+        ("y", C.c_void_p), ("ldy", C.c_int64),
+        ("M", C.c_int32), ("C", C.c_int32),
+        ("eps", C.c_float),
     ]
 
 
@@ -142,7 +160,11 @@ SIGNATURES = {
     "sg_gemm_f16": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p]),
     "sg_gemm_stats_tile_rows": (C.c_int, [C.POINTER(GemmDesc)]),
     "sg_conv3x3_stats_tile_rows": (C.c_int, [C.POINTER(ConvDesc)]),
+    "sg_conv3x3_planned_splits": (C.c_int, [C.POINTER(ConvDesc)]),
     "sg_groupnorm_uses_pstats": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "sg_groupnorm_is_fused": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
+    "sg_ff_fused_pack_bytes": (C.c_size_t, [C.c_int32]),
+    "sg_ff_geglu_fused_f16": (C.c_int, [C.POINTER(FfDesc), C.c_void_p]),
     "sg_gemm_pair_f16": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(GemmDesc), C.c_void_p]),
     "sg_gemm_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
     "sg_conv3x3_nhwc_f16": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p]),
@@ -210,6 +232,7 @@ SIGNATURES = {
     "sg_debug_set_option": (C.c_int, [C.c_char_p, C.c_int64]),
     "sg_debug_gemm_anatomy": (C.c_int, [C.POINTER(GemmDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
     "sg_debug_conv_anatomy": (C.c_int, [C.POINTER(ConvDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
+    "sg_debug_ff_anatomy": (C.c_int, [C.POINTER(FfDesc), C.c_void_p, C.c_size_t, C.c_void_p]),
 }
 
 _lib = None

@@ -22,14 +22,17 @@ CSRC = os.path.join(PKG, "csrc")
 LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libstorygen_hip.so")
 LIB_EXP = os.path.join(LIBDIR, "libstorygen_hip_exp.so")      # --experiments: a SEPARATE library that only tools/anatomy.py loads
-SOURCES = ["gemm_conv.hip", "attention.hip", "attention_f8.hip", "norm.hip", "misc.hip", "backward.hip", "attention_bwd.hip", "encoders.hip", "optim.hip"]
+SOURCES = ["gemm_conv.hip", "attention.hip", "attention_f8.hip", "norm.hip", "misc.hip", "backward.hip", "attention_bwd.hip", "encoders.hip", "optim.hip", "ff_fused.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
          "-Rpass-analysis=kernel-resource-usage"]          # remarks only: parsed into lib/kernel_resources.json
 RESOURCES = os.path.join(LIBDIR, "kernel_resources.json")
 # attention keeps its O^T accumulators live across the softmax VALU code of every tile: with MFMA results in AGPRs the
 # compiler shuttles them through v_accvgpr_read/write around each tile (137 of 281 VALU instructions per tile,
 # profiles/r01d_pmc_kernels.txt); the VGPR form of MFMA (gfx950's register file is unified) removes all of them.
-EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "attention_f8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "attention_f8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               # the GELU polynomial of the fused feed-forward runs beside MFMAs: packed fp32 VALU (what SLP vectorisation makes of it)
+               # is slower there than the scalar forms (MI355X_MICROARCH.md, price of fillers beside MFMAs)
+               "ff_fused.hip": ["-fno-slp-vectorize"]}
 
 
 def _hipcc() -> str:

@@ -42,7 +42,7 @@ struct SgOptions {
     int attn_d40_general = 0;          // 1 = the D = 40 launches use the general softmax path (A/B against the padded-dimension fast path)
     int gn_no_fused = 0, gn_wide = 1;
     int gn_no_splitk_in = 0;           // reserved (A/B switches of round 4)
-    int ff_fused = 1;
+    int ff_variant = 0;                // fused feed-forward: bit 0 = refill spread over the k-steps, bit 1 = fragments two k-steps ahead
     long gn_fused_max = -1;            // -1 = the kernel's default threshold
 };
 SgOptions& sg_options();

@@ -78,6 +78,7 @@ struct MmaParams {
     const void* res2; long ldr2;
     // decomposition
     float* ws; int splits; int kt_per_split; int tiles_m, tiles_n;
+    int defer;                     // split-K: stop after the partial tiles (sg_conv3x3_desc.defer_reduce); the consumer reduces
     float* stats; int stats_batch_rows;   // optional GroupNorm partial statistics of the output (epi_finish), else nullptr
     // LayerNorm folded into this GEMM (sg_gemm_desc.ln_*): consumer side = per-token (mean, M2) partials of the raw operand,
     // c / d vectors of the folded weight; producer side = where to write the partials of THIS output
@@ -1082,6 +1083,7 @@ void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st) {
 thread_local unsigned long long* g_prof = nullptr;     // set by sg_debug_*_anatomy around one launch
 thread_local int g_query_rows = 0;                     // result of a stats query (rows per partial = the tile height), 0 = none
 thread_local bool g_stats_query = false;               // sg_*_stats_tile_rows: plan only, report eligibility instead of failing
+thread_local bool g_plan_query = false;                // sg_conv3x3_planned_splits: plan only, report the number of K slices
 
 // GroupNorm statistics from the epilogue (MmaParams::stats) need whole tiles inside one image and the linear epilogue; a split-K
 // launch emits them from its second pass.  A launch that was asked for them but cannot deliver fails (the caller asks
@@ -1166,6 +1168,12 @@ int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws
         g_query_rows = p.stats ? (pl.splits > 1 ? reduce_stats_rows(p) : pl.bm) : 0;
         return SG_OK;
     }
+    if (g_plan_query) {
+        g_query_rows = pl.splits;
+        return SG_OK;
+    }
+    if (p.defer && pl.splits <= 1)
+        return sg_set_error(SG_EINVAL, "%s: defer_reduce needs a split-K launch (query sg_conv3x3_planned_splits first)", name);
     dim3 grid(p.tiles_m * p.tiles_n * pl.splits);
     if (pipe) {
         if (pl.bm == 256 && pl.bn == 128) launch_pipe<4, 2, CONV>(p, grid, st);
@@ -1181,6 +1189,7 @@ int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws
         else return sg_set_error(SG_EINVAL, "%s: internal: the register-staged kernel has only the 128x128 tile", name);
     }
     SG_CHECK_LAUNCH(name);
+    if (p.defer) return SG_OK;          // the consumer sums the slices (sg_groupnorm_desc.split_ws)
     return launch_reduce(p, st);
 }
 
@@ -1349,6 +1358,8 @@ extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream)
     p.res1 = d->res1; p.ldr1 = d->ldr1;
     SG_REQUIRE(!d->stats || sg_aligned16(d->stats), "sg_conv3x3: stats alignment");
     p.stats = d->stats; p.stats_batch_rows = Ho * Wo;
+    SG_REQUIRE(d->defer_reduce == 0 || (d->defer_reduce == 1 && !d->stats), "sg_conv3x3: defer_reduce is 0 or 1 and excludes stats");
+    p.defer = d->defer_reduce;
     if (int rc = check_tile_hint("sg_conv3x3", d->tile_m, d->tile_n, d->tile_waves)) return rc;
     return launch_mma<true>(p, d->split_k, d->tile_m, d->tile_n, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_conv3x3_nhwc_f16");
 }
@@ -1361,6 +1372,16 @@ extern "C" int sg_gemm_stats_tile_rows(const sg_gemm_desc* d) {
     g_stats_query = true; g_query_rows = 0;
     const int rc = sg_gemm_f16(d, nullptr);
     g_stats_query = false;
+    return rc ? rc : g_query_rows;
+}
+
+extern "C" int sg_conv3x3_planned_splits(const sg_conv3x3_desc* d) {
+    SG_REQUIRE(d != nullptr, "sg_conv3x3_planned_splits: null descriptor");
+    sg_conv3x3_desc q = *d;
+    q.defer_reduce = 0;
+    g_plan_query = true; g_query_rows = 0;
+    const int rc = sg_conv3x3_nhwc_f16(&q, nullptr);
+    g_plan_query = false;
     return rc ? rc : g_query_rows;
 }
 

@@ -19,6 +19,11 @@ struct GnParams {
     // statistics from the producers' epilogues (sg_gemm_desc.stats): source i covers channels [ps_c0[i], ps_c0[i] + ps_nc[i]) of x
     // with per-(row tile of ps_rows[i] pixels, channel) sums: ps[i][((b * tiles_i + tile) * 2 + plane) * ps_nc[i] + (c - ps_c0[i])]
     const float* ps[2]; int ps_rows[2], ps_c0[2], ps_nc[2];
+    // x as the unreduced output of a split-K launch (sg_groupnorm_desc.split_*), gn_fused_kernel<true> only
+    const float* sp_ws; int sp_splits; long sp_MN;
+    const f16* sp_bias; const float* sp_rowbias; long sp_rowbias_ld;
+    const void* sp_res; long sp_ldr; int sp_res_f32;
+    void* sp_out; long sp_ldo; int sp_out_f32, sp_round;
 };
 
 __device__ __forceinline__ float load1f(const void* base, long off, bool f32) {
@@ -252,7 +257,7 @@ __global__ __launch_bounds__(GNW_NT) void gn_stats_wide_kernel(const GnParams p)
 
 __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p) {
     __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
-    __shared__ float s_ps[GNW_NT], s_pq[GNW_NT];
+    __shared__ float s_ps[GNW_NT], s_pq[GNW_NT], s_pn[GNW_NT];
     const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
     const int vpr = p.C >> 3, rpp = GNW_NT / vpr;
     const int my_row = t / vpr, cv = t - my_row * vpr;
@@ -277,13 +282,16 @@ __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p)
     if (active) { gam.u = ldg16(p.gamma + c0); bet.u = ldg16(p.beta + c0); }
     if (p.ps[0]) {
         // Statistics from the producers' partials (fused epilogues and split-K second passes).  Entry e of group g = (channel of the
-        // group, row tile of that channel's source): n_e rows, S1 = sum x, S2 = sum x^2.  ONE pass over the (few hundred) entries:
-        //   mean = sum_e S1 / N
-        //   M2   = sum_e [ (S2 - S1^2 / n_e) + n_e (S1 / n_e - K)^2 ] - N (mean - K)^2          (Chan et al. about a pivot K)
-        // with K = the mean of the group's first entry, a sample of the means being merged: every entry is centred on its own mean
-        // first, and what is subtracted at the end is the small (mean - K)^2, so nothing cancels.  A thread's entries (part, part +
-        // parts, ...) travel in chunks of GNW_CH with all loads of a chunk in flight (clamped addresses, no predicate on the loads),
-        // and the index arithmetic is division-free ((e + 0.5) * (1 / tmax) is exact far beyond the 5120 entries a group can have).
+        // group, row tile of that channel's source): n_e rows, S1 = sum x, S2 = sum x^2.  ONE pass over the (few hundred) entries, merged
+        // with Chan et al.'s formula on two levels so that no step subtracts large, nearly equal numbers:
+        //   thread t (its entries e = part, part + parts, ...), about a pivot K_t = the mean of ITS first entry:
+        //       n_t = sum n_e,  s_t = sum S1,  q_t = sum [ (S2 - S1^2 / n_e) + n_e (S1 / n_e - K_t)^2 ]
+        //       M2_t = q_t - n_t (s_t / n_t - K_t)^2        — the cancellation is bounded by the thread's own few entries (<= ~40),
+        //   group: mean = sum s_t / N,  M2 = sum [ M2_t + n_t (s_t / n_t - mean)^2 ]                    — every term is non-negative.
+        // (Round 3 used one pivot per GROUP: an outlier first channel or tile — (mean - K)^2 up to var N / n_e with N / n_e in the
+        // thousands — cost up to 3 of fp32's 7 digits)  A thread's entries travel in chunks of GNW_CH with all loads of a
+        // chunk in flight (clamped addresses, no predicate on the loads), and the index arithmetic is division-free ((e + 0.5) *
+        // (1 / tmax) is exact far beyond the 5120 entries a group can have).
         const int parts = GNW_NT / p.G;
         const int grp = t % p.G, part = t / p.G;
         const int t0 = p.HW / p.ps_rows[0], t1 = p.ps[1] ? p.HW / p.ps_rows[1] : 0;
@@ -294,14 +302,9 @@ __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p)
         const float inv_tmax = 1.0f / (float)tmax;
         const float rows0 = (float)p.ps_rows[0], rows1 = p.ps[1] ? (float)p.ps_rows[1] : 1.f;
         const float inv_rows0 = 1.0f / rows0, inv_rows1 = 1.0f / rows1;
-        float K;
-        {
-            const int c = grp * p.cpg;
-            const int src = (p.ps[1] && c >= p.ps_c0[1]) ? 1 : 0;
-            K = p.ps[src][((long)(b * (src ? t1 : t0)) * 2) * p.ps_nc[src] + (c - p.ps_c0[src])] * (src ? inv_rows1 : inv_rows0);
-        }
         constexpr int GNW_CH = 8;
-        float a_s = 0.f, a_q = 0.f;
+        float a_s = 0.f, a_q = 0.f, a_n = 0.f, K = 0.f;
+        bool have_k = false;
         for (int i0 = 0; i0 < per; i0 += GNW_CH) {
             float s1[GNW_CH], s2[GNW_CH], nr[GNW_CH], inr[GNW_CH];
 #pragma unroll
@@ -324,20 +327,32 @@ __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p)
 #pragma unroll
             for (int u = 0; u < GNW_CH; ++u)
                 if (nr[u] > 0.f) {
-                    const float me = s1[u] * inr[u], dm = me - K;
+                    const float me = s1[u] * inr[u];
+                    if (!have_k) { K = me; have_k = true; }
+                    const float dm = me - K;
                     a_s += s1[u];
+                    a_n += nr[u];
                     a_q += fmaxf(s2[u] - s1[u] * me, 0.f) + nr[u] * dm * dm;
                 }
         }
-        s_ps[t] = a_s; s_pq[t] = a_q;
+        {   // this thread's (n, sum, M2 about its own mean)
+            const float mt = a_n > 0.f ? a_s / a_n : 0.f, dk = mt - K;
+            s_ps[t] = a_s; s_pq[t] = fmaxf(a_q - a_n * dk * dk, 0.f); s_pn[t] = a_n;
+        }
         __syncthreads();
-        if (t < p.G) {          // t < G: part == 0 and grp == t, so K is this group's pivot
-            float sm = 0.f, q = 0.f;
-            for (int k = 0; k < parts; ++k) { sm += s_ps[k * p.G + t]; q += s_pq[k * p.G + t]; }
+        if (t < p.G) {
+            float sm = 0.f;
+            for (int k = 0; k < parts; ++k) sm += s_ps[k * p.G + t];
             const float ntot = (float)p.HW * (float)p.cpg;
-            const float mean = sm / ntot, dk = mean - K;
+            const float mean = sm / ntot;
+            float m2 = 0.f;
+            for (int k = 0; k < parts; ++k) {
+                const float nt = s_pn[k * p.G + t];
+                const float d = nt > 0.f ? s_ps[k * p.G + t] / nt - mean : 0.f;
+                m2 += s_pq[k * p.G + t] + nt * d * d;
+            }
             s_mean[t] = mean;
-            s_rstd[t] = rsqrtf(fmaxf(q / ntot - dk * dk, 0.f) + p.eps);
+            s_rstd[t] = rsqrtf(m2 / ntot + p.eps);
         }
         __syncthreads();
     } else
@@ -599,6 +614,11 @@ constexpr int GNF_MAXI = 24;   // 4-element items per thread: slabs of up to 256
 // 32x32x640: 22.7 vs 11.9 us — 40-byte row pieces, 128 workgroups)
 constexpr long GNF_DEFAULT_MAX = 10240;
 
+// SPLIT (round 4): x is the unreduced output of a split-K convolution — the slab's values are the sums of the fp32 partial slices
+// (slice order) + bias + temb row + residual, i.e. exactly what splitk_reduce_kernel would have stored, computed while the slab is
+// loaded; the reduced tensor is written only if somebody else needs it.  conv1 -> norm2 and conv2 -> Transformer2DModel.norm at the
+// 16x16 / 8x8 levels lose their second pass (and the round trip of the reduced tensor through memory).
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void gn_fused_kernel(const GnParams p) {
     __shared__ float s_red[8];
     const int t = threadIdx.x, b = blockIdx.y, g = blockIdx.x;
@@ -608,18 +628,103 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GnParams p) {
     const bool f32 = p.x_f32;
     float v[GNF_MAXI][4];
     f16x4 gm[GNF_MAXI], bt[GNF_MAXI];    // the affine parameters travel with the data, not after the statistics
+    if constexpr (SPLIT) {
+        // Batched pre-pass: 4 items x 4 slices = 16 independent 16-byte loads in flight per thread, addresses clamped instead of
+        // predicated (a load inside a per-item `if` is waited for where it is issued: one exposed round trip per item and slice group).
+        // Slices are added in slice order, then bias, temb row, residual — the order of splitk_reduce_kernel: bit-identical values.
+#pragma unroll
+        for (int i0 = 0; i0 < GNF_MAXI; i0 += 4) {
+            if (i0 * 256 < items) {                         // block-uniform
+                const float* sl[4];
+                long mm[4];
+                int nn[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const int it = min(t + (i0 + k) * 256, items - 1);
+                    const int px = it / q, c4 = it - px * q;
+                    mm[k] = (long)b * p.HW + px;
+                    nn[k] = g * p.cpg + c4 * 4;
+                    sl[k] = p.sp_ws + mm[k] * p.C + nn[k];
+                }
+                float4 a[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) a[k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int z0 = 0; z0 < p.sp_splits; z0 += 4) {
+                    float4 q4[4][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const long zo = (long)min(z0 + u, p.sp_splits - 1) * p.sp_MN;
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) q4[k][u] = *reinterpret_cast<const float4*>(sl[k] + zo);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (z0 + u < p.sp_splits) {
+#pragma unroll
+                            for (int k = 0; k < 4; ++k) { a[k].x += q4[k][u].x; a[k].y += q4[k][u].y; a[k].z += q4[k][u].z; a[k].w += q4[k][u].w; }
+                        }
+                }
+                if (p.sp_bias) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const f16x4 bb = *reinterpret_cast<const f16x4*>(p.sp_bias + nn[k]);
+                        a[k].x += (float)bb[0]; a[k].y += (float)bb[1]; a[k].z += (float)bb[2]; a[k].w += (float)bb[3];
+                    }
+                }
+                if (p.sp_rowbias) {
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) {
+                        const float4 rb = *reinterpret_cast<const float4*>(p.sp_rowbias + (long)b * p.sp_rowbias_ld + nn[k]);
+                        a[k].x += rb.x; a[k].y += rb.y; a[k].z += rb.z; a[k].w += rb.w;
+                    }
+                }
+                if (p.sp_res) {
+                    if (p.sp_res_f32) {
+                        float4 r4[4];
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) r4[k] = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.sp_res) + mm[k] * p.sp_ldr + nn[k]);
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) { a[k].x += r4[k].x; a[k].y += r4[k].y; a[k].z += r4[k].z; a[k].w += r4[k].w; }
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < 4; ++k) {
+                            const f16x4 r4 = *reinterpret_cast<const f16x4*>(reinterpret_cast<const f16*>(p.sp_res) + mm[k] * p.sp_ldr + nn[k]);
+                            a[k].x += (float)r4[0]; a[k].y += (float)r4[1]; a[k].z += (float)r4[2]; a[k].w += (float)r4[3];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const bool mine = t + (i0 + k) * 256 < items;
+                    if (mine && p.sp_out && p.sp_out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.sp_out) + mm[k] * p.sp_ldo + nn[k]) = a[k];
+                    if (p.sp_round) {      // the tensor is (or would have been) stored in fp16: normalise what a reader of it would see
+                        const f16x4 hh = {(f16)a[k].x, (f16)a[k].y, (f16)a[k].z, (f16)a[k].w};
+                        if (mine && p.sp_out && !p.sp_out_f32) *reinterpret_cast<f16x4*>(reinterpret_cast<f16*>(p.sp_out) + mm[k] * p.sp_ldo + nn[k]) = hh;
+                        a[k] = make_float4((float)hh[0], (float)hh[1], (float)hh[2], (float)hh[3]);
+                    }
+                    v[i0 + k][0] = mine ? a[k].x : 0.f; v[i0 + k][1] = mine ? a[k].y : 0.f;
+                    v[i0 + k][2] = mine ? a[k].z : 0.f; v[i0 + k][3] = mine ? a[k].w : 0.f;
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) v[i0 + k][0] = v[i0 + k][1] = v[i0 + k][2] = v[i0 + k][3] = 0.f;
+            }
+        }
+    }
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < GNF_MAXI; ++i) {
         const int it = t + i * 256;
-        v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
+        if constexpr (!SPLIT) v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
         gm[i] = bt[i] = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
         if (it < items) {
             const int px = it / q, c4 = it - px * q;
             const long off = xb + (long)px * p.ldx + c4 * 4;
             gm[i] = *reinterpret_cast<const f16x4*>(p.gamma + g * p.cpg + c4 * 4);
             bt[i] = *reinterpret_cast<const f16x4*>(p.beta + g * p.cpg + c4 * 4);
-            if (f32) {
+            if constexpr (SPLIT) {
+                // (v[i] was filled by the batched pre-pass above)
+            } else if (f32) {
                 const float4 a = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.x) + off);
                 v[i][0] = a.x; v[i][1] = a.y; v[i][2] = a.z; v[i][3] = a.w;
             } else {
@@ -749,6 +854,15 @@ void gn_geometry(int B, int HW, int C, bool f32, int* nchunks, int* rows_per_chu
     *apply_blocks = sg_cdiv(HW, *apply_rows);
 }
 
+// does a GroupNorm of this shape run as the one-launch kernel?
+bool gn_takes_fused(int HW, int C, int groups) {
+    const SgOptions& opt = sg_options();
+    const long fused_max = opt.gn_fused_max >= 0 ? opt.gn_fused_max : GNF_DEFAULT_MAX;
+    const int cpg = C / groups;
+    const long slab = (long)HW * cpg;
+    return cpg % 4 == 0 && slab <= 256L * 4 * GNF_MAXI && slab <= fused_max && !opt.gn_no_fused;
+}
+
 }  // namespace
 
 extern "C" size_t sg_groupnorm_workspace_bytes(int32_t B, int32_t groups) {
@@ -758,22 +872,25 @@ extern "C" size_t sg_groupnorm_workspace_bytes(int32_t B, int32_t groups) {
 extern "C" int sg_groupnorm_uses_pstats(int32_t HW, int32_t C, int32_t groups) {
     if (HW <= 0 || C <= 0 || groups <= 0 || C % groups) return 0;
     const SgOptions& opt = sg_options();
-    const long fused_max = opt.gn_fused_max >= 0 ? opt.gn_fused_max : GNF_DEFAULT_MAX;
     const int cpg = C / groups;
-    const long slab = (long)HW * cpg;
-    if (cpg % 4 == 0 && slab <= 256L * 4 * GNF_MAXI && slab <= fused_max && !opt.gn_no_fused) return 0;      // gn_fused_kernel
+    if (gn_takes_fused(HW, C, groups)) return 0;      // gn_fused_kernel
     return (opt.gn_wide != 0 && cpg >= 8 && C / 8 <= GNW_MAX_VPR) ? 1 : 0;
+}
+
+extern "C" int sg_groupnorm_is_fused(int32_t HW, int32_t C, int32_t groups) {
+    if (HW <= 0 || C <= 0 || groups <= 0 || C % groups) return 0;
+    return gn_takes_fused(HW, C, groups) ? 1 : 0;
 }
 
 extern "C" int sg_groupnorm_nhwc_f16(const sg_groupnorm_desc* d, sg_stream_t stream) {
     SG_REQUIRE(d != nullptr, "sg_groupnorm: null descriptor");
-    SG_REQUIRE(d->x && d->y && d->gamma && d->beta && d->workspace, "sg_groupnorm: null pointer");
+    SG_REQUIRE((d->x || d->split_ws) && d->y && d->gamma && d->beta && d->workspace, "sg_groupnorm: null pointer");
     SG_REQUIRE(d->B > 0 && d->HW > 0 && d->C > 0 && d->groups > 0, "sg_groupnorm: bad shape");
     SG_REQUIRE(d->C % 8 == 0 && d->C % d->groups == 0 && d->C <= 2560,
                "sg_groupnorm: C=%d must be a multiple of 8 and of groups, <= 2560", d->C);
     SG_REQUIRE(d->groups <= GN_MAX_GROUPS, "sg_groupnorm: at most %d groups", GN_MAX_GROUPS);
-    SG_REQUIRE(d->ldx % 8 == 0 && d->ldy % 8 == 0 && d->ldx >= d->C && d->ldy >= d->C, "sg_groupnorm: bad ldx/ldy");
-    SG_REQUIRE(sg_aligned16(d->x) && sg_aligned16(d->y) && sg_aligned16(d->gamma) && sg_aligned16(d->beta),
+    SG_REQUIRE(d->ldy % 8 == 0 && d->ldy >= d->C && (d->split_ws || (d->ldx % 8 == 0 && d->ldx >= d->C)), "sg_groupnorm: bad ldx/ldy");
+    SG_REQUIRE((d->split_ws || sg_aligned16(d->x)) && sg_aligned16(d->y) && sg_aligned16(d->gamma) && sg_aligned16(d->beta),
                "sg_groupnorm: 16-byte alignment");
     SG_REQUIRE(d->y_pad_w >= 0 && (d->y_pad_w == 0 || d->HW % d->y_pad_w == 0), "sg_groupnorm: y_pad_w must divide HW");
     SG_REQUIRE(!d->xcopy || (sg_aligned16(d->xcopy) && d->ldxc % 8 == 0 && d->ldxc >= d->C), "sg_groupnorm: xcopy alignment / ld");
@@ -801,8 +918,27 @@ extern "C" int sg_groupnorm_nhwc_f16(const sg_groupnorm_desc* d, sg_stream_t str
     const bool no_fused = opt.gn_no_fused != 0, wide = opt.gn_wide != 0;
     const long fused_max = opt.gn_fused_max >= 0 ? opt.gn_fused_max : GNF_DEFAULT_MAX;
     const long slab = (long)p.HW * p.cpg;
-    if (p.cpg % 4 == 0 && slab <= 256L * 4 * GNF_MAXI && slab <= fused_max && !no_fused) {
-        hipLaunchKernelGGL(gn_fused_kernel, dim3(p.G, d->B), dim3(256), 0, st0, p);
+    (void)fused_max; (void)no_fused; (void)slab;
+    if (d->split_ws) {
+        SG_REQUIRE(gn_takes_fused(p.HW, p.C, p.G), "sg_groupnorm: split_ws needs the one-launch variant (sg_groupnorm_is_fused)");
+        SG_REQUIRE(d->split_count >= 2 && d->split_count <= 64 && sg_aligned16(d->split_ws), "sg_groupnorm: split_count in [2, 64], aligned split_ws");
+        SG_REQUIRE(!d->pstats[0], "sg_groupnorm: split_ws excludes pstats");
+        SG_REQUIRE(!d->split_bias || sg_aligned16(d->split_bias), "sg_groupnorm: split_bias alignment");
+        SG_REQUIRE(!d->split_rowbias || (sg_aligned16(d->split_rowbias) && d->split_rowbias_ld % 4 == 0), "sg_groupnorm: split_rowbias alignment");
+        SG_REQUIRE(!d->split_res || (sg_aligned16(d->split_res) && d->split_ldr % 8 == 0 && d->split_ldr >= d->C), "sg_groupnorm: split_res alignment / ld");
+        SG_REQUIRE(!d->split_out || (sg_aligned16(d->split_out) && d->split_ldo % 8 == 0 && d->split_ldo >= d->C), "sg_groupnorm: split_out alignment / ld");
+        p.sp_ws = d->split_ws; p.sp_splits = d->split_count; p.sp_MN = (long)d->B * d->HW * d->C;
+        p.sp_bias = reinterpret_cast<const f16*>(d->split_bias);
+        p.sp_rowbias = d->split_rowbias; p.sp_rowbias_ld = d->split_rowbias_ld;
+        p.sp_res = d->split_res; p.sp_ldr = d->split_ldr; p.sp_res_f32 = d->split_res_f32 ? 1 : 0;
+        p.sp_out = d->split_out; p.sp_ldo = d->split_ldo; p.sp_out_f32 = d->split_out_f32 ? 1 : 0;
+        p.sp_round = (d->split_out ? !d->split_out_f32 : d->split_round_f16 != 0) ? 1 : 0;
+        hipLaunchKernelGGL(gn_fused_kernel<true>, dim3(p.G, d->B), dim3(256), 0, st0, p);
+        SG_CHECK_LAUNCH("gn_fused<split>");
+        return SG_OK;
+    }
+    if (gn_takes_fused(p.HW, p.C, p.G)) {
+        hipLaunchKernelGGL(gn_fused_kernel<false>, dim3(p.G, d->B), dim3(256), 0, st0, p);
         SG_CHECK_LAUNCH("gn_fused");
         return SG_OK;
     }

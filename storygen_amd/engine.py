@@ -33,7 +33,7 @@ import torch
 
 from . import ops
 from .arch import BlockSpec, ResnetSpec, UNetArch, XfSpec, feature_shapes
-from .repack import conv1x1_nk, conv3x3_krsc, conv_in_kn, fold_layernorm, interleave_geglu
+from .repack import conv1x1_nk, conv3x3_krsc, conv_in_kn, ff_fused_pack, fold_layernorm, interleave_geglu
 
 F16 = torch.float16
 GN_EPILOGUE_STATS = True   # GroupNorm statistics from the producing conv / GEMM epilogues (False = every GroupNorm makes its own pass)
@@ -52,6 +52,15 @@ LN_FOLD = True
 # 14.70 ms paired vs 14.62 ms): the text attention already runs on the side stream beside the context K / V^T projections, and one
 # grid after them gives that overlap up — so the default stays two launches (A/B: bench.py --attn-pair).
 ATTN_PAIR = False
+# Split-K convolutions at the 16x16 / 8x8 levels leave their second pass to the one-launch GroupNorm that consumes them (round 4;
+# sg_conv3x3_desc.defer_reduce + sg_groupnorm_desc.split_*): conv1 -> norm2 of every ResnetBlock2D there, and conv2 -> Transformer2DModel.norm
+# where a transformer follows.  Bit-identical values, one launch and one round trip of the tensor less per site.  False = separate
+# splitk_reduce launches (A/B switch).
+SPLITK_IN_GN = True
+# GEGLU feed-forward of a transformer block as ONE launch where the kernel exists (C = 320, the 64x64 level: sg_ff_geglu_fused_f16;
+# SURVEY 8(f) rank 2 — cross-layer fusion): norm3 -> Linear(C, 8C) -> a gelu(g) -> Linear(4C, C) -> + h with the [M, 4C] intermediate
+# kept in registers.  False = LayerNorm-folded GEGLU GEMM + second GEMM (A/B switch: bench.py --no-ff-fused).
+FF_FUSED = True
 LN_EPS = 1e-5         # torch.nn.LayerNorm default, as the reference constructs norm1..norm4 (model/attention.py:213-233)
 
 
@@ -72,7 +81,8 @@ class _Xf:
                  "w_v2", "w_o2", "b_o2", "w_q3", "w_k3", "w_v3", "w_o3", "b_o3", "w_o23", "b_o23", "w_ff1", "b_ff1", "w_ff2", "b_ff2",
                  # LayerNorm-folded copies (repack.fold_layernorm): weight gamma (.) W in fp16, c / d in fp32
                  "w_qk1f", "c_qk1", "d_qk1", "w_v1f", "c_v1", "d_v1", "w_q2f", "c_q2", "d_q2", "w_q3f", "c_q3", "d_q3",
-                 "w_ff1f", "c_ff1", "d_ff1")
+                 "w_ff1f", "c_ff1", "d_ff1",
+                 "ff_pack")     # weight stream of the fused feed-forward kernel (repack.ff_fused_pack), or None
 
 
 class EngineWeights:
@@ -151,6 +161,7 @@ class EngineWeights:
                 o.w_ff2, o.b_ff2 = g(f"{t}.ff.net.2.weight"), g(f"{t}.ff.net.2.bias")
                 for name, val in self._pack_folds(o).items():
                     setattr(o, name, val)
+                o.ff_pack = ff_fused_pack(o.w_ff1f, o.d_ff1, o.w_ff2) if (ops.ff_fused_supported(a.channels) and dev.type == "cuda") else None
                 self.xfs[p] = o
         self.samplers = {}
         for blk in arch.down + arch.up:
@@ -321,6 +332,8 @@ class UNetEngine:
         self._stats_rows: Dict[str, int] = {}
         self._stats_want: Dict[tuple, bool] = {}
         self._pstats: Dict[int, tuple] = {}           # data_ptr of a produced tensor -> (buffer, rows per partial, channels)
+        self._splits: Dict[str, int] = {}             # conv site -> planned K slices (sg_conv3x3_planned_splits), asked once
+        self._pending_split: Dict[int, dict] = {}     # data_ptr of a tensor whose split-K reduction its GroupNorm consumer will do
         self.text_cache: Dict[str, torch.Tensor] = {}
         self._alloc(splitk_workspace_mb)
 
@@ -502,6 +515,16 @@ class UNetEngine:
                 return [a, b]
         return None
 
+    def _defer_splits(self, site: str, lvl: int, cout: int, query) -> int:
+        """K slices (> 1) of the convolution at `site` when it may leave its split-K reduction to the GroupNorm that consumes its
+        [B*hw, cout] output (the one-launch variant sums the slices while loading its slab), else 0."""
+        if not SPLITK_IN_GN or not ops.groupnorm_is_fused(self.hw[lvl], cout, self.groups):
+            return 0
+        n = self._splits.get(site)
+        if n is None:
+            n = self._splits[site] = int(query())
+        return n if n > 1 else 0
+
     def _attention(self, q, k, vt, out, heads: int, scale: float, nk: Optional[int] = None, short: Optional[tuple] = None):
         """softmax(scale q k^T) v on the HIP kernels: fp16 MFMA, or e4m3 MFMA for the D = 40 image / self attentions when the
         engine was built with fp8_attention (text attention — 77 keys — and every other head dim stay fp16).
@@ -516,9 +539,10 @@ class UNetEngine:
         else:
             ops.attention(q, k, vt, out, heads, scale, nk=nk, short=short)
 
-    def _resnet(self, rn: _Resnet, x: torch.Tensor, out: torch.Tensor, lvl: int):
+    def _resnet(self, rn: _Resnet, x: torch.Tensor, out: torch.Tensor, lvl: int, defer_out: bool = False):
         """diffusers ResnetBlock2D.  x fp32 [M,Cin] contiguous; out fp32 [M,Cout], possibly a column
-        slice of a concat buffer."""
+        slice of a concat buffer.  defer_out: the only reader of `out` before anything else is the GroupNorm of the transformer that
+        follows — a split-K conv2 may leave its reduction to it (SPLITK_IN_GN)."""
         L, M, r, B, hw = self.lv[lvl], x.shape[0], rn.spec, self.B, self.hw[lvl]
         ws = self.ws_split
         p_in, p_mid = self.padded[(lvl, r.cin)], self.padded[(lvl, r.cout)]
@@ -537,18 +561,33 @@ class UNetEngine:
         h1 = L["c1"]
         rb = self.tproj[:, rn.temb_off: rn.temb_off + r.cout]
         kw1 = dict(rowbias=rb, workspace=ws, x_padded=True)
-        s1 = self._stats_for(r.prefix + ".conv1", lvl, r.cout,
-                             lambda buf: ops.conv3x3_stats_rows(p_in, rn.w1, self._img(h1, lvl), stats=buf, **kw1))
-        ops.conv3x3(p_in, rn.w1, self._img(h1, lvl), stats=s1, **kw1)
-        if s1 is not None:
-            self._publish(h1, r.prefix + ".conv1", r.cout)
-        else:
+        d1 = self._defer_splits(r.prefix + ".conv1", lvl, r.cout, lambda: ops.conv3x3_planned_splits(p_in, rn.w1, self._img(h1, lvl), **kw1))
+        if d1:      # conv1 -> norm2: the GroupNorm sums the K slices itself; h1 is never stored (fp16 rounding kept: bit-identical)
+            ops.conv3x3(p_in, rn.w1, self._img(h1, lvl), defer_reduce=True, **kw1)
             self._pstats.pop(h1.data_ptr(), None)
-        ops.groupnorm(h1.unflatten(0, (B, hw)), rn.n2g, rn.n2b, p_mid, self.groups, self.eps, True, self.ws_gn,
-                      pstats=self._pstats_of(h1))
+            ops.groupnorm(h1.unflatten(0, (B, hw)), rn.n2g, rn.n2b, p_mid, self.groups, self.eps, True, self.ws_gn,
+                          split=dict(ws=ws, splits=d1, rowbias=rb, store=False))
+        else:
+            s1 = self._stats_for(r.prefix + ".conv1", lvl, r.cout,
+                                 lambda buf: ops.conv3x3_stats_rows(p_in, rn.w1, self._img(h1, lvl), stats=buf, **kw1))
+            ops.conv3x3(p_in, rn.w1, self._img(h1, lvl), stats=s1, **kw1)
+            if s1 is not None:
+                self._publish(h1, r.prefix + ".conv1", r.cout)
+            else:
+                self._pstats.pop(h1.data_ptr(), None)
+            ops.groupnorm(h1.unflatten(0, (B, hw)), rn.n2g, rn.n2b, p_mid, self.groups, self.eps, True, self.ws_gn,
+                          pstats=self._pstats_of(h1))
         if forked:
             self._join()
         kw2 = dict(bias=rn.b2, res1=self._img(res, lvl), workspace=ws, x_padded=True)
+        d2 = 0
+        if defer_out:
+            d2 = self._defer_splits(r.prefix + ".conv2", lvl, r.cout, lambda: ops.conv3x3_planned_splits(p_mid, rn.w2, self._img(out, lvl), **kw2))
+        if d2:      # conv2 -> Transformer2DModel.norm: that GroupNorm reduces, and stores `out` (the residual of proj_out)
+            ops.conv3x3(p_mid, rn.w2, self._img(out, lvl), defer_reduce=True, **kw2)
+            self._pstats.pop(out.data_ptr(), None)
+            self._pending_split[out.data_ptr()] = dict(ws=ws, splits=d2, bias=rn.b2, res1=res.unflatten(0, (B, hw)), store=True)
+            return
         s2 = self._stats_for(r.prefix + ".conv2", lvl, r.cout,
                              lambda buf: ops.conv3x3_stats_rows(p_mid, rn.w2, self._img(out, lvl), stats=buf, **kw2))
         ops.conv3x3(p_mid, rn.w2, self._img(out, lvl), stats=s2, **kw2)
@@ -596,9 +635,11 @@ class UNetEngine:
         scale = xf.spec.dim_head ** -0.5
         ws = self.ws_split
         ops.groupnorm(x.unflatten(0, (B, hw)), xf.ng, xf.nb, L["gn"].unflatten(0, (B, hw)), self.groups, 1e-6, False,
-                      self.ws_gn, pstats=self._pstats_of(x))                              # :99 (eps 1e-6, :55)
+                      self.ws_gn, pstats=self._pstats_of(x), split=self._pending_split.pop(x.data_ptr(), None))   # :99 (eps 1e-6, :55)
         h0 = L["h0"]
         fold = LN_FOLD and C % 64 == 0 and C // 64 <= 20
+        # fused feed-forward: needs the fp32 stream (it reads h3 itself: no raw copy, no LayerNorm partials from h3's producer)
+        ff1 = FF_FUSED and xf.ff_pack is not None and not FP16_BLOCK_STREAM
         # with the fold, the producer of a stream tensor also writes its raw fp16 copy and the LayerNorm partials of its rows
         raw = lambda t, buf: t if t.dtype == F16 else buf                                 # noqa: E731  (fp16 stream: it IS the copy)
         prod = lambda t, buf, st: dict(out2=None if t.dtype == F16 else buf, ln_out=st) if fold else {}   # noqa: E731
@@ -706,7 +747,7 @@ class UNetEngine:
                 self._join()
             h3 = L["h3"]
             ops.gemm(att23, xf.w_o23, h3, bias=xf.b_o23, res1=h1, res2=h1, workspace=ws,  # (a2 + h) + (a3 + h)
-                     **prod(h3, L["ln"], L["lnst3"]))
+                     **({} if ff1 else prod(h3, L["ln"], L["lnst3"])))
         else:
             if fold:
                 ops.gemm(h1r, xf.w_q2f, L["q"], ln=(1, L["lnst1"], xf.c_q2, xf.d_q2, LN_EPS))
@@ -714,14 +755,17 @@ class UNetEngine:
                 ops.gemm(L["ln"], xf.w_q2, L["q"], workspace=ws)
             ops.attention(L["q"].view(B, hw, C), kt3, vtt3, att.view(B, hw, C), heads, scale, nk=S)
             h3 = L["h2"]
-            ops.gemm(att, xf.w_o2, h3, bias=xf.b_o2, res1=h1, workspace=ws, **prod(h3, L["ln"], L["lnst3"]))   # :277,295
+            ops.gemm(att, xf.w_o2, h3, bias=xf.b_o2, res1=h1, workspace=ws, **({} if ff1 else prod(h3, L["ln"], L["lnst3"])))   # :277,295
         # --- feed-forward :298-300
-        if fold:
+        if ff1:      # one launch: LayerNorm in registers, GEGLU intermediate never materialised (h4 is fp16: it only feeds proj_out)
+            ops.ff_fused(h3, xf.ff_pack, xf.b_ff2, L["h4"], LN_EPS)
+        elif fold:
             ops.gemm(raw(h3, L["ln"]), xf.w_ff1f, L["ffi"], epilogue=ops.EPI_GEGLU, ln=(1, L["lnst3"], xf.c_ff1, xf.d_ff1, LN_EPS))
         else:
             ops.layernorm(h3, *xf.ln["norm3"], L["ln"])
             ops.gemm(L["ln"], xf.w_ff1, L["ffi"], bias=xf.b_ff1, epilogue=ops.EPI_GEGLU, workspace=ws)
-        ops.gemm(L["ffi"], xf.w_ff2, L["h4"], bias=xf.b_ff2, res1=h3, workspace=ws)       # fp16: only feeds proj_out
+        if not ff1:
+            ops.gemm(L["ffi"], xf.w_ff2, L["h4"], bias=xf.b_ff2, res1=h3, workspace=ws)   # fp16: only feeds proj_out
         kwo = dict(bias=xf.b_out, res1=x, workspace=ws)                                   # proj_out + residual :121-123
         site = xf.spec.prefix + ".proj_out"
         so = self._stats_for(site, lvl, C, lambda buf: ops.gemm_stats_rows(L["h4"], xf.w_out, out, stats=(buf, hw), **kwo))
@@ -796,7 +840,7 @@ class UNetEngine:
                     self._resnet(self.resnets[r.prefix], h, out, lvl)
                 else:
                     rt = self.lv[lvl]["r"]
-                    self._resnet(self.resnets[r.prefix], h, rt, lvl)
+                    self._resnet(self.resnets[r.prefix], h, rt, lvl, defer_out=True)
                     self._transformer(self.xfs[xf.prefix], rt, out, lvl, text, harvest, consume, **tk)
                 h, si = out, si + 1
             if blk.sampler_prefix:
@@ -807,7 +851,7 @@ class UNetEngine:
         # --- mid :436-445
         L = self.lv[lvl]
         m0, m1 = arch.mid.resnets
-        self._resnet(self.resnets[m0.prefix], h, L["r"], lvl)
+        self._resnet(self.resnets[m0.prefix], h, L["r"], lvl, defer_out=True)
         self._transformer(self.xfs[arch.mid.attns[0].prefix], L["r"], L["t_out"], lvl, text, harvest, consume, **tk)
         blk0 = arch.up[0]
         k = 0                                                                              # index of the up-path resnet
@@ -829,7 +873,7 @@ class UNetEngine:
                 if xf is None:
                     self._resnet(self.resnets[r.prefix], cat, out, lvl)
                 else:
-                    self._resnet(self.resnets[r.prefix], cat, L["r"], lvl)
+                    self._resnet(self.resnets[r.prefix], cat, L["r"], lvl, defer_out=True)
                     if xf.prefix == last_xf:
                         self._transformer(self.xfs[xf.prefix], L["r"], None, lvl, text, harvest, consume, stop_after_harvest=True)
                         return None

@@ -13,7 +13,7 @@ from typing import Optional
 import torch
 
 from . import _lib
-from ._lib import AttnDesc, ConvDesc, GemmDesc, GroupNormDesc, check
+from ._lib import AttnDesc, ConvDesc, FfDesc, GemmDesc, GroupNormDesc, check
 
 lib = _lib.load()
 
@@ -229,6 +229,32 @@ def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, **kw) -> torch.Ten
     return out
 
 
+def ff_fused_supported(Cc: int) -> bool:
+    """Is there a fused GEGLU feed-forward kernel for this width (sg_ff_fused_pack_bytes != 0)?"""
+    return lib.sg_ff_fused_pack_bytes(int(Cc)) != 0
+
+
+def ff_fused(x: torch.Tensor, wpack: torch.Tensor, b2: torch.Tensor, out: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+    """out[M, C] (fp16) = Linear2(a * gelu(g)) + b2 + x with [a | g] = Linear1(LayerNorm(x)) + b1 in ONE launch (sg_ff_geglu_fused_f16):
+    x fp32 [M, C] (row-strided view allowed), wpack = repack.ff_fused_pack(...) (uint8), b2 fp16 [C]."""
+    _f32(x, "x"), _f16(b2, "b2"), _f16(out, "out")
+    M, Cc = x.shape
+    if tuple(out.shape) != (M, Cc) or b2.numel() != Cc or wpack.dtype != torch.uint8 or not wpack.is_cuda or not wpack.is_contiguous():
+        raise ValueError("ff_fused: out must be [M, C] fp16, b2 [C], wpack a contiguous CUDA uint8 tensor")
+    d = FfDesc()
+    d.x, d.ldx = x.data_ptr(), _row_stride(x, "x")
+    d.wpack, d.wpack_bytes = wpack.data_ptr(), wpack.numel()
+    d.b2 = b2.data_ptr()
+    d.y, d.ldy = out.data_ptr(), _row_stride(out, "out")
+    d.M, d.C, d.eps = M, Cc, float(eps)
+    with _timed("ff_fused", 24.0 * M * Cc * Cc, f"M{M} C{Cc}"):
+        if ANATOMY is not None:
+            check(lib.sg_debug_ff_anatomy(C.byref(d), ANATOMY.data_ptr(), ANATOMY.numel() * ANATOMY.element_size(), _stream()), "sg_debug_ff_anatomy")
+        else:
+            check(lib.sg_ff_geglu_fused_f16(C.byref(d), _stream()), "sg_ff_geglu_fused_f16")
+    return out
+
+
 def gemm_stats_rows(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, **kw) -> int:
     """Rows per partial (= the tile height) a gemm() call with these arguments (incl. stats=...) will write statistics for, or 0
     when that launch cannot emit them (sg_gemm_stats_tile_rows; no launch happens)."""
@@ -252,7 +278,8 @@ def gemm_pair(first: tuple, second: tuple) -> None:
 def _conv_desc(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stride: int = 1, upsample2x: bool = False,
                bias: Optional[torch.Tensor] = None, rowbias: Optional[torch.Tensor] = None,
                res1: Optional[torch.Tensor] = None, split_k: int = 0, workspace: Optional[torch.Tensor] = None,
-               x_padded: bool = False, tile: Optional[tuple] = None, stats: Optional[torch.Tensor] = None):
+               x_padded: bool = False, tile: Optional[tuple] = None, stats: Optional[torch.Tensor] = None,
+               defer_reduce: bool = False):
     """Builds the sg_conv3x3_desc; returns (desc, flops, shape string)."""
     _f16(x, "x"), _f16(w_krsc, "w")
     flags = F_OUT_F32 if _act(out, "out") else 0
@@ -293,6 +320,7 @@ def _conv_desc(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stri
     if stats is not None:
         _f32(stats, "stats")
         d.stats = stats.data_ptr()
+    d.defer_reduce = int(bool(defer_reduce))
     sig = f"c:{B}:{H}:{W}:{Cin}:{Cout}:{stride}:{int(upsample2x)}:{int(x_padded)}:{flags}:{int(bias is not None)}{int(rowbias is not None)}{int(res1 is not None)}"
     _apply_tile(d, tile, split_k, sig)
     if TUNE_SINK is not None:
@@ -305,7 +333,8 @@ def _conv_desc(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stri
 def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, **kw) -> torch.Tensor:
     """x [B,H,W,Cin] (channels-last, pixel-strided view allowed; or the zero-bordered [B,H+2,W+2,Cin] with
     x_padded=True) -> out [B,Ho,Wo,Cout] (fp16 or fp32); w_krsc [Cout,3,3,Cin]; res1 fp16 or fp32.  Keywords: stride, upsample2x,
-    bias, rowbias, res1, split_k, workspace, x_padded, tile, stats (fp32 buffer: GroupNorm partial statistics of the output)."""
+    bias, rowbias, res1, split_k, workspace, x_padded, tile, stats (fp32 buffer: GroupNorm partial statistics of the output),
+    defer_reduce (a split-K launch leaves its partial tiles in the workspace for groupnorm(split=...): sg_conv3x3_desc.defer_reduce)."""
     d, flops, shape = _conv_desc(x, w_krsc, out, **kw)
     with _timed("conv3x3", flops, shape):
         if ANATOMY is not None:
@@ -314,6 +343,16 @@ def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, **kw) -> t
         else:
             check(lib.sg_conv3x3_nhwc_f16(C.byref(d), _stream()), "sg_conv3x3_nhwc_f16")
     return out
+
+
+def conv3x3_planned_splits(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, **kw) -> int:
+    """Number of K slices a conv3x3() call with these arguments will use (sg_conv3x3_planned_splits; no launch).  > 1: the call may
+    pass defer_reduce=True and hand its workspace to groupnorm(split=...)."""
+    d, _, _ = _conv_desc(x, w_krsc, out, **kw)
+    rc = lib.sg_conv3x3_planned_splits(C.byref(d))
+    if rc < 0:
+        check(rc, "sg_conv3x3_planned_splits")
+    return rc
 
 
 def conv3x3_stats_rows(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, **kw) -> int:
@@ -518,12 +557,22 @@ def groupnorm_uses_pstats(HW: int, Cc: int, groups: int) -> bool:
     return bool(lib.sg_groupnorm_uses_pstats(HW, Cc, groups))
 
 
+def groupnorm_is_fused(HW: int, Cc: int, groups: int) -> bool:
+    """True when a GroupNorm of this shape runs as the one-launch kernel (the only variant that takes split=...)."""
+    return bool(lib.sg_groupnorm_is_fused(HW, Cc, groups))
+
+
 def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: torch.Tensor, groups: int, eps: float,
-              silu: bool, workspace: torch.Tensor, xcopy: Optional[torch.Tensor] = None, pstats: Optional[list] = None) -> torch.Tensor:
+              silu: bool, workspace: torch.Tensor, xcopy: Optional[torch.Tensor] = None, pstats: Optional[list] = None,
+              split: Optional[dict] = None) -> torch.Tensor:
     """x [B, HW, C] channels-last fp16/fp32 (row-strided views allowed).  out is either [B, HW, C] fp16 or the
     zero-bordered image [B, H+2, W+2, C] (then only the interior is written); xcopy = optional fp16 [B, HW, C] raw copy.
     pstats = [(buffer, rows per partial, channels), ...] (one or two sources, in channel order): statistics written by the
-    producers' epilogues (gemm / conv3x3 stats=...) — the wide variant then skips its own statistics pass."""
+    producers' epilogues (gemm / conv3x3 stats=...) — the wide variant then skips its own statistics pass.
+    split = dict(ws=workspace of a conv3x3(defer_reduce=True) launch, splits=its K slices, bias=, rowbias= [B, >= C] fp32, res1= [B, HW, C]
+    fp16 / fp32, store=bool): x is that launch's UNREDUCED output — the kernel sums the slices and applies bias / rowbias / res1 while it
+    loads (sg_groupnorm_desc.split_*); `x` itself is then only the destination of the reduced tensor, written when store=True (its dtype
+    also says whether the normalisation sees fp16-rounded values)."""
     x_f32 = _act(x, "x")
     _f16(gamma, "gamma"), _f16(beta, "beta"), _f16(out, "out")
     B, HW, Cc = x.shape
@@ -554,7 +603,30 @@ def groupnorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out: tor
             _f32(buf, "pstats")
             d.pstats[i], d.pstats_rows[i], d.pstats_c0[i], d.pstats_nc[i] = buf.data_ptr(), int(rows), c0, int(nc)
             c0 += int(nc)
-    with _timed("groupnorm", B * HW * Cc * ((4 if x_f32 else 2) + 2 + (2 if xcopy is not None else 0)), f"B{B} HW{HW} C{Cc}", aux=True):
+    nbytes = B * HW * Cc * ((4 if x_f32 else 2) + 2 + (2 if xcopy is not None else 0))
+    shape = f"B{B} HW{HW} C{Cc}"
+    if split is not None:
+        ws, ns = split["ws"], int(split["splits"])
+        if ws.numel() * ws.element_size() < ns * B * HW * Cc * 4:
+            raise ValueError("groupnorm: split workspace smaller than splits * B * HW * C floats")
+        d.split_ws, d.split_count = ws.data_ptr(), ns
+        if split.get("bias") is not None:
+            _f16(split["bias"], "split bias")
+            d.split_bias = split["bias"].data_ptr()
+        if split.get("rowbias") is not None:
+            _f32(split["rowbias"], "split rowbias")
+            d.split_rowbias, d.split_rowbias_ld = split["rowbias"].data_ptr(), _row_stride(split["rowbias"], "split rowbias")
+        r = split.get("res1")
+        if r is not None:
+            if tuple(r.shape) != (B, HW, Cc) or r.stride(0) != HW * r.stride(1) or r.stride(2) != 1:
+                raise ValueError("groupnorm: split res1 must be a [B, HW, C] view with one row stride")
+            d.split_res, d.split_ldr, d.split_res_f32 = r.data_ptr(), r.stride(1), int(_act(r, "split res1"))
+        if split.get("store"):
+            d.split_out, d.split_ldo, d.split_out_f32 = x.data_ptr(), x.stride(1), int(x_f32)
+        d.split_round_f16 = int(not x_f32)
+        nbytes = B * HW * Cc * (4 * ns + 2 + (4 if r is not None and r.dtype == torch.float32 else 0) + ((4 if x_f32 else 2) if split.get("store") else 0))
+        shape += f" split{ns}"
+    with _timed("groupnorm", nbytes, shape, aux=True):
         check(lib.sg_groupnorm_nhwc_f16(C.byref(d), _stream()), "sg_groupnorm_nhwc_f16")
     return out
 
@@ -874,7 +946,7 @@ def debug_set_option(name: str, value: int) -> None:
 # library no longer reads the environment: this maps the variables onto sg_debug_set_option, and only when a tool asks for it.
 _ENV_OPTIONS = {"SG_NO_NMAJOR": "no_nmajor", "SG_NO_PIPE": "no_pipe", "SG_NO_SPLIT": "no_split",
                 "SG_ATTN_SUB2": "attn_sub2", "SG_ATTN_PRIO": "attn_prio", "SG_ATTN_D80": "attn_d80", "SG_ATTN_D160": "attn_d160",
-                "SG_ATTN_LEAN": "attn_lean", "SG_ATTN_D40_GENERAL": "attn_d40_general", "SG_NO_GN_FUSED": "gn_no_fused", "SG_GN_WIDE": "gn_wide", "SG_GN_FUSED_MAX": "gn_fused_max"}
+                "SG_FF_VARIANT": "ff_variant", "SG_ATTN_LEAN": "attn_lean", "SG_ATTN_D40_GENERAL": "attn_d40_general", "SG_NO_GN_FUSED": "gn_no_fused", "SG_GN_WIDE": "gn_wide", "SG_GN_FUSED_MAX": "gn_fused_max"}
 
 
 def apply_env_options() -> dict:

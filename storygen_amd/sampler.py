@@ -60,7 +60,7 @@ class StoryGenSampler:
                  schedule: Optional[DDIMSchedule] = None, use_graph: bool = True, dedup: bool = True,
                  weights: Optional[EngineWeights] = None, overlap: bool = True, ref_ahead: int = 1,
                  split_graphs: bool = False, stream_priority: bool = False, fp8_attention: bool = False,
-                 side_streams: str = "auto"):
+                 side_streams: str = "auto", short_rows: bool = True):
         if n_ref < 1:
             raise ValueError("StoryGen's loop needs at least one prior frame")
         if ref_ahead < 1 or (ref_ahead > 1 and not (use_graph and overlap)):
@@ -80,6 +80,9 @@ class StoryGenSampler:
             raise ValueError("side_streams must be auto, none, main or both")
         self.side_streams = side_streams               # intra-pass side-stream forks (engine.forward(side=...)); measured neutral
         self.fp8_attention = bool(fp8_attention)       # BASELINE config 5: D = 40 image / self attention on the e4m3 MFMA path
+        # shared zero-image rows keep ONE frame slot (softmax over R copies of the same keys = softmax over one copy); False = R
+        # copies as written (A/B switch: bench.py --no-short-rows)
+        self.short_rows = bool(short_rows)
         self.arch, self.dev = arch, torch.device(device)
         self.N, self.R, self.h, self.w, self.S = n_samples, n_ref, height, width, seq_len
         self.B = 3 * n_samples
@@ -129,11 +132,15 @@ class StoryGenSampler:
         if self.dedup:
             rows = 2 * N                      # context rows: [zero-image features x N | frame features x N]
             groups = [(0, 2 * N, 0), (2 * N, N, N)]
-            if share_zero:
+            if share_zero and getattr(self, "short_rows", True):
                 short = N
                 for n in range(N):
                     units.append((0, 0, n))
                     hops.append((n, 0, n, 0, 1))                     # one sample -> the single slot of short row n
+            elif share_zero:
+                for n in range(N):
+                    units.append((0, 0, n))
+                    hops.append((n, 0, n, 0, R))                     # one sample -> all R slots of row n (copies, as written)
             else:
                 for n in range(N):
                     for i in range(R):

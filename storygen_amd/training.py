@@ -27,6 +27,25 @@ from .optim import AdamW, AdamW8bit, get_scheduler
 from .train import UNetTrainer, allreduce_gradients
 
 
+def accumulation_plan(mode: str, accum: int, world: int) -> dict:
+    """What `gradient_accumulation_steps = k` means per call of Stage2Trainer.step (pure host logic; tests/test_optim_host.py pins it).
+
+    mode "reference" = what train_StorySalon_stage2.py ACTUALLY does (:326-332).  The loop never enters `accelerator.accumulate`, so
+    `accelerator.sync_gradients` is always True: every micro-batch runs backward on loss / k (accelerate scales the loss by
+    1 / gradient_accumulation_steps), clips, steps the optimizer, steps the LR scheduler and zeroes the gradients, and `step` counts
+    micro-batches.  The scheduler was built with warm-up and total steps multiplied by k (:215-220) and accelerate's wrapper advances
+    it `num_processes` times per call (AcceleratedScheduler.step with split_batches = False).  So k only scales the gradients (and,
+    with scale_lr, the learning rate) and stretches the schedule.
+    mode "true" = real accumulation: k micro-batches are summed (each scaled 1 / k), then ONE clip + optimizer step + scheduler step;
+    warm-up / total steps count optimizer steps (unscaled), the schedule does not depend on the number of processes."""
+    if mode not in ("reference", "true"):
+        raise ValueError(f"accumulation must be 'reference' or 'true', got {mode!r}")
+    k = int(accum)
+    if mode == "reference":
+        return dict(grad_scale=1.0 / k, step_every=1, scheduler_steps_per_optimizer_step=int(world), schedule_multiplier=k)
+    return dict(grad_scale=1.0 / k, step_every=k, scheduler_steps_per_optimizer_step=1, schedule_multiplier=1)
+
+
 def use_refs_for(p: float) -> tuple:
     """The random number of reference frames of train_StorySalon_stage2.py:306-313: p < 0.3 -> frames 0,1,2; p < 0.6 -> 1,2; else 2."""
     return tuple(i for i in range(3) if (p < 0.3) or (0.3 <= p < 0.6 and i > 0) or (p >= 0.6 and i > 1))
@@ -38,10 +57,12 @@ class Stage2Trainer:
                  use_8bit_adam: bool = True, max_grad_norm: float = 1.0, lr_scheduler: str = "constant", lr_warmup_steps: int = 0,
                  train_steps: Optional[int] = None, gradient_accumulation_steps: int = 1, scale_lr: bool = False,
                  trainable_modules: Sequence[str] = ("attn3",), use_graph: bool = True, vae=None, text_encoder=None, tokenizer=None,
-                 seed: Optional[int] = None, variant: str = "storysalon"):
+                 seed: Optional[int] = None, variant: str = "storysalon", accumulation: str = "reference"):
         """unet: the drop-in UNet2DConditionModel in fp32 on the HIP device (the reference keeps it fp32, :226-235).  height / width are
         latent sizes.  vae / text_encoder / tokenizer are only needed for raw batches (`encode_batch`).  variant="coco" =
-        train_COCO.py:286-316: always the three frames, each at noise level ref_t (no `* (3 - i)`), loss without the mask."""
+        train_COCO.py:286-316: always the three frames, each at noise level ref_t (no `* (3 - i)`), loss without the mask.
+        accumulation: what gradient_accumulation_steps means — "reference" (default) = the reference's loop as written, "true" = real
+        gradient accumulation (accumulation_plan)."""
         if variant not in ("storysalon", "coco"):
             raise ValueError(f"variant must be 'storysalon' or 'coco', got {variant!r}")
         self.variant = variant
@@ -69,8 +90,10 @@ class Stage2Trainer:
         # the drop-in UNet's weight-staleness tag (unet_2d_condition.py::_engine_weights)
         self.optimizer = cls({n: p.detach() for n, p in self.named.items()}, lr=learning_rate, betas=(adam_beta1, adam_beta2),
                              weight_decay=adam_weight_decay, eps=adam_epsilon)
-        self.lr_scheduler = get_scheduler(lr_scheduler, self.optimizer, num_warmup_steps=lr_warmup_steps * gradient_accumulation_steps,
-                                          num_training_steps=None if train_steps is None else train_steps * gradient_accumulation_steps)
+        self.plan = accumulation_plan(accumulation, gradient_accumulation_steps, world)
+        mult = self.plan["schedule_multiplier"]
+        self.lr_scheduler = get_scheduler(lr_scheduler, self.optimizer, num_warmup_steps=lr_warmup_steps * mult,
+                                          num_training_steps=None if train_steps is None else train_steps * mult)
         self.max_grad_norm, self.accum = max_grad_norm, int(gradient_accumulation_steps)
         self.trainer = UNetTrainer(unet._arch, unet.state_dict(), self.dev, batch_size, height, width, n_ref=n_ref,
                                    weights=unet._engine_weights(), trainable=self.module)
@@ -112,7 +135,8 @@ class Stage2Trainer:
 
     # ------------------------------------------------------------------------------------------------------- step
     def step(self, batch: dict, use_refs: Optional[Sequence[int]] = None) -> Dict[str, object]:
-        """One micro-step; every `gradient_accumulation_steps`-th call also clips, all-reduces and applies the optimizer.
+        """One micro-batch.  accumulation "reference" (default): clips, all-reduces and applies the optimizer on the gradient of
+        loss / k every call, as the reference's loop does; "true": only every k-th call (accumulation_plan).
         Returns {"loss": device scalar tensor, "lr": float, "optimizer_step": bool}."""
         if "image" in batch:
             batch = self.encode_batch(batch)
@@ -126,14 +150,17 @@ class Stage2Trainer:
         run = self.trainer.train_step_graph if self.use_graph else self.trainer.train_step
         loss, grads = run(batch, use_refs=tuple(use_refs))
         loss = loss.detach().clone()
-        if self.accum > 1:                                          # accelerate scales the loss by 1/k and sums the gradients
+        plan = self.plan
+        if plan["step_every"] > 1:                                  # real accumulation: sum k micro-batches, each scaled 1 / k
             if self._acc is None:
                 self._acc = {n: torch.zeros_like(g) for n, g in grads.items()}
             for n, g in grads.items():
-                self._acc[n].add_(g, alpha=1.0 / self.accum)
+                self._acc[n].add_(g, alpha=plan["grad_scale"])
             grads = self._acc
+        elif plan["grad_scale"] != 1.0:                             # reference: every micro-batch steps on the gradient of loss / k
+            grads = {n: g * plan["grad_scale"] for n, g in grads.items()}
         self._micro += 1
-        stepped = self._micro % self.accum == 0
+        stepped = self._micro % plan["step_every"] == 0
         if stepped:
             allreduce_gradients(grads)                              # DDP's gradient average, :222
             self.optimizer.set_grads(grads)
@@ -145,9 +172,8 @@ class Stage2Trainer:
                     a.zero_()
             self.trainer.set_trainable_parameters(self.named)       # refresh the fp16 operand copies the kernels read
             self.global_step += 1
-        # the reference steps its LR schedule after EVERY micro-batch (train_StorySalon_stage2.py:331, no accelerator.accumulate),
-        # which is why warm-up / total steps are scaled by gradient_accumulation_steps above
-        self.lr_scheduler.step()
+            for _ in range(plan["scheduler_steps_per_optimizer_step"]):     # :331 through accelerate's scheduler wrapper
+                self.lr_scheduler.step()
         return dict(loss=loss, lr=self.lr_scheduler.get_last_lr()[0], optimizer_step=stepped)
 
     # ------------------------------------------------------------------------------------------------ checkpoints

@@ -156,7 +156,7 @@ def test_stage2_trainer_8bit_accumulation_and_checkpoint(gpu, tmp_path):
     unet = _small_unet(gpu)
     before = {n: p.detach().clone() for n, p in unet.named_parameters() if ".attn3." in n}
     tr = Stage2Trainer(unet, 2, 16, 16, learning_rate=1e-4, use_8bit_adam=True, gradient_accumulation_steps=2, lr_scheduler="constant_with_warmup",
-                       lr_warmup_steps=1, use_graph=False, seed=0)
+                       lr_warmup_steps=1, use_graph=False, seed=0, accumulation="true")
     batches = [synthetic_train_batch(2, 16, 768, s) for s in (7, 8, 9, 10)]
     losses = train(tr, iter(batches), train_steps=2)
     assert len(losses) == 2 and tr.global_step == 2 and tr._micro == 4
@@ -171,7 +171,8 @@ def test_stage2_trainer_8bit_accumulation_and_checkpoint(gpu, tmp_path):
     from storygen_amd.model import UNet2DConditionModel
     again = UNet2DConditionModel.from_pretrained(path, subfolder="unet")
     assert all(torch.equal(again.state_dict()[n].cpu(), tr.named[n].detach().cpu()) for n in before)
-    tr2 = Stage2Trainer(again.to(gpu, F32), 2, 16, 16, learning_rate=1e-4, use_8bit_adam=True, gradient_accumulation_steps=2, use_graph=False)
+    tr2 = Stage2Trainer(again.to(gpu, F32), 2, 16, 16, learning_rate=1e-4, use_8bit_adam=True, gradient_accumulation_steps=2, use_graph=False,
+                        accumulation="true")
     tr2.load_training_state(path)
     assert tr2.global_step == 2 and tr2.optimizer.step_count == 2
     i = tr.optimizer.names.index(next(n for n in before if before[n].numel() >= 4096))

@@ -148,3 +148,59 @@ def test_optimizer_rejects_cpu_and_fp16_parameters():
     with pytest.raises(ValueError):
         AdamW([])
     assert math.isclose(1.0, 1.0)
+
+
+@pytest.mark.parametrize("k,world", [(1, 1), (8, 1), (2, 4)])
+def test_reference_accumulation_semantics_lr_and_step_trajectory(k, world):
+    """what `gradient_accumulation_steps = k` means.  The reference's loop (train_StorySalon_stage2.py:326-332) never
+    enters accelerator.accumulate, so accelerate's sync_gradients stays True: EVERY micro-batch clips, steps the optimizer on the gradient
+    of loss / k and steps the scheduler — which accelerate's AcceleratedScheduler advances num_processes times per call — and `step`
+    counts micro-batches; the scheduler was built with warm-up and total steps times k (:215-220).  This transcribes that behaviour
+    with transformers' own schedule (what diffusers restates) and checks Stage2Trainer's plan + get_scheduler against it; the "true"
+    mode steps once per k micro-batches on an unscaled schedule."""
+    import transformers.optimization as to
+    from storygen_amd.optim import get_scheduler
+    from storygen_amd.training import accumulation_plan
+    lr, warm, train_steps, n_calls = 1e-5, 3, 20, 30
+
+    # ---- the reference, transcribed
+    p = torch.nn.Parameter(torch.zeros(1))
+    opt = torch.optim.AdamW([p], lr=lr)
+    ref = to.get_scheduler("linear", opt, num_warmup_steps=warm * k, num_training_steps=train_steps * k)
+    ref_lr, ref_steps, ref_scale = [], [], []
+    step = 0
+    for _ in range(n_calls):
+        ref_scale.append(1.0 / k)            # accelerator.backward(loss): loss / gradient_accumulation_steps
+        opt.step()                           # optimizer.step() (sync_gradients is always True)
+        for _ in range(world):               # AcceleratedScheduler.step(): num_processes steps of the wrapped scheduler
+            ref.step()
+        step += 1                            # `if accelerator.sync_gradients: step += 1`
+        ref_lr.append(ref.get_last_lr()[0])
+        ref_steps.append(step)
+
+    # ---- the trainer's plan
+    plan = accumulation_plan("reference", k, world)
+
+    class _Opt:
+        defaults = dict(lr=lr)
+        param_groups = [dict(lr=lr)]
+    mine = get_scheduler("linear", _Opt(), num_warmup_steps=warm * plan["schedule_multiplier"],
+                         num_training_steps=train_steps * plan["schedule_multiplier"])
+    got_lr, got_steps, got_scale, micro, gstep = [], [], [], 0, 0
+    for _ in range(n_calls):
+        got_scale.append(plan["grad_scale"])
+        micro += 1
+        if micro % plan["step_every"] == 0:
+            gstep += 1
+            for _ in range(plan["scheduler_steps_per_optimizer_step"]):
+                mine.step()
+        got_lr.append(mine.get_last_lr()[0])
+        got_steps.append(gstep)
+    assert got_steps == ref_steps and got_scale == ref_scale
+    assert got_lr == pytest.approx(ref_lr, rel=1e-12, abs=1e-20)
+
+    # ---- real accumulation: one optimizer + scheduler step per k micro-batches, schedule in optimizer steps, independent of world
+    true = accumulation_plan("true", k, world)
+    assert true == dict(grad_scale=1.0 / k, step_every=k, scheduler_steps_per_optimizer_step=1, schedule_multiplier=1)
+    with pytest.raises(ValueError):
+        accumulation_plan("sometimes", k, world)
