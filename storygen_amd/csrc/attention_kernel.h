@@ -270,15 +270,25 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
                     s[kb] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[kb][st], qf[st], st == 0 ? zero16 : s[kb], 0, 0, 0);   // C = inline 0
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
         } else {
+            // D = 160: the K fragments of all 10 k-steps would need 80 VGPRs, so they are read per k-step — ONE k-step ahead of the MFMAs
+            // that consume them (two register sets; the sched_barrier keeps the scheduler from sinking every read to just before its
+            // use, which exposed the full LDS latency on each of the 10 k-steps: round 4, as in ff_fused.hip)
             const char* krow0 = sK + prow * KROW;
             const char* krow1 = sK + (32 + prow) * KROW;
             const int sw0 = kswz<D>(prow), sw1 = kswz<D>(32 + prow);
+            f16x8 k0 = *reinterpret_cast<const f16x8*>(krow0 + ((hi ^ sw0) << 4));
+            f16x8 k1 = *reinterpret_cast<const f16x8*>(krow1 + ((hi ^ sw1) << 4));
 #pragma unroll
             for (int st = 0; st < NDK; ++st) {
-                const f16x8 k0 = *reinterpret_cast<const f16x8*>(krow0 + (((st * 2 + hi) ^ sw0) << 4));
-                const f16x8 k1 = *reinterpret_cast<const f16x8*>(krow1 + (((st * 2 + hi) ^ sw1) << 4));
+                f16x8 k0n = k0, k1n = k1;
+                if (st + 1 < NDK) {
+                    k0n = *reinterpret_cast<const f16x8*>(krow0 + ((((st + 1) * 2 + hi) ^ sw0) << 4));
+                    k1n = *reinterpret_cast<const f16x8*>(krow1 + ((((st + 1) * 2 + hi) ^ sw1) << 4));
+                }
+                __builtin_amdgcn_sched_barrier(0);
                 s[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k0, qf[st], st == 0 ? zero16 : s[0], 0, 0, 0);
                 s[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k1, qf[st], st == 0 ? zero16 : s[1], 0, 0, 0);
+                k0 = k0n; k1 = k1n;
             }
         }
         // ---- V^T fragments of this tile are independent of the softmax: request them now so that their LDS latency
@@ -363,23 +373,40 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
         }
 
         // ---- O^T += VT P^T : 4 k-steps of 16 keys; B fragment = this lane's own P registers
+        if constexpr (!VPRE) {      // (D = 160, LEAN) the first k-step's V^T fragments; every later set is requested one k-step ahead
+#pragma unroll
+            for (int i = 0; i < DT; ++i) {
+                const int d = min(i * 32 + l31, DLAST);
+                vf[0][i] = *reinterpret_cast<const f16x8*>(sV + d * 128 + ((hi ^ ((d >> 1) & 7)) << 4));
+            }
+        }
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             f16x8 pf;
 #pragma unroll
             for (int j = 0; j < 8; ++j) pf[j] = (f16)s[ks >> 1][(ks & 1) * 8 + j];
+            f16x8 vn[VPRE ? 1 : DT];
             if constexpr (!VPRE) {
+                if (ks + 1 < 4) {
 #pragma unroll
-                for (int i = 0; i < DT; ++i) {
-                    const int d = min(i * 32 + l31, DLAST);
-                    vf[0][i] = *reinterpret_cast<const f16x8*>(sV + d * 128 + (((ks * 2 + hi) ^ ((d >> 1) & 7)) << 4));
+                    for (int i = 0; i < DT; ++i) {
+                        const int d = min(i * 32 + l31, DLAST);
+                        vn[i] = *reinterpret_cast<const f16x8*>(sV + d * 128 + ((((ks + 1) * 2 + hi) ^ ((d >> 1) & 7)) << 4));
+                    }
                 }
+                __builtin_amdgcn_sched_barrier(0);
             }
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < DT; ++i)
                 oacc[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[VPRE ? ks : 0][i], pf, oacc[i], 0, 0, 0);
             if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
+            if constexpr (!VPRE) {
+                if (ks + 1 < 4) {
+#pragma unroll
+                    for (int i = 0; i < DT; ++i) vf[0][i] = vn[i];
+                }
+            }
         }
         }
       }   // sub-tiles of the group

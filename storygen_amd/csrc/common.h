@@ -38,11 +38,12 @@ struct SgOptions {
     int tile_m = 0, tile_n = 0;        // force a GEMM / conv tile (0, 0 = heuristic / caller's hint)
     int no_pipe = 0, no_split = 0;     // register-staged kernel only / no automatic split-K
     int no_nmajor = 0;                 // M-major tile order everywhere
+    int pipe_stages = 3;               // 2: 128x128 and 256x64 GEMM / conv tiles on a 2-stage LDS ring (two workgroups per CU)
     int attn_sub2 = 0, attn_prio = 0, attn_d80 = 1, attn_d160 = 3, attn_lean = 0;
     int attn_d40_general = 0;          // 1 = the D = 40 launches use the general softmax path (A/B against the padded-dimension fast path)
     int gn_no_fused = 0, gn_wide = 1;
-    int gn_no_splitk_in = 0;           // reserved (A/B switches of round 4)
-    int ff_variant = 0;                // fused feed-forward: bit 0 = refill spread over the k-steps, bit 1 = fragments two k-steps ahead
+    int gn_fused_nt = 1024;            // threads of the one-launch GroupNorm for slabs <= 16 384 values (256: the round-1 geometry; A/B)
+    int ff_variant = 3;                // fused feed-forward: bit 0 = refill spread over the k-steps, bit 1 = fragments two k-steps ahead
     long gn_fused_max = -1;            // -1 = the kernel's default threshold
 };
 SgOptions& sg_options();

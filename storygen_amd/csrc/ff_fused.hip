@@ -327,7 +327,7 @@ extern "C" int sg_ff_geglu_fused_f16(const sg_ff_desc* d, sg_stream_t stream) {
     p.prof = g_ff_prof;
     const dim3 grid(sg_cdiv(d->M, 32 * FF_NW)), block(64 * FF_NW);
     hipStream_t st = (hipStream_t)stream;
-    const int var = sg_options().ff_variant & 3;        // development option: refill placement / fragment prefetch depth
+    const int var = sg_options().ff_variant & 3;        // development option: refill placement / fragment prefetch depth (default 3: both)
 #ifdef SG_BUILD_EXPERIMENTS
     if (p.prof) {
         if (var == 0) hipLaunchKernelGGL((ff_fused_kernel<5, 0, true>), grid, block, 0, st, p);

@@ -571,15 +571,16 @@ __device__ __forceinline__ void wait_vmcnt() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-constexpr int S = 3;   // LDS ring depth (2 and 4 were measured in round 2: DESIGN.md 5.2)
-
-template <int WGM, int WGN>
+// LDS ring depth S: 3 by default (one slab computing, two in flight).  S = 2 (round 4) halves the bytes in flight but brings the
+// 128x128 and 256x64 tiles down to 74 / 80 KB of LDS, so that TWO workgroups — one of each of the step's two concurrent passes — fit a
+// CU (round 2 measured the forced 128x128 / 2-stage configuration as the fastest whole step; development option pipe_stages).
+template <int WGM, int WGN, int S>
 constexpr int pipe_smem_bytes() {
     constexpr int ring = S * (64 * WGM + 64 * WGN) * 128, epi = WGM * WGN * EPI_WAVE_BYTES;
     return ring > epi ? ring : epi;
 }
 
-template <int WGM, int WGN, bool CONV, bool PROF = false>
+template <int WGM, int WGN, bool CONV, bool PROF = false, int S = 3>
 __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     // PROF (SG_BUILD_EXPERIMENTS): s_memtime stamps around the phases of every slab, summed per wave (sg_debug_gemm_anatomy /
     // _conv_anatomy): [0] slabs [1] vmcnt wait [2] barrier [3] first fragment reads + k-step 0 [4] k-step 1 up to the DMA issue
@@ -599,9 +600,10 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW), LPT = A_IT + B_IT;   // LDS-DMA instructions / lane / slab
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int ISTR = NW * 1024;   // LDS bytes covered by one DMA instruction of the whole workgroup (8 rows / wave)
+    static_assert(S == 2 || S == 3, "ring depth");
     static_assert((S - 2) * LPT < 64, "vmcnt is a 6-bit counter");
     static_assert(S * STAGE <= 160 * 1024, "the ring must fit the 160 KB of LDS");
-    static_assert(S * STAGE == pipe_smem_bytes<WGM, WGN>(), "the ring covers the epilogue's staging regions for every tile shape");
+    static_assert(S * STAGE <= pipe_smem_bytes<WGM, WGN, S>(), "the LDS block covers the ring and the epilogue's staging regions");
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -685,7 +687,7 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         }
     };
     if (nt > 0) issue_a(kt0, 0);
-    if (nt > 1) { issue_a(kt0 + 1, 1); issue_w(kt0 + 1, 1); }
+    if (S > 2 && nt > 1) { issue_a(kt0 + 1, 1); issue_w(kt0 + 1, 1); }
 
     f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -702,7 +704,7 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     auto slab = [&](int it, auto last_tag) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
         // one younger slab stays in flight while we wait for slab `it` (none at the very end)
-        if constexpr (LAST) wait_vmcnt<0>();
+        if constexpr (LAST || S == 2) wait_vmcnt<0>();
         else wait_vmcnt<LPT>();
         stamp(1);
         __builtin_amdgcn_s_barrier();
@@ -765,16 +767,16 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     }
 }
 
-template <int WGM, int WGN, bool CONV>
+template <int WGM, int WGN, bool CONV, int S = 3>
 __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN>()];
-    mma_pipe_body<WGM, WGN, CONV>(p, smem);
+    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN, S>()];
+    mma_pipe_body<WGM, WGN, CONV, false, S>(p, smem);
 }
 
 #ifdef SG_BUILD_EXPERIMENTS
 template <int WGM, int WGN, bool CONV>
 __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_prof_kernel(const MmaParams p) {
-    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN>()];
+    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN, 3>()];
     mma_pipe_body<WGM, WGN, CONV, true>(p, smem);
 }
 #endif
@@ -788,7 +790,7 @@ struct MmaPair { MmaParams p0, p1; };
 
 template <int WGM, int WGN>
 __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_pair_kernel(const MmaPair pp) {
-    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN>()];
+    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN, 3>()];
     if (blockIdx.y == 0) {
         if ((int)blockIdx.x < pp.p0.tiles_m * pp.p0.tiles_n * pp.p0.splits) mma_pipe_body<WGM, WGN, false>(pp.p0, smem);
     } else {
@@ -1077,6 +1079,13 @@ void launch_pipe(const MmaParams& p, dim3 grid, hipStream_t st) {
         return;
     }
 #endif
+    // development option pipe_stages = 2: the tiles whose 3-stage ring keeps a second workgroup off the CU run a 2-stage ring
+    if constexpr ((WGM == 2 && WGN == 2) || (WGM == 4 && WGN == 1)) {
+        if (sg_options().pipe_stages == 2) {
+            hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, CONV, 2>), grid, block, 0, st, p);
+            return;
+        }
+    }
     hipLaunchKernelGGL((mma_pipe_kernel<WGM, WGN, CONV>), grid, block, 0, st, p);
 }
 

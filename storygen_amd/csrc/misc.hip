@@ -19,7 +19,7 @@ extern "C" int sg_debug_set_option(const char* name, int64_t value) {
                            {"no_nmajor", &o.no_nmajor}, {"attn_sub2", &o.attn_sub2}, {"attn_prio", &o.attn_prio},
                            {"attn_d80", &o.attn_d80}, {"attn_d160", &o.attn_d160}, {"gn_no_fused", &o.gn_no_fused},
                            {"gn_wide", &o.gn_wide}, {"attn_lean", &o.attn_lean}, {"attn_d40_general", &o.attn_d40_general},
-                           {"gn_no_splitk_in", &o.gn_no_splitk_in}, {"ff_variant", &o.ff_variant}};
+                           {"gn_fused_nt", &o.gn_fused_nt}, {"pipe_stages", &o.pipe_stages}, {"ff_variant", &o.ff_variant}};
     for (const Entry& e : table)
         if (strcmp(e.n, name) == 0) {
             *e.p = (int)value;

@@ -618,29 +618,33 @@ constexpr long GNF_DEFAULT_MAX = 10240;
 // (slice order) + bias + temb row + residual, i.e. exactly what splitk_reduce_kernel would have stored, computed while the slab is
 // loaded; the reduced tensor is written only if somebody else needs it.  conv1 -> norm2 and conv2 -> Transformer2DModel.norm at the
 // 16x16 / 8x8 levels lose their second pass (and the round trip of the reduced tensor through memory).
-template <bool SPLIT>
-__global__ __launch_bounds__(256) void gn_fused_kernel(const GnParams p) {
-    __shared__ float s_red[8];
+// NT threads per workgroup, MAXI items per thread: 256 x 24 for large slabs; 1024 x 4 (slabs up to 16 384 values) keeps four times
+// as many loads in flight per CU — one workgroup per (batch, group) is at most 128 workgroups, so each CU's memory-level parallelism is
+// what bounds the kernel, above all when the slab arrives as S split-K slices.
+template <bool SPLIT, int NT, int MAXI>
+__global__ __launch_bounds__(NT) void gn_fused_kernel(const GnParams p) {
+    static_assert(MAXI % 4 == 0, "the split pre-pass works in batches of four items");
+    __shared__ float s_red[NT / 64];
     const int t = threadIdx.x, b = blockIdx.y, g = blockIdx.x;
     const int q = p.cpg / 4;                    // 4-channel items per pixel in this group
     const int items = p.HW * q;
     const long xb = (long)b * p.HW * p.ldx + (long)g * p.cpg;
     const bool f32 = p.x_f32;
-    float v[GNF_MAXI][4];
-    f16x4 gm[GNF_MAXI], bt[GNF_MAXI];    // the affine parameters travel with the data, not after the statistics
+    float v[MAXI][4];
+    f16x4 gm[MAXI], bt[MAXI];    // the affine parameters travel with the data, not after the statistics
     if constexpr (SPLIT) {
         // Batched pre-pass: 4 items x 4 slices = 16 independent 16-byte loads in flight per thread, addresses clamped instead of
         // predicated (a load inside a per-item `if` is waited for where it is issued: one exposed round trip per item and slice group).
         // Slices are added in slice order, then bias, temb row, residual — the order of splitk_reduce_kernel: bit-identical values.
 #pragma unroll
-        for (int i0 = 0; i0 < GNF_MAXI; i0 += 4) {
-            if (i0 * 256 < items) {                         // block-uniform
+        for (int i0 = 0; i0 < MAXI; i0 += 4) {
+            if (i0 * NT < items) {                         // block-uniform
                 const float* sl[4];
                 long mm[4];
                 int nn[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const int it = min(t + (i0 + k) * 256, items - 1);
+                    const int it = min(t + (i0 + k) * NT, items - 1);
                     const int px = it / q, c4 = it - px * q;
                     mm[k] = (long)b * p.HW + px;
                     nn[k] = g * p.cpg + c4 * 4;
@@ -695,7 +699,7 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GnParams p) {
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const bool mine = t + (i0 + k) * 256 < items;
+                    const bool mine = t + (i0 + k) * NT < items;
                     if (mine && p.sp_out && p.sp_out_f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.sp_out) + mm[k] * p.sp_ldo + nn[k]) = a[k];
                     if (p.sp_round) {      // the tensor is (or would have been) stored in fp16: normalise what a reader of it would see
                         const f16x4 hh = {(f16)a[k].x, (f16)a[k].y, (f16)a[k].z, (f16)a[k].w};
@@ -713,8 +717,8 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GnParams p) {
     }
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < GNF_MAXI; ++i) {
-        const int it = t + i * 256;
+    for (int i = 0; i < MAXI; ++i) {
+        const int it = t + i * NT;
         if constexpr (!SPLIT) v[i][0] = v[i][1] = v[i][2] = v[i][3] = 0.f;
         gm[i] = bt[i] = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
         if (it < items) {
@@ -739,14 +743,17 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GnParams p) {
         __syncthreads();
         if ((t & 63) == 0) s_red[t >> 6] = x;
         __syncthreads();
-        return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        float tot = 0.f;
+#pragma unroll
+        for (int w = 0; w < NT / 64; ++w) tot += s_red[w];       // fixed order: deterministic
+        return tot;
     };
     const float n = (float)items * 4.f;
     const float mean = block_sum(sum) / n;
     float sq = 0.f;
 #pragma unroll
-    for (int i = 0; i < GNF_MAXI; ++i)
-        if (t + i * 256 < items) {
+    for (int i = 0; i < MAXI; ++i)
+        if (t + i * NT < items) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; sq += d * d; }
         }
@@ -755,8 +762,8 @@ __global__ __launch_bounds__(256) void gn_fused_kernel(const GnParams p) {
     f16* yb = pw ? p.y + ((long)b * (p.HW / pw + 2) * (pw + 2)) * p.ldy : p.y + (long)b * p.HW * p.ldy;
     f16* cb = p.xcopy ? p.xcopy + (long)b * p.HW * p.ldxc : nullptr;
 #pragma unroll
-    for (int i = 0; i < GNF_MAXI; ++i) {
-        const int it = t + i * 256;
+    for (int i = 0; i < MAXI; ++i) {
+        const int it = t + i * NT;
         if (it < items) {
             const int px = it / q, c4 = it - px * q;
             const int ch = g * p.cpg + c4 * 4;
@@ -933,12 +940,17 @@ extern "C" int sg_groupnorm_nhwc_f16(const sg_groupnorm_desc* d, sg_stream_t str
         p.sp_res = d->split_res; p.sp_ldr = d->split_ldr; p.sp_res_f32 = d->split_res_f32 ? 1 : 0;
         p.sp_out = d->split_out; p.sp_ldo = d->split_ldo; p.sp_out_f32 = d->split_out_f32 ? 1 : 0;
         p.sp_round = (d->split_out ? !d->split_out_f32 : d->split_round_f16 != 0) ? 1 : 0;
-        hipLaunchKernelGGL(gn_fused_kernel<true>, dim3(p.G, d->B), dim3(256), 0, st0, p);
+        SG_REQUIRE((long)p.HW * p.cpg <= 1024L * 4 * 4, "sg_groupnorm: split_ws serves slabs of up to 16384 values");
+        hipLaunchKernelGGL((gn_fused_kernel<true, 1024, 4>), dim3(p.G, d->B), dim3(1024), 0, st0, p);
         SG_CHECK_LAUNCH("gn_fused<split>");
         return SG_OK;
     }
     if (gn_takes_fused(p.HW, p.C, p.G)) {
-        hipLaunchKernelGGL(gn_fused_kernel<false>, dim3(p.G, d->B), dim3(256), 0, st0, p);
+        // development option gn_fused_nt = 1024: the 1024-thread instantiation for slabs it can hold (A/B; default 256 threads)
+        if (opt.gn_fused_nt == 1024 && (long)p.HW * p.cpg <= 1024L * 4 * 4)
+            hipLaunchKernelGGL((gn_fused_kernel<false, 1024, 4>), dim3(p.G, d->B), dim3(1024), 0, st0, p);
+        else
+            hipLaunchKernelGGL((gn_fused_kernel<false, 256, GNF_MAXI>), dim3(p.G, d->B), dim3(256), 0, st0, p);
         SG_CHECK_LAUNCH("gn_fused");
         return SG_OK;
     }

@@ -874,7 +874,8 @@ def attention_lse(q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, out: torch
     if tuple(lse2.shape) != (q.shape[0], heads, q.shape[1]) or not lse2.is_contiguous():
         raise ValueError("attention_lse: lse2 must be a contiguous [B, H, Nq]")
     d = _attn_desc(q, k, vt, out, heads, scale, nk)
-    check(lib.sg_attn_fwd_lse_f16(C.byref(d), lse2.data_ptr(), _stream()), "sg_attn_fwd_lse_f16")
+    with _timed(f"attention_d{d.D}", 4.0 * d.B * d.H * d.Nq * d.Nk * d.D, f"B{d.B} H{d.H} Nq{d.Nq} Nk{d.Nk} lse"):
+        check(lib.sg_attn_fwd_lse_f16(C.byref(d), lse2.data_ptr(), _stream()), "sg_attn_fwd_lse_f16")
     return out
 
 
@@ -914,7 +915,8 @@ def attention_bwd_dq(q: torch.Tensor, k: torch.Tensor, kt: torch.Tensor, v: torc
     _f16(kt, "kt"), _f16(dq, "dq")
     d.kt, d.ldkt, d.bskt = kt.data_ptr(), kt.stride(1), kt.stride(0)
     d.dq, d.lddq, d.bsdq = dq.data_ptr(), dq.stride(1), dq.stride(0)
-    check(lib.sg_attn_bwd_dq_f16(C.byref(d), _stream()), "sg_attn_bwd_dq_f16")
+    with _timed("attention_bwd", 6.0 * d.B * d.H * d.Nq * d.Nk * d.D, f"dq B{d.B} H{d.H} Nq{d.Nq} Nk{d.Nk} D{d.D}"):     # S, dP, dQ: 1.5 x forward
+        check(lib.sg_attn_bwd_dq_f16(C.byref(d), _stream()), "sg_attn_bwd_dq_f16")
     return dq
 
 
@@ -928,7 +930,8 @@ def attention_bwd_dkv(q: torch.Tensor, qt: torch.Tensor, k: torch.Tensor, v: tor
     d.dot, d.lddot, d.bsdot = dot.data_ptr(), dot.stride(1), dot.stride(0)
     d.dkt, d.lddkt, d.bsdkt = dkt.data_ptr(), dkt.stride(1), dkt.stride(0)
     d.dvt, d.lddvt, d.bsdvt = dvt.data_ptr(), dvt.stride(1), dvt.stride(0)
-    check(lib.sg_attn_bwd_dkv_f16(C.byref(d), _stream()), "sg_attn_bwd_dkv_f16")
+    with _timed("attention_bwd", 8.0 * d.B * d.H * d.Nq * d.Nk * d.D, f"dkv B{d.B} H{d.H} Nq{d.Nq} Nk{d.Nk} D{d.D}"):    # S, dP, dK, dV: 2 x forward
+        check(lib.sg_attn_bwd_dkv_f16(C.byref(d), _stream()), "sg_attn_bwd_dkv_f16")
     return dkt, dvt
 
 
@@ -946,7 +949,7 @@ def debug_set_option(name: str, value: int) -> None:
 # library no longer reads the environment: this maps the variables onto sg_debug_set_option, and only when a tool asks for it.
 _ENV_OPTIONS = {"SG_NO_NMAJOR": "no_nmajor", "SG_NO_PIPE": "no_pipe", "SG_NO_SPLIT": "no_split",
                 "SG_ATTN_SUB2": "attn_sub2", "SG_ATTN_PRIO": "attn_prio", "SG_ATTN_D80": "attn_d80", "SG_ATTN_D160": "attn_d160",
-                "SG_FF_VARIANT": "ff_variant", "SG_ATTN_LEAN": "attn_lean", "SG_ATTN_D40_GENERAL": "attn_d40_general", "SG_NO_GN_FUSED": "gn_no_fused", "SG_GN_WIDE": "gn_wide", "SG_GN_FUSED_MAX": "gn_fused_max"}
+                "SG_FF_VARIANT": "ff_variant", "SG_PIPE_STAGES": "pipe_stages", "SG_GN_FUSED_NT": "gn_fused_nt", "SG_ATTN_LEAN": "attn_lean", "SG_ATTN_D40_GENERAL": "attn_d40_general", "SG_NO_GN_FUSED": "gn_no_fused", "SG_GN_WIDE": "gn_wide", "SG_GN_FUSED_MAX": "gn_fused_max"}
 
 
 def apply_env_options() -> dict:

@@ -213,6 +213,9 @@ class StoryGenSampler:
         self.side_ref = torch.cuda.Stream(device=self.dev) if want_ref else None
         f32 = dict(dtype=torch.float32, device=self.dev)
         self.ref_src = torch.zeros((self.U,) + tuple(self.latents.shape[1:]), **f32)
+        # the noise of every reference sample (pipeline.py:409: ONE draw per story frame n, shared by its prior frames and its zero-image
+        # sample): expanded per reference unit, because the units are ordered like the context buffer (row-major in n), not n-minor
+        self.ref_noise = torch.zeros((self.U,) + tuple(self.latents.shape[1:]), **f32)
         # per-step parameters: [U] ref timesteps | [B] main timestep | [U,2] add_noise coefs | guidance + update-rule coefs
         self.n_par = 3 * self.U + self.B + 2 + self.schedule.row_len
         self.params = torch.zeros(self.n_par, **f32)
@@ -253,6 +256,7 @@ class StoryGenSampler:
         for u, (kind, i, n) in enumerate(self.units):                                     # :420-430 (none for stage "no")
             self.ref_src[u].copy_(zero[n] if kind == 0 else imgs[i, n])
             self.ref.text_in[u].copy_((pu[i][n] if kind == 0 else inputs["prev_text"][i][n]).to(dev, h))
+            self.ref_noise[u].copy_(self.noise[n])
         self.latents3.copy_(torch.cat([self.latents] * 3))                                # :450
         self.main.cache_text_kv()
         if self.ref is not None:
@@ -286,7 +290,7 @@ class StoryGenSampler:
         """The reference samples of step(s) -> context set `ctx_set` (ref_ahead = G > 1: of G steps -> sets ctx_set ..
         ctx_set + G - 1, one harvest plan per step's slice of the batch)."""
         t_ref, _, an, _ = self._par_views()
-        ops.add_noise(self.ref_src, self.noise, an, self.ref.x_in)                        # :419-429
+        ops.add_noise(self.ref_src, self.ref_noise, an, self.ref.x_in)                    # :419-429 (noise of unit u = noise[n(u)])
         self.ref.t_in.copy_(t_ref)
         plan = self.plans[ctx_set] if self.G == 1 else self.plans[ctx_set:ctx_set + self.G]
         self.ref.forward(harvest=plan, harvest_only=True, text_cache=True, side=self.side_ref)

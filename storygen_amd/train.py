@@ -116,6 +116,12 @@ class UNetTrainer:
         self.last_grad_scale = 1.0
         self._graphs: Dict[tuple, dict] = {}       # train_step_graph: use_refs -> captured hipGraph + static inputs / outputs
         self.check_finite = True                   # train_step_graph: one host read of the gradients' finiteness per step
+        # GradScaler semantics for the graph path (train_StorySalon_stage2.py:138-141,328 trains under accelerate's fp16 GradScaler): a
+        # step whose gradients stay non-finite after the scale has been lowered is SKIPPED (last_step_skipped; the caller must not
+        # apply it) instead of aborting the run; every `scale_growth_interval` good steps the scale is doubled again
+        self.last_step_skipped = False
+        self.scale_growth_interval = 2000
+        self._good_steps = 0
         self._alphas_dev = self.schedule.alphas_cumprod.to(self.dev, F32)
 
     # ------------------------------------------------------------------------------------------------ pieces
@@ -206,9 +212,13 @@ class UNetTrainer:
         into static device tensors, fixes the gradient scale from one eager step ("auto" needs a host read, a graph cannot), warms
         up and captures `_step_device` (its per-call allocations come from the graph's private pool, so replays reuse the same
         addresses); later calls copy the new batch into the static inputs and replay.  The returned loss / gradients are the
-        graph's static outputs: consume them (optimizer step, all-reduce) before the next call.  A non-finite gradient drops
-        the captured graph, lowers the scale 16x and re-captures — at most four times, then raises."""
+        graph's static outputs: consume them (optimizer step, all-reduce) before the next call.  A non-finite gradient drops ALL
+        captured graphs (every `use_refs` variant must run at the same scale), lowers the scale 16x and re-captures — at most four
+        times; if the gradients are still not finite the step is marked skipped (`last_step_skipped`, as torch's GradScaler skips
+        optimizer.step) and the scale stays lowered.  After `scale_growth_interval` consecutive good steps the scale doubles."""
         use_refs = tuple(use_refs)
+        if _retry == 0:
+            self.last_step_skipped = False
         staged = self._stage_inputs(batch)
         st = self._graphs.get(use_refs)
         if st is None:
@@ -237,13 +247,25 @@ class UNetTrainer:
                 # fp16 overflow of the scaled backward: drop the graph and retry with a 16x smaller scale — a BOUNDED number of
                 # times (a NaN that comes from the batch or the weights never goes away: the reference's GradScaler would skip such
                 # a step; here the caller gets an error instead of an endless re-capture)
-                self._graphs.pop(use_refs)
                 s_now = float(self.grad_scale) if self.grad_scale != "auto" else float(self.last_grad_scale)
+                self._good_steps = 0
+                if not bool(torch.isfinite(st["loss"]).all()):
+                    # the LOSS is not finite: the batch (or the weights) is, not the loss scale — skip the step, keep the scale
+                    self.last_step_skipped = True
+                    return st["loss"], st["grads"]
                 if _retry >= 4 or s_now / 16.0 < 2.0 ** -8:
-                    raise FloatingPointError(f"train_step_graph: non-finite gradients at loss scale {s_now:g} after {_retry} retries "
-                                             "(inputs or weights are not finite?)")
+                    # a NaN that comes from the batch or the weights never goes away: skip the step, as GradScaler does
+                    self.last_step_skipped = True
+                    return st["loss"], st["grads"]
+                self._graphs.clear()                 # every variant was captured with the old scale baked in
                 self.grad_scale = s_now / 16.0
                 return self.train_step_graph(batch, use_refs, _retry=_retry + 1)
+            self._good_steps += 1
+            if self._good_steps >= self.scale_growth_interval and self.grad_scale != "auto":
+                self._good_steps = 0
+                self.grad_scale = float(self.grad_scale) * 2.0      # takes effect at the next call (re-capture)
+                self._graphs.clear()
+                return st["loss"].clone(), {k: v.clone() for k, v in st["grads"].items()}     # (the pool of the dropped graph may be reused)
         return st["loss"], st["grads"]
 
     def set_trainable_parameters(self, named_params: Dict[str, torch.Tensor]) -> None:

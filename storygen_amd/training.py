@@ -150,6 +150,9 @@ class Stage2Trainer:
         run = self.trainer.train_step_graph if self.use_graph else self.trainer.train_step
         loss, grads = run(batch, use_refs=tuple(use_refs))
         loss = loss.detach().clone()
+        if self.use_graph and self.trainer.last_step_skipped:       # non-finite gradients at every loss scale: GradScaler skips the step
+            self._micro += 1
+            return dict(loss=loss, lr=self.lr_scheduler.get_last_lr()[0], optimizer_step=False, skipped=True)
         plan = self.plan
         if plan["step_every"] > 1:                                  # real accumulation: sum k micro-batches, each scaled 1 / k
             if self._acc is None:

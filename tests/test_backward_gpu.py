@@ -330,6 +330,50 @@ def test_training_step_graph_replay_matches_eager(gpu):
     assert len(tr._graphs) == 1
 
 
+def test_training_step_graph_skips_a_step_with_non_finite_gradients_and_regrows_the_scale(gpu):
+    """the graph path must behave like the reference's fp16 GradScaler (train_StorySalon_stage2.py:138-141,328) — a batch
+    whose gradients are non-finite at every loss scale is SKIPPED (flag, no exception), all captured graphs share one scale, and the
+    scale grows back after `scale_growth_interval` good steps."""
+    from storygen_amd.arch import build_arch, load_config
+    from storygen_amd.synth import synthetic_state_dict, synthetic_train_batch
+    from storygen_amd.train import UNetTrainer
+    cfg = load_config(dict(block_out_channels=(320, 640), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                           up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), cross_attention_dim=768, attention_head_dim=8,
+                           sample_size=128))
+    arch = build_arch(cfg)
+    tr = UNetTrainer(arch, synthetic_state_dict(arch, 7), gpu, 2, 16, 16, n_ref=3)
+    good = synthetic_train_batch(2, 16, 768, 7)
+    loss, grads = tr.train_step_graph(good)
+    torch.cuda.synchronize()
+    assert not tr.last_step_skipped and all(bool(torch.isfinite(g).all()) for g in grads.values())
+    scale0 = float(tr.grad_scale)
+    tr.train_step_graph(good, use_refs=(2,))                          # a second captured variant at the same scale
+    assert len(tr._graphs) == 2
+    bad = dict(good)
+    bad["noise"] = good["noise"].clone()
+    bad["noise"].view(-1)[0] = float("nan")                           # the loss gradient is NaN whatever the scale
+    loss, grads = tr.train_step_graph(bad)
+    torch.cuda.synchronize()
+    assert tr.last_step_skipped, "a batch with NaN gradients must be reported as skipped, not raise"
+    assert float(tr.grad_scale) == scale0 and len(tr._graphs) == 2, "a non-finite LOSS is the batch's fault: the scale stays"
+    # an overflow of the scaled backward (finite loss): the scale drops 16x and every captured variant is dropped with it
+    tr.grad_scale = scale0 * 2.0 ** 24                                # (the two variants captured at scale0 are still on file)
+    tr._graphs.pop((0, 1, 2))
+    loss, grads = tr.train_step_graph(good)
+    torch.cuda.synchronize()
+    assert not tr.last_step_skipped and all(bool(torch.isfinite(g).all()) for g in grads.values())
+    assert float(tr.grad_scale) < scale0 * 2.0 ** 24 and len(tr._graphs) == 1, "the lowered scale invalidates every captured variant"
+    # good batches again: not skipped, and after `scale_growth_interval` of them the scale doubles
+    tr.scale_growth_interval = 3
+    tr._good_steps = 0
+    lowered = float(tr.grad_scale)
+    for _ in range(3):
+        loss, grads = tr.train_step_graph(good)
+        torch.cuda.synchronize()
+        assert not tr.last_step_skipped and all(bool(torch.isfinite(g).all()) for g in grads.values())
+    assert float(tr.grad_scale) == 2.0 * lowered and not tr._graphs
+
+
 def test_training_step_at_baseline_config4_size_vs_reference_golden(gpu):
     """BASELINE config 4 AT ITS OWN SIZE: SD-1.5 UNet, 64x64 latent, batch 4, reference frames (0, 1, 2) — loss and all 80 attn3
     gradients of UNetTrainer.train_step_graph (the whole step as one hipGraph, loss scaling included) against the gradients the

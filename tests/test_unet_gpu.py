@@ -166,24 +166,27 @@ def test_pndm_loop_vs_oracle_32x32(gpu, sd15, stage):
     from storygen_amd.synth import synthetic_inputs
     arch, sd = sd15
     inputs = synthetic_inputs(1, 2, 32, 32, 9, arch.config["cross_attention_dim"])
+    # all 6 evaluations (every branch of the multistep rule) in the contract stage; the other stage differs only in the reference
+    # passes' noise levels, so its first 3 evaluations (incl. the repeated timestep) are enough — the oracle runs live on the CPU
+    n_eval = 6 if stage == "multi-image-condition" else 3
     want = []
-    O.sample_loop(sd, arch.config, inputs, 5, stage, 7.5, 3.5, trace=want, scheduler="pndm")
+    O.sample_loop(sd, arch.config, inputs, 5, stage, 7.5, 3.5, max_steps=n_eval, trace=want, scheduler="pndm")
     smp = StoryGenSampler(arch, sd, gpu, 1, 32, 32, 2, schedule=PNDMSchedule(skip_prk_steps=True))
     smp.prepare(inputs, 5, stage, 7.5, 3.5)
     assert smp.timesteps == [801, 601, 601, 401, 201, 1] and smp.num_steps == 6
     got = []
-    smp.run(trace=got)
+    smp.run(max_steps=n_eval, trace=got)
     torch.cuda.synchronize()
     errs = [rel_l2(a.cpu(), b) for a, b in zip(got, want)]
     print(stage, [f"{e:.2e}" for e in errs])
     # a 5-step schedule multiplies the per-pass epsilon error by far larger coefficients than the 50-step one the 1e-3 bar
     # is stated for: 3e-3 here
-    assert len(errs) == 6 and max(errs) <= 3e-3, errs
+    assert len(errs) == n_eval and max(errs) <= 3e-3, errs
 
 
 def test_pndm_on_the_50_step_schedule_meets_the_north_star_bar_32x32(gpu, sd15):
-    """The same PNDM / PLMS loop on the schedule the 1e-3 bar is stated for (50 inference steps): the first five UNet evaluations
-    (1, 2, 3, 4 history terms and the repeated second timestep) against the oracle's restatement, bar 1e-3 — the 3e-3 of the
+    """The same PNDM / PLMS loop on the schedule the 1e-3 bar is stated for (50 inference steps): the first four UNet evaluations
+    (1, 2, 3 history terms and the repeated second timestep) against the oracle's restatement, bar 1e-3 — the 3e-3 of the
     5-step test above is the schedule's coefficients, not the update rule."""
     from oracle import storygen_oracle as O
     from storygen_amd.sampler import StoryGenSampler
@@ -192,15 +195,15 @@ def test_pndm_on_the_50_step_schedule_meets_the_north_star_bar_32x32(gpu, sd15):
     arch, sd = sd15
     inputs = synthetic_inputs(1, 2, 32, 32, 9, arch.config["cross_attention_dim"])
     want = []
-    O.sample_loop(sd, arch.config, inputs, 50, "multi-image-condition", 7.5, 3.5, max_steps=5, trace=want, scheduler="pndm")
+    O.sample_loop(sd, arch.config, inputs, 50, "multi-image-condition", 7.5, 3.5, max_steps=4, trace=want, scheduler="pndm")
     smp = StoryGenSampler(arch, sd, gpu, 1, 32, 32, 2, schedule=PNDMSchedule(skip_prk_steps=True))
     smp.prepare(inputs, 50, "multi-image-condition", 7.5, 3.5)
     got = []
-    smp.run(max_steps=5, trace=got)
+    smp.run(max_steps=4, trace=got)
     torch.cuda.synchronize()
     errs = [rel_l2(a.cpu(), b) for a, b in zip(got, want)]
-    print("PNDM, 50-step schedule, evaluations 1..5:", [f"{e:.2e}" for e in errs])
-    assert len(errs) == 5 and max(errs) <= TOL_LATENT, errs
+    print("PNDM, 50-step schedule, evaluations 1..4:", [f"{e:.2e}" for e in errs])
+    assert len(errs) == 4 and max(errs) <= TOL_LATENT, errs      # (the 4-history-term branch: the 5-step test above)
 
 
 def test_unet_single_pass_vs_reference_golden_64x64(gpu, sd15):
@@ -266,7 +269,7 @@ def test_paired_text_image_attention_is_the_same_trajectory(gpu, sd15, monkeypat
 
 
 def test_loop_vs_oracle_both_stages_32x32(gpu, sd15):
-    """The whole loop (R=2, first 3 steps of the 50-step schedule BASELINE config 2 uses — the 1e-3 latent bar is
+    """The whole loop (R=2, first 2 steps of the 50-step schedule BASELINE config 2 uses — the 1e-3 latent bar is
     stated for that schedule: a coarser one multiplies the same epsilon error by a larger DDIM coefficient) in both
     stages against the oracle loop at 32x32."""
     from oracle import storygen_oracle as O
@@ -277,10 +280,10 @@ def test_loop_vs_oracle_both_stages_32x32(gpu, sd15):
     smp = StoryGenSampler(arch, sd, gpu, 1, 32, 32, 2, use_graph=True)
     for stage in ("multi-image-condition", "auto-regressive"):
         want = []
-        O.sample_loop(sd, arch.config, inputs, 50, stage, 7.5, 3.5, max_steps=3, trace=want)
+        O.sample_loop(sd, arch.config, inputs, 50, stage, 7.5, 3.5, max_steps=2, trace=want)      # (3 until round 3: suite time)
         smp.prepare(inputs, 50, stage, 7.5, 3.5)
         got = []
-        smp.run(max_steps=3, trace=got)
+        smp.run(max_steps=2, trace=got)
         torch.cuda.synchronize()
         errs = [rel_l2(a.cpu(), b) for a, b in zip(got, want)]
         print(stage, [f"{e:.2e}" for e in errs])
