@@ -14,7 +14,7 @@ import os
 import sys
 
 GROUPS = {"mma_pipe_kernel (gemm + conv3x3)": ("mma_pipe_kernel", "mma_pipe_pair_kernel", "mma_kernel", "splitk_reduce_kernel"),
-          "attn_fwd_kernel": ("attn_fwd_kernel",),
+          "attn_fwd_kernel": ("attn_fwd_kernel",), "ff_fused_kernel": ("ff_fused_kernel",),
           "groupnorm": ("gn_stats", "gn_apply", "gn_fused"), "layernorm": ("layernorm_kernel",)}
 
 
