@@ -127,6 +127,33 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 #define EPI_PRE_ARGS pre_f, pre_bias
 #define EPI_PRE_PARAMS f32x4 (&pre)[16], u32x2& pbias
 
+// Epilogue traffic is streamed once (outputs written, residuals read): with SG_EPI_NT the accesses carry the non-temporal hint, so
+// they do not evict the operand panels (weights, im2col rows re-read by every tap and column tile) from the XCD's 4 MB L2 — the PMC
+// pass of round 4 measured 150 MB of fabric traffic per 64x64 320->320 convolution against 58 MB of compulsory traffic.
+typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void st_stream(float* p, const f32x4& v) {
+#ifdef SG_EPI_NT
+    __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p));
+#else
+    *reinterpret_cast<f32x4*>(p) = v;
+#endif
+}
+__device__ __forceinline__ void st_stream(f16* p, const uint2& v) {
+    const u32x2v w = {v.x, v.y};
+#ifdef SG_EPI_NT
+    __builtin_nontemporal_store(w, reinterpret_cast<u32x2v*>(p));
+#else
+    *reinterpret_cast<u32x2v*>(p) = w;
+#endif
+}
+__device__ __forceinline__ f32x4 ld_stream(const float* p) {
+#ifdef SG_EPI_NT
+    return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+#else
+    return *reinterpret_cast<const f32x4*>(p);
+#endif
+}
+
 // Everything the fused linear epilogue needs from memory that does not depend on the accumulators is requested early — during the
 // last K slab — into registers: the fp32 residual (the UNet's residual stream) in the row-quad layout (16 B per item; rowq = first
 // row of the wave's sub-tile + (lane >> 4), colq = first column + 4 (lane & 15)) and the bias.  Rows / columns beyond the problem
@@ -144,7 +171,7 @@ __device__ __forceinline__ void epi_prefetch(const MmaParams& p, int m0, int n0,
     const float* r = reinterpret_cast<const float*>(p.res1) + cq;
     const int mlast = p.M - 1;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) pre[k] = *reinterpret_cast<const f32x4*>(r + (long)min(rowq + 4 * k, mlast) * p.ldr1);
+    for (int k = 0; k < 16; ++k) pre[k] = ld_stream(r + (long)min(rowq + 4 * k, mlast) * p.ldr1);
 }
 
 // LayerNorm fold (consumer side).  The GEMM ran on the RAW fp16 activations x with W' = gamma (.) W, so
@@ -177,15 +204,16 @@ __device__ __forceinline__ float2 ln_token_coeffs(const MmaParams& p, int token)
 
 union H4 { uint2 u; f16 h[4]; };
 
+
 __device__ __forceinline__ void store_out4(const MmaParams& p, int gm, int gn, const float (&v)[4]) {
     const bool f32 = p.flags & SG_F_OUT_F32;
-    if (f32) *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn) = make_float4(v[0], v[1], v[2], v[3]);
+    if (f32) st_stream(reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn, f32x4{v[0], v[1], v[2], v[3]});
     if (!f32 || p.C2) {
         H4 o;
 #pragma unroll
         for (int e = 0; e < 4; ++e) o.h[e] = (f16)v[e];
-        if (!f32) *reinterpret_cast<uint2*>(reinterpret_cast<f16*>(p.C) + (long)gm * p.ldc + gn) = o.u;
-        if (p.C2) *reinterpret_cast<uint2*>(p.C2 + (long)gm * p.ldc2 + gn) = o.u;
+        if (!f32) st_stream(reinterpret_cast<f16*>(p.C) + (long)gm * p.ldc + gn, o.u);
+        if (p.C2) st_stream(p.C2 + (long)gm * p.ldc2 + gn, o.u);
     }
 }
 
@@ -267,7 +295,7 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
         for (int k = 0; k < 16; ++k) {
             const int row = 4 * k + lr, gm = rowq + 4 * k;
             const float4 v = *reinterpret_cast<const float4*>(stg + row * EPI_PITCH + 4 * lc);
-            if (gm < p.M && col_ok) *reinterpret_cast<float4*>(wsz + (size_t)gm * p.N) = v;
+            if (gm < p.M && col_ok) st_stream(wsz + (size_t)gm * p.N, f32x4{v.x, v.y, v.z, v.w});
         }
         return;
     }
