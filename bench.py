@@ -310,6 +310,8 @@ def main():
                     help="A/B (changes results, never the contract line): fp16 residual stream inside the transformer blocks")
     ap.add_argument("--no-gemm-pairs", action="store_true", help="A/B: q|k + V^T, q2 + q3, k3 + v3^T as separate launches")
     ap.add_argument("--attn-pair", action="store_true", help="A/B: text and image cross-attention of a block in one launch")
+    ap.add_argument("--no-time-tables", action="store_true",
+                    help="A/B switch: every UNet call recomputes the time-embedding chain (as written) instead of reading the rows tabulated at prepare()")
     ap.add_argument("--no-short-rows", action="store_true",
                     help="A/B: the zero-image context rows keep R copies of their feature map, as written (default: one copy — softmax over R "
                          "copies of the same keys equals softmax over one)")
@@ -392,7 +394,7 @@ def main():
     sampler = StoryGenSampler(arch, sd, dev, N_PER_GPU, hw, hw, n_ref, use_graph=not args.no_graph, dedup=not args.no_dedup,
                               overlap=not args.no_overlap, ref_ahead=G, split_graphs=args.split_graphs,
                               stream_priority=args.stream_priority, fp8_attention=args.fp8_attention,
-                              short_rows=not args.no_short_rows)
+                              short_rows=not args.no_short_rows, time_tables=not args.no_time_tables)
     n_sched = max(T, args.steps + warmup_run)
     sampler.prepare(inputs, n_sched, args.stage, 7.5, 3.5)
 
@@ -444,7 +446,7 @@ def main():
                        "split_graphs": sampler.split, "stream_priority": sampler.stream_priority,
                        "paired_gemm_launches": not args.no_gemm_pairs, "paired_text_image_attention": args.attn_pair,
                        "groupnorm_stats_from_epilogues": not args.no_gn_epilogue, "fp16_block_stream": args.fp16_block_stream,
-                       "short_zero_image_rows": not args.no_short_rows, "splitk_reduce_in_groupnorm": not args.no_splitk_in_gn,
+                       "short_zero_image_rows": not args.no_short_rows, "time_embedding_tables": not args.no_time_tables, "splitk_reduce_in_groupnorm": not args.no_splitk_in_gn,
                        "fused_feed_forward_64x64": not args.no_ff_fused},
             "tflop_per_step_as_written": round(step_tflop, 3),
             "final_allgather_ms": round(gather_ms, 3), "latents_gathered": int(final.shape[0]), "latents_finite": finite,

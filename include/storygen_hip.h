@@ -325,6 +325,13 @@ int sg_timestep_embed_f32(const float* t, const float* freqs, float* out, int32_
 int sg_linear_rows_f32(const float* x, int64_t ldx, const sg_half* W, int64_t ldw, const sg_half* bias, float* y,
                        int64_t ldy, int32_t B, int32_t N, int32_t K, int32_t act_in, int32_t act_out,
                        sg_stream_t stream);
+/* out[b, 0:N] = table[j, 0:N] for the row j whose table_keys[j] == keys[b] (exact fp32 comparison); rows of NaN when no key matches.
+ * The denoising loop knows every timestep at prepare() time (pipeline.py:410-415: `timesteps`, and t // 10 for the reference frames), so
+ * the chain above — Timesteps -> TimestepEmbedding -> 22 x time_emb_proj(silu(emb)) (unet_2d_condition.py:392-398, ResnetBlock2D) — is
+ * evaluated once per distinct timestep with the two functions above and each UNet call reads its rows (bit-identical to recomputing:
+ * those kernels treat rows independently).  N % 4 == 0; keys / table_keys / table / out fp32. */
+int sg_lookup_rows_f32(const float* keys, int32_t B, const float* table_keys, int32_t T, const float* table, int64_t ldt,
+                       float* out, int64_t ldo, int32_t N, sg_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * fp8 (OCP e4m3) attention for head dim 40 — BASELINE config 5 ("768x768 latent, 5 prior-frame context, fp8 MFMA attention

@@ -43,6 +43,7 @@ struct SgOptions {
     int attn_d40_general = 0;          // 1 = the D = 40 launches use the general softmax path (A/B against the padded-dimension fast path)
     int gn_no_fused = 0, gn_wide = 1;
     int gn_fused_nt = 1024;            // threads of the one-launch GroupNorm for slabs <= 16 384 values (256: the round-1 geometry; A/B)
+    int gn_chunks = 0;                 // wide GroupNorm: cap on the row chunks per sample (0 = 256 / B, one round of workgroups; 64 = rounds 1-3)
     int ff_variant = 3;                // fused feed-forward: bit 0 = refill spread over the k-steps, bit 1 = fragments two k-steps ahead
     long gn_fused_max = -1;            // -1 = the kernel's default threshold
 };

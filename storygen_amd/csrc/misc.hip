@@ -19,7 +19,8 @@ extern "C" int sg_debug_set_option(const char* name, int64_t value) {
                            {"no_nmajor", &o.no_nmajor}, {"attn_sub2", &o.attn_sub2}, {"attn_prio", &o.attn_prio},
                            {"attn_d80", &o.attn_d80}, {"attn_d160", &o.attn_d160}, {"gn_no_fused", &o.gn_no_fused},
                            {"gn_wide", &o.gn_wide}, {"attn_lean", &o.attn_lean}, {"attn_d40_general", &o.attn_d40_general},
-                           {"gn_fused_nt", &o.gn_fused_nt}, {"pipe_stages", &o.pipe_stages}, {"ff_variant", &o.ff_variant}};
+                           {"gn_fused_nt", &o.gn_fused_nt}, {"pipe_stages", &o.pipe_stages}, {"ff_variant", &o.ff_variant},
+                           {"gn_chunks", &o.gn_chunks}};
     for (const Entry& e : table)
         if (strcmp(e.n, name) == 0) {
             *e.p = (int)value;
@@ -117,6 +118,22 @@ __global__ __launch_bounds__(256) void linear_rows_kernel(const float* x, long l
             }
         }
     }
+}
+
+// out[b][:] = table[j][:] for the j with table_keys[j] == keys[b] (exact comparison; NaN rows when no key matches, so a stale table
+// cannot go unnoticed).  One workgroup per (row b, 1024-float column block); T is a few dozen: every thread scans the keys itself.
+__global__ __launch_bounds__(256) void lookup_rows_kernel(const float* keys, const float* table_keys, int T, const float* table,
+                                                          long ldt, float* out, long ldo, int N) {
+    const int b = blockIdx.y;
+    const float key = keys[b];
+    int j = -1;
+    for (int i = 0; i < T; ++i)
+        if (j < 0 && table_keys[i] == key) j = i;
+    const int n = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (n >= N) return;
+    float4 v = make_float4(__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""));
+    if (j >= 0) v = *reinterpret_cast<const float4*>(table + (long)j * ldt + n);
+    *reinterpret_cast<float4*>(out + (long)b * ldo + n) = v;
 }
 
 // ------------------------------------------------------------------------------------------------ conv_in / conv_out
@@ -310,6 +327,17 @@ extern "C" int sg_linear_rows_f32(const float* x, int64_t ldx, const sg_half* W,
     else if (B <= 8) hipLaunchKernelGGL(linear_rows_kernel<8>, grid, block, 0, st, x, (long)ldx, w, (long)ldw, bs, y, (long)ldy, B, N, K, act_in, act_out);
     else hipLaunchKernelGGL(linear_rows_kernel<16>, grid, block, 0, st, x, (long)ldx, w, (long)ldw, bs, y, (long)ldy, B, N, K, act_in, act_out);
     SG_CHECK_LAUNCH("sg_linear_rows_f32");
+    return SG_OK;
+}
+
+extern "C" int sg_lookup_rows_f32(const float* keys, int32_t B, const float* table_keys, int32_t T, const float* table, int64_t ldt,
+                                  float* out, int64_t ldo, int32_t N, sg_stream_t stream) {
+    SG_REQUIRE(keys && table_keys && table && out && B > 0 && T > 0 && N > 0, "sg_lookup_rows: bad arguments");
+    SG_REQUIRE(B <= 65535 && N % 4 == 0 && ldt % 4 == 0 && ldo % 4 == 0 && ldt >= N && ldo >= N, "sg_lookup_rows: N and the strides must be multiples of 4");
+    SG_REQUIRE(sg_aligned16(table) && sg_aligned16(out), "sg_lookup_rows: 16-byte alignment");
+    hipLaunchKernelGGL(lookup_rows_kernel, dim3(sg_cdiv(N, 1024), B), dim3(256), 0, (hipStream_t)stream, keys, table_keys, T, table,
+                       (long)ldt, out, (long)ldo, N);
+    SG_CHECK_LAUNCH("sg_lookup_rows_f32");
     return SG_OK;
 }
 

@@ -7,6 +7,7 @@ namespace {
 
 constexpr int GN_MAX_GROUPS = 64;
 constexpr int GN_MAX_CHUNKS = 64;    // partial-sum rows per batch: every pass-2 workgroup re-reads all of them
+constexpr int GNW_MAX_CHUNKS = 256;  // ... of the wide forward pair (one round of workgroups on 256 CUs); sizes the workspace
 
 struct GnParams {
     const void* x; long ldx; int x_f32;
@@ -257,7 +258,8 @@ __global__ __launch_bounds__(GNW_NT) void gn_stats_wide_kernel(const GnParams p)
 
 __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p) {
     __shared__ float s_mean[GN_MAX_GROUPS], s_rstd[GN_MAX_GROUPS];
-    __shared__ float s_ps[GNW_NT], s_pq[GNW_NT], s_pn[GNW_NT];
+    __shared__ float s_ps[GNW_NT], s_pq[GNW_NT];
+    __shared__ float s_cs[GNW_MAX_VPR * 8], s_cq[GNW_MAX_VPR * 8], s_cn[GNW_MAX_VPR * 8];   // per-(slot, channel) partials of the coalesced merge
     const int t = threadIdx.x, b = blockIdx.y, chunk = blockIdx.x;
     const int vpr = p.C >> 3, rpp = GNW_NT / vpr;
     const int my_row = t / vpr, cv = t - my_row * vpr;
@@ -281,78 +283,84 @@ __global__ __launch_bounds__(GNW_NT) void gn_apply_wide_kernel(const GnParams p)
     gam.u = bet.u = make_uint4(0, 0, 0, 0);
     if (active) { gam.u = ldg16(p.gamma + c0); bet.u = ldg16(p.beta + c0); }
     if (p.ps[0]) {
-        // Statistics from the producers' partials (fused epilogues and split-K second passes).  Entry e of group g = (channel of the
-        // group, row tile of that channel's source): n_e rows, S1 = sum x, S2 = sum x^2.  ONE pass over the (few hundred) entries, merged
-        // with Chan et al.'s formula on two levels so that no step subtracts large, nearly equal numbers:
-        //   thread t (its entries e = part, part + parts, ...), about a pivot K_t = the mean of ITS first entry:
-        //       n_t = sum n_e,  s_t = sum S1,  q_t = sum [ (S2 - S1^2 / n_e) + n_e (S1 / n_e - K_t)^2 ]
-        //       M2_t = q_t - n_t (s_t / n_t - K_t)^2        — the cancellation is bounded by the thread's own few entries (<= ~40),
-        //   group: mean = sum s_t / N,  M2 = sum [ M2_t + n_t (s_t / n_t - mean)^2 ]                    — every term is non-negative.
-        // (Round 3 used one pivot per GROUP: an outlier first channel or tile — (mean - K)^2 up to var N / n_e with N / n_e in the
-        // thousands — cost up to 3 of fp32's 7 digits)  A thread's entries travel in chunks of GNW_CH with all loads of a
-        // chunk in flight (clamped addresses, no predicate on the loads), and the index arithmetic is division-free ((e + 0.5) *
-        // (1 / tmax) is exact far beyond the 5120 entries a group can have).
-        const int parts = GNW_NT / p.G;
-        const int grp = t % p.G, part = t / p.G;
+        // Statistics from the producers' partials (fused epilogues and split-K second passes), channel-coalesced (round 4).  The partials
+        // of a sample are C x tiles x 8 bytes and EVERY workgroup of the sample needs all of them; the round-3 merge walked them
+        // group-major — lanes 40 bytes apart, ~20 cache lines per wave load, ~10 000 cycles of the CU's texture path per workgroup, as much
+        // as the rows it normalises.  Here a thread owns ONE channel (and, while C <= 512, every slots-th row tile of it): consecutive
+        // lanes read consecutive floats of one partial row, 2 lines per wave load.  Two-level Chan merge (one pivot per GROUP cost up to 3 of fp32's 7 digits when its first entry was an outlier):
+        //   thread (slot, c): over its tiles, about the pivot K = the mean of its first tile:  n_t, s_t, M2_t   (one channel's tiles only:
+        //       the cancellation (s_t / n_t - K)^2 is between row tiles of one channel)
+        //   group: mean = sum s_t / N,  M2 = sum [ M2_t + n_t (s_t / n_t - mean)^2 ]  over its cpg x slots thread partials (non-negative terms).
+        const int C = p.C;
+        const int slots = C <= GNW_NT ? GNW_NT / C : 1;
         const int t0 = p.HW / p.ps_rows[0], t1 = p.ps[1] ? p.HW / p.ps_rows[1] : 0;
-        const int tmax = t0 > t1 ? t0 : t1;
-        const int nent = p.cpg * tmax;
-        const int per = (nent + parts - 1) / parts;
-        const bool worker = part < parts;
-        const float inv_tmax = 1.0f / (float)tmax;
-        const float rows0 = (float)p.ps_rows[0], rows1 = p.ps[1] ? (float)p.ps_rows[1] : 1.f;
-        const float inv_rows0 = 1.0f / rows0, inv_rows1 = 1.0f / rows1;
-        constexpr int GNW_CH = 8;
-        float a_s = 0.f, a_q = 0.f, a_n = 0.f, K = 0.f;
-        bool have_k = false;
-        for (int i0 = 0; i0 < per; i0 += GNW_CH) {
-            float s1[GNW_CH], s2[GNW_CH], nr[GNW_CH], inr[GNW_CH];
+        constexpr int GNM_U = 8;
+        for (int cb = 0; cb < C; cb += GNW_NT) {
+            const int slot = C <= GNW_NT ? t / C : 0;
+            const int c = C <= GNW_NT ? t - slot * C : cb + t;
+            const bool owner = slot < slots && c < C;
+            const int cc = owner ? c : 0;
+            const int src = (p.ps[1] && cc >= p.ps_c0[1]) ? 1 : 0;
+            const int tiles = src ? t1 : t0;
+            const int nc = p.ps_nc[src];
+            const float rows = (float)p.ps_rows[src], inv_rows = 1.0f / rows;
+            const float* base = p.ps[src] + (long)b * tiles * 2 * nc + (cc - p.ps_c0[src]);
+            float a_s = 0.f, a_q = 0.f, a_n = 0.f, K = 0.f;
+            bool have_k = false;
+            for (int i0 = owner ? slot : tiles; i0 < tiles; i0 += GNM_U * slots) {
+                float s1[GNM_U], s2[GNM_U];
 #pragma unroll
-            for (int u = 0; u < GNW_CH; ++u) {
-                const int e = part + (i0 + u) * parts;
-                const bool inside = worker && e < nent;
-                const int ec = inside ? e : 0;                // entry 0 of a group always exists
-                const int cl = (int)(((float)ec + 0.5f) * inv_tmax);
-                int tile = ec - cl * tmax;
-                const int c = grp * p.cpg + cl;
-                const int src = (p.ps[1] && c >= p.ps_c0[1]) ? 1 : 0;
-                const int tiles = src ? t1 : t0;
-                const bool valid = inside && tile < tiles;
-                if (tile >= tiles) tile = 0;
-                const float* base = p.ps[src] + ((long)(b * tiles + tile) * 2) * p.ps_nc[src] + (c - p.ps_c0[src]);
-                s1[u] = base[0]; s2[u] = base[p.ps_nc[src]];
-                nr[u] = valid ? (src ? rows1 : rows0) : 0.f;
-                inr[u] = src ? inv_rows1 : inv_rows0;
-            }
-#pragma unroll
-            for (int u = 0; u < GNW_CH; ++u)
-                if (nr[u] > 0.f) {
-                    const float me = s1[u] * inr[u];
-                    if (!have_k) { K = me; have_k = true; }
-                    const float dm = me - K;
-                    a_s += s1[u];
-                    a_n += nr[u];
-                    a_q += fmaxf(s2[u] - s1[u] * me, 0.f) + nr[u] * dm * dm;
+                for (int u = 0; u < GNM_U; ++u) {
+                    const int tl = i0 + u * slots;
+                    const float* e = base + (long)(tl < tiles ? tl : i0) * 2 * nc;      // clamped: no predicate on the loads
+                    s1[u] = e[0]; s2[u] = e[nc];
                 }
-        }
-        {   // this thread's (n, sum, M2 about its own mean)
-            const float mt = a_n > 0.f ? a_s / a_n : 0.f, dk = mt - K;
-            s_ps[t] = a_s; s_pq[t] = fmaxf(a_q - a_n * dk * dk, 0.f); s_pn[t] = a_n;
+#pragma unroll
+                for (int u = 0; u < GNM_U; ++u)
+                    if (owner && i0 + u * slots < tiles) {
+                        const float me = s1[u] * inv_rows;
+                        if (!have_k) { K = me; have_k = true; }
+                        const float dm = me - K;
+                        a_s += s1[u];
+                        a_n += rows;
+                        a_q += fmaxf(s2[u] - s1[u] * me, 0.f) + rows * dm * dm;
+                    }
+            }
+            if (owner) {
+                const float mt = a_n > 0.f ? a_s / a_n : 0.f, dk = mt - K;
+                const int idx = slot * C + c;
+                s_cs[idx] = a_s; s_cq[idx] = fmaxf(a_q - a_n * dk * dk, 0.f); s_cn[idx] = a_n;
+            }
         }
         __syncthreads();
-        if (t < p.G) {
-            float sm = 0.f;
-            for (int k = 0; k < parts; ++k) sm += s_ps[k * p.G + t];
+        // group g = half-wave (16 waves x 2 halves = 32 groups per round): its cpg x slots partials are summed by 32 lanes with xor
+        // shuffles (offsets < 32 stay inside the half), mean first, then the non-negative M2 terms about it
+        {
+            const int lane = t & 63, l32 = lane & 31;
             const float ntot = (float)p.HW * (float)p.cpg;
-            const float mean = sm / ntot;
-            float m2 = 0.f;
-            for (int k = 0; k < parts; ++k) {
-                const float nt = s_pn[k * p.G + t];
-                const float d = nt > 0.f ? s_ps[k * p.G + t] / nt - mean : 0.f;
-                m2 += s_pq[k * p.G + t] + nt * d * d;
+            for (int g = (t >> 6) * 2 + (lane >> 5); g < p.G; g += 2 * (GNW_NT / 64)) {
+                const int c_lo = g * p.cpg;
+                float sm = 0.f;
+                for (int sl = 0; sl < slots; ++sl)
+                    for (int k = l32; k < p.cpg; k += 32) sm += s_cs[sl * C + c_lo + k];
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) sm += __shfl_xor(sm, o);
+                const float mean = sm / ntot;
+                float m2 = 0.f;
+                for (int sl = 0; sl < slots; ++sl)
+                    for (int k = l32; k < p.cpg; k += 32) {
+                        const int idx = sl * C + c_lo + k;
+                        const float nt = s_cn[idx];
+                        const float d = nt > 0.f ? s_cs[idx] / nt - mean : 0.f;
+                        m2 += s_cq[idx] + nt * d * d;
+                    }
+#pragma unroll
+                for (int o = 16; o > 0; o >>= 1) m2 += __shfl_xor(m2, o);
+                if (l32 == 0) {
+                    s_mean[g] = mean;
+                    s_rstd[g] = rsqrtf(m2 / ntot + p.eps);
+                }
             }
-            s_mean[t] = mean;
-            s_rstd[t] = rsqrtf(m2 / ntot + p.eps);
         }
         __syncthreads();
     } else
@@ -873,7 +881,7 @@ bool gn_takes_fused(int HW, int C, int groups) {
 }  // namespace
 
 extern "C" size_t sg_groupnorm_workspace_bytes(int32_t B, int32_t groups) {
-    return (size_t)B * GN_MAX_CHUNKS * (size_t)groups * 2 * sizeof(float);
+    return (size_t)B * GNW_MAX_CHUNKS * (size_t)groups * 2 * sizeof(float);
 }
 
 extern "C" int sg_groupnorm_uses_pstats(int32_t HW, int32_t C, int32_t groups) {
@@ -956,8 +964,13 @@ extern "C" int sg_groupnorm_nhwc_f16(const sg_groupnorm_desc* d, sg_stream_t str
     }
     if (wide && p.cpg >= 8 && p.C / 8 <= GNW_MAX_VPR) {
         const int rpp = GNW_NT / (p.C / 8);
-        int want = sg_cdiv(320, d->B);                    // ~256-384 workgroups of 16 waves (two fit a CU)
-        if (want > GN_MAX_CHUNKS) want = GN_MAX_CHUNKS;
+        // One 1024-thread workgroup fits a CU (99 VGPRs), so the launch is ONE round of at most 256 workgroups: 256 / B chunks per
+        // sample (B = 3: 85 chunks of 49 rows = two full passes of the 25 thread rows at 64^2 x 320, where the round-1..3 cap of 64 chunks
+        // left 64 CUs idle and a third, half-empty pass; 128 chunks at B = 3 — a second round — measured 1.6x slower per launch)
+        int want = 256 / d->B;
+        if (opt.gn_chunks > 0 && want > opt.gn_chunks) want = opt.gn_chunks;     // development option (A/B): 64 = the round-1..3 cap
+        if (want < 1) want = 1;
+        if (want > GNW_MAX_CHUNKS) want = GNW_MAX_CHUNKS;
         p.rows_per_chunk = sg_cdiv(p.HW, want);
         if (p.rows_per_chunk < rpp) p.rows_per_chunk = rpp;   // at least one full pass of the thread rows
         p.nchunks = sg_cdiv(p.HW, p.rows_per_chunk);

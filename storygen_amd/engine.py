@@ -365,6 +365,7 @@ class UNetEngine:
         self.temb1 = self._buf(B, arch.temb_dim, dtype=F32)
         self.temb2 = self._buf(B, arch.temb_dim, dtype=F32)
         self.tproj = self._buf(B, self.temb_total, dtype=F32)
+        self.time_table: Optional[tuple] = None                         # (timesteps [T], rows [T, temb_total]) — build_time_table()
         self.ws_split = ops.new_workspace(splitk_mb << 20, self.dev)      # split-K partial tiles (fp32, reduced by a second launch: no initialisation needed)
         self.ws_side = ops.new_workspace(splitk_mb << 20, self.dev)       # split-K scratch of the side-stream branches
         self.ws_pair = ops.new_workspace(splitk_mb << 20, self.dev)       # second problem of a paired GEMM launch
@@ -825,10 +826,10 @@ class UNetEngine:
         arch, text, skips = self.arch, self.text_in, self.skips
         # --- time embedding :392-398, then all 22 time_emb_proj(silu(emb)) in one GEMV bundle.  emb is only ever consumed through
         # silu (resnet.py time_emb_proj), so the second linear writes silu(emb) once instead of every wave of the bundle redoing it
-        ops.timestep_embed(self.t_in, self.freqs, self.temb0, self.cfg["flip_sin_to_cos"])
-        ops.linear_rows(self.temb0, self.w_t1, self.b_t1, self.temb1, act_out=True)
-        ops.linear_rows(self.temb1, self.w_t2, self.b_t2, self.temb2, act_out=True)
-        ops.linear_rows(self.temb2, self.w_temb, self.b_temb, self.tproj)
+        if self.time_table is not None:       # the loop's timesteps were tabulated at prepare() time: one row lookup instead of the chain
+            ops.lookup_rows(self.t_in, self.time_table[0], self.time_table[1], self.tproj)
+        else:
+            self._time_chain(self.t_in, self.temb0, self.temb1, self.temb2, self.tproj)
         # --- conv_in :411
         ops.conv_in(self.x_in, self.w_conv_in, self.b_conv_in, self._img(skips[0], 0))
         h, lvl, si = skips[0], 0, 1
@@ -897,8 +898,46 @@ class UNetEngine:
         return self.eps_out
 
     # ------------------------------------------------------------------------------------------ convenience
+    def _time_chain(self, t, e0, e1, e2, out):
+        """Timesteps -> TimestepEmbedding -> all time_emb_proj(silu(emb)) rows (unet_2d_condition.py:392-398, ResnetBlock2D)."""
+        ops.timestep_embed(t, self.freqs, e0, self.cfg["flip_sin_to_cos"])
+        ops.linear_rows(e0, self.w_t1, self.b_t1, e1, act_out=True)
+        ops.linear_rows(e1, self.w_t2, self.b_t2, e2, act_out=True)
+        ops.linear_rows(e2, self.w_temb, self.b_temb, out)
+
+    def build_time_table(self, timesteps, capacity: int = 256) -> bool:
+        """Tabulate the time-embedding chain for every distinct value in `timesteps` (a sampler knows them all at prepare() time:
+        pipeline.py:410-415).  forward() then reads the rows of self.t_in with ops.lookup_rows — one launch of a few microseconds instead
+        of four (the last one streams the 22 stacked time_emb_proj matrices, ~45 MB, per UNet call) — and gets NaN rows, not stale ones,
+        for a timestep that is not in the table.  Rows are computed by the same kernels four at a time, exactly as forward() would.
+        The table lives in buffers of `capacity` rows (unused keys are NaN, which matches nothing) that later calls refill IN PLACE, so a
+        captured graph stays valid; returns True when the buffers were (re)allocated — or dropped — i.e. when graphs captured before
+        the call must be captured again.  Pass None to drop the table (training, set_inputs() with arbitrary timesteps)."""
+        if timesteps is None:
+            had = self.time_table is not None
+            self.time_table = None
+            return had
+        keys = sorted({float(t) for t in timesteps})
+        if not keys:
+            raise ValueError("build_time_table: no timesteps")
+        F32, dev, T = torch.float32, self.dev, len(keys)
+        fresh = self.time_table is None or self.time_table[0].numel() < T
+        if fresh:
+            cap = max(int(capacity), T)
+            self.time_table = (torch.empty(cap, dtype=F32, device=dev), torch.empty(cap, self.temb_total, dtype=F32, device=dev))
+        tk, tab = self.time_table
+        tk.fill_(float("nan"))
+        tk[:T].copy_(torch.tensor(keys, dtype=F32))
+        e0 = torch.empty(4, self.temb0.shape[1], dtype=F32, device=dev)
+        e1, e2 = (torch.empty(4, self.arch.temb_dim, dtype=F32, device=dev) for _ in range(2))
+        for i in range(0, T, 4):
+            n = min(4, T - i)
+            self._time_chain(tk[i:i + n], e0[:n], e1[:n], e2[:n], tab[i:i + n])
+        return fresh
+
     def set_inputs(self, sample: torch.Tensor, timestep, text: torch.Tensor):
         self.x_in.copy_(sample.to(self.dev, torch.float32))
+        self.time_table = None                  # arbitrary timesteps: the chain itself, not a sampler's table
         t = timestep if torch.is_tensor(timestep) else torch.tensor([float(timestep)])
         self.t_in.copy_(t.to(self.dev, torch.float32).reshape(-1).expand(self.B))
         self.text_in.copy_(text.to(self.dev, F16))

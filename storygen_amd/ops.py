@@ -651,6 +651,17 @@ def timestep_embed(t: torch.Tensor, freqs: torch.Tensor, out: torch.Tensor, flip
     return out
 
 
+def lookup_rows(keys: torch.Tensor, table_keys: torch.Tensor, table: torch.Tensor, out: torch.Tensor) -> torch.Tensor:
+    """out[b] = table[j] for table_keys[j] == keys[b] (fp32, exact match; NaN rows otherwise) — sg_lookup_rows_f32."""
+    _f32(keys, "keys"), _f32(table_keys, "table_keys"), _f32(table, "table"), _f32(out, "out")
+    B, N = out.shape
+    if keys.numel() != B or table.shape[0] != table_keys.numel() or table.shape[1] != N:
+        raise ValueError("lookup_rows: keys [B], table_keys [T], table [T, N], out [B, N]")
+    check(lib.sg_lookup_rows_f32(keys.data_ptr(), B, table_keys.data_ptr(), table_keys.numel(), table.data_ptr(), _row_stride(table, "table"),
+                                 out.data_ptr(), _row_stride(out, "out"), N, _stream()), "sg_lookup_rows_f32")
+    return out
+
+
 def linear_rows(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], out: torch.Tensor, act_in: bool = False,
                 act_out: bool = False) -> torch.Tensor:
     _f32(x, "x"), _f16(w, "w"), _f32(out, "out")
@@ -949,7 +960,7 @@ def debug_set_option(name: str, value: int) -> None:
 # library no longer reads the environment: this maps the variables onto sg_debug_set_option, and only when a tool asks for it.
 _ENV_OPTIONS = {"SG_NO_NMAJOR": "no_nmajor", "SG_NO_PIPE": "no_pipe", "SG_NO_SPLIT": "no_split",
                 "SG_ATTN_SUB2": "attn_sub2", "SG_ATTN_PRIO": "attn_prio", "SG_ATTN_D80": "attn_d80", "SG_ATTN_D160": "attn_d160",
-                "SG_FF_VARIANT": "ff_variant", "SG_PIPE_STAGES": "pipe_stages", "SG_GN_FUSED_NT": "gn_fused_nt", "SG_ATTN_LEAN": "attn_lean", "SG_ATTN_D40_GENERAL": "attn_d40_general", "SG_NO_GN_FUSED": "gn_no_fused", "SG_GN_WIDE": "gn_wide", "SG_GN_FUSED_MAX": "gn_fused_max"}
+                "SG_FF_VARIANT": "ff_variant", "SG_PIPE_STAGES": "pipe_stages", "SG_GN_FUSED_NT": "gn_fused_nt", "SG_GN_CHUNKS": "gn_chunks", "SG_ATTN_LEAN": "attn_lean", "SG_ATTN_D40_GENERAL": "attn_d40_general", "SG_NO_GN_FUSED": "gn_no_fused", "SG_GN_WIDE": "gn_wide", "SG_GN_FUSED_MAX": "gn_fused_max"}
 
 
 def apply_env_options() -> dict:

@@ -60,7 +60,7 @@ class StoryGenSampler:
                  schedule: Optional[DDIMSchedule] = None, use_graph: bool = True, dedup: bool = True,
                  weights: Optional[EngineWeights] = None, overlap: bool = True, ref_ahead: int = 1,
                  split_graphs: bool = False, stream_priority: bool = False, fp8_attention: bool = False,
-                 side_streams: str = "auto", short_rows: bool = True):
+                 side_streams: str = "auto", short_rows: bool = True, time_tables: bool = True):
         if n_ref < 1:
             raise ValueError("StoryGen's loop needs at least one prior frame")
         if ref_ahead < 1 or (ref_ahead > 1 and not (use_graph and overlap)):
@@ -83,6 +83,9 @@ class StoryGenSampler:
         # shared zero-image rows keep ONE frame slot (softmax over R copies of the same keys = softmax over one copy); False = R
         # copies as written (A/B switch: bench.py --no-short-rows)
         self.short_rows = bool(short_rows)
+        # time-embedding chain tabulated per distinct timestep at prepare() (UNetEngine.build_time_table); False = recomputed by
+        # every UNet call as written (A/B switch: bench.py --no-time-tables)
+        self.time_tables = bool(time_tables)
         self.arch, self.dev = arch, torch.device(device)
         self.N, self.R, self.h, self.w, self.S = n_samples, n_ref, height, width, seq_len
         self.B = 3 * n_samples
@@ -270,6 +273,13 @@ class StoryGenSampler:
         self.timesteps = ts
         self.num_steps = len(ts)                  # PNDM: n + 1 UNet evaluations for n inference steps
         self.k = 0
+        if self.time_tables:                      # every timestep of the loop is known now: tabulate the time-embedding chain once
+            U, B = self.U, self.B
+            stale = self.main.build_time_table([r[U] for r in rows] + [row0[U]])
+            if self.ref is not None:
+                stale |= self.ref.build_time_table([t for r in rows + [row0] for t in r[:U]])
+            if stale:                             # first table (or one that outgrew its buffers): graphs captured earlier read the old ones
+                self.graph, self.graphs, self.g_ref, self.g_main = None, [], [], []
         if self.use_graph and self.graph is None and not self.graphs and not self.g_main:
             self._capture()
         if self.overlap and not self.no_ctx:

@@ -315,6 +315,37 @@ def test_dedup_of_identical_reference_samples_is_equivalent(gpu, sd15, stage):
     assert max(errs) <= TOL_LATENT and rel_l2(outs[0], outs[1]) <= TOL_LATENT
 
 
+def test_tabulated_time_embedding_is_the_same_trajectory(gpu, sd15):
+    """StoryGenSampler(time_tables=True, the default): the Timesteps -> TimestepEmbedding -> 22 x time_emb_proj chain
+    (unet_2d_condition.py:392-398) is evaluated once per distinct timestep at prepare() and every UNet call looks its rows up — the same
+    kernels on the same values, so the latents are bit-identical to recomputing the chain in every call.  A second prepare() with another
+    schedule refills the table in place under the captured graph; a timestep that is not in the table gives NaN rows, not stale ones."""
+    from storygen_amd import ops
+    from storygen_amd.engine import EngineWeights
+    from storygen_amd.sampler import StoryGenSampler
+    from storygen_amd.synth import synthetic_inputs
+    arch, sd = sd15
+    inputs = synthetic_inputs(1, 2, 32, 32, 23, arch.config["cross_attention_dim"])
+    wts = EngineWeights(arch, sd, gpu)
+    outs = {}
+    for tab in (False, True):
+        smp = StoryGenSampler(arch, None, gpu, 1, 32, 32, 2, weights=wts, time_tables=tab)
+        for steps, stage in ((50, "auto-regressive"), (20, "multi-image-condition")):          # second prepare: same graph, new timesteps
+            smp.prepare(inputs, steps, stage, 7.5, 3.5)
+            outs[tab, steps] = smp.run(max_steps=4).clone()
+            torch.cuda.synchronize()
+        assert (smp.main.time_table is not None) == tab
+    for steps in (50, 20):
+        assert torch.isfinite(outs[True, steps]).all()
+        assert torch.equal(outs[False, steps], outs[True, steps]), steps
+    # the lookup itself: hits copy the row, a miss is NaN
+    keys, tab_rows = smp.main.time_table
+    t = torch.tensor([float(keys[1]), 12345.0, float(keys[0])], device=gpu)
+    out = torch.zeros(3, tab_rows.shape[1], device=gpu)
+    ops.lookup_rows(t, keys, tab_rows, out)
+    assert torch.equal(out[0], tab_rows[1]) and torch.equal(out[2], tab_rows[0]) and torch.isnan(out[1]).all()
+
+
 def test_split_graphs_with_stream_priority_is_the_same_trajectory(gpu, sd15):
     """split_graphs (+ stream_priority): the same kernels as the single-graph overlap schedule, launched as two graphs
     on two (prioritised) streams — bit-identical latents."""

@@ -57,6 +57,32 @@ def main():
             print(f"{'layernorm2':10s} {B:2d} {hw:4d} {C:5d} {mb:7.2f} {us:8.2f} {mb / us * 1e3:8.0f}")
 
 
+def groupnorm_with_producer_statistics():
+    """The wide GroupNorm as the step runs it: statistics from the producers' per-(row tile, channel) partials (built here with torch),
+    beside the self-contained pair (statistics launch + apply launch).  Round 4, `profiles/r04h_groupnorm_merge_microbench.txt`, also had
+    the round-3 gather merge and a 128-chunk geometry in this table (both removed from the library since)."""
+    dev = "cuda:0"
+    print(f"{'op':10s} {'B':>2s} {'side':>4s} {'C':>5s} {'tile':>4s} {'MB':>7s} {'own':>7s} {'pstats':>7s}  us")
+    for B in (3, 4):
+        # rows = side * side: ONE partial per channel — the merge costs nothing, what is left is the apply kernel's floor
+        for side, C, rows in ((64, 320, 128), (64, 320, 256), (64, 320, 4096), (64, 640, 256), (64, 960, 256), (32, 640, 128), (32, 640, 64),
+                              (32, 640, 1024), (32, 1280, 128), (32, 1280, 1024), (32, 1920, 128), (16, 1920, 64), (16, 2560, 64), (16, 2560, 256)):
+            hw = side * side
+            if not ops.groupnorm_uses_pstats(hw, C, 32):
+                continue
+            x = torch.randn(B, hw, C, device=dev)
+            tiles = x.view(B, hw // rows, rows, C)
+            st = torch.stack([tiles.sum(2), (tiles * tiles).sum(2)], dim=2).contiguous().view(-1)      # [B][tiles][2][C]
+            g, b = torch.randn(C, device=dev).half(), torch.randn(C, device=dev).half()
+            y = torch.zeros(B, side + 2, side + 2, C, dtype=torch.float16, device=dev)
+            ws = torch.empty(ops.groupnorm_workspace_bytes(B, 32), dtype=torch.uint8, device=dev)
+            res = []
+            for pst in (None, [(st, rows, C)]):
+                res.append(timed(lambda: ops.groupnorm(x, g, b, y, 32, 1e-5, True, ws, pstats=pst)))
+            mb = B * hw * C * 6 / 1e6
+            print(f"{'groupnorm':10s} {B:2d} {side:4d} {C:5d} {rows:4d} {mb:7.2f} " + " ".join(f"{u:7.2f}" for u in res))
+
+
 def attention_d160():
     """Attention shapes of the step: head dim 160 (16x16 level: few workgroups, long key loops), 80 and 40."""
     dev = "cuda:0"
@@ -75,6 +101,9 @@ def attention_d160():
 
 
 if __name__ == "__main__":
+    if "--pstats" in sys.argv:
+        groupnorm_with_producer_statistics()
+        sys.exit(0)
     if "--attn" in sys.argv:
         attention_d160()
         sys.exit(0)
