@@ -55,6 +55,12 @@ constexpr int attn_smem_bytes() {
 }
 
 // One workgroup's work: `block` of `nblocks` (the launch's own numbering — a paired launch runs two problems in one grid).
+#ifdef SG_ATTN_RT_STAGE
+constexpr bool UNROLL_STAGES = false;     // A/B build (tools/ab_lib.py): the ring stage as a run-time variable, as in rounds 1-4
+#else
+constexpr bool UNROLL_STAGES = true;
+#endif
+
 template <int D, int NW, int S, int SUB, bool PRIO, bool LSE, bool LEAN = false, bool GENERAL = false>
 __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, const int block, const int nblocks) {
     constexpr bool F40 = D == 40 && !GENERAL;   // softmax bookkeeping in the padded head dimension (see F40_KPAD)
@@ -144,9 +150,9 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
             const f16* Vt = VT + key0;
 #pragma unroll
             for (int i = 0; i < MAXL; ++i) {
-                const int g = i * NW + wave;    // wave-uniform
-                if (g < K_SEG) glds16(Kt + off[i], base + g * 1024);
-                else if (g < NSEG) glds16(Vt + off[i], base + g * 1024);
+                const int g = i * NW + wave;    // wave-uniform: the source is a scalar select, not a branch per segment
+                const f16* src = (g < K_SEG ? Kt : Vt) + off[i];
+                if ((i + 1) * NW <= NSEG || g < NSEG) glds16(src, base + g * 1024);
             }
         } else {
 #pragma unroll
@@ -209,8 +215,19 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
 
     // LDS read coordinates
     const int prow = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);          // pi(l31): swap bits 2 and 3
-    int stage = 0;
-    for (int group = 0; group < ngroups; ++group) {
+    // The ring stage is a compile-time constant inside the loop body (S copies of it per trip): the LDS addresses of the fragment reads
+    // are then per-lane bases + immediates and the DMA destinations constants, where a run-time stage cost 16 v_add_u32 and a dozen scalar
+    // instructions per tile (UNROLL_STAGES = false: the round-1..4 loop with a run-time stage, for A/B builds).  D = 40 only — measured
+    // -3.0 / -3.6 % per launch there (309.7 vs 319.1 us at B3 Nq 4096 Nk 12288, 152.6 vs 158.3 at B4 Nk 4096), nothing at D = 80 / 160,
+    // whose tile bodies are 2 - 4x larger (profiles/r04l_attention_unrolled_stages.txt).
+    constexpr bool UNR = UNROLL_STAGES && D == 40;
+    int rt_stage = 0;
+    for (int group0 = 0; group0 < ngroups; group0 += (UNR ? S : 1)) {
+#pragma unroll
+    for (int ustage = 0; ustage < (UNR ? S : 1); ++ustage) {
+        const int group = group0 + ustage;
+        const int stage = UNR ? ustage : rt_stage;
+        if (group < ngroups) {
         // wait for this wave's share of the group (S = 3: one younger tile may stay in flight), publish, refill the ring
         if (S == 3 && group + 1 < ngroups) {
             if (REM == 0 || wave < REM) wait_vmcnt<MAXL>();
@@ -410,7 +427,9 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
         }
         }
       }   // sub-tiles of the group
-        if (++stage == S) stage = 0;
+        }
+        if (!UNR && ++rt_stage == S) rt_stage = 0;
+    }
     }
 
     // ---- normalise and store O[b, q, h*D + d]  (lane holds d = 32i + (r&3) + 8(r>>2) + 4hi for its query).  F40: the row sum is

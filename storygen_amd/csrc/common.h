@@ -80,7 +80,22 @@ __device__ __forceinline__ void store8h(f16* p, const float (&v)[8]) {
 
 __device__ __forceinline__ float silu_f(float x) { return x / (1.0f + __expf(-x)); }
 // exact (erf) GELU, as torch.nn.functional.gelu(approximate="none") — /root/reference/model/attention.py:385-388
-__device__ __forceinline__ float gelu_erf_f(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// 2 gelu(x) = x + |x| erf(|x| / sqrt 2), erf by Abramowitz-Stegun 7.1.26: erf(z) = 1 - (a1 t + ... + a5 t^5) exp(-z^2), t = 1 / (1 + p z),
+// |error| <= 1.5e-7 — 13 straight-line VALU instructions (two transcendental) where ocml's erff is ~32 with both of its branches executed
+// by a diverged wave.  That matters: this runs in GEMM epilogues BESIDE the matrix pipe, where VALU time adds to MFMA time instead of
+// hiding behind it (tools/probes/README.md); the fused feed-forward kernel has used the same form since it was written.
+__device__ __forceinline__ float gelu_erf_f(float x) {
+    const float ax = fabsf(x);
+    const float t = __builtin_amdgcn_rcpf(fmaf(ax, 0.3275911f * 0.70710678118654752440f, 1.0f));
+    const float zs = ax * 0.84932180028801904272f;          // |x| sqrt(log2(e) / 2): exp(-x^2 / 2) = exp2(-zs^2)
+    const float e = __builtin_amdgcn_exp2f(-zs * zs);
+    float q = fmaf(1.061405429f, t, -1.453152027f);
+    q = fmaf(q, t, 1.421413741f);
+    q = fmaf(q, t, -0.284496736f);
+    q = fmaf(q, t, 0.254829592f);
+    q *= t;
+    return 0.5f * fmaf(ax, fmaf(-q, e, 1.0f), x);
+}
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

@@ -726,11 +726,27 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     EPI_PRE_DECL;
 
-    int stage = 0;
+    // LDS offsets of this lane's fragment reads, per ring stage and k-step (the XOR swizzle makes the k-step term per-lane, and stages
+    // 1 / 2 of the larger tiles lie beyond the 16-bit immediate of ds_read): 2 x 4 x S registers, opaque to the compiler so that it keeps
+    // them instead of re-deriving base + constant with a v_add / v_or before every read of every slab
+    unsigned fa_off[S][4], fb_off[S][4];
+#pragma unroll
+    for (int st = 0; st < S; ++st)
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            fa_off[st][ks] = (unsigned)(st * STAGE + lds_off(wm * WM + l31, ks * 2 + hi));
+            fb_off[st][ks] = (unsigned)(st * STAGE + A_BYTES + lds_off(wn * WN + l31, ks * 2 + hi));
+            asm volatile("" : "+v"(fa_off[st][ks]), "+v"(fb_off[st][ks]));
+        }
     stamp(7);
-    // one K slab; LAST = the final slab of this block (no refill: the residual of the epilogue is requested under its MFMAs instead)
-    auto slab = [&](int it, auto last_tag) __attribute__((always_inline)) {
+    // one K slab; LAST = the final slab of this block (no refill: the residual of the epilogue is requested under its MFMAs instead).
+    // `stage_c` = the ring stage of slab `it`: a std::integral_constant in the steady loop (round 4: S copies of the slab per trip, so the
+    // 16 fragment reads address LDS as loop-invariant per-lane bases + immediates and the DMA destinations are constants — a run-time
+    // stage cost 18 - 26 v_add_u32 per slab and wave, issued BESIDE the MFMAs, where VALU time adds to matrix time,
+    // tools/probes/README.md), a plain int for the last slab.
+    auto slab = [&](int it, auto last_tag, auto stage_c) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
+        const int stage = stage_c;
         // one younger slab stays in flight while we wait for slab `it` (none at the very end)
         if constexpr (LAST || S == 2) wait_vmcnt<0>();
         else wait_vmcnt<LPT>();
@@ -743,12 +759,20 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         // read of a slab exposes LDS latency; the other three hide behind the previous k-step's four MFMAs
         f16x8 af[2][WTM], bf[2][WTN];
         auto load_frags = [&](int buf, int ks) __attribute__((always_inline)) {
+            if constexpr (std::is_same<decltype(stage_c), int>::value) {       // run-time stage (last slab): addresses computed here
 #pragma unroll
-            for (int i = 0; i < WTM; ++i)
-                af[buf][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WM + i * 32 + l31, ks * 2 + hi));
+                for (int i = 0; i < WTM; ++i)
+                    af[buf][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WM + i * 32 + l31, ks * 2 + hi));
 #pragma unroll
-            for (int j = 0; j < WTN; ++j)
-                bf[buf][j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WN + j * 32 + l31, ks * 2 + hi));
+                for (int j = 0; j < WTN; ++j)
+                    bf[buf][j] = *reinterpret_cast<const f16x8*>(sB + lds_off(wn * WN + j * 32 + l31, ks * 2 + hi));
+            } else {                                                            // rows i * 32 further on: + 4096 bytes, an immediate
+                constexpr int ST = decltype(stage_c)::value;
+#pragma unroll
+                for (int i = 0; i < WTM; ++i) af[buf][i] = *reinterpret_cast<const f16x8*>(smem + fa_off[ST][ks] + i * 4096);
+#pragma unroll
+                for (int j = 0; j < WTN; ++j) bf[buf][j] = *reinterpret_cast<const f16x8*>(smem + fb_off[ST][ks] + j * 4096);
+            }
         };
         load_frags(0, 0);
 #pragma unroll
@@ -775,12 +799,28 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
                     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bf[ks & 1][j], af[ks & 1][i], acc[i][j], 0, 0, 0);
             if (ks == 0) stamp(3);
         }
-        if (++stage == S) stage = 0;
         stamp(6);
         if constexpr (PROF) pf_acc[0] += 1;
     };
-    for (int it = 0; it + 1 < nt; ++it) slab(it, std::false_type{});
-    if (nt > 0) slab(nt - 1, std::true_type{});
+#ifdef SG_PIPE_RT_STAGE          // A/B build (tools/ab_lib.py): the ring stage as a run-time variable, as in rounds 1-4
+    {
+        int stage = 0;
+        for (int it = 0; it + 1 < nt; ++it) {
+            slab(it, std::false_type{}, stage);
+            if (++stage == S) stage = 0;
+        }
+        if (nt > 0) slab(nt - 1, std::true_type{}, stage);
+    }
+#else
+    for (int it = 0; it + 1 < nt; it += S) {
+        slab(it, std::false_type{}, std::integral_constant<int, 0>{});
+        if (it + 2 < nt) slab(it + 1, std::false_type{}, std::integral_constant<int, 1>{});
+        if constexpr (S > 2) {
+            if (it + 3 < nt) slab(it + 2, std::false_type{}, std::integral_constant<int, 2>{});
+        }
+    }
+    if (nt > 0) slab(nt - 1, std::true_type{}, (nt - 1) % S);
+#endif
     if (nt <= 0) epi_prefetch(p, m0, n0, wm, wn, lane, EPI_PRE_ARGS);
     epi_finish<WGM, WGN>(p, smem, acc, EPI_PRE_ARGS, m0, n0, z, wave, wm, wn, lane);
     if constexpr (PROF) {
