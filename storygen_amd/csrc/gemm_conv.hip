@@ -628,6 +628,15 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW), LPT = A_IT + B_IT;   // LDS-DMA instructions / lane / slab
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
     constexpr int ISTR = NW * 1024;   // LDS bytes covered by one DMA instruction of the whole workgroup (8 rows / wave)
+    // Refill placement (round 4, profiles/r04p_*): with ONE wave per SIMD (tiles of <= 4 waves) nothing covers the 55 - 90 cycles a wave
+    // spends issuing each LDS-DMA piece, and a burst of 4 - 6 of them behind the first k-step drains the matrix pipe; one or two pieces
+    // behind every k-step measured -2 ... -12 % per launch on the 4-wave tiles (GEMM 12288x320x1280 20.1 -> 17.6 us, conv 64^2 320->320 on
+    // 256x64 40.6 -> 37.4).  The 8-wave 256x128 tile (two waves per SIMD cover each other) measured +3 ... +6 % and keeps the burst.
+#ifdef SG_PIPE_BURST
+    constexpr bool SPREAD = false;       // A/B build (tools/ab_lib.py)
+#else
+    constexpr bool SPREAD = NW <= 4 && !PROF;
+#endif
     static_assert(S == 2 || S == 3, "ring depth");
     static_assert((S - 2) * LPT < 64, "vmcnt is a 6-bit counter");
     static_assert(S * STAGE <= 160 * 1024, "the ring must fit the 160 KB of LDS");
@@ -655,11 +664,14 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
         w_off[i] = (unsigned)((long)min(n0 + row, p.N - 1) * p.ldw + lc * 8);
     }
-    auto issue_w = [&](int kt, int stage) __attribute__((always_inline)) {
+    // `sel` < 0: every piece; otherwise only the pieces whose running index (A pieces first, then W) is sel modulo 4 — the refill of a
+    // slab spread over its four k-steps (SG_PIPE_SPREAD builds)
+    auto issue_w = [&](int kt, int stage, int sel = -1) __attribute__((always_inline)) {
         char* sB = smem + stage * STAGE + A_BYTES + wave * 1024;
         const f16* Wt = p.W + kt * BK;
 #pragma unroll
-        for (int i = 0; i < B_IT; ++i) glds16(Wt + w_off[i], sB + i * ISTR);
+        for (int i = 0; i < B_IT; ++i)
+            if (sel < 0 || ((A_IT + i) & 3) == sel) glds16(Wt + w_off[i], sB + i * ISTR);
     };
     if (nt > 0) issue_w(kt0, 0);
 
@@ -690,30 +702,45 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         }
     }
 
-    auto issue_a = [&](int kt, int stage) __attribute__((always_inline)) {
-        char* sA = smem + stage * STAGE + wave * 1024;
+    // source of slab kt's A operand: the wave-uniform base pointer (and, with nearest-2x upsampling, the tap), computed ONCE per slab;
+    // a_emit then issues the pieces `sel` selects (sel < 0: all; otherwise running piece index == sel modulo 4)
+    struct ABase { const f16* At; int ky, kx; };
+    auto a_base = [&](int kt) __attribute__((always_inline)) {
+        ABase r;
+        r.ky = r.kx = 0;
         if constexpr (CONV) {
             const int tap = (int)fd_div((unsigned)kt, p.fd_cpt), cc = kt - tap * p.cpt;
             const int ky = (tap * 11) >> 5, kx = tap - ky * 3;           // tap / 3 for tap < 9
+            r.ky = ky; r.kx = kx;
+            r.At = !p.ups ? p.A + ((long)(ky * wp + kx) * p.lda + cc * BK) : p.A + cc * BK;
+        } else {
+            r.At = p.A + kt * BK;
+        }
+        return r;
+    };
+    auto a_emit = [&](const ABase& ab, int stage, int sel) __attribute__((always_inline)) {
+        char* sA = smem + stage * STAGE + wave * 1024;
+        if constexpr (CONV) {
             if (!p.ups) {
-                const f16* At = p.A + ((long)(ky * wp + kx) * p.lda + cc * BK);
 #pragma unroll
-                for (int i = 0; i < A_IT; ++i) glds16(At + a_off[i], sA + i * ISTR);
+                for (int i = 0; i < A_IT; ++i)
+                    if (sel < 0 || (i & 3) == sel) glds16(ab.At + a_off[i], sA + i * ISTR);
             } else {
-                const f16* At = p.A + cc * BK;
                 const unsigned rs = (unsigned)(wp * (int)p.lda), cs = (unsigned)p.lda;     // < 2^24 (validated on the host)
 #pragma unroll
                 for (int i = 0; i < A_IT; ++i) {
-                    const unsigned dy = ((unsigned)ky + (a_par[i] & 1u)) >> 1, dx = ((unsigned)kx + (a_par[i] >> 1)) >> 1;
-                    glds16(At + (a_off[i] + __umul24(dy, rs) + __umul24(dx, cs)), sA + i * ISTR);
+                    if (!(sel < 0 || (i & 3) == sel)) continue;
+                    const unsigned dy = ((unsigned)ab.ky + (a_par[i] & 1u)) >> 1, dx = ((unsigned)ab.kx + (a_par[i] >> 1)) >> 1;
+                    glds16(ab.At + (a_off[i] + __umul24(dy, rs) + __umul24(dx, cs)), sA + i * ISTR);
                 }
             }
         } else {
-            const f16* At = p.A + kt * BK;
 #pragma unroll
-            for (int i = 0; i < A_IT; ++i) glds16(At + a_off[i], sA + i * ISTR);
+            for (int i = 0; i < A_IT; ++i)
+                if (sel < 0 || (i & 3) == sel) glds16(ab.At + a_off[i], sA + i * ISTR);
         }
     };
+    auto issue_a = [&](int kt, int stage) __attribute__((always_inline)) { a_emit(a_base(kt), stage, -1); };
     if (nt > 0) issue_a(kt0, 0);
     if (S > 2 && nt > 1) { issue_a(kt0 + 1, 1); issue_w(kt0 + 1, 1); }
 
@@ -775,20 +802,33 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
             }
         };
         load_frags(0, 0);
+        // SPREAD: the refill of the ring (slab it+S-1 into the stage every wave has just left) goes out a quarter behind every k-step's
+        // fragment reads; its wave-uniform base is computed once, here
+        const bool refill = SPREAD && !LAST && it + S - 1 < nt;
+        int rst = stage + S - 1;
+        if (rst >= S) rst -= S;
+        ABase ab = {nullptr, 0, 0};
+        if (refill) ab = a_base(kt0 + it + S - 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
-            if (ks == 1) {
-                // the refill of the ring (slab it+2 into the stage every wave has just left) is issued behind the first
-                // k-step's fragment reads: its address arithmetic then overlaps matrix work instead of delaying it
+            if constexpr (SPREAD) {
+                if constexpr (!LAST) {
+                    if (refill) {
+                        a_emit(ab, rst, ks);
+                        issue_w(kt0 + it + S - 1, rst, ks);
+                    }
+                } else if (ks == 1) {
+                    epi_prefetch(p, m0, n0, wm, wn, lane, EPI_PRE_ARGS);
+                }
+            } else if (ks == 1) {
+                // burst: the whole refill behind the first k-step's fragment reads (its address arithmetic overlaps matrix work)
                 stamp(4);
                 if constexpr (LAST) {
                     epi_prefetch(p, m0, n0, wm, wn, lane, EPI_PRE_ARGS);
                 } else if (it + S - 1 < nt) {
-                    int st = stage + S - 1;
-                    if (st >= S) st -= S;
-                    issue_a(kt0 + it + S - 1, st);
-                    issue_w(kt0 + it + S - 1, st);
+                    issue_a(kt0 + it + S - 1, rst);
+                    issue_w(kt0 + it + S - 1, rst);
                 }
                 stamp(5);
             }
