@@ -632,10 +632,12 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     // spends issuing each LDS-DMA piece, and a burst of 4 - 6 of them behind the first k-step drains the matrix pipe; one or two pieces
     // behind every k-step measured -2 ... -12 % per launch on the 4-wave tiles (GEMM 12288x320x1280 20.1 -> 17.6 us, conv 64^2 320->320 on
     // 256x64 40.6 -> 37.4).  The 8-wave 256x128 tile (two waves per SIMD cover each other) measured +3 ... +6 % and keeps the burst.
+    // There the two waves of a SIMD leave the barrier together and would burst together: waves 4 - 7 issue theirs behind the THIRD k-step
+    // instead (STAGGER: conv 64^2 640->320 92.8 -> 85.5 us, 64^2 320->320 49.3 -> 47.4, 16^2 / 32^2 -2 %, profiles/r04r_*).
 #ifdef SG_PIPE_BURST
-    constexpr bool SPREAD = false;       // A/B build (tools/ab_lib.py)
+    constexpr bool SPREAD = false, STAGGER = false;       // A/B build (tools/ab_lib.py): rounds 1-4, every wave bursts behind the first k-step
 #else
-    constexpr bool SPREAD = NW <= 4 && !PROF;
+    constexpr bool SPREAD = NW <= 4 && !PROF, STAGGER = NW == 8 && !PROF;
 #endif
     static_assert(S == 2 || S == 3, "ring depth");
     static_assert((S - 2) * LPT < 64, "vmcnt is a 6-bit counter");
@@ -821,8 +823,9 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
                 } else if (ks == 1) {
                     epi_prefetch(p, m0, n0, wm, wn, lane, EPI_PRE_ARGS);
                 }
-            } else if (ks == 1) {
-                // burst: the whole refill behind the first k-step's fragment reads (its address arithmetic overlaps matrix work)
+            } else if (LAST || !STAGGER ? ks == 1 : ks == (wave < 4 ? 1 : 3)) {
+                // burst: the whole refill behind the first k-step's fragment reads (its address arithmetic overlaps matrix work);
+                // STAGGER: the second wave of every SIMD two k-steps later, so that one of the two is always on the matrix pipe
                 stamp(4);
                 if constexpr (LAST) {
                     epi_prefetch(p, m0, n0, wm, wn, lane, EPI_PRE_ARGS);
