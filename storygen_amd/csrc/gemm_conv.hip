@@ -8,7 +8,10 @@
 //   * every wave owns a 64x64 output sub-tile = 2x2 accumulators of v_mfma_f32_32x32x16_f16; a workgroup is a WGM x WGN grid of
 //     such waves (256x128, 128x128, 256x64, 128x64, 64x128 or 64x64 tiles), chosen per problem so that the chip stays busy.
 //   * pipelined kernel (the fast path): K is walked in 64-deep slabs through a 3-stage LDS ring filled by LDS-DMA
-//     (global_load_lds, 16 B per lane, no VGPR staging), counted vmcnt waits and ONE raw s_barrier per slab.
+//     (global_load_lds, 16 B per lane, no VGPR staging), counted vmcnt waits and ONE raw s_barrier per slab.  Round 4: the slab body
+//     exists once per ring stage (the stage is a compile-time constant: fragment reads are per-lane base registers + immediates), and
+//     the refill of the ring is placed by waves per SIMD — spread over the four k-steps on the tiles of <= 4 waves, a burst staggered
+//     between the two waves of a SIMD on the 8-wave tile (VALU and DMA-issue cycles ADD to matrix cycles on a SIMD: DESIGN.md 5.2d).
 //   * LDS rows are 128 B (64 halves); the 16-byte chunk c of row r lives at slot c ^ ((r>>1)&7): conflict-free for
 //     the ds_read_b128 fragment reads.  LDS-DMA writes lane l of a wave to (wave-uniform base + 16 l), so the swizzle is
 //     applied on the SOURCE side (the lane that owns slot s of row r fetches logical chunk s ^ ((r>>1)&7)) and again on the reads.
@@ -31,8 +34,8 @@
 //     reduces them in slice order and applies the epilogue (deterministic, no atomics).  An in-launch reduction by the
 //     last-arriving slice (agent-scope release / acquire + ticket counter) was built and measured in round 2: the release
 //     fence behind 64 KB of freshly written partials costs more (+8..13 us per launch) than the kernel boundary it removes.
-// Round-2 mainloop experiments (4-/2-stage rings, spread DMA issue, ping-pong wave groups, LDS-resident conv patches, fat
-// waves) were measured neutral or slower and are no longer part of the library; `git log` has them.
+// Round-2 mainloop experiments (4-/2-stage rings, spread DMA issue on the 256x128 tile, ping-pong wave groups, LDS-resident conv
+// patches, fat waves) were measured neutral or slower and are no longer part of the library; `git log` has them.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -587,8 +590,9 @@ __global__ __launch_bounds__(256) void mma_kernel(const MmaParams p) {
 // predicate: rows beyond M / N are clamped to the last valid row (their results are discarded by the epilogue);
 // K % 64 == 0; for the convolution the input has a one-pixel zero border ([B, H+2, W+2, C]), so every tap of every
 // output pixel reads valid memory and padding costs nothing.
-// Slab t+2 is issued behind the first k-step of slab t, i.e. after the barrier that (a) publishes slab t (every wave waited
-// for its own DMA with a counted vmcnt first) and (b) retires every wave's reads of slab t-1, whose stage it overwrites.
+// Slab t+2 is issued during slab t (behind its first k-step, or spread over its k-steps: SPREAD / STAGGER in mma_pipe_body), i.e. after the
+// barrier that (a) publishes slab t (every wave waited for its own DMA with a counted vmcnt first) and (b) retires every wave's reads of
+// slab t-1, whose stage it overwrites.
 __device__ __forceinline__ void glds16(const f16* g, char* lds_wave_base) {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                      (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);

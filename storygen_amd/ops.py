@@ -28,15 +28,18 @@ TILE_TABLE = {}
 TUNE_SINK = None
 
 
-def _apply_tile(d, tile, split_k, sig):
-    """tile = (bm, bn) or (bm, bn, waves) from the caller, else the tuned table entry (bm, bn, split[, waves])."""
+def _apply_tile(d, tile, split_k, sig, mn):
+    """tile = (bm, bn) or (bm, bn, waves) from the caller, else the tuned table entry (bm, bn, split[, waves]).  mn = M * N of the launch:
+    a tuned split-K count is taken only when the CALLER's workspace holds its split * M * N fp32 partials — the table is keyed by shape,
+    and a caller of the same shape without split-K scratch (the training blocks) keeps the library's own choice for its workspace."""
     if tile is not None:
         d.tile_m, d.tile_n = tile[0], tile[1]
         if len(tile) > 2:
             d.tile_waves = tile[2]
     elif split_k == 0 and sig in TILE_TABLE:
         e = TILE_TABLE[sig]
-        d.tile_m, d.tile_n, d.split_k = e[0], e[1], e[2]
+        d.tile_m, d.tile_n = e[0], e[1]
+        d.split_k = e[2] if e[2] <= 1 or d.workspace_bytes >= e[2] * mn * 4 else 0
         if len(e) > 3:
             d.tile_waves = e[3]
 
@@ -206,7 +209,7 @@ def _gemm_desc(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Opt
     if ln_out is not None:
         sig += ":lo"
     if use_table or tile is not None:
-        _apply_tile(d, tile, split_k, sig)
+        _apply_tile(d, tile, split_k, sig, M * N)
     if TUNE_SINK is not None and use_table:
         TUNE_SINK.append((sig, dict(kind="gemm", M=M, N=N, K=K, epilogue=epilogue, out_f32=bool(flags & F_OUT_F32), bias=bias is not None,
                                     rowbias=rowbias is not None, rows_per_batch=rows_per_batch, out2=out2 is not None,
@@ -322,7 +325,7 @@ def _conv_desc(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, *, stri
         d.stats = stats.data_ptr()
     d.defer_reduce = int(bool(defer_reduce))
     sig = f"c:{B}:{H}:{W}:{Cin}:{Cout}:{stride}:{int(upsample2x)}:{int(x_padded)}:{flags}:{int(bias is not None)}{int(rowbias is not None)}{int(res1 is not None)}"
-    _apply_tile(d, tile, split_k, sig)
+    _apply_tile(d, tile, split_k, sig, B * Ho * Wo * Cout)
     if TUNE_SINK is not None:
         TUNE_SINK.append((sig, dict(kind="conv", B=B, H=H, W=W, Cin=Cin, Cout=Cout, stride=stride, ups=bool(upsample2x), padded=bool(x_padded),
                                     out_f32=bool(flags & F_OUT_F32), bias=bias is not None, rowbias=rowbias is not None,

@@ -344,11 +344,28 @@ def test_tuned_tile_table_is_well_formed():
             assert (e[0], e[1], e[3]) in {(256, 128, 4), (256, 128, 8), (128, 128, 2), (128, 128, 4)}
 
 
+def test_tuned_split_k_is_taken_only_with_a_workspace_that_holds_it(monkeypatch):
+    """The tile table is keyed by shape; its split-K counts (tools/tune_tiles.py measures them with a 256 MB workspace) must not reach a
+    caller of the same shape that passes no split-K scratch — the training blocks' attn1.to_out at the mid level did exactly that with
+    the table of round 4's closing run (sg_gemm_f16: "split_k=3 needs 3932160 workspace bytes, got 0")."""
+    from types import SimpleNamespace
+    from storygen_amd import ops
+    monkeypatch.setitem(ops.TILE_TABLE, "g:test", (128, 64, 3))
+    M, N = 1024, 1280
+    for ws_bytes, want in ((0, 0), (3 * M * N * 4 - 1, 0), (3 * M * N * 4, 3)):
+        d = SimpleNamespace(tile_m=0, tile_n=0, split_k=0, tile_waves=0, workspace_bytes=ws_bytes)
+        ops._apply_tile(d, None, 0, "g:test", M * N)
+        assert (d.tile_m, d.tile_n, d.split_k) == (128, 64, want), ws_bytes
+    d = SimpleNamespace(tile_m=0, tile_n=0, split_k=4, tile_waves=0, workspace_bytes=0)
+    ops._apply_tile(d, None, 4, "g:test", M * N)            # an explicit split_k from the caller bypasses the table
+    assert (d.tile_m, d.tile_n, d.split_k) == (0, 0, 4)
+
+
 def test_committed_bench_line_honours_the_contract():
-    """profiles/r03f_bench.json (and round 1's r01g_final_bench.json) are verbatim `python bench.py` lines from the GPU box: guard the
+    """profiles/r04s_bench.json (round 4's closing line; r03f_bench.json, r01g_final_bench.json: rounds 3 and 1) are verbatim `python bench.py` lines from the GPU box: guard the
     keys the driver and the judge read (a format regression in bench.py shows up here the next time the line is refreshed)."""
     import json
-    for name in ("r03f_bench.json", "r01g_final_bench.json"):
+    for name in ("r04s_bench.json", "r03f_bench.json", "r01g_final_bench.json"):
         path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", name)
         line = [ln for ln in open(path) if ln.startswith("{")][-1]
         _check_bench_line(json.loads(line))
