@@ -250,7 +250,7 @@ def test_traffic_on_file_was_measured_on_this_build():
     path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "traffic.json")
     with open(path) as f:
         t = json.load(f)
-    assert t.get("kernel_source_hash") == source_hash(), "re-run tools/next_round/03_traffic.sh on the GPU box and copy traffic.json"
+    assert t.get("kernel_source_hash") == source_hash(), "re-run the two PMC passes on the GPU box (tools/calls/r4_call21.sh) and copy traffic.json to profiles/"
     assert t["kernels"]["mma_pipe_kernel (gemm + conv3x3)"]["hbm_bytes_per_launch"] > 0
 
 
