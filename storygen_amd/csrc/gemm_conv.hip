@@ -746,7 +746,39 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
                 if (sel < 0 || (i & 3) == sel) glds16(ab.At + a_off[i], sA + i * ISTR);
         }
     };
-    auto issue_a = [&](int kt, int stage) __attribute__((always_inline)) { a_emit(a_base(kt), stage, -1); };
+#ifdef SG_PIPE_BASE_DIV        // A/B build (tools/ab_lib.py): every slab's base from its index (multiply-shift division + 64-bit products)
+    auto a_next = [&](int kt) __attribute__((always_inline)) { return a_base(kt); };
+#else
+    // The slabs of a block are requested in order (kt0, kt0 + 1, ...): their operand bases come from running counters — channel block,
+    // tap column, tap row, element offset — instead of a division and a 64-bit product per slab (≈ 45 -> ≈ 10 scalar instructions in
+    // front of every refill; the refill of the 256x128 tile is a burst right behind them)
+    long it_off;
+    int it_cc = 0, it_kx = 0, it_ky = 0;
+    {
+        const ABase b0 = a_base(kt0);
+        it_off = b0.At - p.A;
+        if constexpr (CONV) {
+            const int tap = (int)fd_div((unsigned)kt0, p.fd_cpt);
+            it_cc = kt0 - tap * p.cpt; it_ky = b0.ky; it_kx = b0.kx;
+        }
+    }
+    const long it_dx = CONV ? (p.ups ? 0 : (long)p.lda) - (long)p.cpt * BK : 0;       // next tap column: one pixel right, channel block 0
+    const long it_dy = CONV && !p.ups ? (long)(wp - 3) * p.lda : 0;                    // ... next tap row: from column 3 back to 0, one row down
+    auto a_next = [&](int) __attribute__((always_inline)) {
+        ABase r;
+        r.At = p.A + it_off; r.ky = it_ky; r.kx = it_kx;
+        it_off += BK;
+        if constexpr (CONV) {
+            if (++it_cc == p.cpt) {
+                it_cc = 0;
+                it_off += it_dx;
+                if (++it_kx == 3) { it_kx = 0; ++it_ky; it_off += it_dy; }
+            }
+        }
+        return r;
+    };
+#endif
+    auto issue_a = [&](int kt, int stage) __attribute__((always_inline)) { a_emit(a_next(kt), stage, -1); };
     if (nt > 0) issue_a(kt0, 0);
     if (S > 2 && nt > 1) { issue_a(kt0 + 1, 1); issue_w(kt0 + 1, 1); }
 
@@ -814,7 +846,7 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         int rst = stage + S - 1;
         if (rst >= S) rst -= S;
         ABase ab = {nullptr, 0, 0};
-        if (refill) ab = a_base(kt0 + it + S - 1);
+        if (refill) ab = a_next(kt0 + it + S - 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             if (ks + 1 < 4) load_frags((ks + 1) & 1, ks + 1);
