@@ -344,6 +344,38 @@ def test_tuned_tile_table_is_well_formed():
             assert (e[0], e[1], e[3]) in {(256, 128, 4), (256, 128, 8), (128, 128, 2), (128, 128, 4)}
 
 
+@pytest.mark.parametrize("ups", [False, True])
+def test_running_counters_of_the_conv_mainloop_visit_the_same_operand_bases_as_the_division(ups):
+    """gemm_conv.hip, mma_pipe_body: slab kt of the implicit-GEMM convolution reads tap (ky, kx) = divmod(kt // cpt, 3), channel block
+    cc = kt % cpt, from element offset (ky * wp + kx) * lda + cc * 64 (nearest-2x upsampling: cc * 64, the tap enters per piece).  Since
+    round 4 the kernel advances running counters instead of dividing per slab: this is the same recurrence in Python, checked against
+    the closed form for every start slab (split-K slices start anywhere) — the derivation the device code relies on."""
+    BK = 64
+    for cpt, wp, lda in ((5, 66, 320), (10, 34, 640), (20, 18, 1280), (40, 10, 2560), (1, 66, 64)):
+        nkt = 9 * cpt
+
+        def closed(kt):
+            tap, cc = divmod(kt, cpt)
+            ky, kx = divmod(tap, 3)
+            return (cc * BK if ups else (ky * wp + kx) * lda + cc * BK), ky, kx
+
+        dx = (0 if ups else lda) - cpt * BK
+        dy = 0 if ups else (wp - 3) * lda
+        for kt0 in range(nkt):
+            off, ky, kx = closed(kt0)
+            cc = kt0 % cpt
+            for kt in range(kt0, nkt):
+                assert (off, ky, kx) == closed(kt), (cpt, kt0, kt)
+                off += BK
+                cc += 1
+                if cc == cpt:
+                    cc = 0
+                    off += dx
+                    kx += 1
+                    if kx == 3:
+                        kx, ky, off = 0, ky + 1, off + dy
+
+
 def test_tuned_split_k_is_taken_only_with_a_workspace_that_holds_it(monkeypatch):
     """The tile table is keyed by shape; its split-K counts (tools/tune_tiles.py measures them with a 256 MB workspace) must not reach a
     caller of the same shape that passes no split-K scratch — the training blocks' attn1.to_out at the mid level did exactly that with
