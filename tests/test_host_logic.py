@@ -4,6 +4,7 @@ data-parallel sharding + the single all-gather (gloo, world_size 2)."""
 import os
 import socket
 
+import numpy as np
 import pytest
 import torch
 import torch.nn.functional as F
@@ -374,6 +375,63 @@ def test_running_counters_of_the_conv_mainloop_visit_the_same_operand_bases_as_t
                     kx += 1
                     if kx == 3:
                         kx, ky, off = 0, ky + 1, off + dy
+
+
+@pytest.mark.parametrize("outlier", ["none", "first-channel", "first-tile", "one-row"])
+def test_groupnorm_merge_arithmetic_in_fp32_against_fp64(outlier):
+    """The arithmetic of gn_apply_wide_kernel's merge of the producers' per-(row tile, channel) partials (norm.hip, round 4), restated in
+    numpy with every intermediate rounded to fp32: a thread owns one channel and every slots-th row tile of it and runs Chan's update about
+    the mean of ITS first tile; a group sums its cpg x slots thread partials as mean first, then non-negative M2 terms.  Against the fp64
+    statistics of the same data, with the outliers ADVICE r3 asked about (a channel / a tile / one pixel off by ~1e3 standard
+    deviations): the variance keeps >= 5 digits.  (The kernel itself is compared with torch on the GPU: tests/test_kernels_gpu.py.)"""
+    f32 = np.float32
+    rng = np.random.default_rng(5)
+    HW, C, G, rows = 1024, 320, 32, 64
+    cpg, tiles, slots = C // G, HW // rows, 1024 // C
+    x = rng.standard_normal((HW, C)).astype(f32) * f32(0.7) + rng.standard_normal(C).astype(f32)
+    if outlier == "first-channel":
+        x[:, 0::cpg] += f32(1000.0)
+    elif outlier == "first-tile":
+        x[:rows] += f32(1000.0)
+    elif outlier == "one-row":
+        x[5, 0::cpg] = f32(30000.0)
+    xt = x.reshape(tiles, rows, C)
+    s1 = xt.sum(1, dtype=f32)                       # what the producers' epilogues write (fp32 sums of fp32 values)
+    s2 = (xt * xt).sum(1, dtype=f32)
+    inv_rows, frows = f32(1.0 / rows), f32(rows)
+    part = {}
+    for slot in range(slots):
+        for c in range(C):
+            a_s = a_q = a_n = f32(0)
+            K = None
+            for t in range(slot, tiles, slots):
+                me = f32(s1[t, c] * inv_rows)
+                if K is None:
+                    K = me
+                dm = f32(me - K)
+                a_s = f32(a_s + s1[t, c])
+                a_n = f32(a_n + frows)
+                a_q = f32(a_q + f32(max(f32(s2[t, c] - f32(s1[t, c] * me)), f32(0)) + f32(frows * f32(dm * dm))))
+            if a_n > 0:
+                dk = f32(f32(a_s / a_n) - K)
+                part[slot, c] = (a_s, f32(max(f32(a_q - f32(a_n * f32(dk * dk))), f32(0))), a_n)
+            else:
+                part[slot, c] = (f32(0), f32(0), f32(0))
+    ntot = f32(HW * cpg)
+    for g in range(G):
+        ent = [part[sl, g * cpg + k] for sl in range(slots) for k in range(cpg)]
+        sm = f32(0)
+        for a_s, _, _ in ent:
+            sm = f32(sm + a_s)
+        mean = f32(sm / ntot)
+        m2 = f32(0)
+        for a_s, q, n in ent:
+            d = f32(f32(a_s / n) - mean) if n > 0 else f32(0)
+            m2 = f32(m2 + f32(q + f32(n * f32(d * d))))
+        var = float(m2 / ntot)
+        ref = x[:, g * cpg:(g + 1) * cpg].astype(np.float64)
+        assert abs(float(mean) - ref.mean()) <= 1e-5 * max(1.0, abs(ref.mean())), (g, outlier)
+        assert abs(var - ref.var()) <= 2e-5 * ref.var(), (g, outlier, var, ref.var())
 
 
 def test_tuned_split_k_is_taken_only_with_a_workspace_that_holds_it(monkeypatch):
