@@ -39,6 +39,7 @@ sys.path.insert(0, ROOT)
 
 PEAK_FP16_TFLOPS = 2500.0          # dense MFMA peak, MI355X_MICROARCH.md "Chip-level parameters"
 HW, R, N_PER_GPU, T = 64, 3, 1, 50
+DEFAULT_REF_AHEAD = 5               # reference passes of 5 consecutive steps as one batched UNet call inside one hipGraph per group
 REF_GF, MAIN_GF = 803.3, 1273.1    # per-sample algorithmic GFLOP of one ref / main pass at 64x64, R=3
 STEP_TFLOP = 3 * (R * REF_GF + MAIN_GF) / 1000.0
 
@@ -292,14 +293,18 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-dedup", action="store_true", help="run all 3R reference samples as written")
     ap.add_argument("--no-overlap", action="store_true", help="one stream: reference pass, then main pass")
-    ap.add_argument("--ref-ahead", type=int, default=1,
-                    help="batch the reference passes of G consecutive steps into one UNet call (sampler ref_ahead). The timed "
-                         "window then starts on a group boundary (extra untimed warm-up steps, reported as warmup_run) and G "
-                         "must divide --steps, so that it contains exactly steps/G batched reference passes")
+    ap.add_argument("--ref-ahead", type=int, default=None,
+                    help="batch the reference passes of G consecutive steps into one UNet call (sampler ref_ahead): one hipGraph per "
+                         "group of G steps, the batched reference pass of the next group forked beside the group's G main passes. The "
+                         "timed window starts on a group boundary (extra untimed warm-up steps, reported as warmup_run) and G must "
+                         "divide --steps, so that it contains exactly steps/G batched reference passes and steps main passes.  Default: "
+                         f"the largest G <= {DEFAULT_REF_AHEAD} that divides --steps (same-box A/B of G = 1 / 2 / 5 / 10: "
+                         "profiles/r05a_ab_ref_ahead_one_graph.txt)")
     ap.add_argument("--config5-shape", action="store_true",
                     help="NOT the contract workload: BASELINE configs[4]'s shape (768x768 = 96x96 latent, 5 prior frames); fp16 "
                          "attention unless --fp8-attention; the JSON names it in config.workload")
-    ap.add_argument("--split-graphs", action="store_true", help="reference and main pass as separate hipGraphs on two streams")
+    ap.add_argument("--split-graphs", action="store_true",
+                    help="A/B: reference and main pass as separately launched hipGraphs on two streams (measured: they do not overlap)")
     ap.add_argument("--stream-priority", action="store_true",
                     help="with --split-graphs / --ref-ahead: main-pass graphs on a high-priority stream")
     ap.add_argument("--fp8-attention", action="store_true",
@@ -387,7 +392,10 @@ def main():
     arch = build_arch(SD15_CONFIG)
     sd = synthetic_state_dict(arch, 0)
     inputs = synthetic_inputs(N_PER_GPU, n_ref, hw, hw, seed=rank, cross_attention_dim=arch.config["cross_attention_dim"])
-    G = max(1, args.ref_ahead)
+    if args.ref_ahead is None:                      # default: the largest group size <= DEFAULT_REF_AHEAD that divides the timed window
+        G = 1 if (args.no_graph or args.no_overlap) else max(g for g in range(1, DEFAULT_REF_AHEAD + 1) if args.steps % g == 0)
+    else:
+        G = max(1, args.ref_ahead)
     if G > 1 and args.steps % G:
         raise SystemExit(f"--ref-ahead {G} must divide --steps {args.steps}")
     warmup_run = -(-args.warmup // G) * G          # the timed window starts on a group boundary

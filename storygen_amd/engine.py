@@ -253,7 +253,8 @@ class HarvestPlan:
     into `count` frame slots)."""
 
     def __init__(self, ctx: Dict[str, torch.Tensor], ops_: List[tuple], kv: Optional[Dict[str, tuple]] = None,
-                 src_offset: int = 0, short: int = 0, slots_per_row: Optional[int] = None, direct: bool = False):
+                 src_offset: int = 0, short: int = 0, slots_per_row: Optional[int] = None, direct: bool = False,
+                 identity: bool = False):
         # kv: feature key -> (K [rows*R*HW, C], VT [C, rows*R*HW]) buffers: when given, the reference pass also runs the
         # attn3 K / V^T projections of each finished context (they depend on nothing else), taking them off the main
         # pass's critical path.
@@ -263,14 +264,21 @@ class HarvestPlan:
         # frame slot, the others slots_per_row; flat slot of (row, slot) = row if row < short else short + (row - short) * R + slot.
         # direct: the pass's sample u belongs in flat slot u for every u (sampler._plan orders the batch that way), so the
         # producer of the feature writes its fp16 copy straight into the context buffer and no copy kernel runs.
+        # identity: the CALLER guarantees that mapping for buffers it laid out itself — `ctx` / `kv` are flat [samples * HW, C]
+        # matrices in the pass's sample order (the sampler's group schedule: the context sets of G steps end to end); no ops.
         self.ctx, self.ops, self.kv, self.src_offset = ctx, list(ops_), kv, int(src_offset)
-        self.short, self.slots_per_row, self.direct = int(short), slots_per_row, bool(direct)
+        self.short, self.slots_per_row, self.direct = int(short), slots_per_row, bool(direct) or bool(identity)
+        self.identity = bool(identity)
+        if self.identity and (self.ops or self.src_offset):
+            raise ValueError("an identity harvest plan has no copy ops and no source offset")
 
     def flat_slot(self, row: int, slot: int, R: int) -> int:
         return row if row < self.short else self.short + (row - self.short) * R + slot
 
     def is_direct(self, n_samples: int, R: int) -> bool:
         """True when this plan alone maps sample u -> flat slot u for all n_samples samples of the pass."""
+        if self.identity:
+            return all(c.dim() == 2 and c.shape[0] % n_samples == 0 for c in self.ctx.values())
         if not self.direct or self.src_offset:
             return False
         seen = {}

@@ -26,14 +26,21 @@ MI355X-first structure
     1 (grids of 60-250 workgroups, latency-bound 5-20-slab pipelines), so the two branches fill each other's gaps;
     the arithmetic and its order inside each pass are unchanged (the eager path runs the same kernels back to back).
 
-  * `ref_ahead = G > 1` (graph + overlap mode) goes one step further down the same road: since no reference pass depends
-    on the latents, the reference samples of G consecutive steps — they differ only in their noise level — run as ONE
-    batched UNet call of G x as many samples, launched (as its own hipGraph, on a second stream) at the start of every
-    group of G steps and producing the G context sets of the NEXT group while this group's G main passes (one hipGraph
-    each, back to back on the first stream) consume theirs.  Per sample the arithmetic is unchanged; what changes is
-    the shape of the work: 4 x larger M for every GEMM / convolution of the reference half of the step (better tile
-    quantisation at the 64x64 level, weights streamed once per G steps at the weight-bound 16x16 / 8x8 levels) and 4 x
-    fewer launches.  2G context sets are kept (set = step mod 2G).
+  * `ref_ahead = G > 1` goes one step further down the same road: since no reference pass depends on the latents, the
+    reference samples of G consecutive steps — they differ only in their noise level — run as ONE batched UNet call of
+    G x as many samples, producing the G context sets of the NEXT group of G steps while this group's G main passes
+    consume theirs.  Per sample the arithmetic is unchanged; what changes is the shape of the work: G x larger M for
+    every GEMM / convolution of the reference half of the step (better tile quantisation at the 64x64 level, weights
+    streamed once per G steps at the weight-bound 16x16 / 8x8 levels) and G x fewer launches.  2G context sets are kept
+    (set = step mod 2G).  Round 5: the whole GROUP is ONE hipGraph — the batched reference pass of group j+1 forked
+    beside the G main passes of group j, each main pass reading its own row of a [G, n] parameter block uploaded once
+    per group — so the two halves interleave inside the graph like the G = 1 schedule's do (separately launched graphs
+    do not overlap at all on this runtime; that older form is kept behind `split_graphs=True`).  The
+    reference batch is ordered like the G context sets laid end to end in one buffer per feature key, so its features
+    (and their attn3 K / V^T projections, one GEMM pair per feature for the whole group) are written in place.  One
+    `step()` call per step still works: the group is enqueued by its first step, the others return at once, and
+    `latents` is the state after the group's LAST step (`lat_trace[g]` = after step g of the group; `run(trace=...)`
+    reads those).  The number of UNet evaluations must be a multiple of G.
 
 Data parallelism (SURVEY §8e): one process per GPU, each running its own samples with no per-step communication;
 `gather_latents` is the single RCCL all-gather of the final [N,4,h,w] latents.
@@ -63,16 +70,20 @@ class StoryGenSampler:
                  side_streams: str = "auto", short_rows: bool = True, time_tables: bool = True):
         if n_ref < 1:
             raise ValueError("StoryGen's loop needs at least one prior frame")
-        if ref_ahead < 1 or (ref_ahead > 1 and not (use_graph and overlap)):
-            raise ValueError("ref_ahead > 1 batches the reference passes of several steps on a second stream: it needs "
-                             "use_graph=True and overlap=True")
+        if ref_ahead < 1 or (ref_ahead > 1 and not overlap):
+            raise ValueError("ref_ahead > 1 runs the batched reference pass of the NEXT group of steps beside this group's main "
+                             "passes: it needs overlap=True")
         self.G = int(ref_ahead)
         # split: reference pass and main pass are separate hipGraphs overlapped at replay time by launching them on two
-        # streams (always so for ref_ahead > 1).  Only then can the two halves run at different queue priorities
-        # (stream_priority: main pass high — it is the step's critical path — reference pass as background filler).
-        self.split = bool(split_graphs) or self.G > 1
+        # streams.  Only then can the two halves run at different queue priorities (stream_priority: main pass high — it is
+        # the step's critical path — reference pass as background filler).  Measured: separately launched graphs do not
+        # overlap on this runtime, so it is an A/B switch only.
+        self.split = bool(split_graphs)
         if self.split and not (use_graph and overlap):
             raise ValueError("split_graphs needs use_graph=True and overlap=True")
+        # group: ref_ahead = G > 1 as ONE graph per group of G steps (batched reference pass of the next group forked beside
+        # this group's G main passes).  Without use_graph the same schedule runs eagerly (tests, instrumentation).
+        self.group = self.G > 1 and not self.split
         if stream_priority and not self.split:
             raise ValueError("stream_priority only applies to separately launched graphs (split_graphs=True or ref_ahead > 1)")
         self.stream_priority = bool(stream_priority)
@@ -93,6 +104,9 @@ class StoryGenSampler:
         self.schedule = schedule or DDIMSchedule()
         self.use_graph, self.dedup = use_graph, dedup
         self.overlap = overlap and use_graph
+        # ahead: the reference pass runs one step (one group) AHEAD of the main pass that consumes it — the table rows carry the
+        # NEXT step's / group's reference scalars, 2G context sets exist and prepare() primes the first one
+        self.ahead = self.overlap or self.group
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.graphs: List[torch.cuda.CUDAGraph] = []
         self.main: Optional[UNetEngine] = None
@@ -174,6 +188,7 @@ class StoryGenSampler:
         if self.no_ctx:
             if self.G > 1 or self.split:
                 raise ValueError("stage 'no' has no reference pass to batch or split off")
+            self.group = False
             self.units, self.U, self.U0 = [], 0, 0
             self.main = UNetEngine(self.arch, None, self.dev, self.B, self.h, self.w, 0, self.S, weights=self.weights,
                                    fp8_attention=self.fp8_attention)
@@ -181,7 +196,8 @@ class StoryGenSampler:
             self.side_main = torch.cuda.Stream(device=self.dev) if self.use_graph else None
             self.side_ref = None
             self.n_par = self.B + 2 + self.schedule.row_len
-            self.params = torch.zeros(self.n_par, dtype=torch.float32, device=self.dev)
+            self.params = torch.zeros(1, self.n_par, dtype=torch.float32, device=self.dev)
+            self.lat_trace, self.group_direct = None, False
             self.layout, self.graph, self.graphs, self.g_ref, self.g_main = key, None, [], [], []
             return
         units, hops, rows, groups, short = self._plan(stage, share_zero)
@@ -193,18 +209,40 @@ class StoryGenSampler:
         self.main = UNetEngine(self.arch, None, self.dev, self.B, self.h, self.w, self.R, self.S, ctx_rows=rows,
                                attn3_groups=groups, ctx_short=short, **kw)
         self.ref = UNetEngine(self.arch, None, self.dev, self.U, self.h, self.w, 0, self.S, **kw)
-        # context sets: the main pass of step k reads set k%2 (only one set without overlap)
-        self.ctx_sets = [self.main.ctx]
-        if self.overlap:
-            for _ in range(2 * G - 1):         # G = 1: sets k%2; G > 1: set = step mod 2G
+        # sample u of one step's reference batch IS context slot u (_plan) when the plan alone is a bijection onto the slots
+        one_step_direct = HarvestPlan(self.main.ctx, hops, short=short, slots_per_row=self.R, direct=True).is_direct(self.U0, self.R)
+        # context sets: the main pass of step k reads set k%2 (only one set when the reference pass is not run ahead); G > 1: set =
+        # step mod 2G.  Group schedule: the G sets of a group parity are consecutive slices of ONE buffer per feature key (and of
+        # one K / V^T buffer), in the order of the batched reference pass's samples — that pass then writes them in place.
+        self.group_direct = self.group and one_step_direct
+        n_sets = 2 * G if self.ahead else 1
+        if self.group_direct:
+            self.ctx_base, self.kv_base, self.ctx_sets, self.kv_sets = [], [], [], []
+            for _ in range(2):
+                cb = {k: torch.empty((G * v.numel() // v.shape[-1], v.shape[-1]), dtype=v.dtype, device=self.dev)
+                      for k, v in self.main.ctx.items()}
+                kb = {k: (torch.empty_like(v), torch.empty(v.shape[1], v.shape[0], dtype=v.dtype, device=self.dev)) for k, v in cb.items()}
+                self.ctx_base.append(cb)
+                self.kv_base.append(kb)
+                for g in range(G):
+                    n = {k: v.numel() // v.shape[-1] for k, v in self.main.ctx.items()}       # token rows of one set
+                    self.ctx_sets.append({k: cb[k][g * n[k]:(g + 1) * n[k]].view(v.shape) for k, v in self.main.ctx.items()})
+                    self.kv_sets.append({k: (kb[k][0][g * n[k]:(g + 1) * n[k]], kb[k][1][:, g * n[k]:(g + 1) * n[k]]) for k in cb})
+            self.main.ctx = self.ctx_sets[0]
+            # one plan for the whole batch: sample g*U0 + u -> slot u of set g = row (g*U0 + u) of the base buffer
+            self.plans = [HarvestPlan(cb, [], kb, identity=True) for cb, kb in zip(self.ctx_base, self.kv_base)]
+        else:
+            self.ctx_sets = [self.main.ctx]
+            for _ in range(n_sets - 1):
                 self.ctx_sets.append({k: torch.empty_like(v) for k, v in self.main.ctx.items()})
-        # attn3 K / V^T per context set: computed by the reference pass right after each feature is harvested
-        self.kv_sets = [{k: (torch.empty(v.numel() // v.shape[-1], v.shape[-1], dtype=v.dtype, device=self.dev),
-                             torch.empty(v.shape[-1], v.numel() // v.shape[-1], dtype=v.dtype, device=self.dev))
-                         for k, v in c.items()} for c in self.ctx_sets]
-        # G = 1: sample u of the reference pass IS context slot u (_plan) -> its feature copies are written in place (direct)
-        self.plans = [HarvestPlan(c, hops, kv, src_offset=(i % G) * self.U0, short=short, slots_per_row=self.R, direct=(G == 1))
-                      for i, (c, kv) in enumerate(zip(self.ctx_sets, self.kv_sets))]
+            # attn3 K / V^T per context set: computed by the reference pass right after each feature is harvested
+            self.kv_sets = [{k: (torch.empty(v.numel() // v.shape[-1], v.shape[-1], dtype=v.dtype, device=self.dev),
+                                 torch.empty(v.shape[-1], v.numel() // v.shape[-1], dtype=v.dtype, device=self.dev))
+                             for k, v in c.items()} for c in self.ctx_sets]
+            # G = 1: the feature copies are written in place (direct); G > 1 (split graphs, or a layout that is not a bijection):
+            # one plan per step's slice of the batch, strided copies
+            self.plans = [HarvestPlan(c, hops, kv, src_offset=(i % G) * self.U0, short=short, slots_per_row=self.R, direct=(G == 1))
+                          for i, (c, kv) in enumerate(zip(self.ctx_sets, self.kv_sets))]
         self.plan = self.plans[0]
         # side streams for the independent branches inside a pass (engine.forward(side=...)).  In overlap mode the
         # reference pass already runs on a forked stream; a second-level fork from it crashed hipGraph capture on
@@ -219,11 +257,13 @@ class StoryGenSampler:
         # the noise of every reference sample (pipeline.py:409: ONE draw per story frame n, shared by its prior frames and its zero-image
         # sample): expanded per reference unit, because the units are ordered like the context buffer (row-major in n), not n-minor
         self.ref_noise = torch.zeros((self.U,) + tuple(self.latents.shape[1:]), **f32)
-        # per-step parameters: [U] ref timesteps | [B] main timestep | [U,2] add_noise coefs | guidance + update-rule coefs
+        # per-step parameters, one row per step of a group (G rows; only the group schedule reads rows > 0):
+        # [U] ref timesteps | [B] main timestep | [U,2] add_noise coefs | guidance + update-rule coefs
         self.n_par = 3 * self.U + self.B + 2 + self.schedule.row_len
-        self.params = torch.zeros(self.n_par, **f32)
+        self.params = torch.zeros(G if self.group else 1, self.n_par, **f32)
+        self.lat_trace = torch.zeros((G,) + tuple(self.latents.shape), **f32) if self.group else None
         self.layout, self.graph, self.graphs = key, None, []
-        self.g_ref, self.g_main = [], []       # ref_ahead > 1: one graph per group parity / per context set
+        self.g_ref, self.g_main = [], []       # split graphs: one graph per group parity / per context set
         self.main_stream = None
         if self.split:
             self.ref_stream = torch.cuda.Stream(device=self.dev)
@@ -231,9 +271,12 @@ class StoryGenSampler:
                 self.main_stream = torch.cuda.Stream(device=self.dev, priority=-1)
             self.ev_ref = [torch.cuda.Event(), torch.cuda.Event()]      # "reference pass of a group of this parity is done"
 
-    def _par_views(self):
+    def _par_views(self, row: int = 0):
+        """(reference timesteps [U], main timesteps [B], add_noise coefficients [U, 2], guidance + update-rule scalars) of parameter
+        row `row` (the group schedule keeps one row per step of the group; everything else uses row 0)."""
         U, B = self.U, self.B
-        return (self.params[:U], self.params[U:U + B], self.params[U + B:3 * U + B].view(U, 2), self.params[3 * U + B:])
+        p = self.params[row]
+        return (p[:U], p[U:U + B], p[U + B:3 * U + B].view(U, 2), p[3 * U + B:])
 
     # ------------------------------------------------------------------------------------------------ setup
     def prepare(self, inputs: Dict[str, torch.Tensor], num_inference_steps: int = 50,
@@ -267,9 +310,13 @@ class StoryGenSampler:
         # per-step table
         ts = self.schedule.timesteps(num_inference_steps)
         rows, row0 = step_table(self.schedule, ts, num_inference_steps, self.units[:self.U0], R, stage, self.B, self.G,
-                                self.overlap and not self.no_ctx, image_guidance_scale, guidance_scale)
-        self.row0_ref = torch.tensor(row0, dtype=torch.float32).pin_memory()
-        self.table = torch.tensor(rows, dtype=torch.float32).pin_memory()
+                                self.ahead and not self.no_ctx, image_guidance_scale, guidance_scale)
+        if self.group and len(rows) % self.G:
+            raise ValueError(f"ref_ahead = {self.G} runs the loop in groups of {self.G} UNet evaluations: {len(rows)} evaluations "
+                             f"({num_inference_steps} inference steps) is not a multiple")
+        pin = (lambda t: t.pin_memory()) if self.dev.type == "cuda" else (lambda t: t)      # pinned: the per-step upload is an async H2D copy
+        self.row0_ref = pin(torch.tensor(row0, dtype=torch.float32))
+        self.table = pin(torch.tensor(rows, dtype=torch.float32))
         self.timesteps = ts
         self.num_steps = len(ts)                  # PNDM: n + 1 UNet evaluations for n inference steps
         self.k = 0
@@ -282,31 +329,34 @@ class StoryGenSampler:
                 self.graph, self.graphs, self.g_ref, self.g_main = None, [], [], []
         if self.use_graph and self.graph is None and not self.graphs and not self.g_main:
             self._capture()
-        if self.overlap and not self.no_ctx:
+        if self.ahead and not self.no_ctx:
             self._prime()
 
     # ------------------------------------------------------------------------------------------------ the step
     def _step_body(self):
         """One whole step, sequentially (eager mode, graph warm-up, bench instrumentation): reference passes :418-438,
-        then the main pass.  NB in overlap mode `self.params` holds the reference-pass scalars of the NEXT step.
-        With ref_ahead = G > 1 this is one whole GROUP: the batched reference pass of G steps and G main passes (all with
-        the scalars of one table row: good for warm-up and kernel timing, not a valid piece of a trajectory)."""
+        then the main pass.  NB when the reference pass runs ahead `self.params` holds the reference-pass scalars of the NEXT step.
+        With ref_ahead = G > 1 this is one whole GROUP: the batched reference pass of G steps and G main passes (as a warm-up all
+        with the scalars of one table row: good for kernel timing, not a valid piece of a trajectory)."""
         if not self.no_ctx:
             self._ref_pass(0)
         for g in range(self.G):
-            self._main_pass(g)
+            self._main_pass(g, row=g if self.group else 0)
 
     def _ref_pass(self, ctx_set: int):
         """The reference samples of step(s) -> context set `ctx_set` (ref_ahead = G > 1: of G steps -> sets ctx_set ..
-        ctx_set + G - 1, one harvest plan per step's slice of the batch)."""
+        ctx_set + G - 1: one harvest plan per step's slice of the batch, or ONE plan over the group's contiguous sets)."""
         t_ref, _, an, _ = self._par_views()
         ops.add_noise(self.ref_src, self.ref_noise, an, self.ref.x_in)                    # :419-429 (noise of unit u = noise[n(u)])
         self.ref.t_in.copy_(t_ref)
-        plan = self.plans[ctx_set] if self.G == 1 else self.plans[ctx_set:ctx_set + self.G]
+        if self.group_direct:
+            plan = self.plans[ctx_set // self.G]
+        else:
+            plan = self.plans[ctx_set] if self.G == 1 else self.plans[ctx_set:ctx_set + self.G]
         self.ref.forward(harvest=plan, harvest_only=True, text_cache=True, side=self.side_ref)
 
-    def _main_pass(self, ctx_set: int):
-        _, t_main, _, cd = self._par_views()
+    def _main_pass(self, ctx_set: int, row: int = 0):
+        _, t_main, _, cd = self._par_views(row)
         main = self.main
         if not self.no_ctx:
             main.ctx, main.kv_ext = self.ctx_sets[ctx_set], self.kv_sets[ctx_set]
@@ -318,8 +368,26 @@ class StoryGenSampler:
         else:
             ops.cfg_ddim_step(eps3, self.latents, self.latents3, cd)
 
+    def _group_body(self, parity: int, side: Optional["torch.cuda.Stream"]):
+        """Group schedule: the G main passes of a group of this parity (context sets parity*G ..) and, beside them, the batched
+        reference pass of the NEXT group (into the other parity's sets).  side = the stream of the forked branch (None: in order,
+        reference pass first — the eager form)."""
+        G, dev = self.G, self.dev
+        if side is not None:
+            cur = torch.cuda.current_stream(dev)
+            side.wait_stream(cur)                                                         # fork
+            with torch.cuda.stream(side):
+                self._ref_pass((1 - parity) * G)
+        else:
+            self._ref_pass((1 - parity) * G)
+        for g in range(G):
+            self._main_pass(parity * G + g, row=g)
+            self.lat_trace[g].copy_(self.latents)
+        if side is not None:
+            cur.wait_stream(side)                                                         # join
+
     def _prime(self):
-        """Overlap mode: the reference pass of step 0 (ref_ahead > 1: of the first group) has no main pass to hide behind."""
+        """The reference pass of step 0 (ref_ahead > 1: of the first group) has no main pass to hide behind."""
         self.params.copy_(self.row0_ref, non_blocking=True)
         self._ref_pass(0)
         if self.split:
@@ -360,12 +428,15 @@ class StoryGenSampler:
             for parity in (0, 1):
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    cur = torch.cuda.current_stream(dev)
-                    side.wait_stream(cur)                                                 # fork
-                    with torch.cuda.stream(side):
-                        self._ref_pass(1 - parity)                                        # reference pass of step k+1
-                    self._main_pass(parity)                                               # main pass of step k
-                    cur.wait_stream(side)                                                 # join
+                    if self.group:                                                        # G main passes of a group || reference pass of the next
+                        self._group_body(parity, side)
+                    else:
+                        cur = torch.cuda.current_stream(dev)
+                        side.wait_stream(cur)                                             # fork
+                        with torch.cuda.stream(side):
+                            self._ref_pass(1 - parity)                                    # reference pass of step k+1
+                        self._main_pass(parity)                                           # main pass of step k
+                        cur.wait_stream(side)                                             # join
                 self.graphs.append(g)
         if not self.no_ctx:
             self.main.ctx, self.main.kv_ext = self.ctx_sets[0], self.kv_sets[0]
@@ -374,15 +445,27 @@ class StoryGenSampler:
         torch.cuda.synchronize(dev)
 
     def step(self, k: Optional[int] = None):
-        """Run denoising step k (default: the next one).  Asynchronous on the current stream."""
+        """Run denoising step k (default: the next one).  Asynchronous on the current stream.  Group schedule (ref_ahead > 1): the
+        first step of a group enqueues the whole group, the others return at once; `latents` is then the state after the group's
+        last step and `lat_trace[g]` the state after its g-th."""
         k = self.k if k is None else k
         if self.table is None or k >= self.table.shape[0]:
             raise RuntimeError("prepare() first / no steps left")
-        if self.overlap and not self.no_ctx and k != self.k:
-            raise RuntimeError("overlapped sampling runs the steps in order (the graph of step k also runs the reference "
+        if self.ahead and not self.no_ctx and k != self.k:
+            raise RuntimeError("look-ahead sampling runs the steps in order (the graph of step k also runs the reference "
                                "pass of step k+1)")
         if self.g_main:
             self._step_ahead(k)
+            self.k = k + 1
+            return
+        if self.group:
+            G = self.G
+            if k % G == 0:
+                self.params.copy_(self.table[k:k + G], non_blocking=True)
+                if self.graphs:
+                    self.graphs[(k // G) % 2].replay()
+                else:
+                    self._group_body((k // G) % 2, None)
             self.k = k + 1
             return
         self.params.copy_(self.table[k], non_blocking=True)
@@ -395,7 +478,7 @@ class StoryGenSampler:
         self.k = k + 1
 
     def _step_ahead(self, k: int):
-        """Split-graph schedule (ref_ahead = G > 1, or split_graphs with G = 1).  At the first step of group j: the batched reference pass of group j+1 goes to the second
+        """Split-graph schedule (split_graphs=True, any G).  At the first step of group j: the batched reference pass of group j+1 goes to the second
         stream (it overwrites the context sets group j-1 read, whose main passes are already enqueued on this stream:
         the fork orders it behind them), and this stream waits for group j's own reference pass, launched one group ago
         (or by _prime).  Then the main pass of step k, on its context set k mod 2G.
@@ -407,29 +490,34 @@ class StoryGenSampler:
         cur = self.main_stream or caller            # stream_priority: the main passes run on their own high-priority stream
         U, B = self.U, self.B
         row = self.table[k]
+        par = self.params[0]
         if cur is not caller:
             cur.wait_stream(caller)
         if g == 0:
             self.ref_stream.wait_stream(cur)
             with torch.cuda.stream(self.ref_stream):
-                self.params[:U].copy_(row[:U], non_blocking=True)                         # reference timesteps
-                self.params[U + B:3 * U + B].copy_(row[U + B:3 * U + B], non_blocking=True)   # add_noise coefficients
+                par[:U].copy_(row[:U], non_blocking=True)                                 # reference timesteps
+                par[U + B:3 * U + B].copy_(row[U + B:3 * U + B], non_blocking=True)       # add_noise coefficients
                 self.g_ref[first_ctx_set_of_group(j + 1, G) // G].replay()
                 self.ev_ref[(j + 1) % 2].record(self.ref_stream)
             cur.wait_event(self.ev_ref[j % 2])
         with torch.cuda.stream(cur):
-            self.params[U:U + B].copy_(row[U:U + B], non_blocking=True)                   # main timestep
-            self.params[3 * U + B:].copy_(row[3 * U + B:], non_blocking=True)             # guidance + DDIM coefficients
+            par[U:U + B].copy_(row[U:U + B], non_blocking=True)                           # main timestep
+            par[3 * U + B:].copy_(row[3 * U + B:], non_blocking=True)                     # guidance + DDIM coefficients
             self.g_main[ctx_set_of_step(k, G)].replay()
         if cur is not caller:
             caller.wait_stream(cur)
 
     def run(self, max_steps: Optional[int] = None, trace: Optional[list] = None) -> torch.Tensor:
         n = self.num_steps if max_steps is None else min(self.num_steps, max_steps)
+        if self.group and n % self.G:
+            raise ValueError(f"ref_ahead = {self.G}: run() works in whole groups, max_steps = {n} is not a multiple")
         for k in range(self.k, n):
             self.step(k)
-            if trace is not None:
+            if trace is not None and not self.group:
                 trace.append(self.latents.clone())
+            elif trace is not None and k % self.G == self.G - 1:
+                trace.extend(self.lat_trace[g].clone() for g in range(self.G))
         return self.latents
 
     def executed_sample_forwards(self):

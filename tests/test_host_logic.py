@@ -523,14 +523,63 @@ def test_step_table_reference_scalars_follow_the_pass_schedule(G, stage):
         assert not set(mine) & set(nxt) and set(mine) | set(nxt) == set(range(2 * G))
 
 
-def test_ref_ahead_needs_graph_and_overlap():
+def test_ref_ahead_needs_overlap_and_split_graphs_needs_a_graph():
     from storygen_amd.arch import build_arch
     from storygen_amd.sampler import StoryGenSampler
     from test_oracle_golden import _load
     arch = build_arch(_load("tiny")["config"])
-    for kw in (dict(use_graph=False), dict(overlap=False), dict(ref_ahead=0)):
+    for kw in (dict(overlap=False), dict(ref_ahead=0), dict(split_graphs=True, use_graph=False), dict(stream_priority=True)):
         with pytest.raises(ValueError):
             StoryGenSampler(arch, None, "cpu", ref_ahead=kw.pop("ref_ahead", 2), weights=object(), **kw)
+    smp = StoryGenSampler(arch, None, "cpu", ref_ahead=2, weights=object(), use_graph=False)     # the group schedule also runs eagerly
+    assert smp.group and smp.ahead and not smp.split and not smp.overlap
+
+
+def _stub_inputs(N, R, hw=4, S=5, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *sh: torch.randn(*sh, generator=g)                                         # noqa: E731
+    return dict(latents=r(N, 4, hw, hw), noise=r(N, 4, hw, hw), image_prompts=r(R, N, 4, hw, hw), zero_prompt=r(N, 4, hw, hw),
+                text=r(N, S, 8), uncond=r(N, S, 8), prev_text=r(R, N, S, 8), prev_uncond=r(1, N, S, 8).expand(R, N, S, 8).clone())
+
+
+@pytest.mark.parametrize("stage", ["multi-image-condition", "auto-regressive"])
+@pytest.mark.parametrize("N,R", [(1, 3), (2, 2)])
+@pytest.mark.parametrize("kw", [dict(ref_ahead=2), dict(ref_ahead=5), dict(ref_ahead=2, short_rows=False), dict(ref_ahead=2, dedup=False)])
+def test_group_schedule_is_the_step_by_step_trajectory(monkeypatch, stage, N, R, kw):
+    """ref_ahead = G as ONE schedule unit per group (sampler._group_body: batched reference pass of the NEXT group, then this group's G
+    main passes on parameter rows 0..G-1 and context sets parity*G + g) against the plain loop (reference pass, then main pass, per
+    step), on a stand-in engine whose arithmetic depends on the context set, the parameter row, the harvest layout and the K / V^T
+    pairing (tests/stub_engine.py): the latents after EVERY step must be bit-identical.  Covers the in-place group layout (one plan
+    over the G context sets laid end to end) and the strided-copy fallback (short_rows=False / dedup=False)."""
+    import stub_engine
+    S = stub_engine.install(monkeypatch)
+    from storygen_amd.arch import build_arch
+    from test_oracle_golden import _load
+    arch = build_arch(_load("tiny")["config"])
+    inp = _stub_inputs(N, R)
+    T = 10
+
+    def run(**skw):
+        smp = S.StoryGenSampler(arch, None, "cpu", N, 4, 4, R, 5, use_graph=False, weights=object(), time_tables=False, **skw)
+        smp.prepare(inp, T, stage, 7.5, 3.5)
+        tr = []
+        smp.run(trace=tr)
+        return smp, tr
+
+    base_kw = {k: v for k, v in kw.items() if k != "ref_ahead"}
+    ref, want = run(**base_kw)
+    smp, got = run(**kw)
+    G = kw["ref_ahead"]
+    assert smp.group and len(got) == len(want) == T
+    assert smp.group_direct == ("short_rows" not in kw or stage == "auto-regressive")
+    for k in range(T):
+        assert torch.equal(got[k], want[k]), f"step {k}"
+    # the work: one batched reference call per group (+ the primer), each G x the per-step batch
+    refs = [b for kind, b in smp.ref.calls if kind == "ref"]
+    assert refs == [G * ref.U0] * (T // G + 1) and smp.U == G * ref.U0
+    assert [b for kind, b in smp.main.calls if kind == "main"] == [3 * N] * T
+    with pytest.raises(ValueError):                                                       # groups of G: the evaluation count must divide
+        smp.prepare(inp, T + 1, stage, 7.5, 3.5)
 
 
 def test_bench_argument_parser_builds():

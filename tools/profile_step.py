@@ -21,25 +21,26 @@ def main():
     arch = build_arch(SD15_CONFIG)
     sd = synthetic_state_dict(arch, 0)
     inputs = synthetic_inputs(1, 3, 64, 64, 0, 768)
-    smp = StoryGenSampler(arch, sd, "cuda:0", 1, 64, 64, 3, use_graph=True)
+    G = int(sys.argv[sys.argv.index("--ref-ahead") + 1]) if "--ref-ahead" in sys.argv else 1
+    smp = StoryGenSampler(arch, sd, "cuda:0", 1, 64, 64, 3, use_graph=True, ref_ahead=G)
     smp.prepare(inputs, 50, "multi-image-condition", 7.5, 3.5)
-    for _ in range(3):
+    for _ in range(2 * G):
         smp.step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(5):
+    for _ in range(4 * G):
         smp.step()
     torch.cuda.synchronize()
-    print(f"graph step: {(time.perf_counter() - t0) / 5 * 1e3:.2f} ms")
+    print(f"graph step (ref_ahead {G}): {(time.perf_counter() - t0) / (4 * G) * 1e3:.2f} ms")
     sink, aux = [], []
     ops.PROFILE_SINK, ops.AUX_SINK = sink, aux
     smp.side_main = smp.side_ref = None   # sequential: per-kernel durations without co-running neighbours
-    smp.params.copy_(smp.table[8])
+    smp.params.copy_(smp.table[8])        # (every parameter row of a group gets this one: timing, not a trajectory)
     torch.cuda._sleep(200_000_000)   # ~100 ms GPU spin so the (slower) eager host stays ahead of the GPU: no launch gaps
     t0 = time.perf_counter()
     smp._step_body()
     torch.cuda.synchronize()
-    print(f"eager instrumented step: {(time.perf_counter() - t0) * 1e3:.2f} ms")
+    print(f"eager instrumented {'group of ' + str(G) + ' steps' if G > 1 else 'step'}: {(time.perf_counter() - t0) * 1e3:.2f} ms")
     ops.PROFILE_SINK = ops.AUX_SINK = None
     rows = defaultdict(lambda: [0, 0.0, 0.0])
     for fam, flops, a, b, shape in sink:
