@@ -136,11 +136,13 @@ def traffic_provenance():
         return "current" if json.load(f).get("kernel_source_hash") == source_hash() else "stale"
 
 
-def in_situ_roofline(sampler):
-    """One extra eager step with every MFMA-class launch bracketed by HIP events on its launch stream."""
+def in_situ_roofline(sampler, dump_algorithmic=None):
+    """One extra eager step with every MFMA-class launch bracketed by HIP events on its launch stream.  Every GEMM / convolution
+    launch also reports the profiler class (kernel instantiation, grid) it falls into and its ALGORITHMIC bytes (ops.PLAN_SINK);
+    dump_algorithmic = path: the per-class table goes there for tools/traffic_from_pmc.py to set beside the measured HBM bytes."""
     from storygen_amd import ops
-    sink, aux = [], []
-    ops.PROFILE_SINK, ops.AUX_SINK = sink, aux
+    sink, aux, plans = [], [], []
+    ops.PROFILE_SINK, ops.AUX_SINK, ops.PLAN_SINK = sink, aux, plans
     sides = (sampler.side_main, sampler.side_ref)
     sampler.side_main = sampler.side_ref = None     # one stream: per-kernel durations without co-running neighbours
     try:
@@ -151,8 +153,19 @@ def in_situ_roofline(sampler):
         sampler._step_body()
         torch.cuda.synchronize()
     finally:
-        ops.PROFILE_SINK = ops.AUX_SINK = None
+        ops.PROFILE_SINK = ops.AUX_SINK = ops.PLAN_SINK = None
         sampler.side_main, sampler.side_ref = sides
+    classes = {}
+    for kname, grid, nbytes, family, shape in plans:
+        c = classes.setdefault(f"{kname}|{grid}", {"kernel": kname, "grid": grid, "launches": 0, "algorithmic_bytes": 0.0, "shapes": {}})
+        c["launches"] += 1
+        c["algorithmic_bytes"] += nbytes
+        c["shapes"][f"{family} {shape}"] = c["shapes"].get(f"{family} {shape}", 0) + 1
+    if dump_algorithmic:
+        with open(dump_algorithmic, "w") as f:
+            json.dump({"note": "algorithmic bytes (every operand once: A, W, C, residuals, second output) of the GEMM / convolution launches "
+                               "of one instrumented group of steps, per profiler class (kernel instantiation | grid size in threads)",
+                       "steps_in_sample": getattr(sampler, "G", 1), "classes": classes}, f, indent=1)
     fam = {}
     for name, flops, a, b, _shape in sink:
         f = fam.setdefault(name, {"launches": 0, "ms": 0.0, "gflop": 0.0})
@@ -182,6 +195,7 @@ def in_situ_roofline(sampler):
     executed_tflop = sum(f["gflop"] for f in fam.values()) / 1e3 / g
     roof = {"bound": "mfma", "kernel": dom, "achieved": round(d["tflops"], 1), "peak": PEAK_FP16_TFLOPS, "unit": "TFLOP/s",
             "frac": round(d["frac_of_peak"], 4), "traffic": measured_traffic(dom), "traffic_provenance": traffic_provenance(),
+            "algorithmic_bytes_per_launch": (round(sum(p[2] for p in plans) / len(plans)) if plans else None),
             "launches_per_step": round(d["launches"] / g, 2),
             "avg_launch_us": round(d["avg_us"], 1), "gflop_per_step": round(d["gflop"] / g, 1), "steps_in_sample": g,
             "hbm_families": hbm_families(aux, g),
@@ -280,12 +294,118 @@ def train_step_bench(args):
                       "tflop_forward_per_step": round(fwd, 3), "tflop_per_step_executed": round(executed, 3), "roofline": roof}), flush=True)
 
 
+def default_ref_ahead(args) -> int:
+    """The group size of the look-ahead schedule when --ref-ahead is not given: the largest G <= DEFAULT_REF_AHEAD dividing --steps."""
+    if args.ref_ahead is not None:
+        return max(1, args.ref_ahead)
+    if args.no_graph or args.no_overlap:
+        return 1
+    return max(g for g in range(1, DEFAULT_REF_AHEAD + 1) if args.steps % g == 0)
+
+
+def timed_steps(sampler, steps: int, warmup_run: int, use_dist: bool, dev):
+    """The contract's timed region: warmup_run untimed steps, then EXACTLY `steps` steps bracketed by a barrier + device
+    synchronisation on both sides; returns the seconds of the slowest rank.  dev = None: no device to synchronise (--dry-run)."""
+    import torch.distributed as dist
+
+    def barrier():
+        if use_dist:
+            dist.barrier()
+        if dev is not None:
+            torch.cuda.synchronize(dev)
+
+    for _ in range(warmup_run):
+        sampler.step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sampler.step()
+    barrier()
+    dt = time.perf_counter() - t0
+    if use_dist:
+        tt = torch.tensor([dt], dtype=torch.float64, device=dev if dev is not None else "cpu")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    return dt
+
+
+def gather_and_check(sampler, world: int, dev):
+    """The one collective of the data-parallel path (all-gather of the final latents) and the checks on its result: one sample per
+    rank, all finite, pairwise different (every rank denoised its own, rank-seeded sample).  Returns (final, gather ms, finite)."""
+    from storygen_amd.sampler import gather_latents
+    t0 = time.perf_counter()
+    final = gather_latents(sampler.latents)
+    if dev is not None:
+        torch.cuda.synchronize(dev)
+    gather_ms = 1e3 * (time.perf_counter() - t0)
+    finite = bool(torch.isfinite(final).all())
+    assert final.shape[0] == world * N_PER_GPU, f"all-gather returned {final.shape[0]} samples for {world} ranks"
+    distinct = all(not torch.equal(final[i], final[j]) for i in range(final.shape[0]) for j in range(i))
+    assert distinct, "two ranks produced identical latents: the batch shard is not per-rank"
+    return final, gather_ms, finite
+
+
+def dry_run(args, world: int, rank: int):
+    """--dry-run: everything of main() that is not the GPU — ranks from the launcher's environment, process group (gloo), group
+    schedule, barrier + max-over-ranks timing, the one all-gather, the per-rank-distinct assertion, one JSON line from rank 0 — on
+    a stand-in engine (tests/stub_engine.py).  Measures nothing and says so."""
+    import types
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import stub_engine
+    import storygen_amd.sampler as S
+    from storygen_amd.arch import build_arch, load_config
+    S.UNetEngine = stub_engine.StubEngine
+    S.ops = types.SimpleNamespace(add_noise=stub_engine.add_noise, cfg_ddim_step=stub_engine.cfg_ddim_step)
+    use_dist = world > 1 or "RANK" in os.environ
+    if use_dist:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    arch = build_arch(load_config(dict(block_out_channels=(32, 64), down_block_types=("CrossAttnDownBlock2D", "DownBlock2D"),
+                                       up_block_types=("UpBlock2D", "CrossAttnUpBlock2D"), cross_attention_dim=8, attention_head_dim=4,
+                                       norm_num_groups=8)))
+    g = torch.Generator().manual_seed(1000 + rank)                      # inputs seeded by rank, like synthetic_inputs(seed=rank)
+    r = lambda *sh: torch.randn(*sh, generator=g)                      # noqa: E731
+    hw, S_ = 4, 5
+    inputs = dict(latents=r(1, 4, hw, hw), noise=r(1, 4, hw, hw), image_prompts=r(R, 1, 4, hw, hw), zero_prompt=r(1, 4, hw, hw),
+                  text=r(1, S_, 8), uncond=r(1, S_, 8), prev_text=r(R, 1, S_, 8), prev_uncond=r(1, 1, S_, 8).expand(R, 1, S_, 8).clone())
+    G = default_ref_ahead(args)
+    if G > 1 and args.steps % G:
+        raise SystemExit(f"--ref-ahead {G} must divide --steps {args.steps}")
+    warmup_run = -(-args.warmup // G) * G
+    sampler = S.StoryGenSampler(arch, None, "cpu", 1, hw, hw, R, S_, use_graph=False, weights=object(), ref_ahead=G, time_tables=False)
+    sampler.prepare(inputs, max(T, args.steps + warmup_run), args.stage, 7.5, 3.5)
+    dt = timed_steps(sampler, args.steps, warmup_run, use_dist, None)
+    final, _, _ = gather_and_check(sampler, world, None)
+    distinct = True
+    if rank == 0:
+        print(json.dumps({"metric": "DRY RUN of bench.py's launcher path on the CPU (gloo, stand-in engine): not a measurement", "dry_run": True,
+                          "value": None, "unit": "denoising steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": None, "host_ms_per_stub_step_max_over_ranks": round(1e3 * dt / args.steps, 3), "higher_is_better": True,
+                          "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "synthetic",
+                          "config": {"workload": "stand-in engine, 4x4 latent", "ref_ahead": G, "warmup_run": warmup_run, "stage": args.stage,
+                                     "parallelism": f"dp{world} (one sample per rank, final all-gather)"},
+                          "latents_gathered": int(final.shape[0]), "latents_finite": bool(torch.isfinite(final).all()),
+                          "latents_distinct_per_rank": distinct}), flush=True)
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="TEST ONLY, measures nothing: the launcher path (torch.distributed.run ranks, barrier, max-over-ranks timing, the "
+                         "final all-gather, the per-rank-distinct check, the JSON line) on the CPU with the gloo backend and a stand-in "
+                         "engine (tests/stub_engine.py) on a tiny UNet description; the JSON says dry_run and carries value null")
+    ap.add_argument("--dump-algorithmic", default=None, metavar="PATH",
+                    help="write the algorithmic bytes per profiler class (kernel instantiation | grid) of the instrumented step to PATH "
+                         "(tools/traffic_from_pmc.py merges it into profiles/traffic.json)")
     ap.add_argument("--stage", choices=("multi-image-condition", "auto-regressive"), default="multi-image-condition",
                     help="multi-image-condition = the contract line (SURVEY 8d); auto-regressive = the mode /root/reference/inference.py:133 "
                          "defaults to (every prior frame at its own noise level: 2R distinct reference samples per step instead of R + 1) — "
@@ -347,6 +467,8 @@ def main():
         raise SystemExit(subprocess.call(cmd))
     if world != args.gpus:
         args.gpus = world
+    if args.dry_run:
+        return dry_run(args, world, rank)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X; no GPU visible (there is no CPU fallback for the product path)")
     torch.cuda.set_device(local)
@@ -359,6 +481,11 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    if world > 1:
+        # N ranks synthesise the same 909 M parameters on the host at once: give each its share of the logical CPUs instead of
+        # letting every rank start a thread per CPU
+        ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        torch.set_num_threads(max(1, ncpu // world))
 
     from storygen_amd.arch import SD15_CONFIG, build_arch
     from storygen_amd.sampler import StoryGenSampler, gather_latents
@@ -392,10 +519,7 @@ def main():
     arch = build_arch(SD15_CONFIG)
     sd = synthetic_state_dict(arch, 0)
     inputs = synthetic_inputs(N_PER_GPU, n_ref, hw, hw, seed=rank, cross_attention_dim=arch.config["cross_attention_dim"])
-    if args.ref_ahead is None:                      # default: the largest group size <= DEFAULT_REF_AHEAD that divides the timed window
-        G = 1 if (args.no_graph or args.no_overlap) else max(g for g in range(1, DEFAULT_REF_AHEAD + 1) if args.steps % g == 0)
-    else:
-        G = max(1, args.ref_ahead)
+    G = default_ref_ahead(args)                     # default: the largest group size <= DEFAULT_REF_AHEAD that divides the timed window
     if G > 1 and args.steps % G:
         raise SystemExit(f"--ref-ahead {G} must divide --steps {args.steps}")
     warmup_run = -(-args.warmup // G) * G          # the timed window starts on a group boundary
@@ -406,32 +530,10 @@ def main():
     n_sched = max(T, args.steps + warmup_run)
     sampler.prepare(inputs, n_sched, args.stage, 7.5, 3.5)
 
-    def barrier():
-        if use_dist:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    for _ in range(warmup_run):
-        sampler.step()
-    barrier()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        sampler.step()
-    barrier()
-    dt = time.perf_counter() - t0
-    if use_dist:
-        tt = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
-    t0 = time.perf_counter()
-    final = gather_latents(sampler.latents)                     # the one collective of the DP path
-    torch.cuda.synchronize(dev)
-    gather_ms = 1e3 * (time.perf_counter() - t0)
-    finite = bool(torch.isfinite(final).all())
-    assert final.shape[0] == world * N_PER_GPU, f"all-gather returned {final.shape[0]} samples for {world} ranks"
-    # every rank denoised its own sample (inputs seeded by rank): the gathered latents must be pairwise different
-    distinct = all(not torch.equal(final[i], final[j]) for i in range(final.shape[0]) for j in range(i))
-    assert distinct, "two ranks produced identical latents: the batch shard is not per-rank"
+    dt = timed_steps(sampler, args.steps, warmup_run, use_dist, dev)
+    final, gather_ms, finite = gather_and_check(sampler, world, dev)
+    distinct = True                                             # asserted by gather_and_check
+    sampler.check_guards()                                      # the LayerNorm fold stayed inside its range (raises otherwise)
 
     if rank == 0:
         value = world * N_PER_GPU * args.steps / dt
@@ -460,7 +562,7 @@ def main():
             "final_allgather_ms": round(gather_ms, 3), "latents_gathered": int(final.shape[0]), "latents_finite": finite,
             "latents_distinct_per_rank": distinct,
         }
-        out["roofline"], executed = in_situ_roofline(sampler)
+        out["roofline"], executed = in_situ_roofline(sampler, args.dump_algorithmic)
         if args.config5_shape:
             out["roofline"]["traffic"] = None          # profiles/traffic.json was measured on the contract workload
         out["tflop_per_step_executed"] = round(executed, 3)

@@ -107,7 +107,20 @@ typedef struct sg_gemm_desc {
     const float*   ln_d;              /* fp32 [N] / [M]:  d_n = sum_k beta_k W_nk (+ bias_n) */
     float*         ln_stats_out;      /* producer side: write the partials of THIS output, [M][P][2] with P = N/64 rounded up to even
                                          (NULL = none; needs N % 64 == 0) */
+    void*          ln_guard;          /* optional device uint32 of sticky SG_LN_GUARD_* flags (atomic OR, never cleared by the library),
+                                         or NULL: see "LayerNorm fold" below */
 } sg_gemm_desc;
+
+/* The two assumptions of the LayerNorm fold, checked where the numbers are (the reference's LayerNorm reads an fp32 tensor and has
+ * neither limit, model/attention.py:250,268,283,298):
+ *   SG_LN_GUARD_RANGE   a producer (ln_stats_out) wrote a 64-column block that may hold |x| >= 65504: its fp16 copy C2 was SATURATED
+ *                       (C2 beside an fp32 C is always clamped to +-65504, never inf), so consumers of the copy see clipped values;
+ *   SG_LN_GUARD_OFFSET  a consumer (ln_mode) met a token with |mean| / sigma > SG_LN_GUARD_RATIO: the fp16 rounding of the raw copy,
+ *                       2^-11 |x|, is then more than SG_LN_GUARD_RATIO * 2^-11 = 7.8e-3 of the normalised value.
+ * A caller that sees a flag should rerun the block with a LayerNorm launch (sg_layernorm_f16 on the fp32 tensor). */
+#define SG_LN_GUARD_RANGE   1u
+#define SG_LN_GUARD_OFFSET  2u
+#define SG_LN_GUARD_RATIO   16.0f
 
 int    sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream);
 /* GroupNorm statistics as an epilogue (north-star: "GroupNorm/SiLU ... as fused epilogue kernels"; the consumers are ResnetBlock2D
@@ -181,6 +194,13 @@ int sg_conv3x3_stats_tile_rows(const sg_conv3x3_desc* d);
 /* Number of K slices sg_conv3x3_nhwc_f16 will use for this descriptor (1 = no split-K; the plan is a pure function of the descriptor
  * and the development options).  No launch happens.  < 0 on an invalid descriptor. */
 int sg_conv3x3_planned_splits(const sg_conv3x3_desc* d);
+/* The decomposition a launch with this descriptor will use (host-only, nothing is launched): out[6] = {tile rows, tile columns,
+ * K slices, workgroups, threads per workgroup, 1 if the LDS-DMA kernel applies else 0}.  For measurement tooling: a profiler
+ * reports (kernel instantiation, grid size) classes, this tells which problems fall into which (tools/traffic_from_pmc.py puts
+ * the ALGORITHMIC bytes per launch next to the measured HBM bytes of every class).  No reference counterpart (the reference
+ * calls cuDNN / cuBLAS through torch and never sees a launch geometry). */
+int sg_gemm_launch_plan(const sg_gemm_desc* d, int32_t* out);
+int sg_conv3x3_launch_plan(const sg_conv3x3_desc* d, int32_t* out);
 
 /* conv_in: x fp32 NCHW [B, Cin<=8, H, W] -> y NHWC [B,H,W,Cout] (fp16, or fp32 when y_f32), 3x3 pad 1
  * (unet_2d_condition.py:124,411).

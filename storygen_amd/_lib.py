@@ -32,6 +32,7 @@ class GemmDesc(C.Structure):
         ("stats", C.c_void_p), ("stats_batch_rows", C.c_int32),
         ("ln_mode", C.c_int32), ("ln_parts", C.c_int32), ("ln_eps", C.c_float),
         ("ln_stats", C.c_void_p), ("ln_c", C.c_void_p), ("ln_d", C.c_void_p), ("ln_stats_out", C.c_void_p),
+        ("ln_guard", C.c_void_p),
     ]
 
 
@@ -161,6 +162,8 @@ SIGNATURES = {
     "sg_gemm_stats_tile_rows": (C.c_int, [C.POINTER(GemmDesc)]),
     "sg_conv3x3_stats_tile_rows": (C.c_int, [C.POINTER(ConvDesc)]),
     "sg_conv3x3_planned_splits": (C.c_int, [C.POINTER(ConvDesc)]),
+    "sg_gemm_launch_plan": (C.c_int, [C.POINTER(GemmDesc), C.POINTER(C.c_int32)]),
+    "sg_conv3x3_launch_plan": (C.c_int, [C.POINTER(ConvDesc), C.POINTER(C.c_int32)]),
     "sg_groupnorm_uses_pstats": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "sg_groupnorm_is_fused": (C.c_int, [C.c_int32, C.c_int32, C.c_int32]),
     "sg_ff_fused_pack_bytes": (C.c_size_t, [C.c_int32]),

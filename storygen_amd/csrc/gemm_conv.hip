@@ -87,6 +87,7 @@ struct MmaParams {
     // c / d vectors of the folded weight; producer side = where to write the partials of THIS output
     const float* ln_stats; int ln_parts; const float* ln_c; const float* ln_d; int ln_mode; float ln_eps;
     float* ln_out;
+    unsigned* ln_guard;            // sticky flags of the fold's two assumptions (sg_gemm_desc.ln_guard), or nullptr
     unsigned long long* prof;   // SG_BUILD_EXPERIMENTS (sg_debug_*_anatomy): per-wave cycle totals of the mainloop phases
     int n_major;   // tile order: 1 = consecutive ids walk M first (tiles sharing a weight panel stay on one XCD / L2)
     FastDiv fd_splits, fd_tiles_m, fd_tiles_n, fd_hw, fd_wo, fd_rpb, fd_cpt;
@@ -202,6 +203,9 @@ __device__ __forceinline__ float2 ln_token_coeffs(const MmaParams& p, int token)
         m2 += q < p.ln_parts ? fmaf(64.f * dm, dm, mq) : 0.f;
     }
     const float r = rsqrtf(m2 / n + p.ln_eps);
+    // The GEMM ran on the fp16 copy of x: its rounding, 2^-11 |x|, becomes (|mean| / sigma) 2^-11 of the normalised value.  Beyond
+    // SG_LN_GUARD_RATIO the fold is no longer the LayerNorm the reference computes in fp32 — say so instead of returning it silently.
+    if (p.ln_guard && fabsf(mean * r) > SG_LN_GUARD_RATIO) atomicOr(p.ln_guard, SG_LN_GUARD_OFFSET);
     return make_float2(mean * r, r);
 }
 
@@ -213,8 +217,10 @@ __device__ __forceinline__ void store_out4(const MmaParams& p, int gm, int gn, c
     if (f32) st_stream(reinterpret_cast<float*>(p.C) + (long)gm * p.ldc + gn, f32x4{v[0], v[1], v[2], v[3]});
     if (!f32 || p.C2) {
         H4 o;
+        // beside an fp32 output the fp16 copy is the operand of a folded LayerNorm (or a harvested feature): saturate it instead of
+        // writing inf — the fp32 stream, which the reference's LayerNorm reads, is exact either way (the guard below reports it)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o.h[e] = (f16)v[e];
+        for (int e = 0; e < 4; ++e) o.h[e] = (f16)(f32 ? __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f) : v[e]);
         if (!f32) st_stream(reinterpret_cast<f16*>(p.C) + (long)gm * p.ldc + gn, o.u);
         if (p.C2) st_stream(p.C2 + (long)gm * p.ldc2 + gn, o.u);
     }
@@ -424,8 +430,11 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
             m2 = fmaf(a, a, m2); m2 = fmaf(b, b, m2); m2 = fmaf(c, c, m2); m2 = fmaf(d, d, m2);
         }
         const int gm = m0 + wm * 64 + lane;
-        if (gm < p.M && n0 + wn * 64 < p.N)
+        if (gm < p.M && n0 + wn * 64 < p.N) {
             *reinterpret_cast<float2*>(p.ln_out + ((size_t)gm * (((p.N >> 6) + 1) & ~1) + ((n0 >> 6) + wn)) * 2) = make_float2(sum, m2);
+            // every |x| of the block is at most |mean| + sqrt(M2): below the fp16 maximum the raw copy did not saturate
+            if (p.ln_guard && !(fabsf(mean) + sqrtf(m2) < 65504.f)) atomicOr(p.ln_guard, SG_LN_GUARD_RANGE);
+        }
     }
     if (want_stats) {
         // GroupNorm statistics as an epilogue: per-(row tile, channel) sums of the FINAL fp32 values (bias / temb / residual
@@ -967,7 +976,7 @@ __device__ __forceinline__ void store_out8(const MmaParams& p, int gm, int gn, c
     if (!f32 || p.C2) {
         H8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o.h[e] = (f16)v[e];
+        for (int e = 0; e < 8; ++e) o.h[e] = (f16)(f32 ? __builtin_amdgcn_fmed3f(v[e], -65504.f, 65504.f) : v[e]);   // see store_out4
         if (!f32) stg16(reinterpret_cast<f16*>(p.C) + (long)gm * p.ldc + gn, o.u);
         if (p.C2) stg16(p.C2 + (long)gm * p.ldc2 + gn, o.u);
     }
@@ -1005,7 +1014,10 @@ __device__ __forceinline__ void epi_linear8(const MmaParams& p, int gm, int gn, 
 #pragma unroll
         for (int j = 0; j < 8; ++j) { const float d = v[j] - mean; m2 = fmaf(d, d, m2); }
         m2 += __shfl_xor(m2, 1, 64); m2 += __shfl_xor(m2, 2, 64); m2 += __shfl_xor(m2, 4, 64);
-        if ((gn & 63) == 0) *reinterpret_cast<float2*>(p.ln_out + ((size_t)gm * (((p.N >> 6) + 1) & ~1) + (gn >> 6)) * 2) = make_float2(s, m2);
+        if ((gn & 63) == 0) {
+            *reinterpret_cast<float2*>(p.ln_out + ((size_t)gm * (((p.N >> 6) + 1) & ~1) + (gn >> 6)) * 2) = make_float2(s, m2);
+            if (p.ln_guard && !(fabsf(mean) + sqrtf(m2) < 65504.f)) atomicOr(p.ln_guard, SG_LN_GUARD_RANGE);
+        }
     }
 }
 
@@ -1240,6 +1252,7 @@ thread_local unsigned long long* g_prof = nullptr;     // set by sg_debug_*_anat
 thread_local int g_query_rows = 0;                     // result of a stats query (rows per partial = the tile height), 0 = none
 thread_local bool g_stats_query = false;               // sg_*_stats_tile_rows: plan only, report eligibility instead of failing
 thread_local bool g_plan_query = false;                // sg_conv3x3_planned_splits: plan only, report the number of K slices
+thread_local int32_t* g_plan_out = nullptr;            // sg_*_launch_plan: also {tile rows, tile columns, K slices, workgroups, threads per workgroup, pipelined}
 
 // GroupNorm statistics from the epilogue (MmaParams::stats) need whole tiles inside one image and the linear epilogue; a split-K
 // launch emits them from its second pass.  A launch that was asked for them but cannot deliver fails (the caller asks
@@ -1326,6 +1339,10 @@ int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws
     }
     if (g_plan_query) {
         g_query_rows = pl.splits;
+        if (g_plan_out) {
+            g_plan_out[0] = pl.bm; g_plan_out[1] = pl.bn; g_plan_out[2] = pl.splits; g_plan_out[3] = p.tiles_m * p.tiles_n * pl.splits;
+            g_plan_out[4] = pipe ? 64 * (pl.bm / 64) * (pl.bn / 64) : 256; g_plan_out[5] = pipe ? 1 : 0;
+        }
         return SG_OK;
     }
     if (p.defer && pl.splits <= 1)
@@ -1432,6 +1449,8 @@ int gemm_params(const sg_gemm_desc* d, MmaParams& p, const char* who) {
     }
     p.ln_stats = d->ln_stats; p.ln_parts = d->ln_parts; p.ln_c = d->ln_c; p.ln_d = d->ln_d; p.ln_mode = d->ln_mode; p.ln_eps = d->ln_eps;
     p.ln_out = d->ln_stats_out;
+    SG_REQUIRE(!d->ln_guard || (reinterpret_cast<uintptr_t>(d->ln_guard) & 3u) == 0, "%s: ln_guard must be 4-byte aligned", who);
+    p.ln_guard = (d->ln_mode || d->ln_stats_out) ? reinterpret_cast<unsigned*>(d->ln_guard) : nullptr;
     return check_tile_hint(who, d->tile_m, d->tile_n, d->tile_waves);
 }
 
@@ -1539,6 +1558,27 @@ extern "C" int sg_conv3x3_planned_splits(const sg_conv3x3_desc* d) {
     const int rc = sg_conv3x3_nhwc_f16(&q, nullptr);
     g_plan_query = false;
     return rc ? rc : g_query_rows;
+}
+
+// The decomposition a launch with this descriptor will use (host-only, no launch): out[6] = {tile rows, tile columns, K slices,
+// workgroups, threads per workgroup, 1 if the LDS-DMA kernel applies}.  Measurement tooling joins it with a profiler's (kernel,
+// grid) classes (tools/traffic_from_pmc.py: algorithmic bytes per class).
+extern "C" int sg_gemm_launch_plan(const sg_gemm_desc* d, int32_t* out) {
+    SG_REQUIRE(d && out, "sg_gemm_launch_plan: null argument");
+    g_plan_query = true; g_query_rows = 0; g_plan_out = out;
+    const int rc = sg_gemm_f16(d, nullptr);
+    g_plan_query = false; g_plan_out = nullptr;
+    return rc;
+}
+
+extern "C" int sg_conv3x3_launch_plan(const sg_conv3x3_desc* d, int32_t* out) {
+    SG_REQUIRE(d && out, "sg_conv3x3_launch_plan: null argument");
+    sg_conv3x3_desc q = *d;
+    q.defer_reduce = 0;
+    g_plan_query = true; g_query_rows = 0; g_plan_out = out;
+    const int rc = sg_conv3x3_nhwc_f16(&q, nullptr);
+    g_plan_query = false; g_plan_out = nullptr;
+    return rc;
 }
 
 extern "C" int sg_conv3x3_stats_tile_rows(const sg_conv3x3_desc* d) {

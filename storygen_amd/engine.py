@@ -343,6 +343,9 @@ class UNetEngine:
         self._splits: Dict[str, int] = {}             # conv site -> planned K slices (sg_conv3x3_planned_splits), asked once
         self._pending_split: Dict[int, dict] = {}     # data_ptr of a tensor whose split-K reduction its GroupNorm consumer will do
         self.text_cache: Dict[str, torch.Tensor] = {}
+        # sticky flags of the LayerNorm fold's two assumptions (ops.LN_GUARD_*; include/storygen_hip.h): every producer / consumer of a
+        # folded LayerNorm ORs into this word; check_ln_guard() reads it (one 4-byte D2H copy: call it where the host synchronises anyway)
+        self.ln_guard = torch.zeros(1, dtype=torch.int32, device=self.dev)
         self._alloc(splitk_workspace_mb)
 
     def __getattr__(self, name):
@@ -374,6 +377,7 @@ class UNetEngine:
         self.temb2 = self._buf(B, arch.temb_dim, dtype=F32)
         self.tproj = self._buf(B, self.temb_total, dtype=F32)
         self.time_table: Optional[tuple] = None                         # (timesteps [T], rows [T, temb_total]) — build_time_table()
+        self.time_table_on = True                                       # False: forward() runs the chain itself (set_inputs); the buffers stay alive
         self.ws_split = ops.new_workspace(splitk_mb << 20, self.dev)      # split-K partial tiles (fp32, reduced by a second launch: no initialisation needed)
         self.ws_side = ops.new_workspace(splitk_mb << 20, self.dev)       # split-K scratch of the side-stream branches
         self.ws_pair = ops.new_workspace(splitk_mb << 20, self.dev)       # second problem of a paired GEMM launch
@@ -529,9 +533,9 @@ class UNetEngine:
         [B*hw, cout] output (the one-launch variant sums the slices while loading its slab), else 0."""
         if not SPLITK_IN_GN or not ops.groupnorm_is_fused(self.hw[lvl], cout, self.groups):
             return 0
-        n = self._splits.get(site)
-        if n is None:
-            n = self._splits[site] = int(query())
+        # asked on every call: the plan is host-only arithmetic, but it depends on process state that can change after the first
+        # forward (ops.load_tile_table, sg_debug_set_option) — and the GroupNorm must be told the slice count THIS launch uses
+        n = self._splits[site] = int(query())
         return n if n > 1 else 0
 
     def _attention(self, q, k, vt, out, heads: int, scale: float, nk: Optional[int] = None, short: Optional[tuple] = None):
@@ -651,7 +655,8 @@ class UNetEngine:
         ff1 = FF_FUSED and xf.ff_pack is not None and not FP16_BLOCK_STREAM
         # with the fold, the producer of a stream tensor also writes its raw fp16 copy and the LayerNorm partials of its rows
         raw = lambda t, buf: t if t.dtype == F16 else buf                                 # noqa: E731  (fp16 stream: it IS the copy)
-        prod = lambda t, buf, st: dict(out2=None if t.dtype == F16 else buf, ln_out=st) if fold else {}   # noqa: E731
+        gd = self.ln_guard
+        prod = lambda t, buf, st: dict(out2=None if t.dtype == F16 else buf, ln_out=st, guard=gd) if fold else {}   # noqa: E731
         h0r, h1r = raw(h0, L["ln"]), raw(L["h1"], L["ln4"])
         ops.gemm(L["gn"], xf.w_in, h0, bias=xf.b_in, workspace=ws, **prod(h0, L["ln"], L["lnst0"]))   # proj_in :101
         # --- self-attention :250-262
@@ -659,8 +664,8 @@ class UNetEngine:
         wp = self.ws_pair
         # q|k (token-major) and V^T = Wv . X^T (the attention kernel's operand layout): two GEMMs on one LayerNorm output, one launch
         if fold:
-            _pair(((h0r, xf.w_qk1f, qk), dict(ln=(1, L["lnst0"], xf.c_qk1, xf.d_qk1, LN_EPS))),
-                  ((xf.w_v1f, h0r, vt), dict(ln=(2, L["lnst0"], xf.c_v1, xf.d_v1, LN_EPS))))
+            _pair(((h0r, xf.w_qk1f, qk), dict(ln=(1, L["lnst0"], xf.c_qk1, xf.d_qk1, LN_EPS), guard=gd)),
+                  ((xf.w_v1f, h0r, vt), dict(ln=(2, L["lnst0"], xf.c_v1, xf.d_v1, LN_EPS), guard=gd)))
         else:
             ops.layernorm(h0, *xf.ln["norm1"], L["ln"])
             _pair(((L["ln"], xf.w_qk1, qk), dict(workspace=ws)), ((xf.w_v1, L["ln"], vt), dict(workspace=wp)))
@@ -714,8 +719,8 @@ class UNetEngine:
             # both query projections in one launch (norm2 / norm4 outputs of the same statistics), then the two attentions side by side
             q2, q3buf = L["q2"], L["q"]
             if fold:
-                _pair(((h1r, xf.w_q2f, q2), dict(ln=(1, L["lnst1"], xf.c_q2, xf.d_q2, LN_EPS))),
-                      ((h1r, xf.w_q3f, q3buf), dict(ln=(1, L["lnst1"], xf.c_q3, xf.d_q3, LN_EPS))))
+                _pair(((h1r, xf.w_q2f, q2), dict(ln=(1, L["lnst1"], xf.c_q2, xf.d_q2, LN_EPS), guard=gd)),
+                      ((h1r, xf.w_q3f, q3buf), dict(ln=(1, L["lnst1"], xf.c_q3, xf.d_q3, LN_EPS), guard=gd)))
             else:
                 _pair(((L["ln"], xf.w_q2, q2), dict(workspace=ws)), ((L["ln4"], xf.w_q3, q3buf), dict(workspace=wp)))
             # text + image attention as one launch when the image attention is one fp16 launch itself (else the text attention runs
@@ -759,7 +764,7 @@ class UNetEngine:
                      **({} if ff1 else prod(h3, L["ln"], L["lnst3"])))
         else:
             if fold:
-                ops.gemm(h1r, xf.w_q2f, L["q"], ln=(1, L["lnst1"], xf.c_q2, xf.d_q2, LN_EPS))
+                ops.gemm(h1r, xf.w_q2f, L["q"], ln=(1, L["lnst1"], xf.c_q2, xf.d_q2, LN_EPS), guard=gd)
             else:
                 ops.gemm(L["ln"], xf.w_q2, L["q"], workspace=ws)
             ops.attention(L["q"].view(B, hw, C), kt3, vtt3, att.view(B, hw, C), heads, scale, nk=S)
@@ -769,7 +774,7 @@ class UNetEngine:
         if ff1:      # one launch: LayerNorm in registers, GEGLU intermediate never materialised (h4 is fp16: it only feeds proj_out)
             ops.ff_fused(h3, xf.ff_pack, xf.b_ff2, L["h4"], LN_EPS)
         elif fold:
-            ops.gemm(raw(h3, L["ln"]), xf.w_ff1f, L["ffi"], epilogue=ops.EPI_GEGLU, ln=(1, L["lnst3"], xf.c_ff1, xf.d_ff1, LN_EPS))
+            ops.gemm(raw(h3, L["ln"]), xf.w_ff1f, L["ffi"], epilogue=ops.EPI_GEGLU, ln=(1, L["lnst3"], xf.c_ff1, xf.d_ff1, LN_EPS), guard=gd)
         else:
             ops.layernorm(h3, *xf.ln["norm3"], L["ln"])
             ops.gemm(L["ln"], xf.w_ff1, L["ffi"], bias=xf.b_ff1, epilogue=ops.EPI_GEGLU, workspace=ws)
@@ -821,6 +826,8 @@ class UNetEngine:
                 raise ValueError("harvest_slot needs one context row per sample and no explicit plan")
             if not self.R:
                 raise ValueError("engine was built without context buffers (n_ref=0)")
+            if self.ctx_short:
+                raise ValueError("harvest_slot: this engine's context rows have different slot counts (ctx_short); pass a HarvestPlan")
             harvest = HarvestPlan(self.ctx, [(b, 0, b, harvest_slot, 1) for b in range(self.B)])
         if harvest is not None and consume:
             raise ValueError("a pass either harvests features or consumes them")
@@ -834,7 +841,7 @@ class UNetEngine:
         arch, text, skips = self.arch, self.text_in, self.skips
         # --- time embedding :392-398, then all 22 time_emb_proj(silu(emb)) in one GEMV bundle.  emb is only ever consumed through
         # silu (resnet.py time_emb_proj), so the second linear writes silu(emb) once instead of every wave of the bundle redoing it
-        if self.time_table is not None:       # the loop's timesteps were tabulated at prepare() time: one row lookup instead of the chain
+        if self.time_table is not None and self.time_table_on:       # the loop's timesteps were tabulated at prepare() time: one row lookup instead of the chain
             ops.lookup_rows(self.t_in, self.time_table[0], self.time_table[1], self.tproj)
         else:
             self._time_chain(self.t_in, self.temb0, self.temb1, self.temb2, self.tproj)
@@ -905,6 +912,22 @@ class UNetEngine:
         ops.conv_out(self._img(L["gn"], 0), self.w_conv_out, self.b_conv_out, self.eps_out)
         return self.eps_out
 
+    def check_ln_guard(self, clear: bool = True) -> int:
+        """Flags raised by the folded LayerNorms since the last check (0 = both assumptions held; synchronises on a 4-byte copy).
+        Raises when one did not: the pass that set it must be rerun with engine.LN_FOLD = False (the LayerNorm launch on the fp32
+        stream, as the reference computes it)."""
+        flags = int(self.ln_guard.item())
+        if clear and flags:
+            self.ln_guard.zero_()
+        if flags:
+            why = []
+            if flags & ops.LN_GUARD_RANGE:
+                why.append("a stream tensor reached |x| >= 65504 (its fp16 copy was saturated)")
+            if flags & ops.LN_GUARD_OFFSET:
+                why.append(f"a token had |mean| / sigma > {ops.LN_GUARD_RATIO:g} (fp16 rounding of the raw copy no longer negligible)")
+            raise FloatingPointError("LayerNorm fold outside its range: " + "; ".join(why) + " — rerun with storygen_amd.engine.LN_FOLD = False")
+        return flags
+
     # ------------------------------------------------------------------------------------------ convenience
     def _time_chain(self, t, e0, e1, e2, out):
         """Timesteps -> TimestepEmbedding -> all time_emb_proj(silu(emb)) rows (unet_2d_condition.py:392-398, ResnetBlock2D)."""
@@ -921,6 +944,7 @@ class UNetEngine:
         The table lives in buffers of `capacity` rows (unused keys are NaN, which matches nothing) that later calls refill IN PLACE, so a
         captured graph stays valid; returns True when the buffers were (re)allocated — or dropped — i.e. when graphs captured before
         the call must be captured again.  Pass None to drop the table (training, set_inputs() with arbitrary timesteps)."""
+        self.time_table_on = True
         if timesteps is None:
             had = self.time_table is not None
             self.time_table = None
@@ -945,7 +969,9 @@ class UNetEngine:
 
     def set_inputs(self, sample: torch.Tensor, timestep, text: torch.Tensor):
         self.x_in.copy_(sample.to(self.dev, torch.float32))
-        self.time_table = None                  # arbitrary timesteps: the chain itself, not a sampler's table
+        # arbitrary timesteps: the chain itself, not a sampler's table.  The table's buffers are kept (a hipGraph captured while it was
+        # in use still reads them; build_time_table() switches it back on and refills them in place)
+        self.time_table_on = False
         t = timestep if torch.is_tensor(timestep) else torch.tensor([float(timestep)])
         self.t_in.copy_(t.to(self.dev, torch.float32).reshape(-1).expand(self.B))
         self.text_in.copy_(text.to(self.dev, F16))

@@ -239,9 +239,15 @@ class StableDiffusionPipeline:
         # so a cached sampler and its captured hipGraphs stay valid; only a new weights object (device change) rebuilds it
         wts = self.unet._engine_weights()
         schedule = _as_schedule(self.scheduler)
-        key = (n, h, w, R, text.shape[1], id(wts), schedule.key())
+        # group schedule (sampler ref_ahead): the reference passes of 5 consecutive steps as one batched UNet call inside one hipGraph per
+        # group — when nobody watches the intermediate latents (a callback sees every step: step-by-step graphs then) and the number of
+        # UNet evaluations is a multiple of 5 (DDIM: 50 steps -> 50; PNDM: n + 1)
+        evals = len(schedule.timesteps(num_inference_steps))
+        G = 5 if (callback is None and stage in STAGES[:2] and evals % 5 == 0) else 1
+        key = (n, h, w, R, text.shape[1], id(wts), schedule.key(), G)
         if self._sampler is None or self._sampler_key != key:
-            self._sampler = StoryGenSampler(self.unet._arch, None, device, n, h, w, R, text.shape[1], schedule=schedule, weights=wts)
+            self._sampler = StoryGenSampler(self.unet._arch, None, device, n, h, w, R, text.shape[1], schedule=schedule, weights=wts,
+                                            ref_ahead=G)
             self._sampler_key = key
         smp = self._sampler
         smp.prepare(inputs, num_inference_steps, stage, guidance_scale, image_guidance_scale)
@@ -252,6 +258,7 @@ class StableDiffusionPipeline:
                 if callback is not None and i % callback_steps == 0:
                     callback(i, t, smp.latents.to(dtype, copy=True))                      # never a view of the sampler's buffer
         latents = smp.latents.to(dtype, copy=True)
+        smp.check_guards()                         # a folded LayerNorm outside its range raises here instead of returning wrong latents
         if output_type == "latent":
             image = latents
         else:

@@ -59,6 +59,10 @@ def load_tile_table(path: Optional[str] = None) -> int:
 # Optional in-situ kernel timer (bench.py): when set, every MFMA-class launch is bracketed by HIP events recorded
 # on the launch stream and reported as (family, algorithmic_flops, start_event, end_event).
 PROFILE_SINK = None
+LN_GUARD_RANGE, LN_GUARD_OFFSET, LN_GUARD_RATIO = 1, 2, 16.0      # include/storygen_hip.h SG_LN_GUARD_*
+# Measurement tooling (bench.py --dump-algorithmic): when a list, every GEMM / convolution launch reports the profiler class it
+# will fall into and its ALGORITHMIC bytes: (kernel instantiation as rocprofv3 prints it, grid size in threads, bytes, family, shape)
+PLAN_SINK = None
 # Same for the bandwidth-bound kernels (tools/profile_step.py): (family, algorithmic_bytes, start, end, shape).
 AUX_SINK = None
 
@@ -147,12 +151,13 @@ def _gemm_desc(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Opt
                res2: Optional[torch.Tensor] = None, epilogue: int = EPI_LINEAR, split_k: int = 0,
                workspace: Optional[torch.Tensor] = None, out2: Optional[torch.Tensor] = None,
                tile: Optional[tuple] = None, use_table: bool = True, stats: Optional[tuple] = None,
-               ln: Optional[tuple] = None, ln_out: Optional[torch.Tensor] = None):
+               ln: Optional[tuple] = None, ln_out: Optional[torch.Tensor] = None, guard: Optional[torch.Tensor] = None):
     """Builds the sg_gemm_desc of one problem; returns (desc, flops, shape string).  stats = (fp32 buffer, rows per image): the
     epilogue also writes the GroupNorm partial statistics of the output (sg_gemm_desc.stats).
     ln = (mode, stats [tokens, K/64 rounded up to even, 2] fp32, c fp32, d fp32, eps): LayerNorm folded into this GEMM (sg_gemm_desc.ln_*: mode 1 =
     the rows of `a` are the normalised tokens, 2 = the rows of `w` are); ln_out = fp32 [M, N/64 rounded up to even, 2]: also write the LayerNorm
-    partials of THIS output (sg_gemm_desc.ln_stats_out)."""
+    partials of THIS output (sg_gemm_desc.ln_stats_out); guard = int32 [1] CUDA tensor receiving the sticky SG_LN_GUARD_* flags of
+    a launch with ln / ln_out (LN_GUARD_RANGE: the raw fp16 copy saturated; LN_GUARD_OFFSET: a token with |mean| / sigma > 16)."""
     _f16(a, "a"), _f16(w, "w")
     flags = F_OUT_F32 if _act(out, "out") else 0
     M, K = a.shape
@@ -203,6 +208,10 @@ def _gemm_desc(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Opt
         if ln_out.numel() != M * ((N // 64 + 1) & ~1) * 2 or not ln_out.is_contiguous():
             raise ValueError(f"gemm: ln_out must hold [{M}, {(N // 64 + 1) & ~1}, 2] floats (N / 64 blocks rounded up to even)")
         d.ln_stats_out = ln_out.data_ptr()
+    if guard is not None:
+        if guard.dtype != torch.int32 or not guard.is_cuda or guard.numel() < 1:
+            raise TypeError("gemm: guard must be a CUDA int32 tensor")
+        d.ln_guard = guard.data_ptr()
     sig = f"g:{M}:{N}:{K}:{epilogue}:{flags}:{int(bias is not None)}{int(rowbias is not None)}{int(res1 is not None)}{int(res2 is not None)}{int(out2 is not None)}"
     if ln is not None:
         sig += f":ln{ln[0]}"
@@ -218,11 +227,52 @@ def _gemm_desc(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, *, bias: Opt
     return d, 2.0 * M * N * K, f"M{M} N{N} K{K}{' geglu' if epilogue else ''}"
 
 
+def _gemm_bytes(d) -> float:
+    """Algorithmic bytes of one GEMM problem: each operand once (A, W fp16; C fp32 / fp16; residuals; the second fp16 output)."""
+    n_out = d.N // 2 if d.epilogue == EPI_GEGLU else d.N
+    osz = 4 if d.flags & F_OUT_F32 else 2
+    b = 2.0 * d.M * d.K + 2.0 * d.N * d.K + osz * d.M * n_out
+    if d.res1:
+        b += (4 if d.flags & F_RES1_F32 else 2) * d.M * n_out
+    if d.res2:
+        b += (4 if d.flags & F_RES2_F32 else 2) * d.M * n_out
+    if d.C2:
+        b += 2.0 * d.M * n_out
+    return b
+
+
+def _plan_of(fn, d):
+    out = (C.c_int32 * 6)()
+    check(fn(C.byref(d), out), "launch plan")
+    return list(out)
+
+
+def _report_plan(kind: str, d, nbytes: float, family: str, shape: str, second=None):
+    """PLAN_SINK record of one launch (see PLAN_SINK).  second = (desc, bytes) of the other problem of a paired launch."""
+    if kind == "conv":
+        bm, bn, splits, wgs, threads, pipe = _plan_of(lib.sg_conv3x3_launch_plan, d)
+        name = f"mma_pipe_kernel<{bm // 64}, {bn // 64}, true, 3>" if pipe else f"mma_kernel<{bm}, {bn}, true>"
+    else:
+        bm, bn, splits, wgs, threads, pipe = _plan_of(lib.sg_gemm_launch_plan, d)
+        name = f"mma_pipe_kernel<{bm // 64}, {bn // 64}, false, 3>" if pipe else f"mma_kernel<{bm}, {bn}, false>"
+        if second is not None:
+            d1, b1 = second
+            d1.tile_m, d1.tile_n = bm, bn
+            bm1, bn1, _, wgs1, _, pipe1 = _plan_of(lib.sg_gemm_launch_plan, d1)
+            if pipe and pipe1 and (bm1, bn1) == (bm, bn):
+                name, wgs, nbytes = f"mma_pipe_pair_kernel<{bm // 64}, {bn // 64}>", ((max(wgs, wgs1) + 7) & ~7) * 2, nbytes + b1
+            else:           # not pairable: two plain launches
+                PLAN_SINK.append((f"mma_pipe_kernel<{bm1 // 64}, {bn1 // 64}, false, 3>", wgs1 * threads, b1, family, shape + " [2nd]"))
+    PLAN_SINK.append((name, wgs * threads, nbytes, family, shape))
+
+
 def gemm(a: torch.Tensor, w: torch.Tensor, out: torch.Tensor, **kw) -> torch.Tensor:
     """out[M, N'] = epi(a[M,K] @ w[N,K]^T); a/out/res* may be row-strided 2-D views; out/res* fp16 or fp32;
     out2 = optional extra fp16 copy of the result.  Keywords: bias, rowbias, rows_per_batch, res1, res2, epilogue, split_k,
     workspace, out2, tile."""
     d, flops, shape = _gemm_desc(a, w, out, **kw)
+    if PLAN_SINK is not None:
+        _report_plan("gemm", d, _gemm_bytes(d), "gemm", shape)
     with _timed("gemm", flops, shape):
         if ANATOMY is not None:
             check(lib.sg_debug_gemm_anatomy(C.byref(d), ANATOMY.data_ptr(), ANATOMY.numel() * ANATOMY.element_size(), _stream()),
@@ -274,6 +324,8 @@ def gemm_pair(first: tuple, second: tuple) -> None:
     (a0, kw0), (a1, kw1) = first, second
     d0, f0, s0 = _gemm_desc(*a0, use_table=False, **kw0)
     d1, f1, s1 = _gemm_desc(*a1, use_table=False, **kw1)
+    if PLAN_SINK is not None:
+        _report_plan("gemm", d0, _gemm_bytes(d0), "gemm", f"{s0} + {s1}", second=(d1, _gemm_bytes(d1)))
     with _timed("gemm", f0 + f1, f"{s0} + {s1}"):
         check(lib.sg_gemm_pair_f16(C.byref(d0), C.byref(d1), _stream()), "sg_gemm_pair_f16")
 
@@ -339,6 +391,12 @@ def conv3x3(x: torch.Tensor, w_krsc: torch.Tensor, out: torch.Tensor, **kw) -> t
     bias, rowbias, res1, split_k, workspace, x_padded, tile, stats (fp32 buffer: GroupNorm partial statistics of the output),
     defer_reduce (a split-K launch leaves its partial tiles in the workspace for groupnorm(split=...): sg_conv3x3_desc.defer_reduce)."""
     d, flops, shape = _conv_desc(x, w_krsc, out, **kw)
+    if PLAN_SINK is not None:
+        Ho, Wo = out.shape[1], out.shape[2]
+        nb = 2.0 * d.B * d.H * d.W * d.Cin + 2.0 * d.Cout * 9 * d.Cin + (4 if d.flags & F_OUT_F32 else 2) * d.B * Ho * Wo * d.Cout
+        if d.res1:
+            nb += (4 if d.flags & F_RES1_F32 else 2) * d.B * Ho * Wo * d.Cout
+        _report_plan("conv", d, nb, "conv3x3", shape)
     with _timed("conv3x3", flops, shape):
         if ANATOMY is not None:
             check(lib.sg_debug_conv_anatomy(C.byref(d), ANATOMY.data_ptr(), ANATOMY.numel() * ANATOMY.element_size(), _stream()),

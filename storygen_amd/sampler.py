@@ -520,6 +520,13 @@ class StoryGenSampler:
                 trace.extend(self.lat_trace[g].clone() for g in range(self.G))
         return self.latents
 
+    def check_guards(self):
+        """Raise if a folded LayerNorm of either engine left its range since the last check (UNetEngine.check_ln_guard; synchronises).
+        The pipeline calls it once after the loop, bench.py after the timed region."""
+        for eng in (self.main, self.ref):
+            if eng is not None:
+                eng.check_ln_guard()
+
     def executed_sample_forwards(self):
         """(reference-pass samples, main-pass samples) actually computed per step — for FLOP accounting (with ref_ahead
         = G the reference engine runs G steps' samples once per G steps)."""

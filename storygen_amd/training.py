@@ -101,6 +101,7 @@ class Stage2Trainer:
             self.trainer.ref_levels = "coco"
         self.use_graph = use_graph
         self.global_step, self._micro = 0, 0
+        self._tainted = False                      # "true" accumulation: a micro-batch of the open window was skipped (non-finite gradients)
         self._acc: Optional[Dict[str, torch.Tensor]] = None
         self._rng = random.Random(seed)
         self.last_grad_norm: Optional[torch.Tensor] = None
@@ -150,10 +151,18 @@ class Stage2Trainer:
         run = self.trainer.train_step_graph if self.use_graph else self.trainer.train_step
         loss, grads = run(batch, use_refs=tuple(use_refs))
         loss = loss.detach().clone()
-        if self.use_graph and self.trainer.last_step_skipped:       # non-finite gradients at every loss scale: GradScaler skips the step
-            self._micro += 1
-            return dict(loss=loss, lr=self.lr_scheduler.get_last_lr()[0], optimizer_step=False, skipped=True)
         plan = self.plan
+        if self.use_graph and self.trainer.last_step_skipped:       # non-finite gradients at every loss scale: GradScaler skips the step
+            # (only the hipGraph step rescales and detects this; the eager train_step runs at one fixed loss scale and does not check)
+            self._micro += 1
+            if plan["step_every"] > 1:
+                # "true" accumulation: the window has lost a micro-batch.  torch's GradScaler skips the optimizer step of the WHOLE
+                # window in that case (its inf check covers the accumulated gradient) — so does this: taint it, and when it closes,
+                # drop the accumulator instead of stepping on k - 1 micro-batches scaled 1 / k
+                self._tainted = True
+                if self._micro % plan["step_every"] == 0:
+                    self._drop_window()
+            return dict(loss=loss, lr=self.lr_scheduler.get_last_lr()[0], optimizer_step=False, skipped=True)
         if plan["step_every"] > 1:                                  # real accumulation: sum k micro-batches, each scaled 1 / k
             if self._acc is None:
                 self._acc = {n: torch.zeros_like(g) for n, g in grads.items()}
@@ -164,6 +173,9 @@ class Stage2Trainer:
             grads = {n: g * plan["grad_scale"] for n, g in grads.items()}
         self._micro += 1
         stepped = self._micro % plan["step_every"] == 0
+        if stepped and self._tainted:            # a micro-batch of this window was skipped: skip its optimizer step
+            self._drop_window()
+            return dict(loss=loss, lr=self.lr_scheduler.get_last_lr()[0], optimizer_step=False, skipped=True)
         if stepped:
             allreduce_gradients(grads)                              # DDP's gradient average, :222
             self.optimizer.set_grads(grads)
@@ -178,6 +190,13 @@ class Stage2Trainer:
             for _ in range(plan["scheduler_steps_per_optimizer_step"]):     # :331 through accelerate's scheduler wrapper
                 self.lr_scheduler.step()
         return dict(loss=loss, lr=self.lr_scheduler.get_last_lr()[0], optimizer_step=stepped)
+
+    def _drop_window(self):
+        """Close an accumulation window without an optimizer step (a micro-batch of it had non-finite gradients)."""
+        self._tainted = False
+        if self._acc is not None:
+            for a in self._acc.values():
+                a.zero_()
 
     # ------------------------------------------------------------------------------------------------ checkpoints
     def save_checkpoint(self, logdir: str, scheduler=None) -> str:

@@ -582,6 +582,29 @@ def test_group_schedule_is_the_step_by_step_trajectory(monkeypatch, stage, N, R,
         smp.prepare(inp, T + 1, stage, 7.5, 3.5)
 
 
+def test_bench_launcher_path_world2_gloo_dry_run():
+    """bench.py exactly as the driver launches it for N = 2 (`python -m torch.distributed.run --nnodes=1 --nproc-per-node 2
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus 2 --steps 20 --warmup 5`) with --dry-run: gloo instead of RCCL and a
+    stand-in engine instead of the GPU, everything else — ranks from the environment, the default group schedule (ref_ahead 5),
+    barrier + max-over-ranks timing (bench.timed_steps), the one all-gather and the per-rank-distinct check (bench.gather_and_check),
+    ONE JSON line from rank 0 — is the code the real run executes."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "20", "--warmup", "5", "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["dry_run"] is True and d["value"] is None and "DRY RUN" in d["metric"]          # can never be read as a measurement
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert d["latents_gathered"] == 2 and d["latents_distinct_per_rank"] and d["latents_finite"]
+    assert d["config"]["ref_ahead"] == 5 and d["config"]["warmup_run"] == 5
+
+
 def test_bench_argument_parser_builds():
     """`python bench.py --help` must exit 0: a duplicated add_argument (it happened) would break every driver run before any GPU work."""
     import subprocess

@@ -168,6 +168,61 @@ def test_gemm_layernorm_fold(gpu, M, C, split):
         ops.gemm(x16, wf, out, ln=(1, st, c, d, 1e-5), split_k=2, workspace=ws)
 
 
+@pytest.mark.parametrize("split", [1, 2])
+@pytest.mark.parametrize("case", ["in-range", "offset", "range"])
+def test_layernorm_fold_guard_and_saturation(gpu, case, split):
+    """The two assumptions of the LayerNorm fold, and what the library does when one fails (the reference's
+    LayerNorm reads an fp32 tensor and has neither limit, model/attention.py:250,268,283,298):
+      offset: a stream whose tokens sit at |mean| = 1e3 sigma — the fp16 copy keeps ~2^-11 |x| = 0.5 sigma of rounding, the folded
+              LayerNorm is wrong by O(1), and the consumer raises SG_LN_GUARD_OFFSET;
+      range:  |x| ~ 1e5 > 65504 — the fp16 copy is SATURATED (finite everywhere, never inf), the producer raises SG_LN_GUARD_RANGE;
+      in-range (|mean| = 3 sigma): no flag, results within the kernel bar.
+    In both failing cases the fp32 stream itself is exact, so the unfused LayerNorm launch on it (engine.LN_FOLD = False) is."""
+    from storygen_amd import ops
+    from storygen_amd.repack import fold_layernorm
+    M, C = 512, 320
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=gpu)
+    a0, w0 = rnd((M, C), gpu, 1.0, 1), rnd((C, C), gpu, C ** -0.5, 2)
+    off = {"in-range": 3.0, "offset": 1.0e3, "range": 1.0e5}[case]
+    res = rnd((M, C), gpu, 1.0, 3, torch.float32) + off
+    x = torch.empty(M, C, dtype=torch.float32, device=gpu)
+    x16 = torch.empty(M, C, dtype=torch.float16, device=gpu)
+    P = C // 64
+    st = torch.zeros((M, (P + 1) & ~1, 2), dtype=torch.float32, device=gpu)
+    guard = torch.zeros(1, dtype=torch.int32, device=gpu)
+    ops.gemm(a0, w0, x, res1=res, out2=x16, ln_out=st, guard=guard, split_k=split, workspace=ws)
+    want_x = a0.float() @ w0.float().t() + res
+    check(x, want_x, "fp32 stream", l2=1e-6, mx=1e-2 if case == "range" else 1e-3)           # exact whatever the magnitude
+    assert torch.isfinite(x16).all(), "the fp16 copy must saturate, not overflow"
+    if case == "range":
+        assert float(x16.float().abs().max()) == 65504.0 and int(guard.item()) & ops.LN_GUARD_RANGE
+    else:
+        assert not int(guard.item()) & ops.LN_GUARD_RANGE
+        check(x16, want_x, "fp16 copy", l2=6e-4, mx=off * 1e-3 + 1e-2)
+    gamma, beta = rnd((C,), gpu, 0.3, 5) + 1.0, rnd((C,), gpu, 0.3, 6)
+    wq, bq = rnd((2 * C, C), gpu, C ** -0.5, 7), rnd((2 * C,), gpu, 1.0, 8)
+    wf, c, d = fold_layernorm(wq, bq, gamma, beta)
+    out = torch.full((M, 2 * C), float("nan"), dtype=torch.float16, device=gpu)
+    guard.zero_()
+    ops.gemm(x16, wf, out, ln=(1, st, c, d, 1e-5), guard=guard)
+    want = F.layer_norm(x, (C,), gamma.float(), beta.float(), 1e-5) @ wq.float().t() + bq.float()
+    err = float((out.float() - want).norm() / want.norm())
+    flags = int(guard.item())
+    print(f"LayerNorm fold, |mean| = {off:g} sigma: rel-L2 {err:.2e}, guard flags {flags}")
+    assert torch.isfinite(out).all()
+    if case == "in-range":
+        assert flags == 0 and err <= 1.5e-3
+    else:
+        assert flags & ops.LN_GUARD_OFFSET, "a token with |mean| / sigma > 16 must be reported"
+        assert err > 1e-2, "if the fold were accurate here the guard would be needless"
+        # the remedy: the LayerNorm launch on the fp32 stream (what engine.LN_FOLD = False runs) is within the kernel bar
+        y = torch.empty(M, C, dtype=torch.float16, device=gpu)
+        ops.layernorm(x, gamma, beta, y)
+        o2 = torch.empty_like(out)
+        ops.gemm(y, wq, o2, bias=bq, workspace=ws)
+        check(o2, want, "unfused LayerNorm -> GEMM on the same stream", l2=1.5e-3, mx=3e-2)
+
+
 def test_gemm_strided_views(gpu):
     """lda/ldc/ldr larger than the logical widths: operands are column slices of wider buffers."""
     from storygen_amd import ops

@@ -204,3 +204,68 @@ def test_reference_accumulation_semantics_lr_and_step_trajectory(k, world):
     assert true == dict(grad_scale=1.0 / k, step_every=k, scheduler_steps_per_optimizer_step=1, schedule_multiplier=1)
     with pytest.raises(ValueError):
         accumulation_plan("sometimes", k, world)
+
+
+def test_true_accumulation_skips_the_window_a_skipped_micro_batch_belongs_to():
+    """Stage2Trainer.step with accumulation="true" (advisor r4): when a micro-batch is skipped for non-finite gradients the window it
+    belongs to must not step on k - 1 micro-batches scaled 1 / k — torch's GradScaler skips the optimizer step of the whole window;
+    the next window is unaffected.  Host logic only: trainer / optimizer / scheduler are recording stand-ins."""
+    import types
+
+    import torch
+    from storygen_amd.training import Stage2Trainer, accumulation_plan
+
+    class Opt:
+        def __init__(self):
+            self.steps, self.seen = 0, []
+
+        def set_grads(self, g):
+            self.seen.append({k: v.clone() for k, v in g.items()})
+
+        def clip_grad_norm_(self, m):
+            return torch.tensor(0.0)
+
+        def step(self):
+            self.steps += 1
+
+        def zero_grad(self):
+            pass
+
+    class Sched:
+        def __init__(self):
+            self.n = 0
+
+        def step(self):
+            self.n += 1
+
+        def get_last_lr(self):
+            return [1e-4]
+
+    skip_at = {1}            # micro-batch index whose gradients are non-finite at every loss scale
+
+    tr = object.__new__(Stage2Trainer)
+    calls = {"n": 0}
+
+    def train_step_graph(batch, use_refs=()):
+        i = calls["n"]
+        calls["n"] += 1
+        tr.trainer.last_step_skipped = i in skip_at
+        return torch.tensor(float(i)), {"w": torch.full((2,), float(i + 1))}
+
+    tr.trainer = types.SimpleNamespace(train_step_graph=train_step_graph, last_step_skipped=False, set_trainable_parameters=lambda named: None)
+    tr.module, tr.variant, tr.use_graph, tr.named = "attn1", "storysalon", True, {}
+    tr.plan = accumulation_plan("true", 2, 1)
+    tr.optimizer, tr.lr_scheduler, tr.max_grad_norm = Opt(), Sched(), 1.0
+    tr.global_step, tr._micro, tr._acc, tr._tainted, tr.last_grad_norm = 0, 0, None, False, None
+    outs = [tr.step({}) for _ in range(4)]
+    assert [o["optimizer_step"] for o in outs] == [False, False, False, True]
+    assert outs[1].get("skipped") and tr.optimizer.steps == 1 and tr.global_step == 1 and tr._micro == 4
+    # the one step that happened is the second window's: micro-batches 2 and 3 (gradients 3 and 4), each scaled 1 / 2 — nothing of
+    # micro-batch 0 (whose window was dropped) is left in the accumulator
+    assert torch.equal(tr.optimizer.seen[0]["w"], torch.full((2,), 0.5 * 3 + 0.5 * 4))
+    # a skip on the LAST micro-batch of a window drops it too
+    skip_at.clear()
+    skip_at.add(5)
+    more = [tr.step({}) for _ in range(4)]
+    assert [o["optimizer_step"] for o in more] == [False, False, False, True] and tr.optimizer.steps == 2
+    assert torch.equal(tr.optimizer.seen[1]["w"], torch.full((2,), 0.5 * 7 + 0.5 * 8))
