@@ -425,6 +425,11 @@ def main():
                          "attention unless --fp8-attention; the JSON names it in config.workload")
     ap.add_argument("--split-graphs", action="store_true",
                     help="A/B: reference and main pass as separately launched hipGraphs on two streams (measured: they do not overlap)")
+    ap.add_argument("--ref-cus", type=int, default=0,
+                    help="EXPERIMENT: launch the batched reference pass eagerly (no graph) on a stream restricted to this many CUs "
+                         "(hipExtStreamCreateWithCUMask), one group ahead of the main-pass graphs; 0 = off")
+    ap.add_argument("--ref-cu-layout", choices=("first", "spread"), default="first")
+    ap.add_argument("--ref-eager", action="store_true", help="EXPERIMENT: the reference pass kernel by kernel from the host instead of a graph replay")
     ap.add_argument("--stream-priority", action="store_true",
                     help="with --split-graphs / --ref-ahead: main-pass graphs on a high-priority stream")
     ap.add_argument("--fp8-attention", action="store_true",
@@ -443,6 +448,9 @@ def main():
     ap.add_argument("--no-splitk-in-gn", action="store_true",
                     help="A/B: split-K convolutions at the 16x16 / 8x8 levels run their own second pass instead of leaving it to the GroupNorm")
     ap.add_argument("--no-ff-fused", action="store_true", help="A/B: GEGLU feed-forward of the 64x64 level as two GEMM launches")
+    ap.add_argument("--no-shared-head", action="store_true",
+                    help="A/B: the main pass runs its three CFG samples at batch 3 from conv_in on, as written (default: everything up to "
+                         "the first cross-attention once — the samples share latent and timestep)")
     ap.add_argument("--optimizer", choices=("none", "adamw", "adamw8bit"), default="none",
                     help="with --train-step: include the reference's clip_grad_norm_ + optimizer step (storygen_amd.training.Stage2Trainer)")
     ap.add_argument("--train-step", action="store_true",
@@ -526,7 +534,9 @@ def main():
     sampler = StoryGenSampler(arch, sd, dev, N_PER_GPU, hw, hw, n_ref, use_graph=not args.no_graph, dedup=not args.no_dedup,
                               overlap=not args.no_overlap, ref_ahead=G, split_graphs=args.split_graphs,
                               stream_priority=args.stream_priority, fp8_attention=args.fp8_attention,
-                              short_rows=not args.no_short_rows, time_tables=not args.no_time_tables)
+                              short_rows=not args.no_short_rows, time_tables=not args.no_time_tables,
+                              shared_head=not args.no_shared_head, ref_cus=args.ref_cus, ref_cu_layout=args.ref_cu_layout,
+                              ref_eager=args.ref_eager)
     n_sched = max(T, args.steps + warmup_run)
     sampler.prepare(inputs, n_sched, args.stage, 7.5, 3.5)
 
@@ -553,11 +563,11 @@ def main():
                        "stage": args.stage, "samples_per_gpu": N_PER_GPU, "parallelism": f"dp{world} (one sample per GPU, final all-gather)",
                        "hipgraph": not args.no_graph, "dedup_identical_reference_samples": not args.no_dedup,
                        "overlap_ref_pass_of_next_step": sampler.overlap, "ref_ahead": G, "warmup_run": warmup_run,
-                       "split_graphs": sampler.split, "stream_priority": sampler.stream_priority,
+                       "split_graphs": sampler.split, "stream_priority": sampler.stream_priority, "ref_pass_on_cus": args.ref_cus, "ref_pass_eager": args.ref_eager,
                        "paired_gemm_launches": not args.no_gemm_pairs, "paired_text_image_attention": args.attn_pair,
                        "groupnorm_stats_from_epilogues": not args.no_gn_epilogue, "fp16_block_stream": args.fp16_block_stream,
                        "short_zero_image_rows": not args.no_short_rows, "time_embedding_tables": not args.no_time_tables, "splitk_reduce_in_groupnorm": not args.no_splitk_in_gn,
-                       "fused_feed_forward_64x64": not args.no_ff_fused},
+                       "fused_feed_forward_64x64": not args.no_ff_fused, "shared_cfg_head_of_main_pass": bool(sampler.main.cfg_shared_head)},
             "tflop_per_step_as_written": round(step_tflop, 3),
             "final_allgather_ms": round(gather_ms, 3), "latents_gathered": int(final.shape[0]), "latents_finite": finite,
             "latents_distinct_per_rank": distinct,

@@ -292,14 +292,21 @@ class UNetEngine:
     def __init__(self, arch: UNetArch, state_dict: Optional[Dict[str, torch.Tensor]], device, batch: int, height: int,
                  width: int, n_ref: int = 0, seq_len: int = 77, splitk_workspace_mb: int = 96,
                  weights: Optional[EngineWeights] = None, ctx_rows: Optional[int] = None,
-                 attn3_groups: Optional[List[tuple]] = None, fp8_attention: bool = False, ctx_short: int = 0):
+                 attn3_groups: Optional[List[tuple]] = None, fp8_attention: bool = False, ctx_short: int = 0,
+                 cfg_shared_head: bool = False):
         """batch = samples per UNet call; n_ref = R prior frames (sizes the context buffers; 0 = an engine that only
         harvests, into another engine's buffers).  ctx_rows = number of distinct context rows (default: one per
         sample); attn3_groups = [(q0, n, c0), ...]: samples [q0, q0+n) cross-attend to context rows [c0, c0+n) — lets
         samples whose prior-frame features are identical (the two image-conditioned CFG branches) share
         one copy of the context and of its K/V projection.  ctx_short = S > 0: the first S context rows hold ONE frame slot instead
         of R (the zero-image rows of `multi-image-condition`, whose R slots would be R copies of one feature map: softmax over R
-        copies of the same keys is softmax over one); the context buffers are then flat [(S + (rows - S) R) HW, C] matrices."""
+        copies of the same keys is softmax over one); the context buffers are then flat [(S + (rows - S) R) HW, C] matrices.
+        cfg_shared_head: the caller guarantees the classifier-free-guidance pattern of the loop's main pass (pipeline.py:448-453) with
+        one story frame: batch 3 = the SAME latent and timestep three times, text rows [uncond, uncond, text], context rows [zero-image,
+        frames, frames].  Until the first cross-attention the three samples are then the same computation, so forward(consume=True) runs
+        conv_in, the first ResnetBlock2D and the first transformer's norm / proj_in / self-attention / to_out / query projections ONCE
+        (batch 1), the text attention for (uncond, text) and the image attention for (zero-image, frames) only, and copies the results to
+        the samples that share them — the same arithmetic on the same values (bit-exact redundancy removal)."""
         self.arch, self.dev = arch, torch.device(device)
         self.B, self.H, self.W, self.R, self.S = batch, height, width, n_ref, seq_len
         cfg = arch.config
@@ -328,6 +335,13 @@ class UNetEngine:
         if self.ctx_short and (not n_ref or self.attn3_share is None or self.ctx_short > rows):
             raise ValueError("ctx_short needs context buffers, at most ctx_rows short rows and the shared-row attn3 pattern")
         self.ctx_slots = self.ctx_short + (rows - self.ctx_short) * n_ref      # frame slots per feature key
+        first = arch.down[0]
+        self.cfg_shared_head = bool(cfg_shared_head)
+        if self.cfg_shared_head and not (batch == 3 and n_ref and rows == 2 and self.attn3_share == 2 and self.ctx_short in (0, 1)
+                                         and first.attns and first.attns[0] is not None and not fp8_attention):
+            raise ValueError("cfg_shared_head needs batch 3 on 2 shared context rows (the CFG main pass of one story frame), a transformer "
+                             "behind the first resnet and the fp16 attention path")
+        self._shared_back = False
         self.wts = weights if weights is not None else EngineWeights(arch, state_dict, device)
         # BASELINE config 5: the head-dim-40 self / image attentions (the 46 080-key context of the 96x96 level) on the fp8 MFMA
         # path (sg_attn_fwd_f8_d40); text attention and the D = 80 / 160 levels stay fp16
@@ -485,6 +499,35 @@ class UNetEngine:
     def _join(self):
         torch.cuda.current_stream(self.dev).wait_stream(self.side)
 
+    # ---- cfg_shared_head: run a stretch of the pass on the first n samples of every buffer
+    def _enter_head(self, n: int):
+        """Make self.B = n and point the level-0 buffers, the conv inputs and the time rows at their first n samples.  Returns the
+        state _leave_head restores."""
+        saved = (self.B, self.lv[0], self.padded, self.tproj)
+        hw, B = self.hw[0], self.B
+        cols = ("vt", "vtt", "vti")                          # transposed buffers [C, tokens]: the samples are column blocks
+        head = {}
+        for k, v in self.lv[0].items():
+            if v is None:
+                head[k] = None
+            elif k in cols:
+                head[k] = v[:, : v.shape[1] // B * n]
+            else:
+                head[k] = v[: v.shape[0] // B * n]
+        self.B, self.lv[0] = n, head
+        self.padded = {k: (v[:n] if k[0] == 0 else v) for k, v in saved[2].items()}
+        self.tproj = saved[3][:n]
+        return saved
+
+    def _leave_head(self, saved):
+        self.B, self.lv[0], self.padded, self.tproj = saved
+
+    def _spread(self, t2d: torch.Tensor, n: int, copies: int):
+        """Rows of samples [0, n) of a [B*hw, C] stream tensor (row-strided views allowed) -> the next `copies` groups of n samples."""
+        rows = n * self.hw[0]
+        src = t2d[:rows].unflatten(0, (1, rows)).expand(copies, rows, t2d.shape[1])
+        ops.copy_rows(t2d[rows:(1 + copies) * rows].unflatten(0, (copies, rows)), src)
+
     # ---- GroupNorm statistics from producer epilogues
     def _stats_for(self, site: str, lvl: int, n_out: int, query) -> Optional[torch.Tensor]:
         """The statistics buffer a producer at `site` (output [B*hw[lvl], n_out]) should write, or None.  `query(buf)` -> rows per
@@ -640,15 +683,17 @@ class UNetEngine:
                 self._project_text(self.xfs[a.prefix], *bufs)
 
     def _transformer(self, xf: _Xf, x: torch.Tensor, out: Optional[torch.Tensor], lvl: int, text: Optional[torch.Tensor],
-                     harvest: Optional[HarvestPlan], consume: bool, text_cache: bool = False, stop_after_harvest: bool = False):
+                     harvest: Optional[HarvestPlan], consume: bool, text_cache: bool = False, stop_after_harvest: bool = False,
+                     phase: str = "all"):
         """Transformer2DModel.forward (attention.py:85-128) + BasicTransformerBlock.forward (:236-302).
-        x, out, h0..h3 fp32; everything that feeds an MFMA fp16."""
+        x, out, h0..h3 fp32; everything that feeds an MFMA fp16.
+        phase: "front" = up to and including the query projections of the cross-attentions (everything that depends on the hidden
+        states alone), "back" = from the cross-attentions on, "all" = both (cfg_shared_head runs the front once for the three
+        CFG samples)."""
         L, B, hw, S = self.lv[lvl], self.B, self.hw[lvl], self.S
         M, C, heads = x.shape[0], xf.spec.channels, xf.spec.heads
         scale = xf.spec.dim_head ** -0.5
         ws = self.ws_split
-        ops.groupnorm(x.unflatten(0, (B, hw)), xf.ng, xf.nb, L["gn"].unflatten(0, (B, hw)), self.groups, 1e-6, False,
-                      self.ws_gn, pstats=self._pstats_of(x), split=self._pending_split.pop(x.data_ptr(), None))   # :99 (eps 1e-6, :55)
         h0 = L["h0"]
         fold = LN_FOLD and C % 64 == 0 and C // 64 <= 20
         # fused feed-forward: needs the fp32 stream (it reads h3 itself: no raw copy, no LayerNorm partials from h3's producer)
@@ -658,82 +703,99 @@ class UNetEngine:
         gd = self.ln_guard
         prod = lambda t, buf, st: dict(out2=None if t.dtype == F16 else buf, ln_out=st, guard=gd) if fold else {}   # noqa: E731
         h0r, h1r = raw(h0, L["ln"]), raw(L["h1"], L["ln4"])
-        ops.gemm(L["gn"], xf.w_in, h0, bias=xf.b_in, workspace=ws, **prod(h0, L["ln"], L["lnst0"]))   # proj_in :101
-        # --- self-attention :250-262
         qk, vt = L["qk"], L["vt"]
         wp = self.ws_pair
-        # q|k (token-major) and V^T = Wv . X^T (the attention kernel's operand layout): two GEMMs on one LayerNorm output, one launch
-        if fold:
-            _pair(((h0r, xf.w_qk1f, qk), dict(ln=(1, L["lnst0"], xf.c_qk1, xf.d_qk1, LN_EPS), guard=gd)),
-                  ((xf.w_v1f, h0r, vt), dict(ln=(2, L["lnst0"], xf.c_v1, xf.d_v1, LN_EPS), guard=gd)))
-        else:
-            ops.layernorm(h0, *xf.ln["norm1"], L["ln"])
-            _pair(((L["ln"], xf.w_qk1, qk), dict(workspace=ws)), ((xf.w_v1, L["ln"], vt), dict(workspace=wp)))
-        qk3 = qk.view(B, hw, 2 * C)
         att = L["att"]
-        self._attention(qk3[:, :, :C], qk3[:, :, C:], vt.view(C, B, hw).permute(1, 0, 2), att.view(B, hw, C), heads, scale)
         h1 = L["h1"]
-        plans = () if harvest is None else (tuple(harvest) if isinstance(harvest, (list, tuple)) else (harvest,))
-        # feature :263.  A plan whose sample order is the context's slot order (HarvestPlan.direct) gets the feature as the second,
-        # fp16 output of this GEMM — written straight into the context buffer, which then also serves as the raw copy of h1 that the
-        # folded query projections read; any other plan is served by strided copies.
-        direct = None
-        if len(plans) == 1 and h1.dtype != F16 and plans[0].is_direct(B, plans[0].slots_per_row or self.R):
-            c = plans[0].ctx[xf.spec.feature_key]
-            direct = c if c.dim() == 2 else c.view(-1, C)
-            assert direct.shape[0] == M, (direct.shape, M)
-        kw1 = prod(h1, L["ln4"], L["lnst1"])
-        if direct is not None:
-            kw1["out2"] = direct
-            h1r = direct
-        ops.gemm(att, xf.w_o1, h1, bias=xf.b_o1, res1=h0, workspace=ws, **kw1)
-        if harvest is not None:
-            h1b = h1.view(B, hw, C)
-            for plan in plans:
-                ctx = plan.ctx[xf.spec.feature_key]
-                c2d = ctx if ctx.dim() == 2 else ctx.view(-1, C)
-                if direct is None:
-                    Rp = plan.slots_per_row or (ctx.shape[1] // hw)
-                    for src, step, row, slot, cnt in plan.ops:
-                        t0 = plan.flat_slot(row, slot, Rp) * hw
-                        dst = c2d[t0:t0 + cnt * hw].view(cnt, hw, C)
-                        ops.copy_rows(dst, h1b[plan.src_offset + src:].as_strided((cnt, hw, C), (step * hw * C, C, 1)))
-                if plan.kv is not None:            # attn3 K / V^T of the finished context (attention.py:215-223)
-                    ki, vti = plan.kv[xf.spec.feature_key]
-                    _pair(((c2d, xf.w_k3, ki), dict(workspace=ws)), ((xf.w_v3, c2d, vti), dict(workspace=wp)))   # VT[C, slots*hw]
-            if stop_after_harvest:
+        q2, q3buf = L["q2"], L["q"]
+        if phase != "back":
+            ops.groupnorm(x.unflatten(0, (B, hw)), xf.ng, xf.nb, L["gn"].unflatten(0, (B, hw)), self.groups, 1e-6, False,
+                          self.ws_gn, pstats=self._pstats_of(x), split=self._pending_split.pop(x.data_ptr(), None))   # :99 (eps 1e-6, :55)
+            ops.gemm(L["gn"], xf.w_in, h0, bias=xf.b_in, workspace=ws, **prod(h0, L["ln"], L["lnst0"]))   # proj_in :101
+            # --- self-attention :250-262
+            # q|k (token-major) and V^T = Wv . X^T (the attention kernel's operand layout): two GEMMs on one LayerNorm output, one launch
+            if fold:
+                _pair(((h0r, xf.w_qk1f, qk), dict(ln=(1, L["lnst0"], xf.c_qk1, xf.d_qk1, LN_EPS), guard=gd)),
+                      ((xf.w_v1f, h0r, vt), dict(ln=(2, L["lnst0"], xf.c_v1, xf.d_v1, LN_EPS), guard=gd)))
+            else:
+                ops.layernorm(h0, *xf.ln["norm1"], L["ln"])
+                _pair(((L["ln"], xf.w_qk1, qk), dict(workspace=ws)), ((xf.w_v1, L["ln"], vt), dict(workspace=wp)))
+            qk3 = qk.view(B, hw, 2 * C)
+            self._attention(qk3[:, :, :C], qk3[:, :, C:], vt.view(C, B, hw).permute(1, 0, 2), att.view(B, hw, C), heads, scale)
+            plans = () if harvest is None else (tuple(harvest) if isinstance(harvest, (list, tuple)) else (harvest,))
+            # feature :263.  A plan whose sample order is the context's slot order (HarvestPlan.direct) gets the feature as the second,
+            # fp16 output of this GEMM — written straight into the context buffer, which then also serves as the raw copy of h1 that the
+            # folded query projections read; any other plan is served by strided copies.
+            direct = None
+            if len(plans) == 1 and h1.dtype != F16 and plans[0].is_direct(B, plans[0].slots_per_row or self.R):
+                c = plans[0].ctx[xf.spec.feature_key]
+                direct = c if c.dim() == 2 else c.view(-1, C)
+                assert direct.shape[0] == M, (direct.shape, M)
+            kw1 = prod(h1, L["ln4"], L["lnst1"])
+            if direct is not None:
+                kw1["out2"] = direct
+                h1r = direct
+            ops.gemm(att, xf.w_o1, h1, bias=xf.b_o1, res1=h0, workspace=ws, **kw1)
+            if harvest is not None:
+                h1b = h1.view(B, hw, C)
+                for plan in plans:
+                    ctx = plan.ctx[xf.spec.feature_key]
+                    c2d = ctx if ctx.dim() == 2 else ctx.view(-1, C)
+                    if direct is None:
+                        Rp = plan.slots_per_row or (ctx.shape[1] // hw)
+                        for src, step, row, slot, cnt in plan.ops:
+                            t0 = plan.flat_slot(row, slot, Rp) * hw
+                            dst = c2d[t0:t0 + cnt * hw].view(cnt, hw, C)
+                            ops.copy_rows(dst, h1b[plan.src_offset + src:].as_strided((cnt, hw, C), (step * hw * C, C, 1)))
+                    if plan.kv is not None:            # attn3 K / V^T of the finished context (attention.py:215-223)
+                        ki, vti = plan.kv[xf.spec.feature_key]
+                        _pair(((c2d, xf.w_k3, ki), dict(workspace=ws)), ((xf.w_v3, c2d, vti), dict(workspace=wp)))   # VT[C, slots*hw]
+                if stop_after_harvest:
+                    return
+            # --- query projections of the text cross-attention :266-277 (norm2) and the image cross-attention :281-291 (norm4): they
+            # share statistics, and both in one launch
+            if fold:
+                pass
+            elif consume:
+                ops.layernorm(h1, *xf.ln["norm2"], L["ln"], 1e-5, *xf.ln["norm4"], L["ln4"])
+            else:
+                ops.layernorm(h1, *xf.ln["norm2"], L["ln"])
+            if consume and fold:
+                _pair(((h1r, xf.w_q2f, q2), dict(ln=(1, L["lnst1"], xf.c_q2, xf.d_q2, LN_EPS), guard=gd)),
+                      ((h1r, xf.w_q3f, q3buf), dict(ln=(1, L["lnst1"], xf.c_q3, xf.d_q3, LN_EPS), guard=gd)))
+            elif consume:
+                _pair(((L["ln"], xf.w_q2, q2), dict(workspace=ws)), ((L["ln4"], xf.w_q3, q3buf), dict(workspace=wp)))
+            elif fold:
+                ops.gemm(h1r, xf.w_q2f, L["q"], ln=(1, L["lnst1"], xf.c_q2, xf.d_q2, LN_EPS), guard=gd)
+            else:
+                ops.gemm(L["ln"], xf.w_q2, L["q"], workspace=ws)
+            if phase == "front":
                 return
-        # --- text cross-attention :266-277 (norm2) and image cross-attention :281-291 (norm4) share statistics
-        if fold:
-            pass
-        elif consume:
-            ops.layernorm(h1, *xf.ln["norm2"], L["ln"], 1e-5, *xf.ln["norm4"], L["ln4"])
-        else:
-            ops.layernorm(h1, *xf.ln["norm2"], L["ln"])
         kt3, vtt3 = self._text_kv(xf, lvl, text_cache)
         if consume:
             # the text branch (q2 -> attn2, :266-276) and the image branch (q3 -> attn3, :281-290) write the two halves
             # of one [M, 2C] buffer; their out-projections, biases and both residual adds (:277,291-293) are one GEMM
             att23 = L["att23"]
             a2v, a3v = att23[:, :C].unflatten(0, (B, hw)), att23[:, C:].unflatten(0, (B, hw))
-            # both query projections in one launch (norm2 / norm4 outputs of the same statistics), then the two attentions side by side
-            q2, q3buf = L["q2"], L["q"]
-            if fold:
-                _pair(((h1r, xf.w_q2f, q2), dict(ln=(1, L["lnst1"], xf.c_q2, xf.d_q2, LN_EPS), guard=gd)),
-                      ((h1r, xf.w_q3f, q3buf), dict(ln=(1, L["lnst1"], xf.c_q3, xf.d_q3, LN_EPS), guard=gd)))
+            shared = self._shared_back      # cfg_shared_head, first transformer: ONE query tensor for the three CFG samples
+            if shared:
+                q2q = q2[:hw].view(1, hw, C).expand(2, hw, C)
+                q3q = q3buf[:hw].view(1, hw, C).expand(2, hw, C)
+                kt3, vtt3, a2o, a3o = kt3[::2], vtt3[::2], a2v[::2], a3v[:2]       # text rows (uncond, text) -> samples 0 and 2
             else:
-                _pair(((L["ln"], xf.w_q2, q2), dict(workspace=ws)), ((L["ln4"], xf.w_q3, q3buf), dict(workspace=wp)))
+                q2q, q3q, a2o, a3o = q2.view(B, hw, C), q3buf.view(B, hw, C), a2v, a3v
             # text + image attention as one launch when the image attention is one fp16 launch itself (else the text attention runs
             # beside the context projections on the side stream)
-            paired = ATTN_PAIR and self.attn3_share is not None and not self.ctx_short and not (self.fp8_attention and C == heads * 40)
+            paired = (ATTN_PAIR and self.attn3_share is not None and not self.ctx_short and not shared
+                      and not (self.fp8_attention and C == heads * 40))
             forked = False if paired else self._fork()
             if paired:
                 pass
             elif forked:
                 with torch.cuda.stream(self.side):
-                    ops.attention(q2.view(B, hw, C), kt3, vtt3, a2v, heads, scale, nk=S)
+                    ops.attention(q2q, kt3, vtt3, a2o, heads, scale, nk=S)
             else:
-                ops.attention(q2.view(B, hw, C), kt3, vtt3, a2v, heads, scale, nk=S)
+                ops.attention(q2q, kt3, vtt3, a2o, heads, scale, nk=S)
             ctx = self.ctx[xf.spec.feature_key]
             ns, rows = self.ctx_short, self.ctx_rows
             nk = self.R * hw
@@ -749,24 +811,23 @@ class UNetEngine:
             short = None
             if ns:
                 short = (ki[: ns * hw].view(ns, hw, C), vti[:, : ns * hw].unflatten(1, (ns, hw)).permute(1, 0, 2))
-            q3 = q3buf.view(B, hw, C)
+            q3 = q3q
             if paired:
-                ops.attention_pair((q3, ki3, vti3, a3v, None), (q2.view(B, hw, C), kt3, vtt3, a2v, S), heads, scale)
+                ops.attention_pair((q3, ki3, vti3, a3v, None), (q2q, kt3, vtt3, a2v, S), heads, scale)
             elif self.attn3_share is not None:    # one launch: batch b reads context row b (b < rows) or b - (B - rows)
-                self._attention(q3, ki3, vti3, a3v, heads, scale, short=short)
+                self._attention(q3, ki3, vti3, a3o, heads, scale, short=short)
             else:
                 for q0, n, c0 in self.attn3_groups:
                     self._attention(q3[q0:q0 + n], ki3[c0:c0 + n], vti3[c0:c0 + n], a3v[q0:q0 + n], heads, scale)
             if forked:
                 self._join()
+            if shared:      # sample 1 = (uncond text, frames): its text attention is sample 0's, its image attention sample 2 shares
+                ops.copy_rows(a2v[1:2], a2v[0:1])
+                ops.copy_rows(a3v[2:3], a3v[1:2])
             h3 = L["h3"]
             ops.gemm(att23, xf.w_o23, h3, bias=xf.b_o23, res1=h1, res2=h1, workspace=ws,  # (a2 + h) + (a3 + h)
                      **({} if ff1 else prod(h3, L["ln"], L["lnst3"])))
         else:
-            if fold:
-                ops.gemm(h1r, xf.w_q2f, L["q"], ln=(1, L["lnst1"], xf.c_q2, xf.d_q2, LN_EPS), guard=gd)
-            else:
-                ops.gemm(L["ln"], xf.w_q2, L["q"], workspace=ws)
             ops.attention(L["q"].view(B, hw, C), kt3, vtt3, att.view(B, hw, C), heads, scale, nk=S)
             h3 = L["h2"]
             ops.gemm(att, xf.w_o2, h3, bias=xf.b_o2, res1=h1, workspace=ws, **({} if ff1 else prod(h3, L["ln"], L["lnst3"])))   # :277,295
@@ -845,12 +906,38 @@ class UNetEngine:
             ops.lookup_rows(self.t_in, self.time_table[0], self.time_table[1], self.tproj)
         else:
             self._time_chain(self.t_in, self.temb0, self.temb1, self.temb2, self.tproj)
-        # --- conv_in :411
-        ops.conv_in(self.x_in, self.w_conv_in, self.b_conv_in, self._img(skips[0], 0))
-        h, lvl, si = skips[0], 0, 1
+        shared = self.cfg_shared_head and consume
+        if shared:
+            # CFG main pass of one story frame: the three samples are ONE computation up to the first cross-attention — conv_in :411,
+            # the first ResnetBlock2D and the first transformer's front half run on sample 0 only, their results are copied to the
+            # other two, and the cross-attentions of that transformer run once per DISTINCT (query, context) pair
+            blk0 = arch.down[0]
+            r0, xf0 = self.resnets[blk0.resnets[0].prefix], self.xfs[blk0.attns[0].prefix]
+            saved = self._enter_head(1)
+            try:
+                sk0 = skips[0][: self.hw[0]]
+                ops.conv_in(self.x_in[:1], self.w_conv_in, self.b_conv_in, self._img(sk0, 0))
+                self._resnet(r0, sk0, self.lv[0]["r"], 0, defer_out=True)
+                self._transformer(xf0, self.lv[0]["r"], None, 0, text, None, True, phase="front", **tk)
+            finally:
+                self._leave_head(saved)
+            for t2d in (skips[0], self.lv[0]["r"], self.lv[0]["h1"]):      # skip tensor, proj_out's residual, the attentions' residual
+                self._spread(t2d, 1, 2)
+            self._shared_back = True
+            try:
+                self._transformer(xf0, self.lv[0]["r"], skips[1], 0, text, None, True, phase="back", **tk)
+            finally:
+                self._shared_back = False
+            h, lvl, si = skips[1], 0, 2
+        else:
+            # --- conv_in :411
+            ops.conv_in(self.x_in, self.w_conv_in, self.b_conv_in, self._img(skips[0], 0))
+            h, lvl, si = skips[0], 0, 1
         # --- down :417-433 — every layer output is a skip tensor, so it is written straight into its skip buffer
-        for blk in arch.down:
+        for bi, blk in enumerate(arch.down):
             for j, r in enumerate(blk.resnets):
+                if shared and bi == 0 and j == 0:
+                    continue                  # done above
                 xf, out = blk.attns[j], skips[si]
                 if xf is None:
                     self._resnet(self.resnets[r.prefix], h, out, lvl)

@@ -67,7 +67,8 @@ class StoryGenSampler:
                  schedule: Optional[DDIMSchedule] = None, use_graph: bool = True, dedup: bool = True,
                  weights: Optional[EngineWeights] = None, overlap: bool = True, ref_ahead: int = 1,
                  split_graphs: bool = False, stream_priority: bool = False, fp8_attention: bool = False,
-                 side_streams: str = "auto", short_rows: bool = True, time_tables: bool = True):
+                 side_streams: str = "auto", short_rows: bool = True, time_tables: bool = True, shared_head: bool = True,
+                 ref_cus: int = 0, ref_cu_layout: str = "first", ref_eager: bool = False):
         if n_ref < 1:
             raise ValueError("StoryGen's loop needs at least one prior frame")
         if ref_ahead < 1 or (ref_ahead > 1 and not overlap):
@@ -78,7 +79,17 @@ class StoryGenSampler:
         # streams.  Only then can the two halves run at different queue priorities (stream_priority: main pass high — it is
         # the step's critical path — reference pass as background filler).  Measured: separately launched graphs do not
         # overlap on this runtime, so it is an A/B switch only.
-        self.split = bool(split_graphs)
+        # EXPERIMENT (measured, not adopted: DESIGN.md 5.2e).  ref_cus = n > 0 (implies the split schedule): the batched reference pass
+        # runs, one group ahead, on a stream whose hardware queue may only use n of the chip's CUs (hipExtStreamCreateWithCUMask), so
+        # that it fills the CUs the latency-bound main passes leave idle instead of competing with them for all of them; the G main
+        # passes of a group stay hipGraphs on the caller's stream.  ref_eager: the reference pass's kernels are launched one by one
+        # from the host instead of as a graph replayed on that stream.  ref_cu_layout: which bits of the mask ("first" n, or "spread").
+        self.ref_cus = int(ref_cus)
+        self.ref_eager = bool(ref_eager)
+        if ref_cu_layout not in ("first", "spread"):
+            raise ValueError("ref_cu_layout must be 'first' or 'spread'")
+        self.ref_cu_layout = ref_cu_layout
+        self.split = bool(split_graphs) or self.ref_cus > 0 or self.ref_eager
         if self.split and not (use_graph and overlap):
             raise ValueError("split_graphs needs use_graph=True and overlap=True")
         # group: ref_ahead = G > 1 as ONE graph per group of G steps (batched reference pass of the next group forked beside
@@ -97,6 +108,10 @@ class StoryGenSampler:
         # time-embedding chain tabulated per distinct timestep at prepare() (UNetEngine.build_time_table); False = recomputed by
         # every UNet call as written (A/B switch: bench.py --no-time-tables)
         self.time_tables = bool(time_tables)
+        # the three CFG samples of the main pass are the same latent at the same timestep (pipeline.py:448-453): everything up to the
+        # first cross-attention is computed once (UNetEngine cfg_shared_head; one story frame per GPU, dedup on).  False = batch 3
+        # throughout, as written (A/B switch: bench.py --no-shared-head)
+        self.shared_head = bool(shared_head)
         self.arch, self.dev = arch, torch.device(device)
         self.N, self.R, self.h, self.w, self.S = n_samples, n_ref, height, width, seq_len
         self.B = 3 * n_samples
@@ -206,15 +221,18 @@ class StoryGenSampler:
         units = units * G                     # unit g*U0 + u = sample u of the g-th step of a group
         self.units, self.U = units, len(units)
         kw = dict(weights=self.weights, fp8_attention=self.fp8_attention)
+        first = self.arch.down[0]
+        head = (self.shared_head and self.dedup and self.N == 1 and not self.fp8_attention
+                and bool(first.attns) and first.attns[0] is not None)
         self.main = UNetEngine(self.arch, None, self.dev, self.B, self.h, self.w, self.R, self.S, ctx_rows=rows,
-                               attn3_groups=groups, ctx_short=short, **kw)
+                               attn3_groups=groups, ctx_short=short, cfg_shared_head=head, **kw)
         self.ref = UNetEngine(self.arch, None, self.dev, self.U, self.h, self.w, 0, self.S, **kw)
         # sample u of one step's reference batch IS context slot u (_plan) when the plan alone is a bijection onto the slots
         one_step_direct = HarvestPlan(self.main.ctx, hops, short=short, slots_per_row=self.R, direct=True).is_direct(self.U0, self.R)
         # context sets: the main pass of step k reads set k%2 (only one set when the reference pass is not run ahead); G > 1: set =
         # step mod 2G.  Group schedule: the G sets of a group parity are consecutive slices of ONE buffer per feature key (and of
         # one K / V^T buffer), in the order of the batched reference pass's samples — that pass then writes them in place.
-        self.group_direct = self.group and one_step_direct
+        self.group_direct = self.G > 1 and self.ahead and one_step_direct
         n_sets = 2 * G if self.ahead else 1
         if self.group_direct:
             self.ctx_base, self.kv_base, self.ctx_sets, self.kv_sets = [], [], [], []
@@ -266,7 +284,8 @@ class StoryGenSampler:
         self.g_ref, self.g_main = [], []       # split graphs: one graph per group parity / per context set
         self.main_stream = None
         if self.split:
-            self.ref_stream = torch.cuda.Stream(device=self.dev)
+            self.ref_stream = (cu_masked_stream(self.dev, self.ref_cus, self.ref_cu_layout) if self.ref_cus
+                               else torch.cuda.Stream(device=self.dev))
             if self.stream_priority:
                 self.main_stream = torch.cuda.Stream(device=self.dev, priority=-1)
             self.ev_ref = [torch.cuda.Event(), torch.cuda.Event()]      # "reference pass of a group of this parity is done"
@@ -412,7 +431,7 @@ class StoryGenSampler:
             # separate graphs, overlapped at replay time by launching them on two streams (step()): the batched reference
             # pass of a group into context sets [p*G, (p+1)*G), and the main pass reading context set s
             self.g_ref, self.g_main = [], []
-            for p in (0, 1):
+            for p in ((0, 1) if not self.ref_eager else ()):        # (ref_eager: the reference pass is launched kernel by kernel, never captured)
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
                     self._ref_pass(first_ctx_set_of_group(p, self.G))
@@ -498,7 +517,10 @@ class StoryGenSampler:
             with torch.cuda.stream(self.ref_stream):
                 par[:U].copy_(row[:U], non_blocking=True)                                 # reference timesteps
                 par[U + B:3 * U + B].copy_(row[U + B:3 * U + B], non_blocking=True)       # add_noise coefficients
-                self.g_ref[first_ctx_set_of_group(j + 1, G) // G].replay()
+                if self.ref_eager:
+                    self._ref_pass(first_ctx_set_of_group(j + 1, G))                      # kernel by kernel, on the (CU-masked) stream
+                else:
+                    self.g_ref[first_ctx_set_of_group(j + 1, G) // G].replay()
                 self.ev_ref[(j + 1) % 2].record(self.ref_stream)
             cur.wait_event(self.ev_ref[j % 2])
         with torch.cuda.stream(cur):
@@ -531,6 +553,26 @@ class StoryGenSampler:
         """(reference-pass samples, main-pass samples) actually computed per step — for FLOP accounting (with ref_ahead
         = G the reference engine runs G steps' samples once per G steps)."""
         return self.U0, self.B
+
+
+def cu_masked_stream(device, n_cus: int, layout: str = "first"):
+    """A HIP stream whose hardware queue may only use n_cus compute units (hipExtStreamCreateWithCUMask: bit i of the mask = CU i),
+    wrapped as a torch stream.  layout "first": CUs 0 .. n-1; "spread": n CUs spaced evenly over the chip's CU numbering."""
+    import ctypes
+    dev = torch.device(device)
+    total = torch.cuda.get_device_properties(dev).multi_processor_count
+    n = max(1, min(int(n_cus), total))
+    bits = range(n) if layout == "first" else sorted({(i * total) // n for i in range(n)})
+    words = [0] * ((total + 31) // 32)
+    for b in bits:
+        words[b // 32] |= 1 << (b % 32)
+    hip = ctypes.CDLL("libamdhip64.so")
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), ctypes.c_uint32(len(words)), (ctypes.c_uint32 * len(words))(*words))
+    if rc != 0 or not handle.value:
+        raise RuntimeError(f"hipExtStreamCreateWithCUMask failed ({rc})")
+    return torch.cuda.ExternalStream(handle.value, device=dev)
 
 
 def ctx_set_of_step(k: int, G: int) -> int:

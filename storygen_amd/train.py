@@ -85,8 +85,13 @@ class UNetTrainer:
         self.wts = weights if weights is not None else EngineWeights(arch, sd, device)
         if ref_engine is None and n_ref == 0:
             ref_engine = object()                                                     # stage 1: no reference pass ever runs
-        self.ref = ref_engine if ref_engine is not None else UNetEngine(arch, None, device, batch, height, width, n_ref, seq_len,
-                                                                        weights=self.wts)
+        # Default (round 5): the reference passes of a step are ONE batched UNet call per number of frames used — batch B * n_used,
+        # samples ordered like the context buffer (row b, frame slot j) so that the features are written in place, and stopped after
+        # the last harvest point (the epsilon a reference pass would go on to produce is discarded, :309-314) — the engine the
+        # sampler's reference pass uses.  An injected ref_engine keeps the one-call-per-frame protocol (set_inputs / forward(harvest_slot=)).
+        self.ref = ref_engine
+        self._ref_batched: Dict[int, tuple] = {}                                      # n_used -> (engine, context buffers, harvest plan)
+        self.seq_len = seq_len
         self.groups, self.eps = self.cfg["norm_num_groups"], self.cfg["norm_eps"]
         g16 = lambda k: sd[k].detach().to(self.dev, F16).contiguous()             # noqa: E731
         self.resnets = {r.prefix: ResnetBlockTrain(sd, r.prefix, self.groups, self.eps, device) for r in arch.resnets}
@@ -123,6 +128,21 @@ class UNetTrainer:
         self.scale_growth_interval = 2000
         self._good_steps = 0
         self._alphas_dev = self.schedule.alphas_cumprod.to(self.dev, F32)
+
+    def _batched_ref_engine(self, n_used: int):
+        """(engine, context buffers, harvest plan) of the batched reference pass over n_used frames: built on first use, kept (a
+        captured hipGraph holds the buffers' addresses)."""
+        st = self._ref_batched.get(n_used)
+        if st is None:
+            from .arch import feature_shapes
+            from .engine import HarvestPlan
+            B = self.B
+            eng = UNetEngine(self.arch, None, self.dev, B * n_used, self.H, self.W, 0, self.seq_len, weights=self.wts)
+            ctx = {k: torch.empty(B, n_used * n, c, dtype=F16, device=self.dev) for k, (n, c) in feature_shapes(self.arch, self.H, self.W).items()}
+            plan = HarvestPlan(ctx, [(b * n_used, 1, b, 0, n_used) for b in range(B)], slots_per_row=n_used, direct=True)
+            assert plan.is_direct(B * n_used, n_used)
+            st = self._ref_batched[n_used] = (eng, ctx, plan)
+        return st
 
     # ------------------------------------------------------------------------------------------------ pieces
     def _add_noise(self, x: torch.Tensor, noise: torch.Tensor, t: torch.Tensor) -> torch.Tensor:
@@ -185,15 +205,26 @@ class UNetTrainer:
         t = inp["timesteps"]
         ref_t = torch.div(t, 10, rounding_mode="floor")                              # (timesteps / 10).long(), :297-300
         # ---- reference passes: features of the frames used, harvested into context slots 0..len(use_refs)-1
-        for slot, i in enumerate(use_refs):                                          # :309-314
-            ti = ref_t * (3 - i) if self.ref_levels == "stage2" else ref_t
-            self.ref.set_inputs(self._add_noise(inp["ref_latents"][i], inp["ref_noise"], ti), ti.float(), inp["prev_text"][i])
-            self.ref.forward(harvest_slot=slot)
         n_used = len(use_refs)
         ctx16 = {} if n_used else None                                               # no frame: image_hidden_states=None (stage 1)
-        for key, buf in (self.ref.ctx.items() if n_used else ()):                    # [B, R*hw_k, C] -> the used slots, flattened
-            n = buf.shape[1] // self.R
-            ctx16[key] = buf[:, : n_used * n].reshape(B * n_used * n, buf.shape[2]).contiguous()
+        levels = [ref_t * (3 - i) if self.ref_levels == "stage2" else ref_t for i in use_refs]                    # :309-314
+        if self.ref is None and n_used:
+            eng, ctx, plan = self._batched_ref_engine(n_used)
+            xs = [self._add_noise(inp["ref_latents"][i], inp["ref_noise"], ti) for i, ti in zip(use_refs, levels)]
+            # sample u = b * n_used + slot: the order of the context buffer's frame slots
+            eng.x_in.copy_(torch.stack(xs, dim=1).flatten(0, 1))
+            eng.t_in.copy_(torch.stack([ti.float() for ti in levels], dim=1).flatten())
+            eng.text_in.copy_(torch.stack([inp["prev_text"][i] for i in use_refs], dim=1).flatten(0, 1))
+            eng.forward(harvest=plan, harvest_only=True)
+            for key, buf in ctx.items():                                             # [B, n_used*hw_k, C], written in place
+                ctx16[key] = buf.view(-1, buf.shape[2])
+        elif n_used:
+            for slot, (i, ti) in enumerate(zip(use_refs, levels)):
+                self.ref.set_inputs(self._add_noise(inp["ref_latents"][i], inp["ref_noise"], ti), ti.float(), inp["prev_text"][i])
+                self.ref.forward(harvest_slot=slot)
+            for key, buf in self.ref.ctx.items():                                    # [B, R*hw_k, C] -> the used slots, flattened
+                n = buf.shape[1] // self.R
+                ctx16[key] = buf[:, : n_used * n].reshape(B * n_used * n, buf.shape[2]).contiguous()
         text16 = inp["text"].reshape(B * inp["text"].shape[1], -1)
         noisy = self._add_noise(inp["latents"], inp["noise"], t).contiguous()        # :303
         pred = self.forward_main(noisy, t, text16, ctx16)

@@ -12,7 +12,7 @@ C = 4
 
 class StubEngine:
     def __init__(self, arch, state_dict, device, batch, height, width, n_ref=0, seq_len=77, weights=None, ctx_rows=None,
-                 attn3_groups=None, fp8_attention=False, ctx_short=0, **_):
+                 attn3_groups=None, fp8_attention=False, ctx_short=0, cfg_shared_head=False, **_):
         f32 = torch.float32
         self.B, self.R, self.hw = batch, n_ref, 2
         self.x_in = torch.zeros(batch, 4, height, width, dtype=f32)

@@ -76,7 +76,8 @@ def test_layernorm_fold_guard_through_a_transformer_block(gpu):
     is outside the fold's range — UNetEngine.check_ln_guard raises instead of returning an epsilon whose LayerNorm inputs were rounded
     at 30 x 2^-11 — and the same pass with engine.LN_FOLD = False (LayerNorm launches on the fp32 stream, as the reference computes
     them, model/attention.py:250,268,283,298) raises nothing and stays within the one-pass bar of the oracle.  |x| >= 65504 in the
-    stream: the fp16 copy saturates, the pass stays finite, and the guard names the range."""
+    stream: the fp16 copy saturates and the guard names the range (the pass itself is lost either way: every fp16 operand derived
+    from such a stream overflows)."""
     import __graft_entry__ as ge
     from oracle import storygen_oracle as O
     from storygen_amd import engine as E
@@ -96,17 +97,13 @@ def test_layernorm_fold_guard_through_a_transformer_block(gpu):
     for off, flag in ((30.0 * sigma, "sigma"), (1.0e5, "65504")):
         sd2 = dict(sd)
         sd2[key] = sd[key].float() + off
-        with torch.no_grad():
-            want, _ = O.unet_forward(sd2, cfg, x, t, e, None)
         errs = {}
-        for fold in (True, False):
+        for fold in ((True, False) if flag == "sigma" else (True,)):
             E.LN_FOLD = fold
             try:
                 eng2 = E.UNetEngine(arch, sd2, gpu, 1, 16, 16, 0)
                 eng2.set_inputs(x, t, e)
                 eps = eng2.forward().float().cpu()
-                assert torch.isfinite(eps).all(), "saturation keeps the pass finite"
-                errs[fold] = rel_l2(eps, want)
                 if fold:
                     with pytest.raises(FloatingPointError, match=flag):
                         eng2.check_ln_guard()
@@ -115,9 +112,17 @@ def test_layernorm_fold_guard_through_a_transformer_block(gpu):
                     assert eng2.check_ln_guard() == 0
             finally:
                 E.LN_FOLD = True
-        print(f"stream offset {off:.3g} (sigma {sigma:.3g}): eps rel-L2 vs oracle, folded {errs[True]:.2e} / LayerNorm launches {errs[False]:.2e}")
+            if flag == "sigma":
+                if not errs:
+                    with torch.no_grad():
+                        want, _ = O.unet_forward(sd2, cfg, x, t, e, None)
+                assert torch.isfinite(eps).all()
+                errs[fold] = rel_l2(eps, want)
         if flag == "sigma":
+            print(f"stream offset {off:.3g} (sigma {sigma:.3g}): eps rel-L2 vs oracle, folded {errs[True]:.2e} / LayerNorm launches {errs[False]:.2e}")
             assert errs[False] <= TOL_EPS, errs
+        # (a stream at 1e5 overflows every fp16 tensor derived from it — h4, q, k — with or without the fold: the engine's fp16 operands
+        # assume |stream| < 65504 throughout, and the guard is where that assumption is checked)
 
 
 def _probe(t, summary):
@@ -480,6 +485,44 @@ def test_ref_ahead_batches_reference_passes_of_G_steps(gpu, sd15, stage, G, spli
     # the fp16 roundings), each within TOL_LATENT of the fp32 truth — the default schedule's distance to the oracle is
     # asserted by the tests above; this one bounds the distance between the two schedules
     assert max(errs) <= 2 * TOL_LATENT, errs
+
+
+@pytest.mark.parametrize("stage", ["multi-image-condition", "auto-regressive"])
+def test_shared_cfg_head_is_the_same_main_pass(gpu, sd15, stage):
+    """cfg_shared_head (default for one story frame per GPU): the three CFG samples of the main pass are the same latent at the same
+    timestep (pipeline.py:448-453), so conv_in, the first ResnetBlock2D and the first transformer up to its query projections run once,
+    its text attention for (uncond, text) and its image attention for (zero-image, frames) only.  Same arithmetic on the same values
+    as the batch-3 pass (only the batch-dependent tile / split-K plans of those few layers differ), so the trajectories must agree far
+    inside the latent bar — and the shared pass must execute fewer FLOPs."""
+    from storygen_amd import ops
+    from storygen_amd.engine import EngineWeights
+    from storygen_amd.sampler import StoryGenSampler
+    from storygen_amd.synth import synthetic_inputs
+    arch, sd = sd15
+    inputs = synthetic_inputs(1, 2, 32, 32, 29, arch.config["cross_attention_dim"])
+    wts = EngineWeights(arch, sd, gpu)
+    traces, flops = [], []
+    for head in (False, True):
+        smp = StoryGenSampler(arch, None, gpu, 1, 32, 32, 2, use_graph=True, weights=wts, shared_head=head)
+        smp.prepare(inputs, 50, stage, 7.5, 3.5)
+        assert smp.main.cfg_shared_head == head
+        tr = []
+        smp.run(max_steps=3, trace=tr)
+        torch.cuda.synchronize()
+        traces.append([t.cpu() for t in tr])
+        sink = []
+        ops.PROFILE_SINK = sink
+        try:
+            smp._main_pass(0)
+            torch.cuda.synchronize()
+        finally:
+            ops.PROFILE_SINK = None
+        flops.append(sum(f for _, f, _, _, _ in sink))
+        smp.check_guards()
+    errs = [rel_l2(a, b) for a, b in zip(traces[1], traces[0])]
+    print(stage, "shared head vs batch 3, per step:", [f"{e:.1e}" for e in errs], f"main-pass GFLOP {flops[0] / 1e9:.1f} -> {flops[1] / 1e9:.1f}")
+    assert max(errs) <= 0.5 * TOL_LATENT, errs
+    assert flops[1] < 0.97 * flops[0]
 
 
 def test_group_schedule_eager_equals_its_graph(gpu, sd15):

@@ -28,15 +28,21 @@ TILES = [(256, 128), (128, 128), (256, 64), (128, 64), (64, 128), (64, 64)]
 F16, F32 = torch.float16, torch.float32
 
 
+G = int(sys.argv[sys.argv.index("--ref-ahead") + 1]) if "--ref-ahead" in sys.argv else 5      # bench.py's default group size
+
+
 def census():
+    """Every GEMM / convolution signature of one unit of the schedule bench.py runs: a group of G steps = the batched reference pass
+    of G steps + G main passes (G = 1: one step)."""
     arch = build_arch(SD15_CONFIG)
     sd = synthetic_state_dict(arch, 0)
     inputs = synthetic_inputs(1, 3, 64, 64, 0, 768)
-    smp = StoryGenSampler(arch, sd, dev, 1, 64, 64, 3, use_graph=False)
+    smp = StoryGenSampler(arch, sd, dev, 1, 64, 64, 3, use_graph=False, ref_ahead=G)
     smp.prepare(inputs, 50, "multi-image-condition", 7.5, 3.5)
     sink = []
     ops.TUNE_SINK = sink
-    smp.step()
+    for _ in range(G):
+        smp.step()
     torch.cuda.synchronize()
     ops.TUNE_SINK = None
     seen = {}
@@ -115,7 +121,7 @@ def make_call(rec, ws):
 def main():
     t0 = time.time()
     shapes = census()
-    print(f"{len(shapes)} distinct gemm/conv signatures ({sum(e['count'] for e in shapes.values())} launches/step), census {time.time() - t0:.0f}s", flush=True)
+    print(f"{len(shapes)} distinct gemm/conv signatures ({sum(e['count'] for e in shapes.values())} launches per group of {G} steps), census {time.time() - t0:.0f}s", flush=True)
     ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
     table, log = {}, []
     saved = 0.0
@@ -141,13 +147,20 @@ def main():
         if best_cfg is not None and best < 0.97 * base:
             table[sig] = list(best_cfg)
             saved += gain
-    out = dict(device="MI355X gfx950", made_by="tools/tune_tiles.py", workload="BASELINE config 2 (512x512, R=3, N=1)",
-               est_saving_us_per_step=round(saved, 1), tiles=table)
     path = os.path.join(ROOT, "storygen_amd", "tuning", "mi355x_tiles.json")
+    kept = 0
+    if os.path.exists(path) and "--fresh" not in sys.argv:      # shapes this census did not meet (other group sizes) keep their entries
+        with open(path) as f:
+            for sig, cfg in json.load(f).get("tiles", {}).items():
+                if sig not in shapes:
+                    table[sig] = cfg
+                    kept += 1
+    out = dict(device="MI355X gfx950", made_by="tools/tune_tiles.py", workload=f"BASELINE config 2 (512x512, R=3, N=1), ref_ahead {G}",
+               est_saving_us_per_step=round(saved / G, 1), entries_kept_from_previous_table=kept, tiles=table)
     os.makedirs(os.path.dirname(path), exist_ok=True)
     with open(path, "w") as f:
         json.dump(out, f, indent=1, sort_keys=True)
-    print(f"wrote {path}: {len(table)} overrides, ~{saved:.0f} us/step (sequential) in {time.time() - t0:.0f}s")
+    print(f"wrote {path}: {len(table)} overrides ({kept} kept from the previous table), ~{saved / G:.0f} us/step (sequential) in {time.time() - t0:.0f}s")
     gdir = os.path.join(ROOT, "gpurun_out")
     if os.path.isdir(gdir):
         with open(os.path.join(gdir, "mi355x_tiles.json"), "w") as f:
