@@ -39,6 +39,7 @@
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
+#include <vector>
 
 namespace {
 
@@ -89,11 +90,31 @@ struct MmaParams {
     float* ln_out;
     unsigned* ln_guard;            // sticky flags of the fold's two assumptions (sg_gemm_desc.ln_guard), or nullptr
     unsigned long long* prof;   // SG_BUILD_EXPERIMENTS (sg_debug_*_anatomy): per-wave cycle totals of the mainloop phases
-    int n_major;   // tile order: 1 = consecutive ids walk M first (tiles sharing a weight panel stay on one XCD / L2)
-    FastDiv fd_splits, fd_tiles_m, fd_tiles_n, fd_hw, fd_wo, fd_rpb, fd_cpt;
+    // tile order (tile_of_id): consecutive logical ids walk group_m row tiles, then move one column tile on; after all column tiles the
+    // next group of row tiles.  group_m >= tiles_m: M first throughout (tiles sharing a weight panel are neighbours); group_m = 1: N first.
+    int group_m;
+    FastDiv fd_splits, fd_group_w /* group_m * tiles_n */, fd_group_m, fd_hw, fd_wo, fd_rpb, fd_cpt;
 };
 
 __device__ __forceinline__ int lds_off(int row, int chunk) { return row * 128 + ((chunk ^ ((row >> 1) & 7)) << 4); }
+
+// Grouped tile order (a bijection of [0, tiles_m * tiles_n) onto the tile grid).  The ~32 workgroups that are resident on an XCD at one
+// time are consecutive logical ids (xcd_remap) and move through K roughly in step, so what that XCD's L2 has to fetch is one operand
+// panel per DISTINCT row tile and per DISTINCT column tile among them: gm row tiles x 32 / gm column tiles.  Walking all of M first
+// (round 1-4 when the weights were the larger operand) puts up to 32 different activation panels and one or two weight panels into a
+// wave of workgroups — for M 5120 x N 10240 x K 1280 that re-fetched the 13 MB of activations for every weight panel, 883 MB per launch
+// against 92 MB algorithmic (profiles/traffic.json, round-5 mid build).  gm is chosen by plan_mma to minimise the bytes of one wave.
+__host__ __device__ __forceinline__ void tile_of_id(unsigned lid, int tiles_m, int tiles_n, int gm, FastDiv fd_w, FastDiv fd_gm,
+                                                    unsigned& tm, unsigned& tn) {
+    const unsigned width = (unsigned)gm * (unsigned)tiles_n;
+    const unsigned group = fd_div(lid, fd_w), r = lid - group * width;
+    const unsigned first = group * (unsigned)gm;
+    const unsigned gsize = min((unsigned)tiles_m - first, (unsigned)gm);
+    // the last group of row tiles may be smaller than gm: a plain division there (once per workgroup)
+    const unsigned q = gsize == (unsigned)gm ? fd_div(r, fd_gm) : r / gsize;
+    tn = q;
+    tm = first + (r - q * gsize);
+}
 
 // logical block id -> (m0, n0, K slice z).  logical id = tile * splits + slice: the K slices of a tile are consecutive ids
 // (one XCD, see xcd_remap)
@@ -102,8 +123,7 @@ __device__ __forceinline__ void decode_block(const MmaParams& p, int BM, int BN,
     const unsigned lid = fd_div(lid2, p.fd_splits);
     z = (int)(lid2 - lid * p.splits);
     unsigned tm, tn;
-    if (p.n_major) { tn = fd_div(lid, p.fd_tiles_m); tm = lid - tn * p.tiles_m; }
-    else { tm = fd_div(lid, p.fd_tiles_n); tn = lid - tm * p.tiles_n; }
+    tile_of_id(lid, p.tiles_m, p.tiles_n, p.group_m, p.fd_group_w, p.fd_group_m, tm, tn);
     m0 = (int)tm * BM;
     n0 = (int)tn * BN;
 }
@@ -681,14 +701,34 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     }
     // `sel` < 0: every piece; otherwise only the pieces whose running index (A pieces first, then W) is sel modulo 4 — the refill of a
     // slab spread over its four k-steps (SG_PIPE_SPREAD builds)
-    auto issue_w = [&](int kt, int stage, int sel = -1) __attribute__((always_inline)) {
+    // K order of the CONVOLUTION (round 5): slab kt = (channel block kt / 9, tap kt % 9) — the nine taps of one 64-channel block are
+    // consecutive slabs.  They re-read the same input pixels (shifted by one): with the taps innermost that working set is one channel
+    // block of the tile's pixels per workgroup (~40 KB; ~1.2 MB for the workgroups of an XCD) and stays in the XCD's 4 MB L2, where the
+    // former order (tap kt / cpt outermost, all channel blocks inside) walked the whole input panel between two taps and re-fetched it
+    // from the fabric nine times (profiles/traffic.json of the round-5 mid build: 1 053 MB per launch against 79 MB algorithmic for
+    // the batch-20 16x16 convolutions).  The weights are [Cout][ky][kx][Cin]: slab kt starts at element (kt % 9) * Cin + (kt / 9) * 64
+    // of a row — either order is a plain offset, nothing is repacked.  -DSG_CONV_TAP_MAJOR rebuilds the former order (A/B builds).
+    // GEMM: slab kt starts at element kt * 64 of both operands.
+    auto w_koff = [&](int kt) __attribute__((always_inline)) -> long {
+        if constexpr (CONV) {
+#ifdef SG_CONV_TAP_MAJOR
+            return (long)kt * BK;
+#else
+            const int cc = (kt * 7282) >> 16, tap = kt - 9 * cc;        // kt / 9 for kt < 3 000 (validated on the host)
+            return (long)tap * p.cpt * BK + (long)cc * BK;
+#endif
+        } else {
+            return (long)kt * BK;
+        }
+    };
+    auto issue_w = [&](long koff, int stage, int sel = -1) __attribute__((always_inline)) {
         char* sB = smem + stage * STAGE + A_BYTES + wave * 1024;
-        const f16* Wt = p.W + kt * BK;
+        const f16* Wt = p.W + koff;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
             if (sel < 0 || ((A_IT + i) & 3) == sel) glds16(Wt + w_off[i], sB + i * ISTR);
     };
-    if (nt > 0) issue_w(kt0, 0);
+    if (nt > 0) issue_w(w_koff(kt0), 0);
 
     unsigned a_off[A_IT];                       // offset of the row (GEMM) / of tap (0, 0) (conv)
     unsigned a_par[A_IT];                       // conv with upsampling: parity bits of (oy - 1, ox - 1)
@@ -719,12 +759,17 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
 
     // source of slab kt's A operand: the wave-uniform base pointer (and, with nearest-2x upsampling, the tap), computed ONCE per slab;
     // a_emit then issues the pieces `sel` selects (sel < 0: all; otherwise running piece index == sel modulo 4)
-    struct ABase { const f16* At; int ky, kx; };
+    struct ABase { const f16* At; int ky, kx; long wk; };      // wk = element offset of the slab's weights in a row of W (w_koff)
     auto a_base = [&](int kt) __attribute__((always_inline)) {
         ABase r;
         r.ky = r.kx = 0;
+        r.wk = w_koff(kt);
         if constexpr (CONV) {
+#ifdef SG_CONV_TAP_MAJOR
             const int tap = (int)fd_div((unsigned)kt, p.fd_cpt), cc = kt - tap * p.cpt;
+#else
+            const int cc = (kt * 7282) >> 16, tap = kt - 9 * cc;
+#endif
             const int ky = (tap * 11) >> 5, kx = tap - ky * 3;           // tap / 3 for tap < 9
             r.ky = ky; r.kx = kx;
             r.At = !p.ups ? p.A + ((long)(ky * wp + kx) * p.lda + cc * BK) : p.A + cc * BK;
@@ -761,22 +806,30 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     // The slabs of a block are requested in order (kt0, kt0 + 1, ...): their operand bases come from running counters — channel block,
     // tap column, tap row, element offset — instead of a division and a 64-bit product per slab (≈ 45 -> ≈ 10 scalar instructions in
     // front of every refill; the refill of the 256x128 tile is a burst right behind them)
-    long it_off;
-    int it_cc = 0, it_kx = 0, it_ky = 0;
+    long it_off, it_wk;
+#ifdef SG_CONV_TAP_MAJOR
+    int it_cc = 0;
+#endif
+    int it_kx = 0, it_ky = 0;
     {
         const ABase b0 = a_base(kt0);
         it_off = b0.At - p.A;
+        it_wk = b0.wk;
         if constexpr (CONV) {
+#ifdef SG_CONV_TAP_MAJOR
             const int tap = (int)fd_div((unsigned)kt0, p.fd_cpt);
-            it_cc = kt0 - tap * p.cpt; it_ky = b0.ky; it_kx = b0.kx;
+            it_cc = kt0 - tap * p.cpt;
+#endif
+            it_ky = b0.ky; it_kx = b0.kx;
         }
     }
+#ifdef SG_CONV_TAP_MAJOR
     const long it_dx = CONV ? (p.ups ? 0 : (long)p.lda) - (long)p.cpt * BK : 0;       // next tap column: one pixel right, channel block 0
     const long it_dy = CONV && !p.ups ? (long)(wp - 3) * p.lda : 0;                    // ... next tap row: from column 3 back to 0, one row down
     auto a_next = [&](int) __attribute__((always_inline)) {
         ABase r;
-        r.At = p.A + it_off; r.ky = it_ky; r.kx = it_kx;
-        it_off += BK;
+        r.At = p.A + it_off; r.ky = it_ky; r.kx = it_kx; r.wk = it_wk;
+        it_off += BK; it_wk += BK;
         if constexpr (CONV) {
             if (++it_cc == p.cpt) {
                 it_cc = 0;
@@ -786,10 +839,38 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         }
         return r;
     };
+#else
+    // taps innermost: one pixel right per slab; after column 2 one row down and back to column 0; after tap 8 back to tap 0 of the
+    // next channel block.  (Nearest-2x upsampling: the pixel offset comes from (ky, kx) in a_emit, only the channel block moves here.)
+    const long it_px = CONV && !p.ups ? (long)p.lda : 0;
+    const long it_dy = CONV && !p.ups ? (long)(wp - 3) * p.lda : 0;
+    const long it_dc = CONV ? (p.ups ? 0 : -3L * wp * p.lda) + BK : 0;
+    const long it_wtap = CONV ? (long)p.cpt * BK : BK, it_wdc = CONV ? BK - 9L * p.cpt * BK : 0;
+    auto a_next = [&](int) __attribute__((always_inline)) {
+        ABase r;
+        r.At = p.A + it_off; r.ky = it_ky; r.kx = it_kx; r.wk = it_wk;
+        it_wk += it_wtap;
+        if constexpr (CONV) {
+            it_off += it_px;
+            if (++it_kx == 3) {
+                it_kx = 0; it_off += it_dy;
+                if (++it_ky == 3) { it_ky = 0; it_off += it_dc; it_wk += it_wdc; }
+            }
+        } else {
+            it_off += BK;
+        }
+        return r;
+    };
 #endif
-    auto issue_a = [&](int kt, int stage) __attribute__((always_inline)) { a_emit(a_next(kt), stage, -1); };
-    if (nt > 0) issue_a(kt0, 0);
-    if (S > 2 && nt > 1) { issue_a(kt0 + 1, 1); issue_w(kt0 + 1, 1); }
+#endif
+    // (A pieces of a slab, then its W pieces: one a_next per slab, in slab order)
+    auto issue_aw = [&](int kt, int stage, bool with_w) __attribute__((always_inline)) {
+        const ABase ab = a_next(kt);
+        a_emit(ab, stage, -1);
+        if (with_w) issue_w(ab.wk, stage);
+    };
+    if (nt > 0) issue_aw(kt0, 0, false);                   // (its weights left first, above)
+    if (S > 2 && nt > 1) issue_aw(kt0 + 1, 1, true);
 
     f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -854,7 +935,7 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         const bool refill = SPREAD && !LAST && it + S - 1 < nt;
         int rst = stage + S - 1;
         if (rst >= S) rst -= S;
-        ABase ab = {nullptr, 0, 0};
+        ABase ab = {nullptr, 0, 0, 0};
         if (refill) ab = a_next(kt0 + it + S - 1);
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
@@ -863,7 +944,7 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
                 if constexpr (!LAST) {
                     if (refill) {
                         a_emit(ab, rst, ks);
-                        issue_w(kt0 + it + S - 1, rst, ks);
+                        issue_w(ab.wk, rst, ks);
                     }
                 } else if (ks == 1) {
                     epi_prefetch(p, m0, n0, wm, wn, lane, EPI_PRE_ARGS);
@@ -875,8 +956,7 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
                 if constexpr (LAST) {
                     epi_prefetch(p, m0, n0, wm, wn, lane, EPI_PRE_ARGS);
                 } else if (it + S - 1 < nt) {
-                    issue_a(kt0 + it + S - 1, rst);
-                    issue_w(kt0 + it + S - 1, rst);
+                    issue_aw(kt0 + it + S - 1, rst, true);
                 }
                 stamp(5);
             }
@@ -1297,10 +1377,35 @@ int plan_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws, 
     // 8x8 latent levels the weights (up to 59 MB per layer) dwarf the activations: walk M first there.
     const double a_bytes = CONV ? 2.0 * p.M * (p.K / 9) * (p.stride == 1 && !p.ups ? 1.0 : (p.ups ? 0.25 : 4.0)) : 2.0 * p.M * p.K;
     const double w_bytes = 2.0 * p.N * p.K;
-    p.n_major = (w_bytes > a_bytes && !g_tune.no_nmajor) ? 1 : 0;
+    // group_m: the number of row tiles a wave of ~32 / splits consecutive tiles spans (tile_of_id).  Bytes that wave asks its L2 for =
+    // gm activation panels + (wave / gm) weight panels; pick the gm in {1, 2, 4, 8, 16, all} with the fewest (ties: the larger gm, i.e.
+    // the former M-first walk).  Development option no_nmajor = 1: N first everywhere (group_m = 1).
+    {
+        const double a_panel = a_bytes / p.tiles_m, w_panel = w_bytes / p.tiles_n;
+        const int wave_tiles = pl.splits >= 32 ? 1 : 32 / pl.splits;
+        int best = 1;
+        double best_bytes = 1e300;
+        const int cands[6] = {1, 2, 4, 8, 16, p.tiles_m};
+        for (int c : cands) {
+            const int gm = c < p.tiles_m ? c : p.tiles_m;
+            const int width = gm * p.tiles_n;
+            int rows, cols;
+            if (width >= wave_tiles) {                     // the wave lies inside one group: gm rows x wave / gm columns
+                rows = gm < wave_tiles ? gm : wave_tiles;
+                cols = (wave_tiles + rows - 1) / rows;
+            } else {                                       // it spans several whole groups: all columns, gm rows per group
+                rows = gm * ((wave_tiles + width - 1) / width);
+                if (rows > p.tiles_m) rows = p.tiles_m;
+                cols = p.tiles_n;
+            }
+            const double bytes = rows * a_panel + cols * w_panel;
+            if (bytes <= best_bytes) { best_bytes = bytes; best = gm; }
+        }
+        p.group_m = g_tune.no_nmajor ? 1 : best;
+    }
     p.fd_splits = make_fastdiv((unsigned)p.splits);
-    p.fd_tiles_m = make_fastdiv((unsigned)p.tiles_m);
-    p.fd_tiles_n = make_fastdiv((unsigned)p.tiles_n);
+    p.fd_group_w = make_fastdiv((unsigned)(p.group_m * p.tiles_n));
+    p.fd_group_m = make_fastdiv((unsigned)p.group_m);
     p.fd_rpb = make_fastdiv((unsigned)(p.rows_per_batch > 0 ? p.rows_per_batch : 1));
     if (CONV) {
         p.fd_hw = make_fastdiv((unsigned)(p.Ho * p.Wo));
@@ -1518,6 +1623,7 @@ extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream)
     SG_REQUIRE((int64_t)d->B * (d->H + 2) * (d->W + 2) * d->ldx < (1ll << 32) && (int64_t)d->Cout * 9 * d->Cin < (1ll << 32),
                "sg_conv3x3: operands larger than 2^32 elements are not supported (32-bit DMA offsets)");
     SG_REQUIRE((int64_t)(d->W + 2) * d->ldx < (1 << 24), "sg_conv3x3: input row pitch must be below 2^24 elements");
+    SG_REQUIRE(9 * (d->Cin / 64) < 3000, "sg_conv3x3: Cin (%d) too large for the slab decode (kt / 9 by multiply-shift, kt < 3000)", d->Cin);
     const int hin = d->H << d->upsample2x, win = d->W << d->upsample2x;
     const int Ho = (hin + 2 - 3) / d->stride + 1, Wo = (win + 2 - 3) / d->stride + 1;
     MmaParams p{};
@@ -1634,6 +1740,22 @@ extern "C" int sg_debug_fastdiv_selftest(void) {
         for (unsigned n = 0; n < 200000; ++n) bad += fd_div(n, f) != n / d;
         bad += fd_div(0xFFFFFFFFu, f) != 0xFFFFFFFFu / d;
     }
+    // the grouped tile order (tile_of_id) is a bijection onto the tile grid for every group size, incl. a smaller last group
+    for (int tiles_m : {1, 2, 3, 5, 8, 20, 33})
+        for (int tiles_n : {1, 3, 10, 80})
+            for (int gm : {1, 2, 4, 7, 8, 16, 64}) {
+                if (gm > tiles_m) gm = tiles_m;
+                const FastDiv fw = make_fastdiv((unsigned)(gm * tiles_n)), fg = make_fastdiv((unsigned)gm);
+                std::vector<char> seen((size_t)tiles_m * tiles_n, 0);
+                for (unsigned lid = 0; lid < (unsigned)(tiles_m * tiles_n); ++lid) {
+                    unsigned tm, tn;
+                    tile_of_id(lid, tiles_m, tiles_n, gm, fw, fg, tm, tn);
+                    if (tm >= (unsigned)tiles_m || tn >= (unsigned)tiles_n || seen[(size_t)tm * tiles_n + tn]) ++bad;
+                    else seen[(size_t)tm * tiles_n + tn] = 1;
+                }
+            }
+    // the convolution's slab decode: kt / 9 by multiply-shift
+    for (int kt = 0; kt < 3000; ++kt) bad += ((kt * 7282) >> 16) != kt / 9;
     return bad;
 }
 
