@@ -375,7 +375,7 @@ def dry_run(args, world: int, rank: int):
         raise SystemExit(f"--ref-ahead {G} must divide --steps {args.steps}")
     warmup_run = -(-args.warmup // G) * G
     sampler = S.StoryGenSampler(arch, None, "cpu", 1, hw, hw, R, S_, use_graph=False, weights=object(), ref_ahead=G, time_tables=False)
-    sampler.prepare(inputs, max(T, args.steps + warmup_run), args.stage, 7.5, 3.5)
+    sampler.prepare(inputs, -(-max(T, args.steps + warmup_run) // G) * G, args.stage, 7.5, 3.5)
     dt = timed_steps(sampler, args.steps, warmup_run, use_dist, None)
     final, _, _ = gather_and_check(sampler, world, None)
     distinct = True
@@ -537,7 +537,9 @@ def main():
                               short_rows=not args.no_short_rows, time_tables=not args.no_time_tables,
                               shared_head=not args.no_shared_head, ref_cus=args.ref_cus, ref_cu_layout=args.ref_cu_layout,
                               ref_eager=args.ref_eager)
-    n_sched = max(T, args.steps + warmup_run)
+    # the schedule holds whole groups: 50 steps (the reference's DDIM table) for G in {1, 2, 5}; any other G (a --steps it must divide)
+    # rounds the table up to the next multiple
+    n_sched = -(-max(T, args.steps + warmup_run) // G) * G
     sampler.prepare(inputs, n_sched, args.stage, 7.5, 3.5)
 
     dt = timed_steps(sampler, args.steps, warmup_run, use_dist, dev)

@@ -605,6 +605,21 @@ def test_bench_launcher_path_world2_gloo_dry_run():
     assert d["config"]["ref_ahead"] == 5 and d["config"]["warmup_run"] == 5
 
 
+@pytest.mark.parametrize("steps,warmup,G", [(3, 1, 3), (7, 2, 1), (8, 3, 4), (10, 3, 5)])
+def test_bench_default_group_size_follows_the_step_count(steps, warmup, G):
+    """`bench.py --steps K --warmup W` for K the driver may pick: the default group size is the largest G <= 5 dividing K, the warm-up is
+    rounded up to whole groups and the schedule to a multiple of G (K = 3 crashed on a 50-step table before the dry run existed)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--dry-run", "--steps", str(steps), "--warmup", str(warmup)],
+                       capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["config"]["ref_ahead"] == G and d["config"]["warmup_run"] == -(-warmup // G) * G and d["steps"] == steps
+
+
 def test_bench_argument_parser_builds():
     """`python bench.py --help` must exit 0: a duplicated add_argument (it happened) would break every driver run before any GPU work."""
     import subprocess
