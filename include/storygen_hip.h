@@ -590,7 +590,7 @@ int sg_debug_ff_anatomy(const sg_ff_desc* d, void* prof, size_t prof_bytes, sg_s
  * library never reads the environment (storygen_amd/ops.py maps the SG_* variables of its tools onto this call).  name / value:
  *   "tile_m", "tile_n"   force a GEMM / conv tile (same effect as sg_debug_set_tile)      "no_pipe", "no_split"  1 = disable
  *   "no_nmajor"          1 = M-major tile order everywhere
- *   "attn_sub2", "attn_prio", "attn_d80" (0..2), "attn_d160" (0..3)                        attention instantiation selectors
+ *   "attn_sub2", "attn_prio", "attn_d80" (0..2), "attn_d160" (0..4; 4 = key-split workgroups at Nq <= 256, default)  attention instantiation selectors
  *   "gn_no_fused", "gn_wide", "gn_fused_max"                                               GroupNorm kernel selection
  *   "reset"              every option back to its default */
 int sg_debug_set_option(const char* name, int64_t value);

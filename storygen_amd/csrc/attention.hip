@@ -108,10 +108,15 @@ static int attn_fwd(const sg_attn_desc* d, float* lse2, sg_stream_t stream) {
         // the 16x16 level has few workgroups with long key loops; measured (tools/bench_norm.py --attn, B3 Nq256 Nk768):
         // 2 waves x 2 stages 30.3 us, 2 x 3 30.2, 4 x 2 25.6, 4 x 3 25.4 -> 4 waves x 3 stages.  option attn_d160 = 0..3 picks
         // one of the four (development knob).
+        // round 5: at Nq <= 256 (the 16x16 / 8x8 levels) the four waves of a workgroup split the KEYS of one 32-query block instead of
+        // taking 32 queries each (attn_fwd_ksplit_kernel) — option attn_d160 = 4 (default); 0..3 = the query-split instantiations
         const int v160 = opt.attn_d160;
-        if (v160 == 1) launch_attn<160, 2, 3>(p, st);
+        // (only where it wins, tools/calls/r5_call09.sh: one round of workgroups — a 160 KB workgroup owns its CU — and at least two
+        // tiles of keys; batch 20 of the batched reference pass, 1 280 workgroups, measured 42.7 vs 27.4 us)
+        if (v160 == 4 && d->Nq <= 256 && d->Nk > KVBLK && (long)sg_cdiv(d->Nq, 32) * d->H * d->B <= 256) launch_attn_ksplit<160, 4>(p, st);
+        else if (v160 == 1) launch_attn<160, 2, 3>(p, st);
         else if (v160 == 2) launch_attn<160, 4, 2>(p, st);
-        else if (v160 == 3) launch_attn<160, 4, 3>(p, st);
+        else if (v160 == 3 || v160 == 4) launch_attn<160, 4, 3>(p, st);
         else launch_attn<160, 2, 2>(p, st);
     }
     SG_CHECK_LAUNCH("sg_attn_fwd_f16");
@@ -129,7 +134,7 @@ extern "C" int sg_attn_fwd_pair_f16(const sg_attn_desc* d0, const sg_attn_desc* 
     if (int rc = attn_params(d1, p1, "sg_attn_fwd_pair_f16[1]")) return rc;
     const SgOptions& opt = sg_options();
     const bool same = d0->D == d1->D && d0->B == d1->B && d0->H == d1->H && d0->Nq == d1->Nq;   // (short K/V rows: either problem)
-    const bool defaults = !opt.attn_sub2 && !opt.attn_prio && opt.attn_d80 == 1 && opt.attn_d160 == 3;
+    const bool defaults = !opt.attn_sub2 && !opt.attn_prio && opt.attn_d80 == 1 && opt.attn_d160 >= 3;
     if (!same || !defaults) {
         if (int rc = attn_fwd(d0, nullptr, stream)) return rc;
         return attn_fwd(d1, nullptr, stream);

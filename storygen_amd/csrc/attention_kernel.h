@@ -51,7 +51,8 @@ constexpr int F40_ONES = 128;        // bytes behind every tile image: one V^T r
 // LDS of one workgroup: the S-stage ring of (K tile | VT tile) images
 template <int D, int S, int SUB>
 constexpr int attn_smem_bytes() {
-    return D == 40 ? F40_KPAD + S * SUB * (KVBLK * D * 2 + D * 128 + F40_ONES) : S * SUB * (KVBLK * D * 2 + D * 128) + 16;
+    // (+ 16: the general path of a head dim that is not a multiple of 16 reads one chunk past its last K row; D = 80 / 160 do not)
+    return D == 40 ? F40_KPAD + S * SUB * (KVBLK * D * 2 + D * 128 + F40_ONES) : S * SUB * (KVBLK * D * 2 + D * 128) + (D % 16 == 0 ? 0 : 16);
 }
 
 // One workgroup's work: `block` of `nblocks` (the launch's own numbering — a paired launch runs two problems in one grid).
@@ -61,7 +62,12 @@ constexpr bool UNROLL_STAGES = false;     // A/B build (tools/ab_lib.py): the ri
 constexpr bool UNROLL_STAGES = true;
 #endif
 
-template <int D, int NW, int S, int SUB, bool PRIO, bool LSE, bool LEAN = false, bool GENERAL = false>
+// KSPLIT (round 5; D = 160, the 16x16 / 8x8 levels): the NW waves of a workgroup share ONE block of 32 queries and split its KEYS — a
+// group of NW tiles is loaded into the single ring stage by all waves, wave w computes tile w of it, and the partial (max, sum, O^T)
+// of the waves are merged through LDS at the end.  At Nq <= 256 the plain decomposition leaves 24 - 48 workgroups walking 12-tile
+// chains at ~5 k cycles per tile (one wave per SIMD: nothing hides the LDS and DMA latencies of a 40 KB tile); splitting the keys
+// across the waves shortens that chain NW-fold for the price of an unpipelined ring (S = 1: load, barrier, compute, barrier).
+template <int D, int NW, int S, int SUB, bool PRIO, bool LSE, bool LEAN = false, bool GENERAL = false, bool KSPLIT = false>
 __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, const int block, const int nblocks) {
     constexpr bool F40 = D == 40 && !GENERAL;   // softmax bookkeeping in the padded head dimension (see F40_KPAD)
     constexpr int DC = D / 8;                   // 16-byte chunks per K row
@@ -76,10 +82,11 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
     constexpr int RING0 = F40 ? F40_KPAD : 0;   // byte offset of the ring
     constexpr int MAXL = (NSEG + NW - 1) / NW;  // DMA instructions per tile of the busiest wave
     constexpr int REM = NSEG % NW;              // waves < REM issue MAXL, the others MAXL - 1 (REM == 0: all MAXL)
-    static_assert(S == 2 || S == 3, "2 or 3 stages");
-    static_assert(SUB == 1 || S == 2, "multi-tile stages use the 2-stage ring (plain vmcnt(0) waits)");
+    static_assert(KSPLIT ? (S == 1 && SUB == NW && !LSE && !(D == 40 && !GENERAL)) : (S == 2 || S == 3), "2 or 3 stages; key split: one stage of NW tiles");
+    static_assert(KSPLIT || SUB == 1 || S == 2, "multi-tile stages use the 2-stage ring (plain vmcnt(0) waits)");
+    static_assert(!KSPLIT || NW * (8 + DT * 64) * 64 <= S * SUB * (KVBLK * D * 2 + D * 128), "the merge images of the waves fit the dead ring");
     static_assert((S - 1) * MAXL < 64, "vmcnt is a 6-bit counter");
-    static_assert(RING0 + S * STAGE + (F40 ? 0 : 16) <= attn_smem_bytes<D, S, SUB>(), "LDS size");
+    static_assert(RING0 + S * STAGE + (F40 || D % 16 == 0 ? 0 : 16) <= attn_smem_bytes<D, S, SUB>(), "LDS size");
     static_assert(!F40 || (32 * KROW + 16 <= F40_KPAD && F40_KPAD % 128 == 0), "K pad constants of both 32-key blocks");
 
     const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
@@ -94,7 +101,7 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
     const int kvb = b < p.kv_batches ? b : b - (p.B - p.kv_batches);
     const bool short_row = kvb < p.kv2;         // wave-uniform: a K/V row with its own key count (sg_attn_desc.k2)
     const int Nk = short_row ? p.Nk2 : p.Nk;
-    const int q0 = (qb * NW + wave) * 32;
+    const int q0 = KSPLIT ? qb * 32 : (qb * NW + wave) * 32;
     const f16* Q = p.q + (long)b * p.bsq + (long)h * D;
     const f16* K = (short_row ? p.k2 + (long)kvb * p.bsk2 : p.k + (long)(kvb - p.kv2) * p.bsk) + (long)h * D;
     const f16* VT = (short_row ? p.vt2 + (long)kvb * p.bsvt2 : p.vt + (long)(kvb - p.kv2) * p.bsvt) + (long)h * D * p.ldvt;
@@ -228,6 +235,13 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
         const int group = group0 + ustage;
         const int stage = UNR ? ustage : rt_stage;
         if (group < ngroups) {
+        if constexpr (KSPLIT) {
+            // one stage: every wave has left the previous group's tiles -> load this group's NW tiles -> everybody's share has landed
+            if (group > 0) __builtin_amdgcn_s_barrier();
+            issue(group, 0);
+            wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+        } else {
         // wait for this wave's share of the group (S = 3: one younger tile may stay in flight), publish, refill the ring
         if (S == 3 && group + 1 < ngroups) {
             if (REM == 0 || wave < REM) wait_vmcnt<MAXL>();
@@ -241,8 +255,10 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
             if (st >= S) st -= S;
             issue(group + S - 1, st);
         }
+        }
 #pragma unroll
-      for (int sub = 0; sub < SUB; ++sub) {
+      for (int subi = 0; subi < (KSPLIT ? 1 : SUB); ++subi) {
+        const int sub = KSPLIT ? wave : subi;      // key split: this wave's tile of the group
         const int tile = group * SUB + sub;
         if (tile < ntiles) {      // (no `break`: it keeps the per-lane arrays from being promoted to registers)
         const char* sK = smem + RING0 + stage * STAGE + sub * TSTAGE;
@@ -437,6 +453,37 @@ __device__ __forceinline__ void attn_fwd_body(const AttnParams& p, char* smem, c
     float l_tot;
     if constexpr (F40) l_tot = oacc[DT - 1][4];
     else l_tot = l_run + __shfl_xor(l_run, 32, 64);
+    if constexpr (KSPLIT) {
+        // merge the waves' partial results for the same 32 queries: wave w > 0 leaves (m, l, O^T) in the dead ring, wave 0 adds them with
+        // the usual two-maximum rescaling.  A wave that had no tile holds m = -inf, l = 0, O = 0 and contributes exp2(-inf) = 0.
+        constexpr int IMG = (8 + DT * 64) * 64;                       // bytes per wave image: m, l per lane + DT x 16 accumulators per lane
+        __builtin_amdgcn_s_barrier();                                 // the last group's tiles have been read by everybody
+        if (wave > 0) {
+            float* img = reinterpret_cast<float*>(smem + (wave - 1) * IMG);
+            img[lane] = m_run;
+            img[64 + lane] = l_tot;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) img[128 + (i * 16 + r) * 64 + lane] = oacc[i][r];
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (wave > 0) return;
+#pragma unroll
+        for (int w = 1; w < NW; ++w) {
+            const float* img = reinterpret_cast<const float*>(smem + (w - 1) * IMG);
+            const float m_o = img[lane], l_o = img[64 + lane];
+            const float m_new = fmaxf(m_run, m_o);
+            const float fa = __builtin_amdgcn_exp2f(m_run - m_new), fb = __builtin_amdgcn_exp2f(m_o - m_new);
+            l_tot = l_tot * fa + l_o * fb;
+            m_run = m_new;
+#pragma unroll
+            for (int i = 0; i < DT; ++i)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) oacc[i][r] = oacc[i][r] * fa + img[128 + (i * 16 + r) * 64 + lane] * fb;
+        }
+    }
     const float inv = 1.0f / l_tot;
     const int qi = q0 + l31;
     if constexpr (LSE) {    // training forward: P = exp2(s * scale_log2 - lse2) is what the backward kernels recompute
@@ -462,6 +509,20 @@ template <int D, int NW, int S, int SUB = 1, bool PRIO = false, bool LSE = false
 __global__ __launch_bounds__(64 * NW) void attn_fwd_kernel(const AttnParams p) {
     __shared__ __attribute__((aligned(16))) char smem[attn_smem_bytes<D, S, SUB>()];
     attn_fwd_body<D, NW, S, SUB, PRIO, LSE, LEAN, GENERAL>(p, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
+// key-split instantiation (KSPLIT above): one workgroup = NW waves on ONE 32-query block of one (batch, head)
+template <int D, int NW>
+__global__ __launch_bounds__(64 * NW) void attn_fwd_ksplit_kernel(const AttnParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[attn_smem_bytes<D, 1, NW>()];
+    attn_fwd_body<D, NW, 1, NW, false, false, false, false, true>(p, smem, (int)blockIdx.x, (int)gridDim.x);
+}
+
+template <int D, int NW>
+void launch_attn_ksplit(const AttnParams& p0, hipStream_t st) {
+    AttnParams p = p0;
+    p.nqb = sg_cdiv(p.Nq, 32);
+    hipLaunchKernelGGL((attn_fwd_ksplit_kernel<D, NW>), dim3(p.nqb * p.H * p.B), dim3(64 * NW), 0, st, p);
 }
 
 // Two attentions of one transformer block in one grid (text: attention.py:271-276, image: :285-290 — same queries' shape, two

@@ -39,7 +39,7 @@ struct SgOptions {
     int no_pipe = 0, no_split = 0;     // register-staged kernel only / no automatic split-K
     int no_nmajor = 0;                 // M-major tile order everywhere
     int pipe_stages = 3;               // 2: 128x128 and 256x64 GEMM / conv tiles on a 2-stage LDS ring (two workgroups per CU)
-    int attn_sub2 = 0, attn_prio = 0, attn_d80 = 1, attn_d160 = 3, attn_lean = 0;
+    int attn_sub2 = 0, attn_prio = 0, attn_d80 = 1, attn_d160 = 4 /* 4: key-split workgroups at Nq <= 256 */, attn_lean = 0;
     int attn_d40_general = 0;          // 1 = the D = 40 launches use the general softmax path (A/B against the padded-dimension fast path)
     int gn_no_fused = 0, gn_wide = 1;
     int gn_fused_nt = 1024;            // threads of the one-launch GroupNorm for slabs <= 16 384 values (256: the round-1 geometry; A/B)

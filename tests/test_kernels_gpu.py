@@ -748,6 +748,8 @@ ATTN_CASES = [
     (2, 8, 256, 256, 40), (1, 8, 200, 77, 40), (3, 8, 64, 192, 160), (2, 8, 256, 768, 80), (1, 8, 1024, 1024, 80),
     (1, 2, 130, 65, 160), (3, 8, 4096, 77, 40), (1, 8, 1024, 3072, 40), (1, 4, 33, 1, 80),
     (2, 8, 4096, 705, 40), (2, 8, 4096, 320, 40),      # big grids: the 4-wave kernels, ragged last tile / odd tile count
+    # D = 160 at Nq <= 256: the key-split workgroups (round 5) — 12 / 4 / 2 / 1 tiles for 4 waves, ragged queries and keys, many batches
+    (3, 8, 256, 768, 160), (3, 8, 256, 256, 160), (3, 8, 256, 77, 160), (1, 8, 250, 330, 160), (20, 8, 256, 256, 160), (2, 8, 64, 64, 160),
 ]
 
 
@@ -804,6 +806,36 @@ def test_attention_deferred_rescale_threshold(gpu):
         return t.float().view(B, -1, H, D).transpose(1, 2)
     ref = (torch.softmax(heads(q) @ heads(k).transpose(-1, -2) * D ** -0.5, -1) @ heads(v)).transpose(1, 2).reshape(B, Nq, C)
     check(out, ref, "attention deferred rescale")
+
+
+def test_attention_key_split_d160_rescale_and_variants(gpu):
+    """The key-split D = 160 kernel (attn_fwd_ksplit_kernel: four waves on one 32-query block, each on every fourth 64-key tile, partial
+    (max, sum, O^T) merged through LDS): row maxima that sit in DIFFERENT waves' tiles — a dominant key in a late tile of wave 2, another in
+    wave 0's first tile, rows whose keys are all tiny in three of the four waves — against fp32 softmax, and against the query-split
+    instantiation (option attn_d160 = 3) on the same operands."""
+    from storygen_amd import ops
+    B, H, Nq, Nk, D = 2, 8, 256, 768, 160
+    C = H * D
+    q, k, v = rnd((B, Nq, C), gpu, seed=1), rnd((B, Nk, C), gpu, 0.3, seed=2), rnd((B, Nk, C), gpu, seed=3)
+    kh, qh = k.view(B, Nk, H, D), q.view(B, Nq, H, D)
+    kh[0, 64 * 6 + 5] = qh[0, 9] * 2.0            # tile 6 -> wave 2: dominates query 9 of every head
+    kh[0, 3] = qh[0, 40] * 2.5                    # tile 0 -> wave 0
+    kh[1, 64 * 11 + 63] = qh[1, 255] * 3.0        # the very last key -> wave 3
+    out = torch.empty(B, Nq, C, dtype=torch.float16, device=gpu)
+    ops.attention(q, k, _vt(v), out, H, D ** -0.5)
+
+    def heads(t):
+        return t.float().view(B, -1, H, D).transpose(1, 2)
+    ref = (torch.softmax(heads(q) @ heads(k).transpose(-1, -2) * D ** -0.5, -1) @ heads(v)).transpose(1, 2).reshape(B, Nq, C)
+    check(out, ref, "key-split attention")
+    ops.debug_set_option("attn_d160", 3)
+    try:
+        old = torch.empty_like(out)
+        ops.attention(q, k, _vt(v), old, H, D ** -0.5)
+    finally:
+        ops.debug_set_option("attn_d160", 4)
+    check(old, ref, "query-split attention")
+    check(out, old, "key-split vs query-split", l2=6e-4, mx=2e-2)
 
 
 @pytest.mark.parametrize("D,Nq,Nk", [(40, 4096, 640), (80, 200, 77), (160, 64, 192)])
@@ -918,8 +950,14 @@ def test_attention_pair_text_and_image_in_one_launch(gpu, D, Nq, Nk_img, Bk):
     a2, a3 = both[:, :, :C], both[:, :, C:]
     ops.attention_pair((q3, ki, vti, a3, None), (q2, kt, vtt, a2, S), H, scale)
     s2, s3 = torch.empty(B, Nq, C, dtype=torch.float16, device=gpu), torch.empty(B, Nq, C, dtype=torch.float16, device=gpu)
-    ops.attention(q2, kt, vtt, s2, H, scale, nk=S)
-    ops.attention(q3, ki, vti, s3, H, scale)
+    # (the paired launch runs the query-split instantiation: at D = 160 select it for the single launches too — their default there is the
+    # key-split kernel of round 5, equal up to the order of the fp32 sums)
+    ops.debug_set_option("attn_d160", 3)
+    try:
+        ops.attention(q2, kt, vtt, s2, H, scale, nk=S)
+        ops.attention(q3, ki, vti, s3, H, scale)
+    finally:
+        ops.debug_set_option("attn_d160", 4)
     torch.cuda.synchronize()
     assert torch.equal(a2, s2) and torch.equal(a3, s3)
     idx = [b if b < Bk else b - (B - Bk) for b in range(B)]
@@ -933,7 +971,11 @@ def test_attention_pair_text_and_image_in_one_launch(gpu, D, Nq, Nk_img, Bk):
     # different query counts: served as two launches, same results
     o2 = torch.full((B, Nq // 2, C), float("nan"), dtype=torch.float16, device=gpu)
     o3 = torch.full((B, Nq, C), float("nan"), dtype=torch.float16, device=gpu)
-    ops.attention_pair((q3, ki, vti, o3, None), (q2[:, : Nq // 2], kt, vtt, o2, S), H, scale)
+    ops.debug_set_option("attn_d160", 3)          # (the two launches it falls back to: the same instantiation as s2 / s3 above)
+    try:
+        ops.attention_pair((q3, ki, vti, o3, None), (q2[:, : Nq // 2], kt, vtt, o2, S), H, scale)
+    finally:
+        ops.debug_set_option("attn_d160", 4)
     torch.cuda.synchronize()
     assert torch.equal(o3, s3) and torch.equal(o2, s2[:, : Nq // 2])
 
