@@ -448,6 +448,9 @@ def main():
     ap.add_argument("--no-splitk-in-gn", action="store_true",
                     help="A/B: split-K convolutions at the 16x16 / 8x8 levels run their own second pass instead of leaving it to the GroupNorm")
     ap.add_argument("--no-ff-fused", action="store_true", help="A/B: GEGLU feed-forward of the 64x64 level as two GEMM launches")
+    ap.add_argument("--no-ff-split", action="store_true",
+                    help="A/B: the fused feed-forward of a small launch (<= 16 k tokens) as one workgroup per 128 tokens (default: the hidden "
+                         "units split over two workgroups, partial sums added by proj_out's contraction)")
     ap.add_argument("--no-shared-head", action="store_true",
                     help="A/B: the main pass runs its three CFG samples at batch 3 from conv_in on, as written (default: everything up to "
                          "the first cross-attention once — the samples share latent and timestep)")
@@ -519,6 +522,9 @@ def main():
     if args.no_ff_fused:
         from storygen_amd import engine as _engine
         _engine.FF_FUSED = False
+    if args.no_ff_split:
+        from storygen_amd import engine as _engine
+        _engine.FF_SPLIT_MAX_TOKENS = 0
 
     hw, n_ref = (96, 5) if args.config5_shape else (HW, R)
     # per-sample GFLOP of one ref / main pass: 64x64 R=3, or 96x96 R=5
@@ -569,7 +575,7 @@ def main():
                        "paired_gemm_launches": not args.no_gemm_pairs, "paired_text_image_attention": args.attn_pair,
                        "groupnorm_stats_from_epilogues": not args.no_gn_epilogue, "fp16_block_stream": args.fp16_block_stream,
                        "short_zero_image_rows": not args.no_short_rows, "time_embedding_tables": not args.no_time_tables, "splitk_reduce_in_groupnorm": not args.no_splitk_in_gn,
-                       "fused_feed_forward_64x64": not args.no_ff_fused, "shared_cfg_head_of_main_pass": bool(sampler.main.cfg_shared_head)},
+                       "fused_feed_forward_64x64": not args.no_ff_fused, "fused_feed_forward_hidden_split": not (args.no_ff_fused or args.no_ff_split), "shared_cfg_head_of_main_pass": bool(sampler.main.cfg_shared_head)},
             "tflop_per_step_as_written": round(step_tflop, 3),
             "final_allgather_ms": round(gather_ms, 3), "latents_gathered": int(final.shape[0]), "latents_finite": finite,
             "latents_distinct_per_rank": distinct,

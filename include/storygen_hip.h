@@ -227,9 +227,14 @@ typedef struct sg_ff_desc {
     const float*   x;  int64_t ldx;      /* [M, C] fp32 */
     const void*    wpack; size_t wpack_bytes;
     const sg_half* b2;                   /* [C] bias of the second linear */
-    sg_half*       y;  int64_t ldy;      /* [M, C] fp16 */
+    sg_half*       y;  int64_t ldy;      /* [M, C] fp16 ([M, 2C] with hidden_split) */
     int32_t        M, C;
     float          eps;                  /* LayerNorm eps */
+    int32_t        hidden_split;         /* 0: y = Linear2(geglu) + b2 + x in one workgroup per 128 tokens.  2 (round 5): two workgroups per 128
+                                            tokens, each over half of the 4C hidden units; y is [M, 2C]: columns [0, C) = first half's sum
+                                            + b2 + x, columns [C, 2C) = the second half's partial sum alone.  Their sum is the result;
+                                            the consumer adds them for free by contracting [y_a | y_b] with [W | W] (proj_out,
+                                            model/attention.py:121-123) — for launches too small to fill the chip (M <= 16 k tokens) */
 } sg_ff_desc;
 
 size_t sg_ff_fused_pack_bytes(int32_t C);

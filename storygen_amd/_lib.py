@@ -117,6 +117,7 @@ class FfDesc(C.Structure):
         ("y", C.c_void_p), ("ldy", C.c_int64),
         ("M", C.c_int32), ("C", C.c_int32),
         ("eps", C.c_float),
+        ("hidden_split", C.c_int32),
     ]
 
 

@@ -38,6 +38,7 @@ struct FfParams {
     const f16* b2;
     f16* y; long ldy;
     int M; float eps;
+    int hsplit;                    // 1: blockIdx.y = 0 / 1 takes the first / second half of the hidden chunks (sg_ff_desc.hidden_split)
     unsigned long long* prof;      // experiments library (sg_debug_ff_anatomy): 8 cycle counters per wave
 };
 
@@ -54,7 +55,7 @@ __device__ __forceinline__ void ff_glds16(const char* g, char* lds_wave_base) {
 // VAR bit 1 (DEEP): W1 fragment reads run two k-steps ahead of their MFMAs instead of one.  PROF (experiments library): s_memtime stamps
 // around the phases of every iteration, summed per wave (sg_debug_ff_anatomy): [0] iterations [1] vmcnt wait [2] barrier [3] DMA issue
 // (burst form) + d1 -> accumulators [4] GEMM1 (+ GEGLU of the previous chunk) [5] GEMM2 [6] prologue (entry -> loop) [7] total
-template <int KS, int VAR, bool PROF>      // KS = C / 64
+template <int KS, int VAR, bool PROF, bool HS = false>      // KS = C / 64; HS = hidden split (two workgroups per 128 tokens)
 __global__ __launch_bounds__(64 * FF_NW) void ff_fused_kernel(const FfParams p) {
     constexpr bool SPREAD = (VAR & 1) != 0, DEEP = (VAR & 2) != 0;
     constexpr int C = 64 * KS, NS = 4 * KS /* k-steps of GEMM1 */, NCT = C / 32 /* output-column tiles */, NCH = 4 * C / 32 /* chunks */;
@@ -81,6 +82,12 @@ __global__ __launch_bounds__(64 * FF_NW) void ff_fused_kernel(const FfParams p) 
     const int t = threadIdx.x, lane = t & 63, l31 = lane & 31, hi = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
     const int m0 = blockIdx.x * (32 * FF_NW) + wave * 32;
+    // Hidden split (round 5): at M <= 16 k (the main pass: 96 workgroups for 256 CUs) the launch is as long as ONE wave's walk over the 40
+    // hidden chunks.  With hsplit a second workgroup (blockIdx.y = 1) takes chunks [NCH / 2, NCH) of the same tokens and writes its partial
+    // sum — no bias, no residual — into columns [C, 2C) of y; the consumer (proj_out) contracts [y_a | y_b] with [W | W].
+    // (a separate instantiation: without HS the chunk range is the compile-time [0, NCH) of round 4, instruction for instruction)
+    const int half = HS ? (int)blockIdx.y : 0;
+    const int c0 = HS ? half * (NCH / 2) : 0, c_end = HS ? c0 + NCH / 2 : NCH;
 
     // One iteration's refill: W1 part of chunk c1 and W2 part of chunk c2 (each only if it exists).  Linear copies; wave w moves the
     // 1 KiB segments w, w + 4, ... of either part: a compile-time list of DMA instructions per wave (j = 0 .. N1 - 1: W1 segments,
@@ -91,11 +98,11 @@ __global__ __launch_bounds__(64 * FF_NW) void ff_fused_kernel(const FfParams p) 
     auto issue_one = [&](int c1, int c2, int j) __attribute__((always_inline)) {      // j is a compile-time constant at every call site
         if (j < N1) {
             const int g = j * FF_NW;                           // + wave
-            if (c1 < NCH && (g + FF_NW <= W1_SEG || g + wave < W1_SEG))
+            if (c1 < c_end && (g + FF_NW <= W1_SEG || g + wave < W1_SEG))
                 ff_glds16(p.wpack + (size_t)c1 * CHUNK + wofs + g * 1024 + lane16, w1_ring + (c1 & 1) * W1_PART + wofs + g * 1024);
         } else if (j < N1 + N2) {
             const int g = (j - N1) * FF_NW;
-            if (c2 >= 0 && c2 < NCH && (g + FF_NW <= W2_SEG || g + wave < W2_SEG))
+            if (c2 >= c0 && c2 < c_end && (g + FF_NW <= W2_SEG || g + wave < W2_SEG))
                 ff_glds16(p.wpack + (size_t)c2 * CHUNK + W1_PART + wofs + g * 1024 + lane16, w2_ring + (c2 & 1) * W2_PART + wofs + g * 1024);
         }
     };
@@ -103,7 +110,7 @@ __global__ __launch_bounds__(64 * FF_NW) void ff_fused_kernel(const FfParams p) 
 #pragma unroll
         for (int j = 0; j < N1 + N2; ++j) issue_one(c1, c2, j);
     };
-    issue(0, -1);
+    issue(c0, -1);
 
     // ---- this wave's 32 token rows: load (fp32), LayerNorm in registers, keep as fp16 B-operand fragments.  Lane (token l31, hi) holds
     // columns 16 s + 8 hi .. + 7 of its row for s = 0 .. NS - 1 (rows beyond M: a clamped duplicate, never stored).
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(64 * FF_NW) void ff_fused_kernel(const FfParams p) 
         __builtin_amdgcn_s_barrier();                            // ... everybody's has; the slots of W1(i-1) / W2(i-2) are free
         stamp(2);
         if constexpr (!SPREAD) issue(i + 1, i);
-        const bool g1 = i < NCH, g2 = i >= 1;                    // wave-uniform
+        const bool g1 = i < c_end, g2 = i > c0;                  // wave-uniform
         const char* w1s = w1_ring + (i & 1) * W1_PART;
         const char* w2s = w2_ring + ((i - 1) & 1) * W2_PART;
         // GEGLU of the previous chunk, four elements at a time in four stages of ~13-20 instructions (four independent dependency
@@ -260,26 +267,31 @@ __global__ __launch_bounds__(64 * FF_NW) void ff_fused_kernel(const FfParams p) 
         stamp(5);
         if constexpr (PROF) pf_acc[0] += 1;
     };
-    static_assert(NCH % 2 == 0, "the loop is unrolled by two");
-    for (int i = 0; i < NCH; i += 2) {
+    static_assert(NCH % 4 == 0, "the loop is unrolled by two, over all chunks or over either half of them");
+    for (int i = c0; i < c_end; i += 2) {
         body(i, std::integral_constant<int, 0>{});
         body(i + 1, std::integral_constant<int, 1>{});
     }
-    body(NCH, std::integral_constant<int, 0>{});
+    body(c_end, std::integral_constant<int, 0>{});
 
     // ---- epilogue: y = out + b2 + x (fp32 residual), fp16.  Lane (token l31, hi) register r of tile ct = column ct*32 + 8 (r>>2) + 4 hi + (r&3)
+    // (hidden split: the second half writes its partial sum alone, into columns [C, 2C))
     const int m = m0 + l31;
     if (m < p.M) {
         const float* xr = p.x + (long)m * p.ldx + 4 * hi;
-        f16* yr = p.y + (long)m * p.ldy + 4 * hi;
+        f16* yr = p.y + (long)m * p.ldy + half * C + 4 * hi;
 #pragma unroll
         for (int ct = 0; ct < NCT; ++ct) {
             float4 res[4];
             f16x4 bb[4];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                res[q] = *reinterpret_cast<const float4*>(xr + ct * 32 + 8 * q);
-                bb[q] = *reinterpret_cast<const f16x4*>(p.b2 + ct * 32 + 8 * q + 4 * hi);
+                res[q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                bb[q] = f16x4{(f16)0.f, (f16)0.f, (f16)0.f, (f16)0.f};
+                if (half == 0) {
+                    res[q] = *reinterpret_cast<const float4*>(xr + ct * 32 + 8 * q);
+                    bb[q] = *reinterpret_cast<const f16x4*>(p.b2 + ct * 32 + 8 * q + 4 * hi);
+                }
             }
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -292,7 +304,7 @@ __global__ __launch_bounds__(64 * FF_NW) void ff_fused_kernel(const FfParams p) 
     if constexpr (PROF) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0 && p.prof) {
-            unsigned long long* dst = p.prof + ((size_t)blockIdx.x * FF_NW + wave) * 8;
+            unsigned long long* dst = p.prof + (((size_t)blockIdx.y * gridDim.x + blockIdx.x) * FF_NW + wave) * 8;
 #pragma unroll
             for (int k = 0; k < 7; ++k) dst[k] = pf_acc[k];
             dst[7] = __builtin_readcyclecounter() - pf_entry;
@@ -316,7 +328,9 @@ extern "C" int sg_ff_geglu_fused_f16(const sg_ff_desc* d, sg_stream_t stream) {
     SG_REQUIRE(d->x && d->wpack && d->b2 && d->y, "sg_ff_geglu_fused_f16: null pointer");
     if (d->C != 320) return sg_set_error(SG_EUNSUP, "sg_ff_geglu_fused_f16: built for C = 320 (got %d)", d->C);
     SG_REQUIRE(d->M > 0 && d->eps > 0.f, "sg_ff_geglu_fused_f16: bad M / eps");
-    SG_REQUIRE(d->ldx % 4 == 0 && d->ldx >= d->C && d->ldy % 4 == 0 && d->ldy >= d->C, "sg_ff_geglu_fused_f16: bad ldx / ldy");
+    SG_REQUIRE(d->hidden_split == 0 || d->hidden_split == 2, "sg_ff_geglu_fused_f16: hidden_split must be 0 or 2");
+    const int ycols = d->hidden_split ? 2 * d->C : d->C;
+    SG_REQUIRE(d->ldx % 4 == 0 && d->ldx >= d->C && d->ldy % 4 == 0 && d->ldy >= ycols, "sg_ff_geglu_fused_f16: bad ldx / ldy");
     SG_REQUIRE(sg_aligned16(d->x) && sg_aligned16(d->wpack) && sg_aligned16(d->b2) && (reinterpret_cast<uintptr_t>(d->y) & 7u) == 0,
                "sg_ff_geglu_fused_f16: alignment");
     SG_REQUIRE(d->wpack_bytes >= sg_ff_fused_pack_bytes(d->C), "sg_ff_geglu_fused_f16: wpack holds %zu bytes, need %zu", d->wpack_bytes,
@@ -324,13 +338,15 @@ extern "C" int sg_ff_geglu_fused_f16(const sg_ff_desc* d, sg_stream_t stream) {
     FfParams p{};
     p.x = d->x; p.ldx = d->ldx; p.wpack = reinterpret_cast<const char*>(d->wpack); p.b2 = reinterpret_cast<const f16*>(d->b2);
     p.y = reinterpret_cast<f16*>(d->y); p.ldy = d->ldy; p.M = d->M; p.eps = d->eps;
+    p.hsplit = d->hidden_split ? 1 : 0;
     p.prof = g_ff_prof;
-    const dim3 grid(sg_cdiv(d->M, 32 * FF_NW)), block(64 * FF_NW);
+    const dim3 grid(sg_cdiv(d->M, 32 * FF_NW), p.hsplit ? 2 : 1), block(64 * FF_NW);
     hipStream_t st = (hipStream_t)stream;
     const int var = sg_options().ff_variant & 3;        // development option: refill placement / fragment prefetch depth (default 3: both)
 #ifdef SG_BUILD_EXPERIMENTS
     if (p.prof) {
-        if (var == 0) hipLaunchKernelGGL((ff_fused_kernel<5, 0, true>), grid, block, 0, st, p);
+        if (p.hsplit) hipLaunchKernelGGL((ff_fused_kernel<5, 3, true, true>), grid, block, 0, st, p);
+        else if (var == 0) hipLaunchKernelGGL((ff_fused_kernel<5, 0, true>), grid, block, 0, st, p);
         else if (var == 1) hipLaunchKernelGGL((ff_fused_kernel<5, 1, true>), grid, block, 0, st, p);
         else if (var == 2) hipLaunchKernelGGL((ff_fused_kernel<5, 2, true>), grid, block, 0, st, p);
         else hipLaunchKernelGGL((ff_fused_kernel<5, 3, true>), grid, block, 0, st, p);
@@ -338,7 +354,8 @@ extern "C" int sg_ff_geglu_fused_f16(const sg_ff_desc* d, sg_stream_t stream) {
         return SG_OK;
     }
 #endif
-    if (var == 0) hipLaunchKernelGGL((ff_fused_kernel<5, 0, false>), grid, block, 0, st, p);
+    if (p.hsplit) hipLaunchKernelGGL((ff_fused_kernel<5, 3, false, true>), grid, block, 0, st, p);      // (one schedule: the default one)
+    else if (var == 0) hipLaunchKernelGGL((ff_fused_kernel<5, 0, false>), grid, block, 0, st, p);
     else if (var == 1) hipLaunchKernelGGL((ff_fused_kernel<5, 1, false>), grid, block, 0, st, p);
     else if (var == 2) hipLaunchKernelGGL((ff_fused_kernel<5, 2, false>), grid, block, 0, st, p);
     else hipLaunchKernelGGL((ff_fused_kernel<5, 3, false>), grid, block, 0, st, p);
@@ -350,7 +367,7 @@ extern "C" int sg_ff_geglu_fused_f16(const sg_ff_desc* d, sg_stream_t stream) {
 // 8 uint64 per wave ([workgroup][wave][8], see ff_fused_kernel).
 extern "C" int sg_debug_ff_anatomy(const sg_ff_desc* d, void* prof, size_t prof_bytes, sg_stream_t stream) {
 #ifdef SG_BUILD_EXPERIMENTS
-    SG_REQUIRE(d && prof && prof_bytes >= (size_t)sg_cdiv(d->M, 32 * FF_NW) * FF_NW * 64, "sg_debug_ff_anatomy: need 64 bytes per wave");
+    SG_REQUIRE(d && prof && prof_bytes >= (size_t)sg_cdiv(d->M, 32 * FF_NW) * FF_NW * 64 * (d->hidden_split ? 2 : 1), "sg_debug_ff_anatomy: need 64 bytes per wave");
     g_ff_prof = reinterpret_cast<unsigned long long*>(prof);
     const int rc = sg_ff_geglu_fused_f16(d, stream);
     g_ff_prof = nullptr;

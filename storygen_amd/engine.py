@@ -61,6 +61,11 @@ SPLITK_IN_GN = True
 # SURVEY 8(f) rank 2 — cross-layer fusion): norm3 -> Linear(C, 8C) -> a gelu(g) -> Linear(4C, C) -> + h with the [M, 4C] intermediate
 # kept in registers.  False = LayerNorm-folded GEGLU GEMM + second GEMM (A/B switch: bench.py --no-ff-fused).
 FF_FUSED = True
+# Fused feed-forward launches of at most this many tokens split the hidden dimension over two workgroups per 128 tokens (round 5;
+# sg_ff_desc.hidden_split): 12 288 tokens of the main pass are 96 workgroups on 256 CUs and the launch lasts as long as ONE wave's walk
+# over the 40 hidden chunks.  The two partial sums land in the halves of an [M, 2C] buffer and proj_out contracts them with [W | W].
+# 0 = never (A/B switch: bench.py --no-ff-split).
+FF_SPLIT_MAX_TOKENS = 16384
 LN_EPS = 1e-5         # torch.nn.LayerNorm default, as the reference constructs norm1..norm4 (model/attention.py:213-233)
 
 
@@ -82,7 +87,8 @@ class _Xf:
                  # LayerNorm-folded copies (repack.fold_layernorm): weight gamma (.) W in fp16, c / d in fp32
                  "w_qk1f", "c_qk1", "d_qk1", "w_v1f", "c_v1", "d_v1", "w_q2f", "c_q2", "d_q2", "w_q3f", "c_q3", "d_q3",
                  "w_ff1f", "c_ff1", "d_ff1",
-                 "ff_pack")     # weight stream of the fused feed-forward kernel (repack.ff_fused_pack), or None
+                 "ff_pack",     # weight stream of the fused feed-forward kernel (repack.ff_fused_pack), or None
+                 "w_out2")      # [W_out | W_out]: proj_out over the two partial sums of a hidden-split fused feed-forward
 
 
 class EngineWeights:
@@ -162,6 +168,7 @@ class EngineWeights:
                 for name, val in self._pack_folds(o).items():
                     setattr(o, name, val)
                 o.ff_pack = ff_fused_pack(o.w_ff1f, o.d_ff1, o.w_ff2) if (ops.ff_fused_supported(a.channels) and dev.type == "cuda") else None
+                o.w_out2 = torch.cat([o.w_out, o.w_out], dim=1).contiguous() if o.ff_pack is not None else None
                 self.xfs[p] = o
         self.samplers = {}
         for blk in arch.down + arch.up:
@@ -342,6 +349,7 @@ class UNetEngine:
             raise ValueError("cfg_shared_head needs batch 3 on 2 shared context rows (the CFG main pass of one story frame), a transformer "
                              "behind the first resnet and the fp16 attention path")
         self._shared_back = False
+        self._head_checked = False
         self.wts = weights if weights is not None else EngineWeights(arch, state_dict, device)
         # BASELINE config 5: the head-dim-40 self / image attentions (the 46 080-key context of the 96x96 level) on the fp8 MFMA
         # path (sg_attn_fwd_f8_d40); text attention and the D = 80 / 160 levels stay fp16
@@ -832,7 +840,11 @@ class UNetEngine:
             h3 = L["h2"]
             ops.gemm(att, xf.w_o2, h3, bias=xf.b_o2, res1=h1, workspace=ws, **({} if ff1 else prod(h3, L["ln"], L["lnst3"])))   # :277,295
         # --- feed-forward :298-300
-        if ff1:      # one launch: LayerNorm in registers, GEGLU intermediate never materialised (h4 is fp16: it only feeds proj_out)
+        h4, w_out = L["h4"], xf.w_out
+        if ff1 and M <= FF_SPLIT_MAX_TOKENS:      # small launch: two workgroups per 128 tokens, partial sums side by side (att23 is free here)
+            h4, w_out = L["att23"], xf.w_out2
+            ops.ff_fused(h3, xf.ff_pack, xf.b_ff2, h4, LN_EPS, split=True)
+        elif ff1:    # one launch: LayerNorm in registers, GEGLU intermediate never materialised (h4 is fp16: it only feeds proj_out)
             ops.ff_fused(h3, xf.ff_pack, xf.b_ff2, L["h4"], LN_EPS)
         elif fold:
             ops.gemm(raw(h3, L["ln"]), xf.w_ff1f, L["ffi"], epilogue=ops.EPI_GEGLU, ln=(1, L["lnst3"], xf.c_ff1, xf.d_ff1, LN_EPS), guard=gd)
@@ -843,8 +855,8 @@ class UNetEngine:
             ops.gemm(L["ffi"], xf.w_ff2, L["h4"], bias=xf.b_ff2, res1=h3, workspace=ws)   # fp16: only feeds proj_out
         kwo = dict(bias=xf.b_out, res1=x, workspace=ws)                                   # proj_out + residual :121-123
         site = xf.spec.prefix + ".proj_out"
-        so = self._stats_for(site, lvl, C, lambda buf: ops.gemm_stats_rows(L["h4"], xf.w_out, out, stats=(buf, hw), **kwo))
-        ops.gemm(L["h4"], xf.w_out, out, stats=None if so is None else (so, hw), **kwo)
+        so = self._stats_for(site, lvl, C, lambda buf: ops.gemm_stats_rows(h4, w_out, out, stats=(buf, hw), **kwo))
+        ops.gemm(h4, w_out, out, stats=None if so is None else (so, hw), **kwo)
         if so is not None:
             self._publish(out, site, C)
         else:
@@ -907,6 +919,14 @@ class UNetEngine:
         else:
             self._time_chain(self.t_in, self.temb0, self.temb1, self.temb2, self.tproj)
         shared = self.cfg_shared_head and consume
+        if shared and not self._head_checked and not torch.cuda.is_current_stream_capturing():
+            # the caller's guarantee, verified on the first eager pass (the sampler's warm-up before capture): one latent, one timestep,
+            # text rows 0 and 1 alike.  (One host synchronisation, once per engine.)
+            self._head_checked = True
+            if not (torch.equal(self.x_in[0], self.x_in[1]) and torch.equal(self.x_in[0], self.x_in[2])
+                    and bool((self.t_in == self.t_in[0]).all()) and torch.equal(self.text_in[0], self.text_in[1])):
+                raise ValueError("cfg_shared_head: the three samples must be the same latent at the same timestep with text rows "
+                                 "[uncond, uncond, text] (the CFG main pass of one story frame, pipeline.py:448-453)")
         if shared:
             # CFG main pass of one story frame: the three samples are ONE computation up to the first cross-attention — conv_in :411,
             # the first ResnetBlock2D and the first transformer's front half run on sample 0 only, their results are copied to the

@@ -287,20 +287,23 @@ def ff_fused_supported(Cc: int) -> bool:
     return lib.sg_ff_fused_pack_bytes(int(Cc)) != 0
 
 
-def ff_fused(x: torch.Tensor, wpack: torch.Tensor, b2: torch.Tensor, out: torch.Tensor, eps: float = 1e-5) -> torch.Tensor:
+def ff_fused(x: torch.Tensor, wpack: torch.Tensor, b2: torch.Tensor, out: torch.Tensor, eps: float = 1e-5, split: bool = False) -> torch.Tensor:
     """out[M, C] (fp16) = Linear2(a * gelu(g)) + b2 + x with [a | g] = Linear1(LayerNorm(x)) + b1 in ONE launch (sg_ff_geglu_fused_f16):
-    x fp32 [M, C] (row-strided view allowed), wpack = repack.ff_fused_pack(...) (uint8), b2 fp16 [C]."""
+    x fp32 [M, C] (row-strided view allowed), wpack = repack.ff_fused_pack(...) (uint8), b2 fp16 [C].
+    split=True (sg_ff_desc.hidden_split): out is [M, 2C] — two workgroups per 128 tokens, each over half of the hidden units; columns
+    [0, C) + columns [C, 2C) = the result (the consumer contracts [y_a | y_b] with [W | W])."""
     _f32(x, "x"), _f16(b2, "b2"), _f16(out, "out")
     M, Cc = x.shape
-    if tuple(out.shape) != (M, Cc) or b2.numel() != Cc or wpack.dtype != torch.uint8 or not wpack.is_cuda or not wpack.is_contiguous():
-        raise ValueError("ff_fused: out must be [M, C] fp16, b2 [C], wpack a contiguous CUDA uint8 tensor")
+    if tuple(out.shape) != (M, 2 * Cc if split else Cc) or b2.numel() != Cc or wpack.dtype != torch.uint8 or not wpack.is_cuda or not wpack.is_contiguous():
+        raise ValueError("ff_fused: out must be [M, C] fp16 ([M, 2C] with split), b2 [C], wpack a contiguous CUDA uint8 tensor")
     d = FfDesc()
     d.x, d.ldx = x.data_ptr(), _row_stride(x, "x")
     d.wpack, d.wpack_bytes = wpack.data_ptr(), wpack.numel()
     d.b2 = b2.data_ptr()
     d.y, d.ldy = out.data_ptr(), _row_stride(out, "out")
     d.M, d.C, d.eps = M, Cc, float(eps)
-    with _timed("ff_fused", 24.0 * M * Cc * Cc, f"M{M} C{Cc}"):
+    d.hidden_split = 2 if split else 0
+    with _timed("ff_fused", 24.0 * M * Cc * Cc, f"M{M} C{Cc}" + (" split" if split else "")):
         if ANATOMY is not None:
             check(lib.sg_debug_ff_anatomy(C.byref(d), ANATOMY.data_ptr(), ANATOMY.numel() * ANATOMY.element_size(), _stream()), "sg_debug_ff_anatomy")
         else:

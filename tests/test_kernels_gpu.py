@@ -326,7 +326,19 @@ def test_fused_geglu_feed_forward(gpu, M):
             torch.cuda.synchronize()
             assert torch.equal(o, out), f"ff_variant {var}"
     finally:
-        ops.debug_set_option("ff_variant", 0)
+        ops.debug_set_option("ff_variant", 3)
+    # hidden split (round 5, sg_ff_desc.hidden_split): two workgroups per 128 tokens, each over half of the hidden units; the first half's
+    # sum + b2 + x in columns [0, C), the second half's partial sum in [C, 2C) — their sum is the result, and the consumer gets it for
+    # free by contracting [y_a | y_b] with [W | W] (what the engine's proj_out does)
+    sp = torch.full((M, 2 * C), float("nan"), dtype=torch.float16, device=gpu)
+    ops.ff_fused(x, pack, b2, sp, 1e-5, split=True)
+    check(sp[:, :C].float() + sp[:, C:].float(), ref, "hidden-split feed-forward, sum of the halves, vs torch")
+    wo, bo = rnd((C, C), gpu, C ** -0.5, 8), rnd((C,), gpu, 0.5, 9)
+    y1, y2 = torch.empty(M, C, dtype=torch.float32, device=gpu), torch.empty(M, C, dtype=torch.float32, device=gpu)
+    ops.gemm(out, wo, y1, bias=bo, res1=xc)
+    ops.gemm(sp, torch.cat([wo, wo], dim=1).contiguous(), y2, bias=bo, res1=xc)
+    check(y2, ref @ wo.float().t() + bo.float() + xc, "proj_out over the two halves vs torch")
+    assert rel_l2(y2.cpu(), y1.cpu()) < 6e-4
 
 
 @pytest.mark.parametrize("M,C,split", [(256, 320, 1), (100, 64, 1), (192, 1280, 3)])

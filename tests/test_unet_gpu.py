@@ -525,6 +525,12 @@ def test_shared_cfg_head_is_the_same_main_pass(gpu, sd15, stage):
     # TOL_LATENT of the fp32 truth (asserted against the goldens above, on the default = shared-head path): as for ref_ahead, this
     # bounds their distance from each other — measured 3.7e-4 ... 6.2e-4 over three steps on different boxes
     assert max(errs) <= 2 * TOL_LATENT, errs
+    # the guarantee the engine relies on is checked on its first eager pass: three different latents are refused, not averaged away
+    eng = smp.main
+    eng._head_checked = False
+    eng.x_in[1].add_(1.0)
+    with pytest.raises(ValueError, match="same latent"):
+        eng.forward(consume=True, text_cache=True)
     assert flops[1] < 0.98 * flops[0]          # (32x32, R = 2: 2.7 % of the main pass; 512x512, R = 3: the step executes 6.435 instead of 6.585 TFLOP)
 
 
