@@ -39,6 +39,9 @@ struct SgOptions {
     int no_pipe = 0, no_split = 0;     // register-staged kernel only / no automatic split-K
     int no_nmajor = 0;                 // M-major tile order everywhere
     int pipe_stages = 3;               // 2: 128x128 and 256x64 GEMM / conv tiles on a 2-stage LDS ring (two workgroups per CU)
+    int lat_tiles = 640;               // GEMMs of at most this many 64x64 tiles run the 32x32-per-wave deep-ring kernel (mma_lat_kernel); 0 = only on a caller's hint
+    int lat_min_kt = 8, lat_max_kt = 64;   // ... with this many 64-deep K slabs
+    int lat_stages = 4;                // ring depth of that kernel: 4 (default) or 8
     int attn_sub2 = 0, attn_prio = 0, attn_d80 = 1, attn_d160 = 4 /* 4: key-split workgroups at Nq <= 256 */, attn_lean = 0;
     int attn_d40_general = 0;          // 1 = the D = 40 launches use the general softmax path (A/B against the padded-dimension fast path)
     int gn_no_fused = 0, gn_wide = 1;

@@ -142,6 +142,7 @@ constexpr int EPI_PITCH = 68;                         // floats per staged row
 constexpr int EPI_XTR = 64 * EPI_PITCH;               // float offset of a wave's 1 KB extra area: [0,128) LayerNorm coefficients,
                                                       // [128,256) its 64 columns x 2 planes of GroupNorm statistics (or more LN rows)
 constexpr int EPI_WAVE_BYTES = 64 * EPI_PITCH * 4 + 1024;    // 18432
+constexpr int EPIQ_GROUP_BYTES = 64 * EPI_PITCH * 4 + 4 * 1024;     // epi_finish_q: one 64x64 fp32 image + 1 KB per wave of a 2x2 group
 
 constexpr int LN_MAX_PARTS = 20;      // 64-column blocks per token: C <= 1280
 // Prefetched epilogue operands (native clang vectors, not HIP's float4 class: as members of a struct, or as HIP vector classes,
@@ -489,6 +490,231 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
 }
 
 // ------------------------------------------------------------------------------------------------------------
+// Epilogue of the 32x32-per-wave kernel (mma_lat_kernel, WT = 1 in mma_pipe_body).  The waves of a workgroup form 2x2 GROUPS; a group
+// owns one 64x64 block of the tile: its four waves write their accumulators into ONE row-major fp32 image (same pitch as above), and
+// after the barrier wave q of the group finishes rows 16 q .. 16 q + 15 of the block — the row-quad scheme of epi_finish with 4 quads
+// per lane instead of 16 (instruction k: lane l holds columns 4 (l & 15) .. +3 of block row 16 q + 4 k + (l >> 4)), so every global
+// access is still 4 rows x 256 contiguous bytes.  Everything the linear epilogue of epi_finish offers except GEGLU: bias, temb row
+// bias, two residuals, fp32 / fp16 outputs, the LayerNorm fold on both sides, GroupNorm partials (one per tile: 32 WGM rows), split-K
+// partial tiles.  Row sums for the LayerNorm partials come from 16-lane exchanges (a row of the strip lives in 16 lanes).
+template <int WGN>
+__device__ __forceinline__ void epi_prefetch_q(const MmaParams& p, int m0, int n0, int wave, int lane, f32x4 (&pre)[4], u32x2& pbias) {
+    if (p.splits > 1 || p.mode != SG_EPI_LINEAR) return;
+    const int wm32 = wave / WGN, wn32 = wave % WGN, q = (wm32 & 1) * 2 + (wn32 & 1);
+    const int rowq = m0 + (wm32 >> 1) * 64 + q * 16 + (lane >> 4), cq = min(n0 + (wn32 >> 1) * 64 + 4 * (lane & 15), p.N - 4);
+    if (p.bias) pbias = *reinterpret_cast<const u32x2*>(p.bias + cq);
+    if (!epi_prefetches(p)) return;
+    const float* r = reinterpret_cast<const float*>(p.res1) + cq;
+    const int mlast = p.M - 1;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pre[k] = ld_stream(r + (long)min(rowq + 4 * k, mlast) * p.ldr1);
+}
+
+template <int WGM, int WGN>
+__device__ __forceinline__ void epi_finish_q(const MmaParams& p, char* smem, f32x16& acc, f32x4 (&pre)[4], u32x2& pbias,
+                                             int m0, int n0, int z, int wave, int lane) {
+    constexpr int GN_ = WGN / 2, NW = WGM * WGN, BM = 32 * WGM, BN = 32 * WGN, NT = 64 * NW;
+    const int wm32 = wave / WGN, wn32 = wave % WGN;
+    const int gm_ = wm32 >> 1, gn_ = wn32 >> 1, wi = wm32 & 1, wj = wn32 & 1, q = wi * 2 + wj;
+    const int l31 = lane & 31, hi = lane >> 5, lr = lane >> 4, lc = lane & 15;
+    const int lnm = p.ln_mode;
+    char* grp = smem + (gm_ * GN_ + gn_) * EPIQ_GROUP_BYTES;
+    float* stg = reinterpret_cast<float*>(grp);
+    float* xtr = reinterpret_cast<float*>(grp + 64 * EPI_PITCH * 4 + q * 1024);     // this wave's own 1 KB
+    const int rbase = m0 + gm_ * 64 + q * 16, cbase = n0 + gn_ * 64;                 // first row of the strip, first column of the block
+    // the ring is dead once every wave has issued its last fragment reads (raw barrier: a prefetched residual stays in flight)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<float4*>(stg + (wi * 32 + l31) * EPI_PITCH + wj * 32 + 8 * g + 4 * hi) =
+            make_float4(acc[4 * g], acc[4 * g + 1], acc[4 * g + 2], acc[4 * g + 3]);
+    // LayerNorm coefficients depend on no other wave: computed while the other waves are still writing the image
+    if (lnm == 1) {          // rows are tokens: lane l -> strip row l & 15 (the four lane rows compute the same value; one stores)
+        const float2 c = ln_token_coeffs(p, min(rbase + lc, p.M - 1));
+        if (lr == 0) *reinterpret_cast<float2*>(xtr + 2 * lc) = c;
+    } else if (lnm == 2) {   // columns are tokens: lane l -> block column l; c / d of the strip's rows
+        *reinterpret_cast<float2*>(xtr + 2 * lane) = ln_token_coeffs(p, min(cbase + lane, p.N - 1));
+        const int rr = min(rbase + lc, p.M - 1);
+        if (lr == 0) *reinterpret_cast<float2*>(xtr + 128 + 2 * lc) = make_float2(p.ln_c[rr], p.ln_d[rr]);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const int rowq = rbase + lr, colq = cbase + 4 * lc;
+    const bool col_ok = colq < p.N;
+    const float* img = stg + (q * 16 + lr) * EPI_PITCH + 4 * lc;             // + 4 k rows
+    if (p.splits > 1) {      // raw fp32 partial tile; the epilogue happens in splitk_reduce_kernel (or in the consumer)
+        float* wsz = p.ws + (size_t)z * p.M * p.N + colq;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int gm = rowq + 4 * k;
+            const float4 v = *reinterpret_cast<const float4*>(img + 4 * k * EPI_PITCH);
+            if (gm < p.M && col_ok) st_stream(wsz + (size_t)gm * p.N, f32x4{v.x, v.y, v.z, v.w});
+        }
+        return;
+    }
+    const bool want_stats = p.stats != nullptr;
+    const bool r1f32 = p.flags & SG_F_RES1_F32, r2f32 = p.flags & SG_F_RES2_F32;
+    const bool res2_same = p.res2 != nullptr && p.res2 == p.res1 && p.ldr2 == p.ldr1 && r1f32 == r2f32;
+    const int cq = min(colq, p.N - 4), mlast = p.M - 1;
+    float v[4][4];
+    {
+        float bias4[4] = {0, 0, 0, 0};
+        if (p.bias) {
+            H4 b; b.u = make_uint2(pbias.x, pbias.y);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) bias4[e] = (float)b.h[e];
+        }
+        if (lnm == 1) {
+            const f32x4 lc4 = *reinterpret_cast<const f32x4*>(p.ln_c + cq), ld4 = *reinterpret_cast<const f32x4*>(p.ln_d + cq);
+            const float c4[4] = {lc4.x, lc4.y, lc4.z, lc4.w};
+            const float d4[4] = {ld4.x + bias4[0], ld4.y + bias4[1], ld4.z + bias4[2], ld4.w + bias4[3]};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 a = *reinterpret_cast<const float4*>(img + 4 * k * EPI_PITCH);
+                const float2 mr = *reinterpret_cast<const float2*>(xtr + 2 * (4 * k + lr));
+                const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[k][e] = fmaf(mr.y, av[e], d4[e]) - mr.x * c4[e];
+            }
+        } else if (lnm == 2) {
+            float mrx[4], mry[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const float2 t = *reinterpret_cast<const float2*>(xtr + 2 * (4 * lc + e)); mrx[e] = t.x; mry[e] = t.y; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 a = *reinterpret_cast<const float4*>(img + 4 * k * EPI_PITCH);
+                const float2 cd = *reinterpret_cast<const float2*>(xtr + 128 + 2 * (4 * k + lr));
+                const float av[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[k][e] = fmaf(mry[e], av[e], cd.y + bias4[e]) - mrx[e] * cd.x;
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const float4 a = *reinterpret_cast<const float4*>(img + 4 * k * EPI_PITCH);
+                v[k][0] = a.x + bias4[0]; v[k][1] = a.y + bias4[1]; v[k][2] = a.z + bias4[2]; v[k][3] = a.w + bias4[3];
+            }
+        }
+    }
+    auto add_f32 = [&](const float* base, long ld) __attribute__((always_inline)) {
+        float4 t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = *reinterpret_cast<const float4*>(base + (long)min(rowq + 4 * k, mlast) * ld + cq);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k][0] += t[k].x; v[k][1] += t[k].y; v[k][2] += t[k].z; v[k][3] += t[k].w; }
+    };
+    auto add_f16 = [&](const f16* base, long ld) __attribute__((always_inline)) {
+        uint2 t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) t[k] = *reinterpret_cast<const uint2*>(base + (long)min(rowq + 4 * k, mlast) * ld + cq);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            H4 h; h.u = t[k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[k][e] += (float)h.h[e];
+        }
+    };
+    if (p.rowbias) {
+        float4 t[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            t[k] = *reinterpret_cast<const float4*>(p.rowbias + (long)fd_div((unsigned)min(rowq + 4 * k, mlast), p.fd_rpb) * p.rowbias_ld + cq);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k][0] += t[k].x; v[k][1] += t[k].y; v[k][2] += t[k].z; v[k][3] += t[k].w; }
+    }
+    if (p.res1) {
+        if (r1f32) {
+            const float w = res2_same ? 2.f : 1.f;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                v[k][0] = fmaf(w, pre[k].x, v[k][0]); v[k][1] = fmaf(w, pre[k].y, v[k][1]);
+                v[k][2] = fmaf(w, pre[k].z, v[k][2]); v[k][3] = fmaf(w, pre[k].w, v[k][3]);
+            }
+        } else {
+            add_f16(reinterpret_cast<const f16*>(p.res1), p.ldr1);
+            if (res2_same) add_f16(reinterpret_cast<const f16*>(p.res1), p.ldr1);
+        }
+    }
+    if (p.res2 && !res2_same) {
+        if (r2f32) add_f32(reinterpret_cast<const float*>(p.res2), p.ldr2);
+        else add_f16(reinterpret_cast<const f16*>(p.res2), p.ldr2);
+    }
+    float cs[4] = {0, 0, 0, 0}, cq2[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int gm = rowq + 4 * k;
+        if (gm < p.M && col_ok) {
+            store_out4(p, gm, colq, v[k]);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { cs[e] += v[k][e]; cq2[e] = fmaf(v[k][e], v[k][e], cq2[e]); }
+        }
+    }
+    if (p.ln_out) {
+        // LayerNorm fold, producer side: (sum, M2 about the block mean) of the FINAL fp32 values per token and 64-column block.  A row of
+        // the strip lives in the 16 lanes that share lane >> 4: four exchanges per quantity, fixed order.
+        float s4[4], m4[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) s4[k] = (v[k][0] + v[k][1]) + (v[k][2] + v[k][3]);
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) s4[k] += __shfl_xor(s4[k], o, 64);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float mean = s4[k] * (1.f / 64.f);
+            const float a = v[k][0] - mean, b = v[k][1] - mean, c = v[k][2] - mean, d = v[k][3] - mean;
+            m4[k] = fmaf(a, a, fmaf(b, b, fmaf(c, c, d * d)));
+        }
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) m4[k] += __shfl_xor(m4[k], o, 64);
+        if (lc == 0 && cbase < p.N) {
+            const int nblk = ((p.N >> 6) + 1) & ~1, blk = (n0 >> 6) + gn_;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int gm = rowq + 4 * k;
+                if (gm < p.M) {
+                    *reinterpret_cast<float2*>(p.ln_out + ((size_t)gm * nblk + blk) * 2) = make_float2(s4[k], m4[k]);
+                    if (p.ln_guard && !(fabsf(s4[k] * (1.f / 64.f)) + sqrtf(m4[k]) < 65504.f)) atomicOr(p.ln_guard, SG_LN_GUARD_RANGE);
+                }
+            }
+        }
+    }
+    if (want_stats) {
+        // GroupNorm statistics: per-(tile, channel) sums of the final fp32 values.  A lane holds 4 rows of its 4 columns; the 4 lane rows
+        // are added by two exchanges, the strips of the tile (4 per group, WGM / 2 groups per column block) through LDS in fixed order.
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            cs[e] += __shfl_xor(cs[e], 16, 64); cq2[e] += __shfl_xor(cq2[e], 16, 64);
+            cs[e] += __shfl_xor(cs[e], 32, 64); cq2[e] += __shfl_xor(cq2[e], 32, 64);
+        }
+        if (lr == 0) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                xtr[128 + (4 * lc + e) * 2 + 0] = cs[e];
+                xtr[128 + (4 * lc + e) * 2 + 1] = cq2[e];
+            }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < BN * 2; idx += NT) {
+            const int plane = idx / BN, col = idx - plane * BN;
+            const int gn = n0 + col;
+            if (gn < p.N) {
+                float s = 0.f;
+#pragma unroll
+                for (int g = 0; g < WGM / 2; ++g)
+#pragma unroll
+                    for (int w = 0; w < 4; ++w)
+                        s += reinterpret_cast<const float*>(smem + (g * GN_ + (col >> 6)) * EPIQ_GROUP_BYTES + 64 * EPI_PITCH * 4 + w * 1024)[128 + (col & 63) * 2 + plane];
+                p.stats[((size_t)(m0 / BM) * 2 + plane) * p.N + gn] = s;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------------------
 // Generic kernel: 256 threads (2x2 waves), register-staged double buffer, zero-fill predicates.
 template <int BM, int BN, bool CONV>
 __global__ __launch_bounds__(256) void mma_kernel(const MmaParams p) {
@@ -635,13 +861,32 @@ __device__ __forceinline__ void wait_vmcnt() {
 // LDS ring depth S: 3 by default (one slab computing, two in flight).  S = 2 (round 4) halves the bytes in flight but brings the
 // 128x128 and 256x64 tiles down to 74 / 80 KB of LDS, so that TWO workgroups — one of each of the step's two concurrent passes — fit a
 // CU (round 2 measured the forced 128x128 / 2-stage configuration as the fastest whole step; development option pipe_stages).
-template <int WGM, int WGN, int S>
+template <int WGM, int WGN, int S, int WT = 2>
 constexpr int pipe_smem_bytes() {
-    constexpr int ring = S * (64 * WGM + 64 * WGN) * 128, epi = WGM * WGN * EPI_WAVE_BYTES;
+    constexpr int ring = S * (32 * WT * WGM + 32 * WT * WGN) * 128;
+    constexpr int epi = WT == 2 ? WGM * WGN * EPI_WAVE_BYTES : (WGM / 2) * (WGN / 2) * EPIQ_GROUP_BYTES;
     return ring > epi ? ring : epi;
 }
 
-template <int WGM, int WGN, bool CONV, bool PROF = false, int S = 3>
+// The slabs of one trip through the ring, each with its stage as a compile-time constant (mma_pipe_body): stage ST handles slab it + ST
+// while that slab is a steady one.
+template <int ST, int S, int YS, class F>
+__device__ __forceinline__ void slab_seq(F& slab, int it, int nsteady) {
+    if constexpr (ST < S) {
+        if (it + ST < nsteady) {
+            slab(it + ST, std::false_type{}, std::integral_constant<int, YS>{}, std::integral_constant<int, ST>{});
+            slab_seq<ST + 1, S, YS>(slab, it, nsteady);
+        }
+    }
+}
+// The tail: slab nt - 1 - Y has Y younger slabs in flight (Y = TAIL - 1 ... 0; the last one, Y = 0, carries the epilogue's prefetch)
+template <int Y, int S, class F>
+__device__ __forceinline__ void slab_tail(F& slab, int nt) {
+    if (nt > Y) slab(nt - 1 - Y, std::integral_constant<bool, Y == 0>{}, std::integral_constant<int, Y>{}, (nt - 1 - Y) % S);
+    if constexpr (Y > 0) slab_tail<Y - 1, S>(slab, nt);
+}
+
+template <int WGM, int WGN, bool CONV, bool PROF = false, int S = 3, int WT = 2>
 __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     // PROF (SG_BUILD_EXPERIMENTS): s_memtime stamps around the phases of every slab, summed per wave (sg_debug_gemm_anatomy /
     // _conv_anatomy): [0] slabs [1] vmcnt wait [2] barrier [3] first fragment reads + k-step 0 [4] k-step 1 up to the DMA issue
@@ -656,7 +901,10 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         }
     };
     if constexpr (PROF) pf_entry = pf_t = __builtin_readcyclecounter();
-    constexpr int WTM = 2, WTN = 2;
+    // WT = 2: every wave owns 64x64 of the tile (2x2 MFMA accumulators; the throughput shapes).  WT = 1 (round 6, mma_lat_kernel): 32x32 per
+    // wave — a 64x64 tile is shared by FOUR waves, so a slab costs each of them 4 MFMAs and 4 LDS-DMA pieces instead of 16 and 16, and the
+    // ring is 4 - 8 stages deep: the form for the launches whose time is their dependent chain of slabs, not their FLOPs (below).
+    constexpr int WTM = WT, WTN = WT;
     constexpr int NW = WGM * WGN, WM = 32 * WTM, WN = 32 * WTN, BM = WM * WGM, BN = WN * WGN;
     constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW), LPT = A_IT + B_IT;   // LDS-DMA instructions / lane / slab
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -670,12 +918,13 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
 #ifdef SG_PIPE_BURST
     constexpr bool SPREAD = false, STAGGER = false;       // A/B build (tools/ab_lib.py): rounds 1-4, every wave bursts behind the first k-step
 #else
-    constexpr bool SPREAD = NW <= 4 && !PROF, STAGGER = NW == 8 && !PROF;
+    constexpr bool SPREAD = (NW <= 4 || WT == 1) && !PROF, STAGGER = NW == 8 && WT == 2 && !PROF;
 #endif
-    static_assert(S == 2 || S == 3, "ring depth");
-    static_assert((S - 2) * LPT < 64, "vmcnt is a 6-bit counter");
+    static_assert(S >= 2 && S <= 8, "ring depth");
+    static_assert(WT == 2 || (WGM % 2 == 0 && WGN % 2 == 0), "32x32 waves come in 2x2 groups (epi_finish_q)");
+    static_assert((S - 1) * LPT < 64, "vmcnt is a 6-bit counter");
     static_assert(S * STAGE <= 160 * 1024, "the ring must fit the 160 KB of LDS");
-    static_assert(S * STAGE <= pipe_smem_bytes<WGM, WGN, S>(), "the LDS block covers the ring and the epilogue's staging regions");
+    static_assert(S * STAGE <= pipe_smem_bytes<WGM, WGN, S, WT>(), "the LDS block covers the ring and the epilogue's staging regions");
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -870,7 +1119,9 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         if (with_w) issue_w(ab.wk, stage);
     };
     if (nt > 0) issue_aw(kt0, 0, false);                   // (its weights left first, above)
-    if (S > 2 && nt > 1) issue_aw(kt0 + 1, 1, true);
+#pragma unroll
+    for (int st = 1; st < S - 1; ++st)
+        if (nt > st) issue_aw(kt0 + st, st, true);
 
     f32x16 acc[WTM][WTN];
 #pragma unroll
@@ -879,32 +1130,39 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         for (int j = 0; j < WTN; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-    EPI_PRE_DECL;
+    f32x4 pre_f[WT == 2 ? 16 : 4]; u32x2 pre_bias;       // prefetched epilogue operands (epi_prefetch / epi_prefetch_q)
+    auto prefetch = [&]() __attribute__((always_inline)) {
+        if constexpr (WT == 2) epi_prefetch(p, m0, n0, wm, wn, lane, pre_f, pre_bias);
+        else epi_prefetch_q<WGN>(p, m0, n0, wave, lane, pre_f, pre_bias);
+    };
 
     // LDS offsets of this lane's fragment reads, per ring stage and k-step (the XOR swizzle makes the k-step term per-lane, and stages
     // 1 / 2 of the larger tiles lie beyond the 16-bit immediate of ds_read): 2 x 4 x S registers, opaque to the compiler so that it keeps
     // them instead of re-deriving base + constant with a v_add / v_or before every read of every slab
-    unsigned fa_off[S][4], fb_off[S][4];
+    // (WT = 1, deep rings of small stages: SPB consecutive stages share one base register — their distance fits ds_read's 16-bit immediate)
+    constexpr int SPB = WT == 2 ? 1 : ((65536 - 8192) / STAGE > 0 ? (65536 - 8192) / STAGE : 1);
+    constexpr int NBASE = (S + SPB - 1) / SPB;
+    unsigned fa_off[NBASE][4], fb_off[NBASE][4];
 #pragma unroll
-    for (int st = 0; st < S; ++st)
+    for (int st = 0; st < NBASE; ++st)
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
-            fa_off[st][ks] = (unsigned)(st * STAGE + lds_off(wm * WM + l31, ks * 2 + hi));
-            fb_off[st][ks] = (unsigned)(st * STAGE + A_BYTES + lds_off(wn * WN + l31, ks * 2 + hi));
+            fa_off[st][ks] = (unsigned)(st * SPB * STAGE + lds_off(wm * WM + l31, ks * 2 + hi));
+            fb_off[st][ks] = (unsigned)(st * SPB * STAGE + A_BYTES + lds_off(wn * WN + l31, ks * 2 + hi));
             asm volatile("" : "+v"(fa_off[st][ks]), "+v"(fb_off[st][ks]));
         }
     stamp(7);
-    // one K slab; LAST = the final slab of this block (no refill: the residual of the epilogue is requested under its MFMAs instead).
+    // one K slab; LAST = the final slab of this block (no refill: the residual of the epilogue is requested under its MFMAs instead);
+    // YOUNG = the number of younger slabs in flight while this one is waited for (S - 2 in the steady loop, fewer at the tail).
     // `stage_c` = the ring stage of slab `it`: a std::integral_constant in the steady loop (round 4: S copies of the slab per trip, so the
     // 16 fragment reads address LDS as loop-invariant per-lane bases + immediates and the DMA destinations are constants — a run-time
     // stage cost 18 - 26 v_add_u32 per slab and wave, issued BESIDE the MFMAs, where VALU time adds to matrix time,
-    // tools/probes/README.md), a plain int for the last slab.
-    auto slab = [&](int it, auto last_tag, auto stage_c) __attribute__((always_inline)) {
+    // tools/probes/README.md), a plain int for the tail slabs.
+    auto slab = [&](int it, auto last_tag, auto young_tag, auto stage_c) __attribute__((always_inline)) {
         constexpr bool LAST = decltype(last_tag)::value;
+        constexpr int YOUNG = decltype(young_tag)::value;
         const int stage = stage_c;
-        // one younger slab stays in flight while we wait for slab `it` (none at the very end)
-        if constexpr (LAST || S == 2) wait_vmcnt<0>();
-        else wait_vmcnt<LPT>();
+        wait_vmcnt<YOUNG * LPT>();
         stamp(1);
         __builtin_amdgcn_s_barrier();
         stamp(2);
@@ -914,7 +1172,7 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         // read of a slab exposes LDS latency; the other three hide behind the previous k-step's four MFMAs
         f16x8 af[2][WTM], bf[2][WTN];
         auto load_frags = [&](int buf, int ks) __attribute__((always_inline)) {
-            if constexpr (std::is_same<decltype(stage_c), int>::value) {       // run-time stage (last slab): addresses computed here
+            if constexpr (std::is_same<decltype(stage_c), int>::value) {       // run-time stage (tail slabs): addresses computed here
 #pragma unroll
                 for (int i = 0; i < WTM; ++i)
                     af[buf][i] = *reinterpret_cast<const f16x8*>(sA + lds_off(wm * WM + i * 32 + l31, ks * 2 + hi));
@@ -924,9 +1182,11 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
             } else {                                                            // rows i * 32 further on: + 4096 bytes, an immediate
                 constexpr int ST = decltype(stage_c)::value;
 #pragma unroll
-                for (int i = 0; i < WTM; ++i) af[buf][i] = *reinterpret_cast<const f16x8*>(smem + fa_off[ST][ks] + i * 4096);
+                for (int i = 0; i < WTM; ++i)
+                    af[buf][i] = *reinterpret_cast<const f16x8*>(smem + fa_off[ST / SPB][ks] + (ST % SPB) * STAGE + i * 4096);
 #pragma unroll
-                for (int j = 0; j < WTN; ++j) bf[buf][j] = *reinterpret_cast<const f16x8*>(smem + fb_off[ST][ks] + j * 4096);
+                for (int j = 0; j < WTN; ++j)
+                    bf[buf][j] = *reinterpret_cast<const f16x8*>(smem + fb_off[ST / SPB][ks] + (ST % SPB) * STAGE + j * 4096);
             }
         };
         load_frags(0, 0);
@@ -947,14 +1207,14 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
                         issue_w(ab.wk, rst, ks);
                     }
                 } else if (ks == 1) {
-                    epi_prefetch(p, m0, n0, wm, wn, lane, EPI_PRE_ARGS);
+                    prefetch();
                 }
             } else if (LAST || !STAGGER ? ks == 1 : ks == (wave < 4 ? 1 : 3)) {
                 // burst: the whole refill behind the first k-step's fragment reads (its address arithmetic overlaps matrix work);
                 // STAGGER: the second wave of every SIMD two k-steps later, so that one of the two is always on the matrix pipe
                 stamp(4);
                 if constexpr (LAST) {
-                    epi_prefetch(p, m0, n0, wm, wn, lane, EPI_PRE_ARGS);
+                    prefetch();
                 } else if (it + S - 1 < nt) {
                     issue_aw(kt0 + it + S - 1, rst, true);
                 }
@@ -970,27 +1230,25 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         stamp(6);
         if constexpr (PROF) pf_acc[0] += 1;
     };
+    // Steady slabs: S - 2 younger slabs in flight behind each (S = 2: none, but the refill still follows); the last TAIL slabs find fewer
+    // — counted vmcnt waits need the number at compile time, so each of them is its own copy of the slab (run-time stage).
+    constexpr int TAIL = S > 2 ? S - 2 : 1, YS = S - 2;
+    const int nsteady = nt > TAIL ? nt - TAIL : 0;
 #ifdef SG_PIPE_RT_STAGE          // A/B build (tools/ab_lib.py): the ring stage as a run-time variable, as in rounds 1-4
     {
         int stage = 0;
-        for (int it = 0; it + 1 < nt; ++it) {
-            slab(it, std::false_type{}, stage);
+        for (int it = 0; it < nsteady; ++it) {
+            slab(it, std::false_type{}, std::integral_constant<int, YS>{}, stage);
             if (++stage == S) stage = 0;
         }
-        if (nt > 0) slab(nt - 1, std::true_type{}, stage);
     }
 #else
-    for (int it = 0; it + 1 < nt; it += S) {
-        slab(it, std::false_type{}, std::integral_constant<int, 0>{});
-        if (it + 2 < nt) slab(it + 1, std::false_type{}, std::integral_constant<int, 1>{});
-        if constexpr (S > 2) {
-            if (it + 3 < nt) slab(it + 2, std::false_type{}, std::integral_constant<int, 2>{});
-        }
-    }
-    if (nt > 0) slab(nt - 1, std::true_type{}, (nt - 1) % S);
+    for (int it = 0; it < nsteady; it += S) slab_seq<0, S, YS>(slab, it, nsteady);
 #endif
-    if (nt <= 0) epi_prefetch(p, m0, n0, wm, wn, lane, EPI_PRE_ARGS);
-    epi_finish<WGM, WGN>(p, smem, acc, EPI_PRE_ARGS, m0, n0, z, wave, wm, wn, lane);
+    slab_tail<TAIL - 1, S>(slab, nt);
+    if (nt <= 0) prefetch();
+    if constexpr (WT == 2) epi_finish<WGM, WGN>(p, smem, acc, pre_f, pre_bias, m0, n0, z, wave, wm, wn, lane);
+    else epi_finish_q<WGM, WGN>(p, smem, acc[0][0], pre_f, pre_bias, m0, n0, z, wave, lane);
     if constexpr (PROF) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(8);
@@ -1007,6 +1265,17 @@ template <int WGM, int WGN, bool CONV, int S = 3>
 __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParams p) {
     __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN, S>()];
     mma_pipe_body<WGM, WGN, CONV, false, S>(p, smem);
+}
+
+// The latency form (round 6): WGM x WGN waves of 32x32 (a 64x64 tile = 4 waves), S = 4 - 8 ring stages of 16 KB.  The batch-3 main pass
+// runs ~130 GEMMs per step whose FLOPs are worth 1 - 3 us and whose launches took 12 - 24 us inside the step graph (tools/bench_chain.py):
+// on the 64x64-per-wave tiles a slab costs ~1 300 cycles (LDS-DMA latency / the two slabs a 3-stage ring keeps in flight; 16 MFMAs + 6 - 8
+// DMA pieces per wave), and 20 - 80 of them are a dependent chain.  Here a slab is 4 MFMAs + 4 pieces per wave with up to seven slabs in
+// flight, and 240 - 480 tiles fill the chip without split-K.
+template <int WGM, int WGN, bool CONV, int S>
+__global__ __launch_bounds__(64 * WGM * WGN) void mma_lat_kernel(const MmaParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN, S, 1>()];
+    mma_pipe_body<WGM, WGN, CONV, false, S, 1>(p, smem);
 }
 
 #ifdef SG_BUILD_EXPERIMENTS
@@ -1031,6 +1300,16 @@ __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_pair_kernel(const Mma
         if ((int)blockIdx.x < pp.p0.tiles_m * pp.p0.tiles_n * pp.p0.splits) mma_pipe_body<WGM, WGN, false>(pp.p0, smem);
     } else {
         if ((int)blockIdx.x < pp.p1.tiles_m * pp.p1.tiles_n * pp.p1.splits) mma_pipe_body<WGM, WGN, false>(pp.p1, smem);
+    }
+}
+
+template <int S>
+__global__ __launch_bounds__(256) void mma_lat_pair_kernel(const MmaPair pp) {
+    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<2, 2, S, 1>()];
+    if (blockIdx.y == 0) {
+        if ((int)blockIdx.x < pp.p0.tiles_m * pp.p0.tiles_n * pp.p0.splits) mma_pipe_body<2, 2, false, false, S, 1>(pp.p0, smem);
+    } else {
+        if ((int)blockIdx.x < pp.p1.tiles_m * pp.p1.tiles_n * pp.p1.splits) mma_pipe_body<2, 2, false, false, S, 1>(pp.p1, smem);
     }
 }
 
@@ -1260,7 +1539,7 @@ int reduce_stats_rows(const MmaParams& p) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-struct Plan { int bm, bn, splits; };
+struct Plan { int bm, bn, splits; int lat; };      // lat: 0 = 64x64 per wave; else the 32x32-per-wave kernel (mma_lat_kernel) and its ring depth
 
 // Development options: storygen_amd/csrc/common.h SgOptions (set through sg_debug_set_option; never from the environment).
 struct TuneView {
@@ -1281,7 +1560,7 @@ Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool p
     static const int split_opts[] = {1, 2, 3, 4, 5, 6, 8, 10, 12, 16};
     const int ncand = pipe ? 6 : 1;
     const double CUS = 256.0, BW = pipe ? 18.5 : 12.0;
-    Plan best{64, 64, 1};
+    Plan best{64, 64, 1, 0};
     double best_cost = 1e300;
     for (int ci = 0; ci < ncand; ++ci) {
         const int bm = pipe ? cand_pipe[ci][0] : cand_gen[ci][0], bn = pipe ? cand_pipe[ci][1] : cand_gen[ci][1];
@@ -1302,10 +1581,10 @@ Plan choose_plan(int M, int N, int KT, int force_split, int max_ws_split, bool p
             const double t_mfma = waves_per_simd * slabs * mfma_per_slab;
             double cost = (t_bw > t_mfma ? t_bw : t_mfma) + 2500.0 + blocks_per_cu * (bm * bn / 16.0);
             if (s > 1) cost += 5000.0 + (double)M * N * 4.0 * (s + 1) / 1500.0;   // second launch + partial tiles
-            if (cost < best_cost) { best_cost = cost; best = Plan{bm, bn, s}; }
+            if (cost < best_cost) { best_cost = cost; best = Plan{bm, bn, s, 0}; }
         }
     }
-    if (best_cost == 1e300) best = Plan{64, 64, force_split > KT ? KT : (force_split > 0 ? force_split : 1)};
+    if (best_cost == 1e300) best = Plan{64, 64, force_split > KT ? KT : (force_split > 0 ? force_split : 1), 0};
     return best;
 }
 
@@ -1352,15 +1631,51 @@ int check_stats(MmaParams& p, int bm, const char* name) {
 
 // Decomposition of one problem: tile shape, K split, tile order; fills the corresponding fields of p.  `pipe` = the LDS-DMA
 // kernel applies (no load needs a predicate: K % 64 == 0; conv input zero-bordered), else the register-staged kernel.
+// The 32x32-per-wave kernel (mma_lat_kernel, 64x64 tiles of four waves): for launches that are a short dependent chain rather than a
+// volume of FLOPs.  hint_waves = 4 with a 64x64 hint: the caller asks for it; -1: never; 0: by size (development options lat_tiles,
+// lat_min_kt, lat_max_kt).  Returns the ring depth, or 0 when the launch stays on the 64x64-per-wave kernels.
 template <bool CONV>
-int plan_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws, size_t ws_bytes, const char* name,
+int lat_ring(const MmaParams& p, bool pipe, int hint_bm, int hint_bn, int hint_waves, int splits) {
+    if (!pipe || p.mode != SG_EPI_LINEAR || p.prof || hint_waves < 0 || g_tune.bm) return 0;
+    const long tiles = (long)sg_cdiv(p.M, 64) * sg_cdiv(p.N, 64);
+    const SgOptions& o = sg_options();
+    const bool asked = hint_bm == 64 && hint_bn == 64 && hint_waves == 4;
+    const bool by_size = !CONV && hint_bm == 0 && hint_bn == 0 && hint_waves == 0 && tiles <= o.lat_tiles && p.KT >= o.lat_min_kt &&
+                         p.KT <= o.lat_max_kt;
+    if (!asked && !by_size) return 0;
+    (void)splits;
+    // 4 stages (three slabs = 48 KB in flight per workgroup, two workgroups per CU) measured equal or better than 8 on every main-pass
+    // shape, incl. those of <= 256 workgroups (M768 N1280 K1280: 9.9 vs 10.7 us per graph node — the 8-stage prologue issues 28 DMA
+    // pieces per wave before the first slab can land; profiles/r06b_*); 8 stays behind the development option
+    return o.lat_stages == 8 ? 8 : 4;
+}
+
+template <bool CONV>
+int plan_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_waves, void* ws, size_t ws_bytes, const char* name,
              Plan& pl, bool& pipe) {
     p.KT = sg_cdiv(p.K, BK);
     p.prof = g_prof;
     pipe = (p.K % BK == 0) && (!CONV || p.padded) && !g_tune.no_pipe;
     const size_t per_split = (size_t)p.M * p.N * 4;
     const int max_ws_split = ws ? (int)(ws_bytes / per_split > 64 ? 64 : ws_bytes / per_split) : 1;
-    pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, pipe, hint_bm, hint_bn);
+    if (lat_ring<CONV>(p, pipe, hint_bm, hint_bn, hint_waves, 1)) {
+        // K slices only where the 64x64 tiles alone leave most CUs idle (M <= 256 at N = 1280): enough of them for ~256 workgroups,
+        // at least 8 slabs each
+        const long tiles = (long)sg_cdiv(p.M, 64) * sg_cdiv(p.N, 64);
+        int s = 1;
+        if (force_split > 0) s = force_split > p.KT ? p.KT : force_split;
+        else if (tiles <= 128 && !g_tune.no_split) {
+            s = (int)(256 / tiles);
+            if (s > p.KT / 8) s = p.KT / 8;
+            if (s > max_ws_split) s = max_ws_split;
+            if (s > MAX_AUTO_SPLIT) s = MAX_AUTO_SPLIT;
+            if (s < 1) s = 1;
+        }
+        pl = Plan{64, 64, s, lat_ring<CONV>(p, pipe, hint_bm, hint_bn, hint_waves, s)};
+    } else {
+        if (hint_waves == 4 && hint_bm == 64 && hint_bn == 64) hint_bm = hint_bn = 0;      // asked for, not applicable: the cost model decides
+        pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, pipe, hint_bm, hint_bn);
+    }
     if (pl.splits > 1) {
         const size_t need = per_split * pl.splits;
         if (ws == nullptr || ws_bytes < need)
@@ -1434,10 +1749,10 @@ int launch_reduce(const MmaParams& p, hipStream_t st) {
 }
 
 template <bool CONV>
-int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws, size_t ws_bytes, hipStream_t st, const char* name) {
+int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_waves, void* ws, size_t ws_bytes, hipStream_t st, const char* name) {
     Plan pl;
     bool pipe;
-    if (int rc = plan_mma<CONV>(p, force_split, hint_bm, hint_bn, ws, ws_bytes, name, pl, pipe)) return rc;
+    if (int rc = plan_mma<CONV>(p, force_split, hint_bm, hint_bn, hint_waves, ws, ws_bytes, name, pl, pipe)) return rc;
     if (g_stats_query) {
         g_query_rows = p.stats ? (pl.splits > 1 ? reduce_stats_rows(p) : pl.bm) : 0;
         return SG_OK;
@@ -1446,14 +1761,18 @@ int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, void* ws
         g_query_rows = pl.splits;
         if (g_plan_out) {
             g_plan_out[0] = pl.bm; g_plan_out[1] = pl.bn; g_plan_out[2] = pl.splits; g_plan_out[3] = p.tiles_m * p.tiles_n * pl.splits;
-            g_plan_out[4] = pipe ? 64 * (pl.bm / 64) * (pl.bn / 64) : 256; g_plan_out[5] = pipe ? 1 : 0;
+            g_plan_out[4] = pl.lat ? 256 : pipe ? 64 * (pl.bm / 64) * (pl.bn / 64) : 256;
+            g_plan_out[5] = pl.lat ? 16 + pl.lat : pipe ? 1 : 0;                     // 16 + ring depth: the 32x32-per-wave kernel
         }
         return SG_OK;
     }
     if (p.defer && pl.splits <= 1)
         return sg_set_error(SG_EINVAL, "%s: defer_reduce needs a split-K launch (query sg_conv3x3_planned_splits first)", name);
     dim3 grid(p.tiles_m * p.tiles_n * pl.splits);
-    if (pipe) {
+    if (pl.lat) {
+        if (pl.lat == 8) hipLaunchKernelGGL((mma_lat_kernel<2, 2, CONV, 8>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((mma_lat_kernel<2, 2, CONV, 4>), grid, dim3(256), 0, st, p);
+    } else if (pipe) {
         if (pl.bm == 256 && pl.bn == 128) launch_pipe<4, 2, CONV>(p, grid, st);
         else if (pl.bm == 128 && pl.bn == 128) launch_pipe<2, 2, CONV>(p, grid, st);
         else if (pl.bm == 256 && pl.bn == 64) launch_pipe<4, 1, CONV>(p, grid, st);
@@ -1482,8 +1801,9 @@ int check_out_res(const char* who, int flags, const void* C, int64_t ldc, const 
 }
 
 int check_tile_hint(const char* who, int bm, int bn, int waves) {
+    if (bm == 64 && bn == 64 && waves == 4) return SG_OK;       // the 32x32-per-wave kernel (mma_lat_kernel)
     if (waves != 0 && waves != (bm / 64) * (bn / 64))
-        return sg_set_error(SG_EINVAL, "%s: tile_waves=%d is not available for tile %dx%d (64x64 per wave only)", who, waves, bm, bn);
+        return sg_set_error(SG_EINVAL, "%s: tile_waves=%d is not available for tile %dx%d (64x64 per wave; 64x64 with 4 waves of 32x32)", who, waves, bm, bn);
     if (bm == 0 && bn == 0) return SG_OK;
     static const int ok[6][2] = {{256, 128}, {128, 128}, {256, 64}, {128, 64}, {64, 128}, {64, 64}};
     for (auto& t : ok)
@@ -1568,7 +1888,7 @@ void launch_pair(const MmaPair& pp, dim3 grid, hipStream_t st) {
 extern "C" int sg_gemm_f16(const sg_gemm_desc* d, sg_stream_t stream) {
     MmaParams p;
     if (int rc = gemm_params(d, p, "sg_gemm_f16")) return rc;
-    return launch_mma<false>(p, d->ln_mode ? 1 : d->split_k, d->tile_m, d->tile_n, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_gemm_f16");
+    return launch_mma<false>(p, d->ln_mode ? 1 : d->split_k, d->tile_m, d->tile_n, d->tile_waves, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_gemm_f16");
 }
 
 extern "C" int sg_gemm_pair_f16(const sg_gemm_desc* d0, const sg_gemm_desc* d1, sg_stream_t stream) {
@@ -1583,17 +1903,21 @@ extern "C" int sg_gemm_pair_f16(const sg_gemm_desc* d0, const sg_gemm_desc* d1, 
     Plan pl0, pl1;
     bool pipe0, pipe1;
     const int sk0 = d0->ln_mode ? 1 : d0->split_k, sk1 = d1->ln_mode ? 1 : d1->split_k;
-    if (int rc = plan_mma<false>(pp.p0, sk0, d0->tile_m, d0->tile_n, d0->workspace, d0->workspace_bytes, "sg_gemm_pair_f16[0]", pl0, pipe0)) return rc;
-    // one kernel instantiation serves both problems: the second one is planned on the first one's tile shape
-    if (int rc = plan_mma<false>(pp.p1, sk1, pl0.bm, pl0.bn, d1->workspace, d1->workspace_bytes, "sg_gemm_pair_f16[1]", pl1, pipe1)) return rc;
-    if (!pipe0 || !pipe1 || pl1.bm != pl0.bm || pl1.bn != pl0.bn) {        // not pairable (K % 64, forced tile): two launches
-        if (int rc = launch_mma<false>(pp.p0, sk0, d0->tile_m, d0->tile_n, d0->workspace, d0->workspace_bytes, st, "sg_gemm_pair_f16[0]")) return rc;
-        return launch_mma<false>(pp.p1, sk1, d1->tile_m, d1->tile_n, d1->workspace, d1->workspace_bytes, st, "sg_gemm_pair_f16[1]");
+    if (int rc = plan_mma<false>(pp.p0, sk0, d0->tile_m, d0->tile_n, d0->tile_waves, d0->workspace, d0->workspace_bytes, "sg_gemm_pair_f16[0]", pl0, pipe0)) return rc;
+    // one kernel instantiation serves both problems: the second one is planned on the first one's tile shape (and kernel family)
+    if (int rc = plan_mma<false>(pp.p1, sk1, pl0.bm, pl0.bn, pl0.lat ? 4 : -1, d1->workspace, d1->workspace_bytes, "sg_gemm_pair_f16[1]", pl1, pipe1)) return rc;
+    if (!pipe0 || !pipe1 || pl1.bm != pl0.bm || pl1.bn != pl0.bn || (pl0.lat != 0) != (pl1.lat != 0)) {        // not pairable (K % 64, forced tile): two launches
+        if (int rc = launch_mma<false>(pp.p0, sk0, d0->tile_m, d0->tile_n, d0->tile_waves, d0->workspace, d0->workspace_bytes, st, "sg_gemm_pair_f16[0]")) return rc;
+        return launch_mma<false>(pp.p1, sk1, d1->tile_m, d1->tile_n, d1->tile_waves, d1->workspace, d1->workspace_bytes, st, "sg_gemm_pair_f16[1]");
     }
     const int g0 = pp.p0.tiles_m * pp.p0.tiles_n * pp.p0.splits, g1 = pp.p1.tiles_m * pp.p1.tiles_n * pp.p1.splits;
     // grid.x is a multiple of 8 so that block (x, 1) sits on XCD x % 8 like block (x, 0): xcd_remap keeps its meaning
     dim3 grid(((g0 > g1 ? g0 : g1) + 7) & ~7, 2);
-    if (pl0.bm == 256 && pl0.bn == 128) launch_pair<4, 2>(pp, grid, st);
+    if (pl0.lat) {
+        if (sg_options().lat_stages == 8) hipLaunchKernelGGL(mma_lat_pair_kernel<8>, grid, dim3(256), 0, st, pp);
+        else hipLaunchKernelGGL(mma_lat_pair_kernel<4>, grid, dim3(256), 0, st, pp);
+    }
+    else if (pl0.bm == 256 && pl0.bn == 128) launch_pair<4, 2>(pp, grid, st);
     else if (pl0.bm == 128 && pl0.bn == 128) launch_pair<2, 2>(pp, grid, st);
     else if (pl0.bm == 256 && pl0.bn == 64) launch_pair<4, 1>(pp, grid, st);
     else if (pl0.bm == 128 && pl0.bn == 64) launch_pair<2, 1>(pp, grid, st);
@@ -1642,7 +1966,7 @@ extern "C" int sg_conv3x3_nhwc_f16(const sg_conv3x3_desc* d, sg_stream_t stream)
     SG_REQUIRE(d->defer_reduce == 0 || (d->defer_reduce == 1 && !d->stats), "sg_conv3x3: defer_reduce is 0 or 1 and excludes stats");
     p.defer = d->defer_reduce;
     if (int rc = check_tile_hint("sg_conv3x3", d->tile_m, d->tile_n, d->tile_waves)) return rc;
-    return launch_mma<true>(p, d->split_k, d->tile_m, d->tile_n, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_conv3x3_nhwc_f16");
+    return launch_mma<true>(p, d->split_k, d->tile_m, d->tile_n, d->tile_waves, d->workspace, d->workspace_bytes, (hipStream_t)stream, "sg_conv3x3_nhwc_f16");
 }
 
 // Would a launch with this descriptor emit epilogue statistics, and with which tile height?  (Plans the launch exactly as

@@ -247,22 +247,38 @@ def _plan_of(fn, d):
     return list(out)
 
 
+def _kernel_name(bm: int, bn: int, pipe: int, conv: bool) -> str:
+    """The instantiation a plan launches, as rocprofv3 prints it (pipe: 0 = register-staged, 1 = LDS-DMA ring of 64x64-per-wave tiles,
+    16 + S = the 32x32-per-wave kernel on an S-stage ring)."""
+    c = "true" if conv else "false"
+    if pipe >= 16:
+        return f"mma_lat_kernel<{bm // 32}, {bn // 32}, {c}, {pipe - 16}>"
+    return f"mma_pipe_kernel<{bm // 64}, {bn // 64}, {c}, 3>" if pipe else f"mma_kernel<{bm}, {bn}, {c}>"
+
+
 def _report_plan(kind: str, d, nbytes: float, family: str, shape: str, second=None):
-    """PLAN_SINK record of one launch (see PLAN_SINK).  second = (desc, bytes) of the other problem of a paired launch."""
+    """PLAN_SINK record of one launch (see PLAN_SINK).  second = (desc, bytes) of the other problem of a paired launch.  Plans are
+    queried on COPIES of the descriptors: the instrumented step must launch exactly what the uninstrumented one does."""
     if kind == "conv":
         bm, bn, splits, wgs, threads, pipe = _plan_of(lib.sg_conv3x3_launch_plan, d)
-        name = f"mma_pipe_kernel<{bm // 64}, {bn // 64}, true, 3>" if pipe else f"mma_kernel<{bm}, {bn}, true>"
+        name = _kernel_name(bm, bn, pipe, True)
     else:
         bm, bn, splits, wgs, threads, pipe = _plan_of(lib.sg_gemm_launch_plan, d)
-        name = f"mma_pipe_kernel<{bm // 64}, {bn // 64}, false, 3>" if pipe else f"mma_kernel<{bm}, {bn}, false>"
+        name = _kernel_name(bm, bn, pipe, False)
         if second is not None:
             d1, b1 = second
-            d1.tile_m, d1.tile_n = bm, bn
-            bm1, bn1, _, wgs1, _, pipe1 = _plan_of(lib.sg_gemm_launch_plan, d1)
-            if pipe and pipe1 and (bm1, bn1) == (bm, bn):
-                name, wgs, nbytes = f"mma_pipe_pair_kernel<{bm // 64}, {bn // 64}>", ((max(wgs, wgs1) + 7) & ~7) * 2, nbytes + b1
-            else:           # not pairable: two plain launches
-                PLAN_SINK.append((f"mma_pipe_kernel<{bm1 // 64}, {bn1 // 64}, false, 3>", wgs1 * threads, b1, family, shape + " [2nd]"))
+            q = type(d1).from_buffer_copy(d1)
+            q.tile_m, q.tile_n, q.tile_waves = bm, bn, (4 if pipe >= 16 else 0)
+            bm1, bn1, _, wgs1, threads1, pipe1 = _plan_of(lib.sg_gemm_launch_plan, q)
+            if pipe and pipe1 and (bm1, bn1) == (bm, bn) and (pipe >= 16) == (pipe1 >= 16):
+                if pipe >= 16:
+                    name = f"mma_lat_pair_kernel<{pipe - 16}>"
+                else:
+                    name = f"mma_pipe_pair_kernel<{bm // 64}, {bn // 64}>"
+                wgs, nbytes = ((max(wgs, wgs1) + 7) & ~7) * 2, nbytes + b1
+            else:           # not pairable: two plain launches, each on its own plan
+                bm1, bn1, _, wgs1, threads1, pipe1 = _plan_of(lib.sg_gemm_launch_plan, d1)
+                PLAN_SINK.append((_kernel_name(bm1, bn1, pipe1, False), wgs1 * threads1, b1, family, shape + " [2nd]"))
     PLAN_SINK.append((name, wgs * threads, nbytes, family, shape))
 
 
@@ -1024,7 +1040,8 @@ def debug_set_option(name: str, value: int) -> None:
 # library no longer reads the environment: this maps the variables onto sg_debug_set_option, and only when a tool asks for it.
 _ENV_OPTIONS = {"SG_NO_NMAJOR": "no_nmajor", "SG_NO_PIPE": "no_pipe", "SG_NO_SPLIT": "no_split",
                 "SG_ATTN_SUB2": "attn_sub2", "SG_ATTN_PRIO": "attn_prio", "SG_ATTN_D80": "attn_d80", "SG_ATTN_D160": "attn_d160",
-                "SG_FF_VARIANT": "ff_variant", "SG_PIPE_STAGES": "pipe_stages", "SG_GN_FUSED_NT": "gn_fused_nt", "SG_GN_CHUNKS": "gn_chunks", "SG_ATTN_LEAN": "attn_lean", "SG_ATTN_D40_GENERAL": "attn_d40_general", "SG_NO_GN_FUSED": "gn_no_fused", "SG_GN_WIDE": "gn_wide", "SG_GN_FUSED_MAX": "gn_fused_max"}
+                "SG_FF_VARIANT": "ff_variant", "SG_PIPE_STAGES": "pipe_stages", "SG_GN_FUSED_NT": "gn_fused_nt", "SG_GN_CHUNKS": "gn_chunks", "SG_ATTN_LEAN": "attn_lean", "SG_ATTN_D40_GENERAL": "attn_d40_general", "SG_NO_GN_FUSED": "gn_no_fused", "SG_GN_WIDE": "gn_wide", "SG_GN_FUSED_MAX": "gn_fused_max",
+                "SG_LAT_TILES": "lat_tiles", "SG_LAT_MIN_KT": "lat_min_kt", "SG_LAT_MAX_KT": "lat_max_kt", "SG_LAT_STAGES": "lat_stages"}
 
 
 def apply_env_options() -> dict:

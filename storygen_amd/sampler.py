@@ -124,6 +124,7 @@ class StoryGenSampler:
         self.ahead = self.overlap or self.group
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.graphs: List[torch.cuda.CUDAGraph] = []
+        self.tails: Dict[int, torch.cuda.CUDAGraph] = {}          # parity -> graph of the loop's last group (no look-ahead pass)
         self.main: Optional[UNetEngine] = None
         self.ref: Optional[UNetEngine] = None
         self.layout = None
@@ -213,7 +214,7 @@ class StoryGenSampler:
             self.n_par = self.B + 2 + self.schedule.row_len
             self.params = torch.zeros(1, self.n_par, dtype=torch.float32, device=self.dev)
             self.lat_trace, self.group_direct = None, False
-            self.layout, self.graph, self.graphs, self.g_ref, self.g_main = key, None, [], [], []
+            self.layout, self.graph, self.graphs, self.g_ref, self.g_main, self.tails = key, None, [], [], [], {}
             return
         units, hops, rows, groups, short = self._plan(stage, share_zero)
         G = self.G
@@ -280,7 +281,7 @@ class StoryGenSampler:
         self.n_par = 3 * self.U + self.B + 2 + self.schedule.row_len
         self.params = torch.zeros(G if self.group else 1, self.n_par, **f32)
         self.lat_trace = torch.zeros((G,) + tuple(self.latents.shape), **f32) if self.group else None
-        self.layout, self.graph, self.graphs = key, None, []
+        self.layout, self.graph, self.graphs, self.tails = key, None, [], {}
         self.g_ref, self.g_main = [], []       # split graphs: one graph per group parity / per context set
         self.main_stream = None
         if self.split:
@@ -345,9 +346,12 @@ class StoryGenSampler:
             if self.ref is not None:
                 stale |= self.ref.build_time_table([t for r in rows + [row0] for t in r[:U]])
             if stale:                             # first table (or one that outgrew its buffers): graphs captured earlier read the old ones
-                self.graph, self.graphs, self.g_ref, self.g_main = None, [], [], []
+                self.graph, self.graphs, self.g_ref, self.g_main, self.tails = None, [], [], [], {}
         if self.use_graph and self.graph is None and not self.graphs and not self.g_main:
             self._capture()
+        last = self._last_lookahead_at()
+        if last is not None and self.graphs:      # the last group's graph has no look-ahead pass: captured here, before anything is in flight
+            self._tail_graph((last // self.G) % 2)
         if self.ahead and not self.no_ctx:
             self._prime()
 
@@ -387,12 +391,15 @@ class StoryGenSampler:
         else:
             ops.cfg_ddim_step(eps3, self.latents, self.latents3, cd)
 
-    def _group_body(self, parity: int, side: Optional["torch.cuda.Stream"]):
+    def _group_body(self, parity: int, side: Optional["torch.cuda.Stream"], with_ref: bool = True):
         """Group schedule: the G main passes of a group of this parity (context sets parity*G ..) and, beside them, the batched
         reference pass of the NEXT group (into the other parity's sets).  side = the stream of the forked branch (None: in order,
-        reference pass first — the eager form)."""
+        reference pass first — the eager form).  with_ref=False: the LAST group of a loop — there is no next group, so no look-ahead
+        pass (the reference's loop runs no reference pass after its last step either, pipeline.py:412-469)."""
         G, dev = self.G, self.dev
-        if side is not None:
+        if not with_ref:
+            side = None
+        elif side is not None:
             cur = torch.cuda.current_stream(dev)
             side.wait_stream(cur)                                                         # fork
             with torch.cuda.stream(side):
@@ -412,8 +419,33 @@ class StoryGenSampler:
         if self.split:
             self.ev_ref[0].record(torch.cuda.current_stream(self.dev))
 
+    def _last_lookahead_at(self) -> Optional[int]:
+        """The step whose graph would run a look-ahead reference pass that nothing consumes (the first step of the last group; G = 1:
+        the last step), or None when the schedule has no look-ahead to skip (no overlap, stage "no", separately launched graphs)."""
+        if not (self.ahead and not self.no_ctx and not self.split and self.num_steps):
+            return None
+        return (self.num_steps - 1) // self.G * self.G
+
+    def _tail_graph(self, parity: int):
+        """The graph of the loop's LAST group (G = 1: last step): its main pass(es) WITHOUT the forked look-ahead reference pass (round 6:
+        the one-graph form replayed a whole batched reference pass after the last step — ~ 16 ms of a 50-step image at G = 5 whose
+        features nobody reads).  Captured by prepare() for the parity this loop's last group has; replays of it leave every buffer
+        the other graphs use untouched."""
+        g = self.tails.get(parity)
+        if g is None:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                if self.group:
+                    self._group_body(parity, None, with_ref=False)
+                else:
+                    self._main_pass(parity)
+            self.tails[parity] = g
+            self.main.ctx, self.main.kv_ext = self.ctx_sets[0], self.kv_sets[0]
+        return g
+
     def _capture(self):
         dev = self.dev
+        self.tails = {}
         self.params.copy_(self.table[0], non_blocking=True)
         saved = self.latents.clone()
         s = torch.cuda.Stream(device=dev)
@@ -461,6 +493,11 @@ class StoryGenSampler:
             self.main.ctx, self.main.kv_ext = self.ctx_sets[0], self.kv_sets[0]
         self.latents.copy_(saved)
         self.latents3.copy_(torch.cat([saved] * 3))
+        # the warm-up ran main passes on table rows that are not a piece of any trajectory (G > 1: G passes on ONE row): a LayerNorm-fold
+        # guard bit set there says nothing about the run that follows — only flags of the real trajectory may raise (check_guards)
+        for eng in (self.main, self.ref):
+            if eng is not None and getattr(eng, "ln_guard", None) is not None:
+                eng.ln_guard.zero_()
         torch.cuda.synchronize(dev)
 
     def step(self, k: Optional[int] = None):
@@ -477,19 +514,20 @@ class StoryGenSampler:
             self._step_ahead(k)
             self.k = k + 1
             return
+        last = k == self._last_lookahead_at()       # the loop ends with this group / step: no look-ahead reference pass
         if self.group:
             G = self.G
             if k % G == 0:
                 self.params.copy_(self.table[k:k + G], non_blocking=True)
                 if self.graphs:
-                    self.graphs[(k // G) % 2].replay()
+                    (self._tail_graph((k // G) % 2) if last else self.graphs[(k // G) % 2]).replay()
                 else:
-                    self._group_body((k // G) % 2, None)
+                    self._group_body((k // G) % 2, None, with_ref=not last)
             self.k = k + 1
             return
         self.params.copy_(self.table[k], non_blocking=True)
         if self.graphs:
-            self.graphs[k % 2].replay()
+            (self._tail_graph(k % 2) if last else self.graphs[k % 2]).replay()
         elif self.graph is not None:
             self.graph.replay()
         else:

@@ -458,6 +458,21 @@ def allreduce_gradients(grads: Dict[str, torch.Tensor], average: bool = True) ->
     return grads
 
 
+def any_rank(flag: bool, device=None) -> bool:
+    """True on EVERY rank when `flag` is true on ANY rank (one 1-element MAX all-reduce; identity without a process group).  The
+    GradScaler decision of a data-parallel step must be collective: under DDP a non-finite gradient on one rank reaches every rank
+    through the gradient all-reduce and all of them skip the optimizer step in lockstep (train_StorySalon_stage2.py:222,328 through
+    accelerate).  Here the finite check of train_step_graph is local, so the ranks agree on it explicitly — every rank calls this at
+    every point where an optimizer step could happen, so the number of collectives per rank stays identical."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()):
+        return bool(flag)
+    dev = device if device is not None and dist.get_backend() != "gloo" else "cpu"
+    t = torch.tensor([1.0 if flag else 0.0], dtype=torch.float32, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return bool(t.item() > 0.0)
+
+
 class MainPassFunction(torch.autograd.Function):
     """epsilon = UNet(sample, t, text, features) as an autograd node whose only differentiable inputs are the parameters of the
     trainer's trainable module (attn3: train_StorySalon_stage2.py:170-177; attn1 with no features: stage 1): what

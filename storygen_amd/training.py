@@ -24,7 +24,7 @@ import torch
 import torch.nn.functional as F
 
 from .optim import AdamW, AdamW8bit, get_scheduler
-from .train import UNetTrainer, allreduce_gradients
+from .train import UNetTrainer, allreduce_gradients, any_rank
 
 
 def accumulation_plan(mode: str, accum: int, world: int) -> dict:
@@ -152,18 +152,12 @@ class Stage2Trainer:
         loss, grads = run(batch, use_refs=tuple(use_refs))
         loss = loss.detach().clone()
         plan = self.plan
-        if self.use_graph and self.trainer.last_step_skipped:       # non-finite gradients at every loss scale: GradScaler skips the step
-            # (only the hipGraph step rescales and detects this; the eager train_step runs at one fixed loss scale and does not check)
-            self._micro += 1
-            if plan["step_every"] > 1:
-                # "true" accumulation: the window has lost a micro-batch.  torch's GradScaler skips the optimizer step of the WHOLE
-                # window in that case (its inf check covers the accumulated gradient) — so does this: taint it, and when it closes,
-                # drop the accumulator instead of stepping on k - 1 micro-batches scaled 1 / k
-                self._tainted = True
-                if self._micro % plan["step_every"] == 0:
-                    self._drop_window()
-            return dict(loss=loss, lr=self.lr_scheduler.get_last_lr()[0], optimizer_step=False, skipped=True)
-        if plan["step_every"] > 1:                                  # real accumulation: sum k micro-batches, each scaled 1 / k
+        # non-finite gradients at every loss scale: GradScaler skips the step (only the hipGraph step rescales and detects this; the
+        # eager train_step runs at one fixed loss scale and does not check).  The micro-batch is not accumulated and taints its window.
+        skipped = bool(self.use_graph and self.trainer.last_step_skipped)
+        if skipped:
+            self._tainted = True
+        elif plan["step_every"] > 1:                                # real accumulation: sum k micro-batches, each scaled 1 / k
             if self._acc is None:
                 self._acc = {n: torch.zeros_like(g) for n, g in grads.items()}
             for n, g in grads.items():
@@ -173,7 +167,13 @@ class Stage2Trainer:
             grads = {n: g * plan["grad_scale"] for n, g in grads.items()}
         self._micro += 1
         stepped = self._micro % plan["step_every"] == 0
-        if stepped and self._tainted:            # a micro-batch of this window was skipped: skip its optimizer step
+        if not stepped:
+            return dict(loss=loss, lr=self.lr_scheduler.get_last_lr()[0], optimizer_step=False, skipped=skipped)
+        # The window closes here on EVERY rank (the micro-batch count is the same everywhere).  Whether it steps is decided collectively:
+        # torch's GradScaler under DDP skips the optimizer step of the whole window on all ranks when any rank saw a non-finite gradient
+        # (the inf travels through the gradient all-reduce); a rank-local decision would leave the other ranks alone in the all-reduce
+        # below and desynchronise parameters and global_step.
+        if any_rank(self._tainted, self.dev):
             self._drop_window()
             return dict(loss=loss, lr=self.lr_scheduler.get_last_lr()[0], optimizer_step=False, skipped=True)
         if stepped:

@@ -252,7 +252,7 @@ def test_traffic_on_file_was_measured_on_this_build():
     with open(path) as f:
         t = json.load(f)
     assert t.get("kernel_source_hash") == source_hash(), "re-run the two PMC passes on the GPU box (tools/calls/r4_call21.sh) and copy traffic.json to profiles/"
-    assert t["kernels"]["mma_pipe_kernel (gemm + conv3x3)"]["hbm_bytes_per_launch"] > 0
+    assert t["kernels"]["mma_pipe_body (gemm + conv3x3: mma_pipe_kernel / mma_lat_kernel)"]["hbm_bytes_per_launch"] > 0
 
 
 def test_producers_emit_groupnorm_statistics_for_the_wider_concats_of_the_up_path():
@@ -574,9 +574,11 @@ def test_group_schedule_is_the_step_by_step_trajectory(monkeypatch, stage, N, R,
     assert smp.group_direct == ("short_rows" not in kw or stage == "auto-regressive")
     for k in range(T):
         assert torch.equal(got[k], want[k]), f"step {k}"
-    # the work: one batched reference call per group (+ the primer), each G x the per-step batch
+    # the work: one batched reference call per group, each G x the per-step batch — the primer + one look-ahead per group BUT the
+    # last (round 6: the last group's graph runs no look-ahead pass; the reference's loop runs none after its last step either)
     refs = [b for kind, b in smp.ref.calls if kind == "ref"]
-    assert refs == [G * ref.U0] * (T // G + 1) and smp.U == G * ref.U0
+    assert refs == [G * ref.U0] * (T // G) and smp.U == G * ref.U0
+    assert smp._last_lookahead_at() == T - G
     assert [b for kind, b in smp.main.calls if kind == "main"] == [3 * N] * T
     with pytest.raises(ValueError):                                                       # groups of G: the evaluation count must divide
         smp.prepare(inp, T + 1, stage, 7.5, 3.5)

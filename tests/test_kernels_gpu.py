@@ -668,7 +668,7 @@ def test_two_stage_ring_computes_the_same_values(gpu, tile):
         assert torch.isfinite(a).all() and torch.equal(a, b)
 
 
-@pytest.mark.parametrize("tile", [(256, 128), (256, 64), (128, 128), (128, 64), (64, 128), (64, 64)])
+@pytest.mark.parametrize("tile", [(256, 128), (256, 64), (128, 128), (128, 64), (64, 128), (64, 64), (64, 64, 4)])
 def test_register_epilogue_every_tile_every_mode(gpu, tile):
     """The round-3 epilogue (transposed accumulators + half-wave register swap, residual requested under the last K slab, no LDS
     staging) on every tile shape against fp32 references: GEMM with bias + fp32 residual (1, 5 and odd slab counts, ragged M and N),
@@ -718,6 +718,104 @@ def test_register_epilogue_every_tile_every_mode(gpu, tile):
             check(o, ref, "register epilogue vs fp32 reference", l2=2e-6, mx=2e-5)
         else:
             check(o, ref, "register epilogue (fp16 output) vs fp32 reference")
+
+
+@pytest.mark.parametrize("stages", [0, 4, 8])
+def test_latency_kernel_every_mode(gpu, stages):
+    """The 32x32-per-wave deep-ring kernel (mma_lat_kernel, round 6: tile 64x64 = four waves, 4 / 8 LDS stages) on the shapes of the
+    batch-3 main pass it serves, against fp32 references and against the 64x64-per-wave kernels on the same operands: every term of
+    the linear epilogue at once, ragged M / N, 1 ... 80 K slabs (fewer than the ring is deep, not a multiple of it), split-K partial
+    tiles, the LayerNorm fold on both sides (producer partials, rows-are-tokens and columns-are-tokens consumers), GroupNorm
+    partials, paired launches, and the 3x3 convolution gather."""
+    from storygen_amd import ops
+    from storygen_amd.repack import fold_layernorm
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=gpu)
+    ws2 = torch.empty(32 << 20, dtype=torch.uint8, device=gpu)
+    lat = (64, 64, 4)
+    try:
+        ops.debug_set_option("lat_stages", stages)
+        for M, N, K, split in [(768, 1280, 1280, 1), (3072, 640, 640, 1), (192, 1280, 2560, 0), (192, 1280, 1280, 3), (300, 200, 64, 1),
+                               (1000, 72, 448, 1), (768, 1280, 5120, 1), (64, 64, 192, 1), (130, 1288, 576, 2)]:
+            a, w = rnd((M, K), gpu, 1.0, 1), rnd((N, K), gpu, K ** -0.5, 2)
+            bias, r1, r2 = rnd((N,), gpu, 1.0, 3), rnd((M, N), gpu, 1.0, 4, torch.float32), rnd((M, N), gpu, 1.0, 5)
+            rpb = max(1, M // 3)
+            rb = rnd((-(-M // rpb), N), gpu, 1.0, 6, torch.float32)
+            ref = a.float() @ w.float().t() + bias.float() + r1 + r2.float() + rb.repeat_interleave(rpb, 0)[:M]
+            o = torch.full((M, N), float("nan"), dtype=torch.float32, device=gpu)
+            o16 = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+            ops.gemm(a, w, o, bias=bias, res1=r1, res2=r2, rowbias=rb, rows_per_batch=rpb, out2=o16, split_k=split, workspace=ws, tile=lat)
+            check(o, ref, f"lat M{M} N{N} K{K} split {split}: fp32 out", l2=2e-6, mx=2e-5)
+            check(o16, ref, "fp16 copy")
+            ops.gemm(a, w, o16, bias=bias, res1=r2, split_k=split, workspace=ws, tile=lat)
+            check(o16, a.float() @ w.float().t() + bias.float() + r2.float(), "fp16 out + fp16 residual")
+            # (a2 + h) + (a3 + h): one tensor as both residuals
+            ops.gemm(a, w, o, bias=bias, res1=r1, res2=r1, split_k=split, workspace=ws, tile=lat)
+            check(o, a.float() @ w.float().t() + bias.float() + 2.0 * r1, "res1 == res2", l2=2e-6, mx=2e-5)
+        # LayerNorm fold: producer (fp32 stream + raw copy + partials) -> consumers in both orientations, all on the latency kernel
+        for M, C in [(768, 1280), (3072, 640), (200, 320)]:
+            a0, w0 = rnd((M, C), gpu, 1.0, 1), rnd((C, C), gpu, C ** -0.5, 2)
+            res = rnd((M, C), gpu, 1.0, 3, torch.float32) + 3.0
+            x = torch.empty(M, C, dtype=torch.float32, device=gpu)
+            x16 = torch.empty(M, C, dtype=torch.float16, device=gpu)
+            st = torch.zeros(M, (C // 64 + 1) & ~1, 2, dtype=torch.float32, device=gpu)
+            guard = torch.zeros(1, dtype=torch.int32, device=gpu)
+            ops.gemm(a0, w0, x, res1=res, out2=x16, ln_out=st, guard=guard, tile=lat, workspace=ws)
+            xr = a0.float() @ w0.float().t() + res
+            check(x, xr, "producer stream", l2=2e-6, mx=2e-5)
+            blk = xr.view(M, C // 64, 64).double()
+            got = st[:, : C // 64].double()
+            assert rel_l2(got[..., 0].cpu(), blk.sum(-1).cpu()) < 1e-5
+            assert rel_l2(got[..., 1].cpu(), ((blk - blk.mean(-1, keepdim=True)) ** 2).sum(-1).cpu()) < 1e-4
+            g, b = rnd((C,), gpu, 0.2, 7, torch.float32) + 1.0, rnd((C,), gpu, 0.1, 8, torch.float32)
+            wq = rnd((2 * C, C), gpu, C ** -0.5, 9)
+            wf, cq, dq = fold_layernorm(wq, None, g, b)
+            y = torch.empty(M, 2 * C, dtype=torch.float16, device=gpu)
+            ops.gemm(x16, wf, y, ln=(1, st, cq, dq, 1e-5), guard=guard, tile=lat)
+            lnx = F.layer_norm(xr, (C,), g, b, 1e-5)
+            check(y, lnx @ wq.float().t(), "folded consumer, rows are tokens", l2=1.5e-3, mx=2e-2)
+            wv = rnd((C, C), gpu, C ** -0.5, 10)
+            wvf, cv, dv = fold_layernorm(wv, None, g, b)
+            yt = torch.empty(C, M, dtype=torch.float16, device=gpu)
+            ops.gemm(wvf, x16, yt, ln=(2, st, cv, dv, 1e-5), guard=guard, tile=lat)
+            check(yt, wv.float() @ lnx.t(), "folded consumer, columns are tokens", l2=1.5e-3, mx=2e-2)
+            # the same two as one paired launch: bit-identical
+            y2, yt2 = torch.empty_like(y), torch.empty_like(yt)
+            ops.gemm_pair(((x16, wf, y2), dict(ln=(1, st, cq, dq, 1e-5), guard=guard, tile=lat)),
+                          ((wvf, x16, yt2), dict(ln=(2, st, cv, dv, 1e-5), guard=guard)))
+            assert torch.equal(y, y2) and torch.equal(yt, yt2)
+            assert int(guard.item()) == 0
+        # GroupNorm partials from the epilogue (one per 64-row tile)
+        a, w = rnd((3072, 2560), gpu, 1.0, 11), rnd((640, 2560), gpu, 2560 ** -0.5, 12)
+        o = torch.empty(3072, 640, dtype=torch.float32, device=gpu)
+        stt = torch.zeros(3072 // 64 * 2 * 640, dtype=torch.float32, device=gpu)
+        rows = ops.gemm_stats_rows(a, w, o, stats=(stt, 1024), workspace=ws, tile=lat)
+        assert rows == 64
+        ops.gemm(a, w, o, stats=(stt, 1024), workspace=ws, tile=lat)
+        t = o.view(3072 // rows, rows, 640).double()
+        got = stt.view(3072 // rows, 2, 640).double()
+        assert rel_l2(got[:, 0].cpu(), t.sum(1).cpu()) < 1e-6 and rel_l2(got[:, 1].cpu(), (t * t).sum(1).cpu()) < 1e-6
+        # 3x3 convolution on the same mainloop (implicit-GEMM gather, stride 2, nearest-2x upsample, split-K)
+        for B, H, W, Ci, Co, stride, ups, split in [(3, 8, 8, 1280, 1280, 1, False, 0), (2, 16, 16, 640, 128, 2, False, 1), (1, 16, 16, 128, 192, 1, True, 1),
+                                                     (3, 16, 16, 640, 200, 1, False, 2)]:
+            xx = rnd((B, Ci, H, W), gpu, 1.0, 8)
+            xp = torch.zeros(B, H + 2, W + 2, Ci, dtype=torch.float16, device=gpu)
+            xp[:, 1:-1, 1:-1] = xx.permute(0, 2, 3, 1)
+            wk = rnd((Co, Ci, 3, 3), gpu, (9 * Ci) ** -0.5, 9)
+            xin = F.interpolate(xx.float(), scale_factor=2.0, mode="nearest") if ups else xx.float()
+            ref = F.conv2d(xin, wk.float(), rnd((Co,), gpu, 1.0, 10).float(), stride=stride, padding=1)
+            oc = torch.full((B, ref.shape[2], ref.shape[3], Co), float("nan"), dtype=torch.float32, device=gpu)
+            ops.conv3x3(xp, wk.permute(0, 2, 3, 1).contiguous(), oc, stride=stride, upsample2x=ups, bias=rnd((Co,), gpu, 1.0, 10),
+                        split_k=split, workspace=ws, x_padded=True, tile=lat)
+            check(oc, ref.permute(0, 2, 3, 1), f"lat conv {B}x{H}x{W} {Ci}->{Co}", l2=2e-6, mx=2e-5)
+        # automatic selection (no hint) against the 64x64-per-wave kernels: same sums in a different order
+        a, w = rnd((768, 1280), gpu, 1.0, 13), rnd((1280, 1280), gpu, 1280 ** -0.5, 14)
+        o1, o2 = torch.empty(768, 1280, dtype=torch.float32, device=gpu), torch.empty(768, 1280, dtype=torch.float32, device=gpu)
+        ops.gemm(a, w, o1, workspace=ws, use_table=False)
+        ops.debug_set_option("lat_tiles", 0)
+        ops.gemm(a, w, o2, workspace=ws, use_table=False)
+        check(o1, o2, "auto-selected latency kernel vs 64x64-per-wave kernel", l2=1e-6, mx=1e-5)
+    finally:
+        ops.debug_set_option("reset", 0)
 
 
 PATCH_CASES = [

@@ -1,6 +1,7 @@
 """CPU: the optimizer oracle pinned to torch.optim.AdamW / clip_grad_norm_ (the classes the reference's loop uses when 8-bit Adam is
 off), the 8-bit restatement's tracking property, learning-rate schedules, and the host pieces of storygen_amd.optim / training."""
 import math
+import os
 
 import pytest
 import torch
@@ -253,7 +254,7 @@ def test_true_accumulation_skips_the_window_a_skipped_micro_batch_belongs_to():
         return torch.tensor(float(i)), {"w": torch.full((2,), float(i + 1))}
 
     tr.trainer = types.SimpleNamespace(train_step_graph=train_step_graph, last_step_skipped=False, set_trainable_parameters=lambda named: None)
-    tr.module, tr.variant, tr.use_graph, tr.named = "attn1", "storysalon", True, {}
+    tr.module, tr.variant, tr.use_graph, tr.named, tr.dev = "attn1", "storysalon", True, {}, torch.device("cpu")
     tr.plan = accumulation_plan("true", 2, 1)
     tr.optimizer, tr.lr_scheduler, tr.max_grad_norm = Opt(), Sched(), 1.0
     tr.global_step, tr._micro, tr._acc, tr._tainted, tr.last_grad_norm = 0, 0, None, False, None
@@ -269,3 +270,86 @@ def test_true_accumulation_skips_the_window_a_skipped_micro_batch_belongs_to():
     more = [tr.step({}) for _ in range(4)]
     assert [o["optimizer_step"] for o in more] == [False, False, False, True] and tr.optimizer.steps == 2
     assert torch.equal(tr.optimizer.seen[1]["w"], torch.full((2,), 0.5 * 7 + 0.5 * 8))
+
+
+def _skip_worker(rank, world, port, out_dir):
+    """One rank of test_skip_decision_is_collective_world2_gloo: a recording Stage2Trainer whose rank-1 copy sees non-finite gradients
+    on micro-batch 1 (accumulation "true", k = 2) and, in a second run, on step 2 of the reference's every-call stepping."""
+    import types
+
+    import torch
+    import torch.distributed as dist
+    from storygen_amd.training import Stage2Trainer, accumulation_plan
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+
+    class Opt:
+        def __init__(self):
+            self.steps, self.seen = 0, []
+
+        def set_grads(self, g):
+            self.seen.append({k: v.clone() for k, v in g.items()})
+
+        def clip_grad_norm_(self, m):
+            return torch.tensor(0.0)
+
+        def step(self):
+            self.steps += 1
+
+        def zero_grad(self):
+            pass
+
+    class Sched:
+        def step(self):
+            pass
+
+        def get_last_lr(self):
+            return [1e-4]
+
+    results = {}
+    for mode, k, bad in (("true", 2, 1), ("reference", 1, 2)):
+        tr = object.__new__(Stage2Trainer)
+        calls = {"n": 0}
+
+        def train_step_graph(batch, use_refs=(), tr=tr, calls=calls, bad=bad):
+            i = calls["n"]
+            calls["n"] += 1
+            tr.trainer.last_step_skipped = rank == 1 and i == bad              # ONLY rank 1 sees the non-finite gradients
+            return torch.tensor(float(i)), {"w": torch.full((2,), float((i + 1) * (rank + 1)))}
+
+        tr.trainer = types.SimpleNamespace(train_step_graph=train_step_graph, last_step_skipped=False, set_trainable_parameters=lambda named: None)
+        tr.module, tr.variant, tr.use_graph, tr.named, tr.dev = "attn1", "storysalon", True, {}, torch.device("cpu")
+        tr.plan = accumulation_plan(mode, k, world)
+        tr.optimizer, tr.lr_scheduler, tr.max_grad_norm = Opt(), Sched(), 1.0
+        tr.global_step, tr._micro, tr._acc, tr._tainted, tr.last_grad_norm = 0, 0, None, False, None
+        outs = [tr.step({}) for _ in range(4)]
+        results[mode] = dict(stepped=[bool(o["optimizer_step"]) for o in outs], steps=tr.optimizer.steps, global_step=tr.global_step,
+                             seen=[s["w"] for s in tr.optimizer.seen])
+    torch.save(results, os.path.join(out_dir, f"skip{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_skip_decision_is_collective_world2_gloo(tmp_path):
+    """Advisor r5 (medium): a rank whose gradients are non-finite must not leave the window's all-reduce to the other ranks.  With the
+    flag agreed by a MAX all-reduce at every window close (train.any_rank), BOTH ranks drop the window rank 1 tainted and both step on
+    the next one: the same optimizer-step count and global_step everywhere, the averaged gradients identical, and no rank hangs in a
+    collective the other never enters (this test would time out).  Covers real accumulation (k = 2) and the reference's
+    step-every-call mode."""
+    import socket
+
+    import torch
+    import torch.multiprocessing as mp
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_skip_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    a, b = torch.load(tmp_path / "skip0.pt"), torch.load(tmp_path / "skip1.pt")
+    for mode in ("true", "reference"):
+        assert a[mode]["stepped"] == b[mode]["stepped"] and a[mode]["steps"] == b[mode]["steps"] and a[mode]["global_step"] == b[mode]["global_step"]
+        for x, y in zip(a[mode]["seen"], b[mode]["seen"]):
+            assert torch.equal(x, y)
+    # "true", k = 2: window 0 (micro-batches 0, 1) dropped on both ranks, window 1 steps: mean over ranks of (3 + 4) / 2 * (rank + 1)
+    assert a["true"]["stepped"] == [False, False, False, True] and a["true"]["steps"] == 1
+    assert torch.equal(a["true"]["seen"][0], torch.full((2,), 0.5 * (3.5 + 7.0)))
+    # "reference", k = 1: step 2 skipped everywhere, steps 0, 1, 3 taken
+    assert a["reference"]["stepped"] == [True, True, False, True] and a["reference"]["steps"] == 3

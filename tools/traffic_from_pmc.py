@@ -17,7 +17,7 @@ import json
 import os
 import sys
 
-GROUPS = {"mma_pipe_kernel (gemm + conv3x3)": ("mma_pipe_kernel", "mma_pipe_pair_kernel", "mma_kernel", "splitk_reduce_kernel"),
+GROUPS = {"mma_pipe_body (gemm + conv3x3: mma_pipe_kernel / mma_lat_kernel)": ("mma_pipe_kernel", "mma_pipe_pair_kernel", "mma_lat_kernel", "mma_lat_pair_kernel", "mma_kernel", "splitk_reduce_kernel"),
           "attn_fwd_kernel": ("attn_fwd_kernel",), "ff_fused_kernel": ("ff_fused_kernel",),
           "groupnorm": ("gn_stats", "gn_apply", "gn_fused"), "layernorm": ("layernorm_kernel",)}
 
@@ -88,7 +88,7 @@ def main():
     if alg:     # the whole GEMM / convolution group: launch-weighted algorithmic bytes (same launches as `kernels` above, reduce passes excluded)
         tot_b = sum(a["algorithmic_bytes"] for a in alg.values())
         tot_n = sum(a["launches"] for a in alg.values())
-        g = out["kernels"].get("mma_pipe_kernel (gemm + conv3x3)")
+        g = out["kernels"].get("mma_pipe_body (gemm + conv3x3: mma_pipe_kernel / mma_lat_kernel)")
         if g is not None and tot_n:
             g["algorithmic_bytes_per_launch"] = round(tot_b / tot_n)
             g["hbm_over_algorithmic"] = round(g["hbm_bytes_per_launch"] / (tot_b / tot_n), 2)
