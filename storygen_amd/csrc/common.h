@@ -42,6 +42,10 @@ struct SgOptions {
     int lat_tiles = 640;               // GEMMs of at most this many 64x64 tiles run the 32x32-per-wave deep-ring kernel (mma_lat_kernel); 0 = only on a caller's hint
     int lat_min_kt = 8, lat_max_kt = 64;   // ... with this many 64-deep K slabs
     int lat_stages = 4;                // ring depth of that kernel: 4 (default) or 8
+    int lat_mask = 62;                 // launch kinds that may take it by size: 1 paired launches (OFF: with pairs on it the one-graph loop differed run to run
+                                       // in 6 - 12 of 30 repeats, profiles/r06h_*; every other kind 30 / 30 bit-identical), 2 LN-folded consumers, 4 GroupNorm
+                                       // partials, 8 K slices, 16 LN-partial producers, 32 others
+    int lat_wide = 0, lat_wide_m = 256;   // 1: M <= lat_wide_m (the 8x8 level) takes the 64x128-tile / 6-stage weight-streaming form (measured neutral: default off; tile hint (64, 128, 8) selects it per launch)
     int attn_sub2 = 0, attn_prio = 0, attn_d80 = 1, attn_d160 = 4 /* 4: key-split workgroups at Nq <= 256 */, attn_lean = 0;
     int attn_d40_general = 0;          // 1 = the D = 40 launches use the general softmax path (A/B against the padded-dimension fast path)
     int gn_no_fused = 0, gn_wide = 1;

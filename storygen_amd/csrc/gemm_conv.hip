@@ -11,7 +11,7 @@
 //     (global_load_lds, 16 B per lane, no VGPR staging), counted vmcnt waits and ONE raw s_barrier per slab.  Round 4: the slab body
 //     exists once per ring stage (the stage is a compile-time constant: fragment reads are per-lane base registers + immediates), and
 //     the refill of the ring is placed by waves per SIMD — spread over the four k-steps on the tiles of <= 4 waves, a burst staggered
-//     between the two waves of a SIMD on the 8-wave tile (VALU and DMA-issue cycles ADD to matrix cycles on a SIMD: DESIGN.md 5.2d).
+//     between the two waves of a SIMD on the 8-wave tile (VALU and DMA-issue cycles ADD to matrix cycles on a SIMD: HISTORY.md 5.2d).
 //   * LDS rows are 128 B (64 halves); the 16-byte chunk c of row r lives at slot c ^ ((r>>1)&7): conflict-free for
 //     the ds_read_b128 fragment reads.  LDS-DMA writes lane l of a wave to (wave-uniform base + 16 l), so the swizzle is
 //     applied on the SOURCE side (the lane that owns slot s of row r fetches logical chunk s ^ ((r>>1)&7)) and again on the reads.
@@ -35,7 +35,7 @@
 //     last-arriving slice (agent-scope release / acquire + ticket counter) was built and measured in round 2: the release
 //     fence behind 64 KB of freshly written partials costs more (+8..13 us per launch) than the kernel boundary it removes.
 // Round-2 mainloop experiments (4-/2-stage rings, spread DMA issue on the 256x128 tile, ping-pong wave groups, LDS-resident conv
-// patches, fat waves) were measured neutral or slower and are no longer part of the library; `git log` has them.
+// patches, fat waves) were measured neutral or slower (HISTORY.md 5.2) and are no longer part of the library; `git log` has them.
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -1631,23 +1631,50 @@ int check_stats(MmaParams& p, int bm, const char* name) {
 
 // Decomposition of one problem: tile shape, K split, tile order; fills the corresponding fields of p.  `pipe` = the LDS-DMA
 // kernel applies (no load needs a predicate: K % 64 == 0; conv input zero-bordered), else the register-staged kernel.
-// The 32x32-per-wave kernel (mma_lat_kernel, 64x64 tiles of four waves): for launches that are a short dependent chain rather than a
-// volume of FLOPs.  hint_waves = 4 with a 64x64 hint: the caller asks for it; -1: never; 0: by size (development options lat_tiles,
-// lat_min_kt, lat_max_kt).  Returns the ring depth, or 0 when the launch stays on the 64x64-per-wave kernels.
+// The 32x32-per-wave kernels (mma_lat_kernel): for launches that are a short dependent chain rather than a volume of FLOPs.
+//   64x64 tile, four waves, 4-stage ring: GEMMs of <= lat_tiles tiles and lat_min_kt .. lat_max_kt K slabs (development options);
+//   64x128 tile, eight waves, 6-stage ring (80 KB of WEIGHTS in flight per workgroup): M <= 256 — the 8x8 level, where a launch is its
+//   weight stream (29.5 MB for a 1280 -> 1280 convolution against 0.5 MB of activations) and what bounds it is the bytes a CU keeps in
+//   flight (the 64x64-per-wave tiles: 16 - 32 KB).
+// hint_waves = 4 with a 64x64 hint / 8 with 64x128: the caller asks for one; -1: never; 0: by size.  Fills pl (tile, K slices, ring
+// depth) and returns true, or returns false when the launch stays on the 64x64-per-wave kernels.
+thread_local bool g_in_pair = false;        // sg_gemm_pair_f16 is planning (development option lat_mask)
+
 template <bool CONV>
-int lat_ring(const MmaParams& p, bool pipe, int hint_bm, int hint_bn, int hint_waves, int splits) {
-    if (!pipe || p.mode != SG_EPI_LINEAR || p.prof || hint_waves < 0 || g_tune.bm) return 0;
-    const long tiles = (long)sg_cdiv(p.M, 64) * sg_cdiv(p.N, 64);
+bool lat_plan(const MmaParams& p, bool pipe, int force_split, int max_ws_split, int hint_bm, int hint_bn, int hint_waves, Plan& pl) {
+    if (!pipe || p.mode != SG_EPI_LINEAR || p.prof || hint_waves < 0 || g_tune.bm) return false;
     const SgOptions& o = sg_options();
-    const bool asked = hint_bm == 64 && hint_bn == 64 && hint_waves == 4;
-    const bool by_size = !CONV && hint_bm == 0 && hint_bn == 0 && hint_waves == 0 && tiles <= o.lat_tiles && p.KT >= o.lat_min_kt &&
-                         p.KT <= o.lat_max_kt;
-    if (!asked && !by_size) return 0;
-    (void)splits;
-    // 4 stages (three slabs = 48 KB in flight per workgroup, two workgroups per CU) measured equal or better than 8 on every main-pass
-    // shape, incl. those of <= 256 workgroups (M768 N1280 K1280: 9.9 vs 10.7 us per graph node — the 8-stage prologue issues 28 DMA
-    // pieces per wave before the first slab can land; profiles/r06b_*); 8 stays behind the development option
-    return o.lat_stages == 8 ? 8 : 4;
+    // development option lat_mask (bisecting): which launch kinds may take the kernel by size — 1 paired launches, 2 LayerNorm-folded
+    // consumers, 4 GroupNorm partials, 8 K slices, 16 LayerNorm-partial producers, 32 everything else
+    if (hint_waves == 0) {
+        const int kind = g_in_pair ? 1 : p.ln_mode ? 2 : p.stats ? 4 : p.ln_out ? 16 : 32;
+        if (!(o.lat_mask & kind)) return false;
+    }
+    const bool hinted = hint_bm != 0 || hint_bn != 0 || hint_waves != 0;
+    const bool ask_sq = hint_bm == 64 && hint_bn == 64 && hint_waves == 4, ask_wide = hint_bm == 64 && hint_bn == 128 && hint_waves == 8;
+    if (hinted && !ask_sq && !ask_wide) return false;
+    const long tiles_sq = (long)sg_cdiv(p.M, 64) * sg_cdiv(p.N, 64), tiles_wide = (long)sg_cdiv(p.M, 64) * sg_cdiv(p.N, 128);
+    const bool wide = ask_wide || (!hinted && o.lat_wide && p.M <= o.lat_wide_m && p.N >= 256 && p.KT >= 40);
+    const bool sq = !wide && (ask_sq || (!hinted && !CONV && tiles_sq <= o.lat_tiles && p.KT >= o.lat_min_kt &&
+                                         (p.KT <= o.lat_max_kt || tiles_sq <= 128)));
+    if (!wide && !sq) return false;
+    const long tiles = wide ? tiles_wide : tiles_sq;
+    // K slices only where the tiles alone leave most CUs idle (M <= 256 at N = 1280): enough for ~256 workgroups, >= min_slabs each
+    const int min_slabs = wide ? 8 : 16;
+    int sp = 1;
+    if (force_split > 0) sp = force_split > p.KT ? p.KT : force_split;
+    else if (tiles <= 128 && !g_tune.no_split && (o.lat_mask & 8)) {
+        sp = (int)(256 / tiles);
+        if (sp > p.KT / min_slabs) sp = p.KT / min_slabs;
+        if (sp > max_ws_split) sp = max_ws_split;
+        if (sp > MAX_AUTO_SPLIT) sp = MAX_AUTO_SPLIT;
+        if (sp < 1) sp = 1;
+    }
+    // 64x64: 4 stages (three slabs = 48 KB in flight per workgroup, two workgroups per CU) measured equal or better than 8 on every
+    // main-pass shape, incl. those of <= 256 workgroups (M768 N1280 K1280: 9.9 vs 10.7 us per graph node — the 8-stage prologue issues
+    // 28 DMA pieces per wave before the first slab can land; profiles/r06b_*); 8 stays behind the development option
+    pl = Plan{64, wide ? 128 : 64, sp, wide ? 6 : (o.lat_stages == 8 ? 8 : 4)};
+    return true;
 }
 
 template <bool CONV>
@@ -1658,22 +1685,9 @@ int plan_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_w
     pipe = (p.K % BK == 0) && (!CONV || p.padded) && !g_tune.no_pipe;
     const size_t per_split = (size_t)p.M * p.N * 4;
     const int max_ws_split = ws ? (int)(ws_bytes / per_split > 64 ? 64 : ws_bytes / per_split) : 1;
-    if (lat_ring<CONV>(p, pipe, hint_bm, hint_bn, hint_waves, 1)) {
-        // K slices only where the 64x64 tiles alone leave most CUs idle (M <= 256 at N = 1280): enough of them for ~256 workgroups,
-        // at least 8 slabs each
-        const long tiles = (long)sg_cdiv(p.M, 64) * sg_cdiv(p.N, 64);
-        int s = 1;
-        if (force_split > 0) s = force_split > p.KT ? p.KT : force_split;
-        else if (tiles <= 128 && !g_tune.no_split) {
-            s = (int)(256 / tiles);
-            if (s > p.KT / 8) s = p.KT / 8;
-            if (s > max_ws_split) s = max_ws_split;
-            if (s > MAX_AUTO_SPLIT) s = MAX_AUTO_SPLIT;
-            if (s < 1) s = 1;
-        }
-        pl = Plan{64, 64, s, lat_ring<CONV>(p, pipe, hint_bm, hint_bn, hint_waves, s)};
-    } else {
-        if (hint_waves == 4 && hint_bm == 64 && hint_bn == 64) hint_bm = hint_bn = 0;      // asked for, not applicable: the cost model decides
+    if (!lat_plan<CONV>(p, pipe, force_split, max_ws_split, hint_bm, hint_bn, hint_waves, pl)) {
+        if ((hint_waves == 4 && hint_bm == 64 && hint_bn == 64) || (hint_waves == 8 && hint_bm == 64 && hint_bn == 128))
+            hint_bm = hint_bn = 0;                                                          // asked for, not applicable: the cost model decides
         pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, pipe, hint_bm, hint_bn);
     }
     if (pl.splits > 1) {
@@ -1761,7 +1775,7 @@ int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint
         g_query_rows = pl.splits;
         if (g_plan_out) {
             g_plan_out[0] = pl.bm; g_plan_out[1] = pl.bn; g_plan_out[2] = pl.splits; g_plan_out[3] = p.tiles_m * p.tiles_n * pl.splits;
-            g_plan_out[4] = pl.lat ? 256 : pipe ? 64 * (pl.bm / 64) * (pl.bn / 64) : 256;
+            g_plan_out[4] = pl.lat ? 64 * (pl.bm / 32) * (pl.bn / 32) : pipe ? 64 * (pl.bm / 64) * (pl.bn / 64) : 256;
             g_plan_out[5] = pl.lat ? 16 + pl.lat : pipe ? 1 : 0;                     // 16 + ring depth: the 32x32-per-wave kernel
         }
         return SG_OK;
@@ -1770,7 +1784,8 @@ int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint
         return sg_set_error(SG_EINVAL, "%s: defer_reduce needs a split-K launch (query sg_conv3x3_planned_splits first)", name);
     dim3 grid(p.tiles_m * p.tiles_n * pl.splits);
     if (pl.lat) {
-        if (pl.lat == 8) hipLaunchKernelGGL((mma_lat_kernel<2, 2, CONV, 8>), grid, dim3(256), 0, st, p);
+        if (pl.bn == 128) hipLaunchKernelGGL((mma_lat_kernel<2, 4, CONV, 6>), grid, dim3(512), 0, st, p);
+        else if (pl.lat == 8) hipLaunchKernelGGL((mma_lat_kernel<2, 2, CONV, 8>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((mma_lat_kernel<2, 2, CONV, 4>), grid, dim3(256), 0, st, p);
     } else if (pipe) {
         if (pl.bm == 256 && pl.bn == 128) launch_pipe<4, 2, CONV>(p, grid, st);
@@ -1801,7 +1816,7 @@ int check_out_res(const char* who, int flags, const void* C, int64_t ldc, const 
 }
 
 int check_tile_hint(const char* who, int bm, int bn, int waves) {
-    if (bm == 64 && bn == 64 && waves == 4) return SG_OK;       // the 32x32-per-wave kernel (mma_lat_kernel)
+    if ((bm == 64 && bn == 64 && waves == 4) || (bm == 64 && bn == 128 && waves == 8)) return SG_OK;       // the 32x32-per-wave kernels (mma_lat_kernel)
     if (waves != 0 && waves != (bm / 64) * (bn / 64))
         return sg_set_error(SG_EINVAL, "%s: tile_waves=%d is not available for tile %dx%d (64x64 per wave; 64x64 with 4 waves of 32x32)", who, waves, bm, bn);
     if (bm == 0 && bn == 0) return SG_OK;
@@ -1903,10 +1918,11 @@ extern "C" int sg_gemm_pair_f16(const sg_gemm_desc* d0, const sg_gemm_desc* d1, 
     Plan pl0, pl1;
     bool pipe0, pipe1;
     const int sk0 = d0->ln_mode ? 1 : d0->split_k, sk1 = d1->ln_mode ? 1 : d1->split_k;
+    struct PairScope { PairScope() { g_in_pair = true; } ~PairScope() { g_in_pair = false; } } pair_scope;
     if (int rc = plan_mma<false>(pp.p0, sk0, d0->tile_m, d0->tile_n, d0->tile_waves, d0->workspace, d0->workspace_bytes, "sg_gemm_pair_f16[0]", pl0, pipe0)) return rc;
     // one kernel instantiation serves both problems: the second one is planned on the first one's tile shape (and kernel family)
-    if (int rc = plan_mma<false>(pp.p1, sk1, pl0.bm, pl0.bn, pl0.lat ? 4 : -1, d1->workspace, d1->workspace_bytes, "sg_gemm_pair_f16[1]", pl1, pipe1)) return rc;
-    if (!pipe0 || !pipe1 || pl1.bm != pl0.bm || pl1.bn != pl0.bn || (pl0.lat != 0) != (pl1.lat != 0)) {        // not pairable (K % 64, forced tile): two launches
+    if (int rc = plan_mma<false>(pp.p1, sk1, pl0.bm, pl0.bn, pl0.lat ? (pl0.bn == 128 ? 8 : 4) : -1, d1->workspace, d1->workspace_bytes, "sg_gemm_pair_f16[1]", pl1, pipe1)) return rc;
+    if (!pipe0 || !pipe1 || pl1.bm != pl0.bm || pl1.bn != pl0.bn || (pl0.lat != 0) != (pl1.lat != 0) || (pl0.lat && pl0.bn == 128)) {        // not pairable (K % 64, forced tile): two launches
         if (int rc = launch_mma<false>(pp.p0, sk0, d0->tile_m, d0->tile_n, d0->tile_waves, d0->workspace, d0->workspace_bytes, st, "sg_gemm_pair_f16[0]")) return rc;
         return launch_mma<false>(pp.p1, sk1, d1->tile_m, d1->tile_n, d1->tile_waves, d1->workspace, d1->workspace_bytes, st, "sg_gemm_pair_f16[1]");
     }

@@ -66,6 +66,12 @@ FF_FUSED = True
 # over the 40 hidden chunks.  The two partial sums land in the halves of an [M, 2C] buffer and proj_out contracts them with [W | W].
 # 0 = never (A/B switch: bench.py --no-ff-split).
 FF_SPLIT_MAX_TOKENS = 16384
+# ff.net.2 and proj_out are two linear maps with nothing but a residual add between them (model/attention.py:300 `ff(norm3(h)) + h`, then
+# :121-123 proj_out + the block's input): out = W_out (W_2 g + b_2 + h3) + b_out + x = [g | h3] [W_out W_2 | W_out]^T + (W_out b_2 + b_out) + x
+# — ONE GEMM with K = 4C + C over the GEGLU output and the raw fp16 copy of h3 side by side in one buffer, the same FLOPs, one launch
+# (and one fp16 rounding of an intermediate) less per transformer block at C = 640 / 1280 (round 6; the 64x64 level runs the fused
+# feed-forward kernel instead).  False = the two GEMMs as written (A/B switch: bench.py --no-ff-proj-merge).
+FF_PROJ_MERGE = True
 LN_EPS = 1e-5         # torch.nn.LayerNorm default, as the reference constructs norm1..norm4 (model/attention.py:213-233)
 
 
@@ -88,7 +94,8 @@ class _Xf:
                  "w_qk1f", "c_qk1", "d_qk1", "w_v1f", "c_v1", "d_v1", "w_q2f", "c_q2", "d_q2", "w_q3f", "c_q3", "d_q3",
                  "w_ff1f", "c_ff1", "d_ff1",
                  "ff_pack",     # weight stream of the fused feed-forward kernel (repack.ff_fused_pack), or None
-                 "w_out2")      # [W_out | W_out]: proj_out over the two partial sums of a hidden-split fused feed-forward
+                 "w_out2",      # [W_out | W_out]: proj_out over the two partial sums of a hidden-split fused feed-forward
+                 "w_ffo", "b_ffo")   # FF_PROJ_MERGE: [W_out W_ff2 | W_out] (fp32 product rounded once) and W_out b_ff2 + b_out, or None
 
 
 class EngineWeights:
@@ -97,6 +104,7 @@ class EngineWeights:
 
     def __init__(self, arch: UNetArch, state_dict: Dict[str, torch.Tensor], device):
         self.arch, self.dev, self.cfg = arch, torch.device(device), arch.config
+        self.version = 0                 # bumped by reload_(): anything derived from the weights and cached by an engine (time tables) is stale then
         self._load_weights(state_dict)
 
     def _w(self, sd, key) -> torch.Tensor:
@@ -169,6 +177,12 @@ class EngineWeights:
                     setattr(o, name, val)
                 o.ff_pack = ff_fused_pack(o.w_ff1f, o.d_ff1, o.w_ff2) if (ops.ff_fused_supported(a.channels) and dev.type == "cuda") else None
                 o.w_out2 = torch.cat([o.w_out, o.w_out], dim=1).contiguous() if o.ff_pack is not None else None
+                if o.ff_pack is None:         # ff.net.2 and proj_out as one K = 5C GEMM (FF_PROJ_MERGE)
+                    wo32 = o.w_out.float()
+                    o.w_ffo = torch.cat([(wo32 @ o.w_ff2.float()).to(F16), o.w_out], dim=1).contiguous()
+                    o.b_ffo = (wo32 @ o.b_ff2.float() + o.b_out.float()).to(F16).contiguous()
+                else:
+                    o.w_ffo = o.b_ffo = None
                 self.xfs[p] = o
         self.samplers = {}
         for blk in arch.down + arch.up:
@@ -247,8 +261,9 @@ class EngineWeights:
                     if k != "spec" and getattr(old, k, None) is not None:
                         walk(getattr(old, k), getattr(new, k))
         for k, v in self.__dict__.items():
-            if k not in ("arch", "dev", "cfg"):
+            if k not in ("arch", "dev", "cfg", "version"):
                 walk(v, getattr(fresh, k))
+        self.version += 1
 
 
 class HarvestPlan:
@@ -354,7 +369,7 @@ class UNetEngine:
         # BASELINE config 5: the head-dim-40 self / image attentions (the 46 080-key context of the 96x96 level) on the fp8 MFMA
         # path (sg_attn_fwd_f8_d40); text attention and the D = 80 / 160 levels stay fp16
         self.fp8_attention = bool(fp8_attention)
-        # GroupNorm statistics as producer epilogues (north-star): a conv / GEMM whose output feeds a wide GroupNorm also
+        # GroupNorm statistics as producer epilogues (north-star; HISTORY.md 5): a conv / GEMM whose output feeds a wide GroupNorm also
         # writes per-(row tile, channel) sums, and that GroupNorm skips its own statistics pass.  Per producer site: one buffer and
         # the cached answer of sg_*_stats_tile_rows (0 = this launch cannot emit them -> the consumer makes its own pass).
         self.gn_epilogue_stats = GN_EPILOGUE_STATS
@@ -454,6 +469,7 @@ class UNetEngine:
                 # LayerNorm fold: per-token (sum, M2) partials of h0 / h1 / h3 per 64-channel block
                 **{n: torch.zeros(M, (C // 64 + 1) & ~1, 2, dtype=F32, device=self.dev) for n in ("lnst0", "lnst1", "lnst3")}, vt=self._buf(C, M), q=self._buf(M, C),
                 att=self._buf(M, C), q2=self._buf(M, C), att23=self._buf(M, 2 * C), ffi=self._buf(M, 4 * C),
+                ffo=self._buf(M, 5 * C),          # FF_PROJ_MERGE: [GEGLU output | raw fp16 copy of h3], the K = 5C operand of the merged GEMM
                 kt=self._buf(B * self.Sp, C), vtt=self._buf(C, B * self.Sp),
                 ki=self._buf(self.ctx_slots * self.hw[l], C) if self.R else None,
                 vti=self._buf(C, self.ctx_slots * self.hw[l]) if self.R else None,
@@ -711,6 +727,9 @@ class UNetEngine:
         gd = self.ln_guard
         prod = lambda t, buf, st: dict(out2=None if t.dtype == F16 else buf, ln_out=st, guard=gd) if fold else {}   # noqa: E731
         h0r, h1r = raw(h0, L["ln"]), raw(L["h1"], L["ln4"])
+        # ff.net.2 + proj_out as one GEMM (FF_PROJ_MERGE): h3's raw copy lives beside the GEGLU output in L["ffo"]
+        merge = FF_PROJ_MERGE and fold and not ff1 and xf.w_ffo is not None and L["h3"].dtype != F16 and out is not None
+        h3raw = L["ffo"][:M, 4 * C:5 * C] if merge else L["ln"]
         qk, vt = L["qk"], L["vt"]
         wp = self.ws_pair
         att = L["att"]
@@ -834,11 +853,11 @@ class UNetEngine:
                 ops.copy_rows(a3v[2:3], a3v[1:2])
             h3 = L["h3"]
             ops.gemm(att23, xf.w_o23, h3, bias=xf.b_o23, res1=h1, res2=h1, workspace=ws,  # (a2 + h) + (a3 + h)
-                     **({} if ff1 else prod(h3, L["ln"], L["lnst3"])))
+                     **({} if ff1 else prod(h3, h3raw, L["lnst3"])))
         else:
             ops.attention(L["q"].view(B, hw, C), kt3, vtt3, att.view(B, hw, C), heads, scale, nk=S)
             h3 = L["h2"]
-            ops.gemm(att, xf.w_o2, h3, bias=xf.b_o2, res1=h1, workspace=ws, **({} if ff1 else prod(h3, L["ln"], L["lnst3"])))   # :277,295
+            ops.gemm(att, xf.w_o2, h3, bias=xf.b_o2, res1=h1, workspace=ws, **({} if ff1 else prod(h3, h3raw, L["lnst3"])))   # :277,295
         # --- feed-forward :298-300
         h4, w_out = L["h4"], xf.w_out
         if ff1 and M <= FF_SPLIT_MAX_TOKENS:      # small launch: two workgroups per 128 tokens, partial sums side by side (att23 is free here)
@@ -846,14 +865,17 @@ class UNetEngine:
             ops.ff_fused(h3, xf.ff_pack, xf.b_ff2, h4, LN_EPS, split=True)
         elif ff1:    # one launch: LayerNorm in registers, GEGLU intermediate never materialised (h4 is fp16: it only feeds proj_out)
             ops.ff_fused(h3, xf.ff_pack, xf.b_ff2, L["h4"], LN_EPS)
+        elif merge:      # GEGLU into columns [0, 4C) of the buffer whose columns [4C, 5C) hold h3's raw copy; ff.net.2 happens inside proj_out's GEMM
+            ops.gemm(h3raw, xf.w_ff1f, L["ffo"][:M, :4 * C], epilogue=ops.EPI_GEGLU, ln=(1, L["lnst3"], xf.c_ff1, xf.d_ff1, LN_EPS), guard=gd)
+            h4, w_out = L["ffo"][:M], xf.w_ffo
         elif fold:
             ops.gemm(raw(h3, L["ln"]), xf.w_ff1f, L["ffi"], epilogue=ops.EPI_GEGLU, ln=(1, L["lnst3"], xf.c_ff1, xf.d_ff1, LN_EPS), guard=gd)
         else:
             ops.layernorm(h3, *xf.ln["norm3"], L["ln"])
             ops.gemm(L["ln"], xf.w_ff1, L["ffi"], bias=xf.b_ff1, epilogue=ops.EPI_GEGLU, workspace=ws)
-        if not ff1:
+        if not ff1 and not merge:
             ops.gemm(L["ffi"], xf.w_ff2, L["h4"], bias=xf.b_ff2, res1=h3, workspace=ws)   # fp16: only feeds proj_out
-        kwo = dict(bias=xf.b_out, res1=x, workspace=ws)                                   # proj_out + residual :121-123
+        kwo = dict(bias=xf.b_ffo if merge else xf.b_out, res1=x, workspace=ws)            # proj_out + residual :121-123
         site = xf.spec.prefix + ".proj_out"
         so = self._stats_for(site, lvl, C, lambda buf: ops.gemm_stats_rows(h4, w_out, out, stats=(buf, hw), **kwo))
         ops.gemm(h4, w_out, out, stats=None if so is None else (so, hw), **kwo)
@@ -1056,10 +1078,14 @@ class UNetEngine:
         if timesteps is None:
             had = self.time_table is not None
             self.time_table = None
+            self._time_keys = None
             return had
         keys = sorted({float(t) for t in timesteps})
         if not keys:
             raise ValueError("build_time_table: no timesteps")
+        tag = (keys, getattr(self.wts, "version", 0))
+        if self.time_table is not None and getattr(self, "_time_keys", None) == tag:
+            return False                          # the same schedule on the same weights as the last call (a pipeline called again): the rows are already there
         F32, dev, T = torch.float32, self.dev, len(keys)
         fresh = self.time_table is None or self.time_table[0].numel() < T
         if fresh:
@@ -1073,6 +1099,7 @@ class UNetEngine:
         for i in range(0, T, 4):
             n = min(4, T - i)
             self._time_chain(tk[i:i + n], e0[:n], e1[:n], e2[:n], tab[i:i + n])
+        self._time_keys = tag
         return fresh
 
     def set_inputs(self, sample: torch.Tensor, timestep, text: torch.Tensor):

@@ -268,7 +268,7 @@ def _report_plan(kind: str, d, nbytes: float, family: str, shape: str, second=No
         if second is not None:
             d1, b1 = second
             q = type(d1).from_buffer_copy(d1)
-            q.tile_m, q.tile_n, q.tile_waves = bm, bn, (4 if pipe >= 16 else 0)
+            q.tile_m, q.tile_n, q.tile_waves = bm, bn, ((8 if bn == 128 else 4) if pipe >= 16 else 0)
             bm1, bn1, _, wgs1, threads1, pipe1 = _plan_of(lib.sg_gemm_launch_plan, q)
             if pipe and pipe1 and (bm1, bn1) == (bm, bn) and (pipe >= 16) == (pipe1 >= 16):
                 if pipe >= 16:
@@ -1041,7 +1041,7 @@ def debug_set_option(name: str, value: int) -> None:
 _ENV_OPTIONS = {"SG_NO_NMAJOR": "no_nmajor", "SG_NO_PIPE": "no_pipe", "SG_NO_SPLIT": "no_split",
                 "SG_ATTN_SUB2": "attn_sub2", "SG_ATTN_PRIO": "attn_prio", "SG_ATTN_D80": "attn_d80", "SG_ATTN_D160": "attn_d160",
                 "SG_FF_VARIANT": "ff_variant", "SG_PIPE_STAGES": "pipe_stages", "SG_GN_FUSED_NT": "gn_fused_nt", "SG_GN_CHUNKS": "gn_chunks", "SG_ATTN_LEAN": "attn_lean", "SG_ATTN_D40_GENERAL": "attn_d40_general", "SG_NO_GN_FUSED": "gn_no_fused", "SG_GN_WIDE": "gn_wide", "SG_GN_FUSED_MAX": "gn_fused_max",
-                "SG_LAT_TILES": "lat_tiles", "SG_LAT_MIN_KT": "lat_min_kt", "SG_LAT_MAX_KT": "lat_max_kt", "SG_LAT_STAGES": "lat_stages"}
+                "SG_LAT_TILES": "lat_tiles", "SG_LAT_MIN_KT": "lat_min_kt", "SG_LAT_MAX_KT": "lat_max_kt", "SG_LAT_STAGES": "lat_stages", "SG_LAT_WIDE": "lat_wide", "SG_LAT_MASK": "lat_mask", "SG_LAT_WIDE_M": "lat_wide_m"}
 
 
 def apply_env_options() -> dict:

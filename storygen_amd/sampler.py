@@ -35,7 +35,7 @@ MI355X-first structure
     (set = step mod 2G).  Round 5: the whole GROUP is ONE hipGraph — the batched reference pass of group j+1 forked
     beside the G main passes of group j, each main pass reading its own row of a [G, n] parameter block uploaded once
     per group — so the two halves interleave inside the graph like the G = 1 schedule's do (separately launched graphs
-    do not overlap at all on this runtime; that older form is kept behind `split_graphs=True`).  The
+    do not overlap at all on this runtime, HISTORY.md 5.2b; that older form is kept behind `split_graphs=True`).  The
     reference batch is ordered like the G context sets laid end to end in one buffer per feature key, so its features
     (and their attn3 K / V^T projections, one GEMM pair per feature for the whole group) are written in place.  One
     `step()` call per step still works: the group is enqueued by its first step, the others return at once, and
@@ -79,7 +79,7 @@ class StoryGenSampler:
         # streams.  Only then can the two halves run at different queue priorities (stream_priority: main pass high — it is
         # the step's critical path — reference pass as background filler).  Measured: separately launched graphs do not
         # overlap on this runtime, so it is an A/B switch only.
-        # EXPERIMENT (measured, not adopted: DESIGN.md 5.2e).  ref_cus = n > 0 (implies the split schedule): the batched reference pass
+        # EXPERIMENT (measured, not adopted: HISTORY.md 5.2e).  ref_cus = n > 0 (implies the split schedule): the batched reference pass
         # runs, one group ahead, on a stream whose hardware queue may only use n of the chip's CUs (hipExtStreamCreateWithCUMask), so
         # that it fills the CUs the latency-bound main passes leave idle instead of competing with them for all of them; the G main
         # passes of a group stay hipGraphs on the caller's stream.  ref_eager: the reference pass's kernels are launched one by one
@@ -282,7 +282,7 @@ class StoryGenSampler:
         self.params = torch.zeros(G if self.group else 1, self.n_par, **f32)
         self.lat_trace = torch.zeros((G,) + tuple(self.latents.shape), **f32) if self.group else None
         self.layout, self.graph, self.graphs, self.tails = key, None, [], {}
-        self.g_ref, self.g_main = [], []       # split graphs: one graph per group parity / per context set
+        self.g_ref, self.g_main, self.g_prime = [], [], None       # split graphs: one graph per group parity / per context set; the primer's graph
         self.main_stream = None
         if self.split:
             self.ref_stream = (cu_masked_stream(self.dev, self.ref_cus, self.ref_cu_layout) if self.ref_cus
@@ -313,47 +313,69 @@ class StoryGenSampler:
         share_zero = (self.dedup and stage == "multi-image-condition"
                       and all(torch.equal(pu[i], pu[0]) for i in range(1, R)))
         self._build(stage, share_zero)
-        self.latents.copy_(inputs["latents"].to(dev, torch.float32) * self.schedule.init_noise_sigma)
-        self.noise.copy_(inputs["noise"].to(dev, torch.float32))
-        h = torch.float16
-        unc, txt = inputs["uncond"].to(dev, h), inputs["text"].to(dev, h)
-        self.main.text_in.copy_(torch.cat([unc, unc, txt]))                               # pipeline.py:448
-        zero, imgs = inputs["zero_prompt"].to(dev, torch.float32), inputs["image_prompts"].to(dev, torch.float32)
-        for u, (kind, i, n) in enumerate(self.units):                                     # :420-430 (none for stage "no")
-            self.ref_src[u].copy_(zero[n] if kind == 0 else imgs[i, n])
-            self.ref.text_in[u].copy_((pu[i][n] if kind == 0 else inputs["prev_text"][i][n]).to(dev, h))
-            self.ref_noise[u].copy_(self.noise[n])
-        self.latents3.copy_(torch.cat([self.latents] * 3))                                # :450
-        self.main.cache_text_kv()
-        if self.ref is not None:
-            self.ref.cache_text_kv()
-        # per-step table
+        # ---- the per-step table: host arithmetic only
         ts = self.schedule.timesteps(num_inference_steps)
         rows, row0 = step_table(self.schedule, ts, num_inference_steps, self.units[:self.U0], R, stage, self.B, self.G,
                                 self.ahead and not self.no_ctx, image_guidance_scale, guidance_scale)
         if self.group and len(rows) % self.G:
             raise ValueError(f"ref_ahead = {self.G} runs the loop in groups of {self.G} UNet evaluations: {len(rows)} evaluations "
                              f"({num_inference_steps} inference steps) is not a multiple")
-        pin = (lambda t: t.pin_memory()) if self.dev.type == "cuda" else (lambda t: t)      # pinned: the per-step upload is an async H2D copy
-        self.row0_ref = pin(torch.tensor(row0, dtype=torch.float32))
-        self.table = pin(torch.tensor(rows, dtype=torch.float32))
+        self.row0_ref = self._pinned("row0", torch.tensor(row0, dtype=torch.float32))      # pinned: the per-step upload is an async H2D copy
+        self.table = self._pinned("table", torch.tensor(rows, dtype=torch.float32))
         self.timesteps = ts
         self.num_steps = len(ts)                  # PNDM: n + 1 UNet evaluations for n inference steps
         self.k = 0
-        if self.time_tables:                      # every timestep of the loop is known now: tabulate the time-embedding chain once
-            U, B = self.U, self.B
-            stale = self.main.build_time_table([r[U] for r in rows] + [row0[U]])
-            if self.ref is not None:
+        # ---- uploads.  The inputs are pageable host tensors, i.e. every .to(device) blocks the host until the stream reaches it: all of
+        # them go first (few, batched — one stacked copy per kind instead of one per reference sample), nothing long is queued yet
+        self.latents.copy_(inputs["latents"].to(dev, torch.float32) * self.schedule.init_noise_sigma)
+        self.noise.copy_(inputs["noise"].to(dev, torch.float32))
+        h = torch.float16
+        unc, txt = inputs["uncond"].to(dev, h), inputs["text"].to(dev, h)
+        self.main.text_in.copy_(torch.cat([unc, unc, txt]))                               # pipeline.py:448
+        if self.units:                                                                    # :420-430 (none for stage "no")
+            zero, imgs = inputs["zero_prompt"].to(dev, torch.float32), inputs["image_prompts"].to(dev, torch.float32)
+            src = torch.cat([zero, imgs.flatten(0, 1)])                                   # [N + R N, ...]: zero-image latents, then frame i of sample n at N + i N + n
+            pick = torch.tensor([n if kind == 0 else N + i * N + n for kind, i, n in self.units], device=dev)
+            self.ref_src.copy_(src[pick])
+            self.ref_noise.copy_(self.noise[torch.tensor([n for _, _, n in self.units], device=dev)])
+            self.ref.text_in.copy_(torch.stack([(pu[i][n] if kind == 0 else inputs["prev_text"][i][n]) for kind, i, n in self.units]).to(dev, h))
+        self.latents3.copy_(torch.cat([self.latents] * 3))                                # :450
+        # ---- the reference engine's side first: with the graphs of an earlier prepare() still valid, the primer pass (nothing overlaps
+        # with it) is enqueued BEFORE the main engine's tables and text projections are made, so that their host time runs under it
+        U, B = self.U, self.B
+        stale = False
+        primed = False
+        if self.ref is not None:
+            if self.time_tables:                  # every timestep of the loop is known now: tabulate the time-embedding chain once
                 stale |= self.ref.build_time_table([t for r in rows + [row0] for t in r[:U]])
-            if stale:                             # first table (or one that outgrew its buffers): graphs captured earlier read the old ones
-                self.graph, self.graphs, self.g_ref, self.g_main, self.tails = None, [], [], [], {}
+            self.ref.cache_text_kv()
+            if self.ahead and not self.no_ctx and not stale and (self.graphs or self.g_main):
+                self._prime()
+                primed = True
+        if self.time_tables:
+            stale |= self.main.build_time_table([r[U] for r in rows] + [row0[U]])
+        self.main.cache_text_kv()
+        if stale:                                 # first table (or one that outgrew its buffers): graphs captured earlier read the old ones
+            self.graph, self.graphs, self.g_ref, self.g_main, self.tails = None, [], [], [], {}
         if self.use_graph and self.graph is None and not self.graphs and not self.g_main:
-            self._capture()
+            self._capture()                       # (its warm-up step overwrites context set 0: the primer follows)
+            primed = False
         last = self._last_lookahead_at()
-        if last is not None and self.graphs:      # the last group's graph has no look-ahead pass: captured here, before anything is in flight
+        if last is not None and self.graphs:      # the last group's graph has no look-ahead pass: captured here (a capture synchronises once, the first time)
             self._tail_graph((last // self.G) % 2)
-        if self.ahead and not self.no_ctx:
+        if self.ahead and not self.no_ctx and not primed:
             self._prime()
+
+    def _pinned(self, name: str, t: torch.Tensor) -> torch.Tensor:
+        """t in a pinned host buffer kept across prepare() calls (a fresh pin_memory() allocation costs milliseconds per call)."""
+        if self.dev.type != "cuda":
+            return t
+        bufs = self.__dict__.setdefault("_pin_bufs", {})
+        b = bufs.get(name)
+        if b is None or b.shape != t.shape:
+            b = bufs[name] = torch.empty_like(t).pin_memory()
+        b.copy_(t)
+        return b
 
     # ------------------------------------------------------------------------------------------------ the step
     def _step_body(self):
@@ -413,9 +435,13 @@ class StoryGenSampler:
             cur.wait_stream(side)                                                         # join
 
     def _prime(self):
-        """The reference pass of step 0 (ref_ahead > 1: of the first group) has no main pass to hide behind."""
+        """The reference pass of step 0 (ref_ahead > 1: of the first group) has no main pass to hide behind.  Replayed from its own
+        graph when the schedule is captured (round 6: launched kernel by kernel it cost the host ~10 ms of every prepare())."""
         self.params.copy_(self.row0_ref, non_blocking=True)
-        self._ref_pass(0)
+        if getattr(self, "g_prime", None) is not None:
+            self.g_prime.replay()
+        else:
+            self._ref_pass(0)
         if self.split:
             self.ev_ref[0].record(torch.cuda.current_stream(self.dev))
 
@@ -446,6 +472,7 @@ class StoryGenSampler:
     def _capture(self):
         dev = self.dev
         self.tails = {}
+        self.g_prime = None
         self.params.copy_(self.table[0], non_blocking=True)
         saved = self.latents.clone()
         s = torch.cuda.Stream(device=dev)
@@ -489,6 +516,9 @@ class StoryGenSampler:
                         self._main_pass(parity)                                           # main pass of step k
                         cur.wait_stream(side)                                             # join
                 self.graphs.append(g)
+            self.g_prime = torch.cuda.CUDAGraph()          # the primer: the reference pass into context set(s) 0 .., alone
+            with torch.cuda.graph(self.g_prime):
+                self._ref_pass(0)
         if not self.no_ctx:
             self.main.ctx, self.main.kv_ext = self.ctx_sets[0], self.kv_sets[0]
         self.latents.copy_(saved)

@@ -720,18 +720,16 @@ def test_register_epilogue_every_tile_every_mode(gpu, tile):
             check(o, ref, "register epilogue (fp16 output) vs fp32 reference")
 
 
-@pytest.mark.parametrize("stages", [0, 4, 8])
-def test_latency_kernel_every_mode(gpu, stages):
+@pytest.mark.parametrize("stages,lat", [(0, (64, 64, 4)), (4, (64, 64, 4)), (8, (64, 64, 4)), (0, (64, 128, 8))])
+def test_latency_kernel_every_mode(gpu, stages, lat):
     """The 32x32-per-wave deep-ring kernel (mma_lat_kernel, round 6: tile 64x64 = four waves, 4 / 8 LDS stages) on the shapes of the
     batch-3 main pass it serves, against fp32 references and against the 64x64-per-wave kernels on the same operands: every term of
     the linear epilogue at once, ragged M / N, 1 ... 80 K slabs (fewer than the ring is deep, not a multiple of it), split-K partial
-    tiles, the LayerNorm fold on both sides (producer partials, rows-are-tokens and columns-are-tokens consumers), GroupNorm
+    tiles — also on the 64x128-tile / eight-wave / 6-stage weight-streaming form of the 8x8 level (tile hint (64, 128, 8)) —, the LayerNorm fold on both sides (producer partials, rows-are-tokens and columns-are-tokens consumers), GroupNorm
     partials, paired launches, and the 3x3 convolution gather."""
     from storygen_amd import ops
     from storygen_amd.repack import fold_layernorm
     ws = torch.empty(64 << 20, dtype=torch.uint8, device=gpu)
-    ws2 = torch.empty(32 << 20, dtype=torch.uint8, device=gpu)
-    lat = (64, 64, 4)
     try:
         ops.debug_set_option("lat_stages", stages)
         for M, N, K, split in [(768, 1280, 1280, 1), (3072, 640, 640, 1), (192, 1280, 2560, 0), (192, 1280, 1280, 3), (300, 200, 64, 1),

@@ -14,7 +14,8 @@ from conftest import rel_l2
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TOL_EPS = 6e-3        # one UNet pass, epsilon / features (fp16 residual stream: ~100 roundings of 2^-11)
+TOL_EPS = 6e-3        # one UNet pass, epsilon (fp16 operands: ~100 roundings of 2^-11 down the whole pass)
+TOL_FEAT = 2e-3       # ... each of the 16 harvested features against the reference's own (round 6: a 10x regression of ONE block shows here)
 TOL_LATENT = 1e-3     # latents after a denoising step (north-star)
 
 
@@ -67,6 +68,48 @@ def test_unet_passes_vs_oracle_32x32(gpu, sd15):
     eps_m = eng.forward(consume=True)
     torch.cuda.synchronize()
     errs["eps(main)"] = rel_l2(eps_m.cpu(), o_main)
+    print({k: f"{v:.2e}" for k, v in errs.items()})
+    assert max(errs.values()) <= TOL_EPS, errs
+
+
+def test_ff2_and_proj_out_as_one_gemm_is_the_same_pass_32x32(gpu, sd15):
+    """engine.FF_PROJ_MERGE (round 6): ff.net.2 and proj_out of a transformer block (model/attention.py:300,121-123) contracted in ONE
+    K = 5C GEMM over [GEGLU output | raw copy of h3] with the host-made product [W_out W_2 | W_out] — against the two GEMMs as
+    written on the same inputs (both within the one-pass bar of the oracle, and within it of each other), for a reference-style pass
+    and a main pass consuming context.  The C = 320 level runs the fused feed-forward kernel either way."""
+    from oracle import storygen_oracle as O
+    from storygen_amd import engine as E
+    from storygen_amd.synth import synthetic_inputs
+    arch, sd = sd15
+    cfg, hw, R = arch.config, 32, 2
+    inputs = synthetic_inputs(1, R, hw, hw, 3, cfg["cross_attention_dim"])
+    sched = O.DDIM()
+    t_main = sched.timesteps(5)[0]
+    ref_t, x, e, xm, em = _ref_and_main_inputs(inputs, sched, t_main)
+    with torch.no_grad():
+        o_eps, o_feats = O.unet_forward(sd, cfg, x, ref_t, e, None)
+        ctx = {k: torch.cat([v, 0.5 * v], dim=1) for k, v in o_feats.items()}
+        o_main, _ = O.unet_forward(sd, cfg, xm, t_main, em, ctx)
+    got = {}
+    try:
+        for merge in (True, False):
+            E.FF_PROJ_MERGE = merge
+            eng = E.UNetEngine(arch, sd, gpu, 3, hw, hw, R)
+            assert any(xf.w_ffo is not None for xf in eng.xfs.values())
+            eng.set_inputs(x, ref_t, e)
+            eps_r = eng.forward(harvest_slot=0).clone().cpu()
+            for k, v in ctx.items():
+                eng.ctx[k].copy_(v.to(gpu, torch.float16))
+            eng.set_inputs(xm, t_main, em)
+            eps_m = eng.forward(consume=True).clone().cpu()
+            assert eng.check_ln_guard() == 0
+            got[merge] = (eps_r, eps_m)
+            del eng
+    finally:
+        E.FF_PROJ_MERGE = True
+    errs = {f"{'merged' if m else 'as written'} {n}": rel_l2(t, o) for m in (True, False) for n, t, o in (("ref", got[m][0], o_eps), ("main", got[m][1], o_main))}
+    errs["merged vs as written (ref)"] = rel_l2(got[True][0], got[False][0])
+    errs["merged vs as written (main)"] = rel_l2(got[True][1], got[False][1])
     print({k: f"{v:.2e}" for k, v in errs.items()})
     assert max(errs.values()) <= TOL_EPS, errs
 
@@ -291,6 +334,8 @@ def test_unet_single_pass_vs_reference_golden_64x64(gpu, sd15):
     errs["eps(main)"] = rel_l2(eps_m.cpu(), u["main_sample"]["full"])
     print({k: f"{v:.2e}" for k, v in errs.items()})
     assert max(errs.values()) <= TOL_EPS, errs
+    feats = {k: v for k, v in errs.items() if not k.startswith("eps")}
+    assert len(feats) == 16 and max(feats.values()) <= TOL_FEAT, feats      # per-block bar: every harvested feature on its own
 
 
 def test_graph_replay_matches_eager(gpu, sd15):
@@ -348,28 +393,30 @@ def test_loop_vs_oracle_both_stages_32x32(gpu, sd15):
         assert max(errs) <= TOL_LATENT, (stage, errs)
 
 
-@pytest.mark.skipif(os.environ.get("SG_SLOW_TESTS") != "1", reason="~4 CPU-minutes of oracle (N = 2, 3 steps, both stages); SG_SLOW_TESTS=1")
 @pytest.mark.parametrize("stage", ["multi-image-condition", "auto-regressive"])
-def test_loop_vs_oracle_two_samples_three_steps_32x32_slow(gpu, sd15, stage):
-    """The depth the quick suite gave up in round 4 (advisor r4): N = 2 story frames, R = 2, THREE steps against the oracle loop, on the
-    default schedule and on the group schedule (ref_ahead = 3) — pins the row-major unit order of the reference batch, the per-unit
-    noise expansion (noise[n(u)]) and the later steps of the trajectory for N > 1."""
-    from oracle import storygen_oracle as O
+def test_loop_two_samples_three_steps_vs_oracle_golden_32x32(gpu, sd15, stage):
+    """N = 2 story frames, R = 2, THREE steps against the oracle loop's latents (tests/golden/sd15_32_n2_r2.pt, oracle/make_golden_n2.py;
+    until round 6 the oracle ran live, ~4 CPU-minutes, behind SG_SLOW_TESTS — i.e. never under the driver), on the default schedule and
+    on the group schedule (ref_ahead = 3): pins the row-major unit order of the reference batch, the per-unit noise expansion
+    (noise[n(u)]) and the later steps of the trajectory for N > 1."""
     from storygen_amd.sampler import StoryGenSampler
     from storygen_amd.synth import synthetic_inputs
+    path = os.path.join(GOLDEN, "sd15_32_n2_r2.pt")
+    if not os.path.exists(path):
+        pytest.skip(f"{path} not generated (oracle/make_golden_n2.py)")
+    gold = torch.load(path, weights_only=False)
     arch, sd = sd15
-    inputs = synthetic_inputs(2, 2, 32, 32, 9, arch.config["cross_attention_dim"])
-    want = []
-    O.sample_loop(sd, arch.config, inputs, 51, stage, 7.5, 3.5, max_steps=3, trace=want)
+    inputs = synthetic_inputs(gold["n_samples"], gold["n_ref"], gold["hw"], gold["hw"], gold["seed_inputs"], arch.config["cross_attention_dim"])
+    want = gold["latents"][stage]
     for G in (1, 3):
         smp = StoryGenSampler(arch, sd, gpu, 2, 32, 32, 2, use_graph=True, ref_ahead=G)
-        smp.prepare(inputs, 51, stage, 7.5, 3.5)
+        smp.prepare(inputs, gold["table_steps"], stage, *gold["guidance"])
         got = []
         smp.run(max_steps=3, trace=got)
         torch.cuda.synchronize()
         errs = [rel_l2(a.cpu(), b) for a, b in zip(got, want)]
         print(stage, f"N=2 ref_ahead={G}", [f"{e:.2e}" for e in errs])
-        assert max(errs) <= TOL_LATENT, (stage, G, errs)
+        assert len(errs) == 3 and max(errs) <= TOL_LATENT, (stage, G, errs)
 
 
 @pytest.mark.parametrize("stage", ["multi-image-condition", "auto-regressive"])
@@ -599,7 +646,8 @@ def _config5_golden():
     return gold
 
 
-def test_config5_fp16_path_vs_oracle_golden_96x96_r5(gpu, sd15):
+@pytest.mark.parametrize("G", [1, 5])
+def test_config5_fp16_path_vs_oracle_golden_96x96_r5(gpu, sd15, G):
     """BASELINE config 5's shape (768x768 = 96x96 latent, 5 prior frames; 46 080 context tokens at the first level) through the fp16
     path, against the latents of the oracle's loop at that shape (tests/golden/sd15_96_r5.pt: oracle.storygen_oracle with
     block-index feature keys — the reference's own height heuristic cannot run 96x96; the restatement is pinned to the
@@ -613,15 +661,17 @@ def test_config5_fp16_path_vs_oracle_golden_96x96_r5(gpu, sd15):
     assert gold["seed_weights"] == 0
     inputs = synthetic_inputs(1, 5, 96, 96, gold["seed_inputs"], arch.config["cross_attention_dim"])
     wts = EngineWeights(arch, sd, gpu)
-    n = len(gold["latents"])
-    smp = StoryGenSampler(arch, None, gpu, 1, 96, 96, 5, weights=wts)
+    n = len(gold["latents"]) // G * G
+    smp = StoryGenSampler(arch, None, gpu, 1, 96, 96, 5, weights=wts, ref_ahead=G)
     smp.prepare(inputs, gold["n_steps"], gold["stage"], *gold["guidance"])
     trace = []
     smp.run(max_steps=n, trace=trace)
     torch.cuda.synchronize()
     errs = [rel_l2(a.cpu(), b) for a, b in zip(trace, gold["latents"])]
-    print(f"config 5 shape, fp16 path vs oracle, steps 1..{n}:", [f"{e:.2e}" for e in errs])
-    assert len(errs) == n and max(errs) <= TOL_LATENT, errs
+    print(f"config 5 shape, fp16 path vs oracle, ref_ahead {G}, steps 1..{n}:", [f"{e:.2e}" for e in errs])
+    assert n >= 5 and len(errs) == n and max(errs) <= TOL_LATENT, errs
+    if G > 1:
+        return
     first = trace[0].clone().cpu()
     del smp
     torch.cuda.empty_cache()
@@ -631,7 +681,8 @@ def test_config5_fp16_path_vs_oracle_golden_96x96_r5(gpu, sd15):
     assert rel_l2(aw, gold["latents"][0]) <= TOL_LATENT and rel_l2(aw, first) <= TOL_LATENT
 
 
-def test_config5_fp8_attention_vs_oracle_golden_96x96_r5(gpu, sd15):
+@pytest.mark.parametrize("G", [1, 5])
+def test_config5_fp8_attention_vs_oracle_golden_96x96_r5(gpu, sd15, G):
     """BASELINE config 5 as named: 768x768 (96x96 latent), 5 prior frames, the head-dim-40 image / self attention on the fp8
     (e4m3) MFMA path — deviation stated AGAINST THE ORACLE at steps 1, 2 and the last stored step (10 when the golden holds ten).
     e4m3 keeps 3 mantissa bits of Q, K, V and P: the attention outputs move by 3-6e-2 (test_attention_fp8_d40), the predicted noise
@@ -644,14 +695,14 @@ def test_config5_fp8_attention_vs_oracle_golden_96x96_r5(gpu, sd15):
     gold = _config5_golden()
     arch, sd = sd15
     inputs = synthetic_inputs(1, 5, 96, 96, gold["seed_inputs"], arch.config["cross_attention_dim"])
-    n = len(gold["latents"])
-    smp = StoryGenSampler(arch, sd, gpu, 1, 96, 96, 5, fp8_attention=True)
+    n = len(gold["latents"]) // G * G
+    smp = StoryGenSampler(arch, sd, gpu, 1, 96, 96, 5, fp8_attention=True, ref_ahead=G)
     smp.prepare(inputs, gold["n_steps"], gold["stage"], *gold["guidance"])
     trace = []
     smp.run(max_steps=n, trace=trace)
     torch.cuda.synchronize()
     errs = [rel_l2(a.cpu(), b) for a, b in zip(trace, gold["latents"])]
-    print(f"config 5, fp8 attention vs oracle, steps 1..{n}:", [f"{e:.2e}" for e in errs])
+    print(f"config 5, fp8 attention vs oracle, ref_ahead {G}, steps 1..{n}:", [f"{e:.2e}" for e in errs])
     assert all(torch.isfinite(t).all() for t in trace)
     assert max(errs) <= 1.5e-2, errs
 

@@ -47,18 +47,67 @@ def chain_us(fn, nodes=NODES, reps=8):
     return a.elapsed_time(b) / (reps * nodes) * 1e3
 
 
+def chain_us_rot(fns, reps=8):
+    """As chain_us, but the chain is the given list of DIFFERENT calls (e.g. one launch per weight copy: cold operands)."""
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        for f in fns[:2]:
+            f()
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g, stream=s):
+            for f in fns:
+                f()
+        g.replay()
+        torch.cuda.synchronize()
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s)
+        for _ in range(reps):
+            g.replay()
+        b.record(s)
+        torch.cuda.synchronize()
+    return a.elapsed_time(b) / (reps * len(fns)) * 1e3
+
+
+def cold_weights():
+    """What a weight panel that is NOT in L2 / MALL costs a dependent launch: the same GEMM chained over 1 (warm), 16 and 160 distinct
+    weight copies (160 x 3.3 MB = 524 MB > the 256 MB Infinity Cache: every launch streams its weights from HBM, as in the step,
+    where 1.8 GB of weights pass between two uses of a layer)."""
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
+    print("cold weights: us per graph node by number of distinct weight copies in the chain")
+    for M, N, K in [(768, 1280, 1280), (768, 1280, 2560), (3072, 640, 640), (192, 1280, 1280)]:
+        a = torch.randn(M, K, device=dev).half()
+        out = torch.empty(M, N, dtype=F32, device=dev)
+        res = torch.randn(M, N, device=dev)
+        row = f"M{M} N{N} K{K} res".ljust(34)
+        for copies in (1, 16, 160):
+            wsx = [(torch.randn(N, K, device=dev) / K ** 0.5).half() for _ in range(copies)]
+            fns = [(lambda w=w: ops.gemm(a, w, out, res1=res, workspace=ws)) for w in wsx] * (160 // copies)
+            row += f"{chain_us_rot(fns, reps=4):12.2f}"
+            del wsx
+        print(row, flush=True)
+
+
+def split_of(name):
+    """'lat/s2' -> split_k 2 (0 = the plan's own choice)."""
+    return int(name.split("/s")[1]) if "/s" in name else 0
+
+
 def plan_of(name):
+    name = name.split("/s")[0]
     if name == "default":
         return None
     if name == "lat":
         return (64, 64, 4)
-    if name == "lat8":
-        return (128, 64, 8)
+    if name == "latw":
+        return (64, 128, 8)
     bm, bn = name.split("x")
     return (int(bm), int(bn))
 
 
 def main():
+    if "--cold" in sys.argv:
+        return cold_weights()
     plans = [a for a in sys.argv[1:] if not a.startswith("-")] or ["default"]
     ws = torch.empty(256 << 20, dtype=torch.uint8, device=dev)
     ws2 = torch.empty(64 << 20, dtype=torch.uint8, device=dev)
@@ -107,7 +156,9 @@ def main():
                 if rows:
                     kk["stats"] = (buf, hw)
             try:
-                us = chain_us(lambda: ops.gemm(a, w, out, tile=tile, workspace=ws, **kk))
+                if kind == "ln" and split_of(name) > 1:
+                    raise ValueError("a folded LayerNorm does not split K")
+                us = chain_us(lambda: ops.gemm(a, w, out, tile=tile, workspace=ws, split_k=split_of(name), **kk))
                 row += f"{us:12.2f}"
             except Exception as e:     # a plan this launch cannot take
                 row += f"{'n/a':>12s}"

@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""Bisect a schedule-dependent difference (development tool): the same 5 steps under the one-graph schedule, separately launched
+graphs, and separately launched graphs with a high-priority main stream — every output should be bit-identical.  Repeats each variant
+to tell a race (run-to-run differences) from a plan difference (stable difference between variants).
+
+    python tools/exp_determinism.py [nolat] [nomerge] [nowide] [reps=N] [only=one-graph]"""
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from storygen_amd import engine as E, ops  # noqa: E402
+from storygen_amd.arch import SD15_CONFIG, build_arch  # noqa: E402
+from storygen_amd.engine import EngineWeights  # noqa: E402
+from storygen_amd.sampler import StoryGenSampler  # noqa: E402
+from storygen_amd.synth import synthetic_inputs, synthetic_state_dict  # noqa: E402
+
+
+def main():
+    try:
+        if "nolat" in sys.argv:
+            ops.debug_set_option("lat_tiles", 0)
+        if "nowide" in sys.argv:
+            ops.debug_set_option("lat_wide", 0)
+    except RuntimeError as e:        # an older library without these options
+        print("option not available:", e)
+    print("development options:", ops.apply_env_options())
+    if "nomerge" in sys.argv:
+        E.FF_PROJ_MERGE = False
+    reps = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("reps=")), 3)
+    only = next((a.split("=")[1] for a in sys.argv if a.startswith("only=")), None)
+    dev = torch.device("cuda:0")
+    arch = build_arch(SD15_CONFIG)
+    sd = synthetic_state_dict(arch, 0)
+    inputs = synthetic_inputs(1, 2, 32, 32, 21, arch.config["cross_attention_dim"])
+    wts = EngineWeights(arch, sd, dev)
+    outs = {}
+    snap0 = None
+    for name, kw in (("one graph", dict()), ("split", dict(split_graphs=True)), ("split+priority", dict(split_graphs=True, stream_priority=True)),
+                     ("eager", dict(use_graph=False))):
+        if only and name.replace(" ", "-") != only:
+            continue
+        for rep in range(reps):
+            smp = StoryGenSampler(arch, None, dev, 1, 32, 32, 2, weights=wts, **({"use_graph": True} | kw))
+            smp.prepare(inputs, 50, "multi-image-condition", 7.5, 3.5)
+            outs[name, rep] = smp.run(max_steps=5).clone()
+            torch.cuda.synchronize()
+            if "buffers" in sys.argv:      # which intermediate buffers differ from the first repeat's?  (reference-pass outputs do not depend on the latents)
+                snap = {}
+                for i, (c, kv) in enumerate(zip(smp.ctx_sets, smp.kv_sets)):
+                    for k in c:
+                        snap[f"ctx{i}.{k}"] = c[k].clone()
+                        snap[f"k{i}.{k}"], snap[f"vt{i}.{k}"] = kv[k][0].clone(), kv[k][1].clone()
+                for l, L in enumerate(smp.main.lv):
+                    for k, v in L.items():
+                        if v is not None:
+                            snap[f"main.lv{l}.{k}"] = v.clone()
+                for l, L in enumerate(smp.ref.lv):
+                    for k, v in L.items():
+                        if v is not None:
+                            snap[f"ref.lv{l}.{k}"] = v.clone()
+                if rep == 0:
+                    snap0 = snap
+                else:
+                    bad = [k for k in snap if not torch.equal(snap[k], snap0[k])]
+                    for k in bad:
+                        if k.endswith(".vt") or k.endswith(".qk") or k.endswith(".q2") or k.endswith(".q"):
+                            a, b = snap[k].float(), snap0[k].float()
+                            d = (a - b).abs()
+                            nz = d.nonzero()
+                            rows, cols = nz[:, 0].unique(), nz[:, 1].unique()
+                            print(f"   {k} {tuple(a.shape)}: {nz.shape[0]} elements differ, max {float(d.max()):.3e}; rows {rows[:12].tolist()}..{rows[-4:].tolist()} ({rows.numel()}), "
+                                  f"cols {cols[:12].tolist()}..{cols[-4:].tolist()} ({cols.numel()}); nan in either: {bool(torch.isnan(a).any() or torch.isnan(b).any())}")
+                    if bad:
+                        print(f"rep {rep}: {len(bad)} buffers differ: ref-pass outputs {[k for k in bad if k[0] in 'ckv']}; ref engine {[k for k in bad if k.startswith('ref.')]}; "
+                              f"main engine {[k for k in bad if k.startswith('main.')][:40]}", flush=True)
+            del smp
+    base = outs[next(iter(outs))]
+    for (name, rep), t in outs.items():
+        d = float((t - base).abs().max())
+        print(f"{name:16s} rep {rep}: max |diff| vs one-graph rep 0 = {d:.3e}{'' if d else '  (bit-identical)'}")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Study for round 5 (CPU only): how cheap can the erf of the GEGLU get before the fp16 rounding that follows it notices?
 
-The GEGLU runs beside the MFMAs, where VALU time adds to matrix time: 13 VALU per element (two transcendental) is ~45 % of the
+The GEGLU runs beside the MFMAs, where VALU time adds to matrix time (HISTORY 5.2d): 13 VALU per element (two transcendental) is ~45 % of the
 fused feed-forward's iteration and +20..37 % on the matrix time of the C = 640 / 1280 first-linear GEMMs.  Candidates, all in fp32 arithmetic
 as the kernel would run them (numpy, every intermediate rounded to fp32), against erf in fp64:
   as26    Abramowitz-Stegun 7.1.26 (shipped): t = 1/(1+pz), 5-term polynomial, exp(-z^2)           13 VALU (2 transcendental)

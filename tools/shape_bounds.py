@@ -5,7 +5,7 @@
   t_mfma  = FLOPs / 2.5 PFLOP/s                                  (dense fp16 MFMA peak, 256 CUs)
   t_hbm   = minimal operand + result bytes / 8 TB/s
   t_feed  = bytes the tiles must pull into LDS / (active CUs x 18.5 B/clk x 2.4 GHz)   (measured L2->LDS feed rate of the
-            mainloop; active CUs = min(256, tiles x split) with the 256x128 tile unless the shape is smaller)
+            mainloop, HISTORY §5.2; active CUs = min(256, tiles x split) with the 256x128 tile unless the shape is smaller)
   t_lds   = fragment reads (1 KiB per 64x64x16 MFMA step per wave = FLOPs / 32 bytes) + the DMA writes, at 128 B/clk/CU on the
             active CUs
   floor   = 5 us (launch + pipeline fill + epilogue of a single-wave-of-tiles kernel)
