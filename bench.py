@@ -519,6 +519,8 @@ def main():
     ap.add_argument("--no-splitk-in-gn", action="store_true",
                     help="A/B: split-K convolutions at the 16x16 / 8x8 levels run their own second pass instead of leaving it to the GroupNorm")
     ap.add_argument("--no-ff-fused", action="store_true", help="A/B: GEGLU feed-forward of the 64x64 level as two GEMM launches")
+    ap.add_argument("--ref-fp32-stream", action="store_true",
+                    help="A/B switch: the reference engine's residual stream in fp32 like the main engine's (default since round 6: fp16 — its outputs are fp16 features)")
     ap.add_argument("--no-ff-proj-merge", action="store_true",
                     help="A/B switch: ff.net.2 and proj_out as two GEMMs (as written) instead of one K = 5C GEMM at C = 640 / 1280 (engine.FF_PROJ_MERGE)")
     ap.add_argument("--no-ff-split", action="store_true",
@@ -618,7 +620,7 @@ def main():
                               stream_priority=args.stream_priority, fp8_attention=args.fp8_attention,
                               short_rows=not args.no_short_rows, time_tables=not args.no_time_tables,
                               shared_head=not args.no_shared_head, ref_cus=args.ref_cus, ref_cu_layout=args.ref_cu_layout,
-                              ref_eager=args.ref_eager)
+                              ref_eager=args.ref_eager, ref_fp16_stream=None if args.ref_fp32_stream else (True, True))
     # the schedule holds whole groups: 50 steps (the reference's DDIM table) for G in {1, 2, 5}; any other G (a --steps it must divide)
     # rounds the table up to the next multiple
     n_sched = -(-max(T, args.steps + warmup_run) // G) * G
@@ -658,7 +660,7 @@ def main():
                        "paired_gemm_launches": not args.no_gemm_pairs, "paired_text_image_attention": args.attn_pair,
                        "groupnorm_stats_from_epilogues": not args.no_gn_epilogue, "fp16_block_stream": args.fp16_block_stream,
                        "short_zero_image_rows": not args.no_short_rows, "time_embedding_tables": not args.no_time_tables, "splitk_reduce_in_groupnorm": not args.no_splitk_in_gn,
-                       "fused_feed_forward_64x64": not args.no_ff_fused, "fused_feed_forward_hidden_split": not (args.no_ff_fused or args.no_ff_split), "ff2_proj_out_one_gemm": not args.no_ff_proj_merge, "shared_cfg_head_of_main_pass": bool(sampler.main.cfg_shared_head)},
+                       "fused_feed_forward_64x64": not args.no_ff_fused, "fused_feed_forward_hidden_split": not (args.no_ff_fused or args.no_ff_split), "ff2_proj_out_one_gemm": not args.no_ff_proj_merge, "reference_engine_fp16_stream": not args.ref_fp32_stream, "shared_cfg_head_of_main_pass": bool(sampler.main.cfg_shared_head)},
             "tflop_per_step_as_written": round(step_tflop, 3),
             "final_allgather_ms": round(gather_ms, 3), "latents_gathered": int(final.shape[0]), "latents_finite": finite,
             "latents_distinct_per_rank": distinct,

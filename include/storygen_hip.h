@@ -90,7 +90,11 @@ typedef struct sg_gemm_desc {
     int32_t        split_k;           /* 0 = auto, 1 = none, >1 = forced */
     int32_t        tile_m, tile_n;    /* 0, 0 = library heuristic; else one of 256x128, 128x128, 256x64, 128x64, 64x128,
                                          64x64 (a tuning hint: results are identical up to fp32 summation order) */
-    int32_t        tile_waves;        /* 0, or the tile's wave count (64x64 per wave: (tile_m/64)*(tile_n/64)); anything else is rejected */
+    int32_t        tile_waves;        /* 0, or the tile's wave count: 64x64 per wave = (tile_m/64)*(tile_n/64); round 6: 4 with a 64x64 tile /
+                                         8 with a 64x128 tile = the 32x32-per-wave latency kernel (mma_lat_kernel: deep LDS ring, for launches
+                                         that are a short dependent chain; linear epilogue only — a GEGLU launch falls back to the heuristic).
+                                         Anything else is rejected.  With 0, 0, 0 the library picks that kernel itself for GEMMs of at most 640
+                                         64x64 tiles and 8 - 64 K slabs, paired launches excepted (sg_debug_set_option "lat_*"). */
     const void*    res1; int64_t ldr1;   /* fp16, or fp32 with SG_F_RES1_F32 */
     const void*    res2; int64_t ldr2;   /* fp16, or fp32 with SG_F_RES2_F32 */
     void*          workspace; size_t workspace_bytes;
@@ -597,6 +601,8 @@ int sg_debug_ff_anatomy(const sg_ff_desc* d, void* prof, size_t prof_bytes, sg_s
  *   "no_nmajor"          1 = M-major tile order everywhere
  *   "attn_sub2", "attn_prio", "attn_d80" (0..2), "attn_d160" (0..4; 4 = key-split workgroups at Nq <= 256, default)  attention instantiation selectors
  *   "gn_no_fused", "gn_wide", "gn_fused_max"                                               GroupNorm kernel selection
+ *   "lat_tiles" (640; 0 = only on a tile hint), "lat_min_kt" (8), "lat_max_kt" (64), "lat_stages" (4 | 8), "lat_wide" (0 | 1: M <= "lat_wide_m"
+ *   takes the 64x128 / 6-stage form), "lat_mask" (62: bit 1 = paired launches, off by default)   when a GEMM runs the 32x32-per-wave kernel
  *   "reset"              every option back to its default */
 int sg_debug_set_option(const char* name, int64_t value);
 

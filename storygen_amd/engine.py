@@ -315,8 +315,11 @@ class UNetEngine:
                  width: int, n_ref: int = 0, seq_len: int = 77, splitk_workspace_mb: int = 96,
                  weights: Optional[EngineWeights] = None, ctx_rows: Optional[int] = None,
                  attn3_groups: Optional[List[tuple]] = None, fp8_attention: bool = False, ctx_short: int = 0,
-                 cfg_shared_head: bool = False):
-        """batch = samples per UNet call; n_ref = R prior frames (sizes the context buffers; 0 = an engine that only
+                 cfg_shared_head: bool = False, fp16_stream: Optional[tuple] = None):
+        """fp16_stream = (block, resnet) or None (= the module switches FP16_BLOCK_STREAM / FP16_RESNET_STREAM): per ENGINE, which
+        parts of the residual stream are stored as fp16 — block: the transformer state h0 / h1 (h2 / h3 stay fp32: they feed the fused
+        feed-forward and the merged proj_out); resnet: block inputs / outputs, shortcut outputs, skip / concat buffers.
+        batch = samples per UNet call; n_ref = R prior frames (sizes the context buffers; 0 = an engine that only
         harvests, into another engine's buffers).  ctx_rows = number of distinct context rows (default: one per
         sample); attn3_groups = [(q0, n, c0), ...]: samples [q0, q0+n) cross-attend to context rows [c0, c0+n) — lets
         samples whose prior-frame features are identical (the two image-conditioned CFG branches) share
@@ -365,6 +368,7 @@ class UNetEngine:
                              "behind the first resnet and the fp16 attention path")
         self._shared_back = False
         self._head_checked = False
+        self.fp16_block, self.fp16_resnet = (FP16_BLOCK_STREAM, FP16_RESNET_STREAM) if fp16_stream is None else map(bool, fp16_stream)
         self.wts = weights if weights is not None else EngineWeights(arch, state_dict, device)
         # BASELINE config 5: the head-dim-40 self / image attentions (the 46 080-key context of the 96x96 level) on the fp8 MFMA
         # path (sg_attn_fwd_f8_d40); text attention and the D = 80 / 160 levels stay fp16
@@ -461,8 +465,11 @@ class UNetEngine:
             f32 = lambda *sh: self._buf(*sh, dtype=F32)  # noqa: E731
             d = dict(
                 # fp32 residual stream
-                **{n: (self._buf(M, C) if FP16_RESNET_STREAM else f32(M, C)) for n in ("r", "t_out", "sc")},
-                **{n: (self._buf(M, C) if FP16_BLOCK_STREAM else f32(M, C)) for n in ("h0", "h1", "h2", "h3")},
+                **{n: (self._buf(M, C) if self.fp16_resnet else f32(M, C)) for n in ("r", "t_out", "sc")},
+                **{n: (self._buf(M, C) if self.fp16_block else f32(M, C)) for n in ("h0", "h1")},
+                # h2 / h3 (the input of the feed-forward; in a reference pass h2 plays h3) stay fp32 unless the MODULE switch asks for
+                # the round-2 experiment's all-fp16 block stream: the fused feed-forward kernel reads the fp32 stream
+                **{n: (self._buf(M, C) if (self.fp16_block and FP16_BLOCK_STREAM) else f32(M, C)) for n in ("h2", "h3")},
                 # fp16 MFMA operands
                 gn=self._buf(M, C), x16=self._buf(M * Cw), c1=self._buf(M, C), h4=self._buf(M, C),
                 ln=self._buf(M, C), ln4=self._buf(M, C), qk=self._buf(M, 2 * C),
@@ -483,7 +490,7 @@ class UNetEngine:
         lvl = nlev - 1
         for blk in arch.up:
             for j, r in enumerate(blk.resnets):
-                buf = self._buf(B * self.hw[lvl], r.cin, dtype=F16 if FP16_RESNET_STREAM else F32)
+                buf = self._buf(B * self.hw[lvl], r.cin, dtype=F16 if self.fp16_resnet else F32)
                 self.up_cats.append(buf)
                 skip_views.append(buf[:, r.cin - blk.skip_channels[j]:])
             if blk.sampler_prefix:
@@ -721,7 +728,7 @@ class UNetEngine:
         h0 = L["h0"]
         fold = LN_FOLD and C % 64 == 0 and C // 64 <= 20
         # fused feed-forward: needs the fp32 stream (it reads h3 itself: no raw copy, no LayerNorm partials from h3's producer)
-        ff1 = FF_FUSED and xf.ff_pack is not None and not FP16_BLOCK_STREAM
+        ff1 = FF_FUSED and xf.ff_pack is not None and L["h3"].dtype != F16
         # with the fold, the producer of a stream tensor also writes its raw fp16 copy and the LayerNorm partials of its rows
         raw = lambda t, buf: t if t.dtype == F16 else buf                                 # noqa: E731  (fp16 stream: it IS the copy)
         gd = self.ln_guard
@@ -754,7 +761,7 @@ class UNetEngine:
             # fp16 output of this GEMM — written straight into the context buffer, which then also serves as the raw copy of h1 that the
             # folded query projections read; any other plan is served by strided copies.
             direct = None
-            if len(plans) == 1 and h1.dtype != F16 and plans[0].is_direct(B, plans[0].slots_per_row or self.R):
+            if len(plans) == 1 and plans[0].is_direct(B, plans[0].slots_per_row or self.R):
                 c = plans[0].ctx[xf.spec.feature_key]
                 direct = c if c.dim() == 2 else c.view(-1, C)
                 assert direct.shape[0] == M, (direct.shape, M)

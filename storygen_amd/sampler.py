@@ -68,7 +68,7 @@ class StoryGenSampler:
                  weights: Optional[EngineWeights] = None, overlap: bool = True, ref_ahead: int = 1,
                  split_graphs: bool = False, stream_priority: bool = False, fp8_attention: bool = False,
                  side_streams: str = "auto", short_rows: bool = True, time_tables: bool = True, shared_head: bool = True,
-                 ref_cus: int = 0, ref_cu_layout: str = "first", ref_eager: bool = False):
+                 ref_cus: int = 0, ref_cu_layout: str = "first", ref_eager: bool = False, ref_fp16_stream: Optional[tuple] = (True, True)):
         if n_ref < 1:
             raise ValueError("StoryGen's loop needs at least one prior frame")
         if ref_ahead < 1 or (ref_ahead > 1 and not overlap):
@@ -84,6 +84,13 @@ class StoryGenSampler:
         # that it fills the CUs the latency-bound main passes leave idle instead of competing with them for all of them; the G main
         # passes of a group stay hipGraphs on the caller's stream.  ref_eager: the reference pass's kernels are launched one by one
         # from the host instead of as a graph replayed on that stream.  ref_cu_layout: which bits of the mask ("first" n, or "spread").
+        # Round 6: (block, resnet) — which parts of the REFERENCE engine's residual stream are stored as fp16 (UNetEngine fp16_stream).
+        # What a reference pass hands on are fp16 features (attention.py:263 via the context buffers), and at batch 20 its transformer GEMMs
+        # and GroupNorms are HBM-bound on an fp32 stream.  Measured on all 50 steps of config 2 against the reference's own latents
+        # (tools/exp_fp16_stream.py ref, profiles/r06m_*): 5.75e-4 with the fp32 stream, 5.75e-4 with both parts in fp16, -0.10 ms per
+        # step.  The MAIN engine keeps the fp32 stream (round 2: fp16 there costs 1e-4 of the 1e-3 budget).  None = fp32 (A/B: bench.py
+        # --ref-fp32-stream).
+        self.ref_fp16_stream = ref_fp16_stream
         self.ref_cus = int(ref_cus)
         self.ref_eager = bool(ref_eager)
         if ref_cu_layout not in ("first", "spread"):
@@ -227,7 +234,7 @@ class StoryGenSampler:
                 and bool(first.attns) and first.attns[0] is not None)
         self.main = UNetEngine(self.arch, None, self.dev, self.B, self.h, self.w, self.R, self.S, ctx_rows=rows,
                                attn3_groups=groups, ctx_short=short, cfg_shared_head=head, **kw)
-        self.ref = UNetEngine(self.arch, None, self.dev, self.U, self.h, self.w, 0, self.S, **kw)
+        self.ref = UNetEngine(self.arch, None, self.dev, self.U, self.h, self.w, 0, self.S, fp16_stream=self.ref_fp16_stream, **kw)
         # sample u of one step's reference batch IS context slot u (_plan) when the plan alone is a bijection onto the slots
         one_step_direct = HarvestPlan(self.main.ctx, hops, short=short, slots_per_row=self.R, direct=True).is_direct(self.U0, self.R)
         # context sets: the main pass of step k reads set k%2 (only one set when the reference pass is not run ahead); G > 1: set =

@@ -91,16 +91,26 @@ class DDIMSchedule:
         return [int(round(i * ratio)) + self.steps_offset for i in reversed(range(n))]
 
     def add_noise_coef(self, t: int):
-        """(sqrt(abar_t), sqrt(1 - abar_t)) as fp32 python floats."""
-        a = self.alphas_cumprod[t]
-        return float(a ** 0.5), float((1 - a) ** 0.5)
+        """(sqrt(abar_t), sqrt(1 - abar_t)) as fp32 python floats (memoised per timestep: a sampler's step table asks for the same few
+        hundred values a thousand times per prepare(), ~10 us of tensor indexing each)."""
+        memo = self.__dict__.setdefault("_add_noise_memo", {})
+        t = int(t)
+        v = memo.get(t)
+        if v is None:
+            a = self.alphas_cumprod[t]
+            v = memo[t] = (float(a ** 0.5), float((1 - a) ** 0.5))
+        return v
 
     def step_coef(self, t: int, n: int):
         """(sqrt(abar_t), sqrt(1-abar_t), sqrt(abar_prev), sqrt(1-abar_prev)) for x_t -> x_{t - T/n}, eta = 0."""
-        prev = t - self.num_train_timesteps // n
-        a_t = self.alphas_cumprod[t]
-        a_p = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
-        return float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(a_p ** 0.5), float((1 - a_p) ** 0.5)
+        memo = self.__dict__.setdefault("_step_coef_memo", {})
+        v = memo.get((int(t), int(n)))
+        if v is None:
+            prev = t - self.num_train_timesteps // n
+            a_t = self.alphas_cumprod[t]
+            a_p = self.alphas_cumprod[prev] if prev >= 0 else self.final_alpha_cumprod
+            v = memo[(int(t), int(n))] = (float(a_t ** 0.5), float((1 - a_t) ** 0.5), float(a_p ** 0.5), float((1 - a_p) ** 0.5))
+        return v
 
 
 class PNDMSchedule(DDIMSchedule):

@@ -30,9 +30,17 @@ def main():
     inputs = synthetic_inputs(1, R, hw, hw, gold["seed"], arch.config["cross_attention_dim"])
     want = gold["stages"]["multi-image-condition"]["latents"]
     out = {}
-    for name, blk, res in (("fp32_stream", False, False), ("fp16_block_stream", True, False), ("fp16_whole_stream", True, True)):
-        engine.FP16_BLOCK_STREAM, engine.FP16_RESNET_STREAM = blk, res
-        smp = StoryGenSampler(arch, sd, dev, 1, hw, hw, R)
+    if "ref" in sys.argv:      # round 6: fp16 stream in the REFERENCE engine only (batch 20, group schedule), main pass fp32 as shipped
+        variants = (("fp32_stream", None), ("ref_fp16_block", (True, False)), ("ref_fp16_resnet", (False, True)), ("ref_fp16_both", (True, True)))
+    else:
+        variants = (("fp32_stream", False, False), ("fp16_block_stream", True, False), ("fp16_whole_stream", True, True))
+    for var in variants:
+        name = var[0]
+        if "ref" in sys.argv:
+            smp = StoryGenSampler(arch, sd, dev, 1, hw, hw, R, ref_ahead=5, ref_fp16_stream=var[1])
+        else:
+            engine.FP16_BLOCK_STREAM, engine.FP16_RESNET_STREAM = var[1], var[2]
+            smp = StoryGenSampler(arch, sd, dev, 1, hw, hw, R)
         smp.prepare(inputs, gold["n_steps"], "multi-image-condition", *gold["guidance"])
         trace = []
         smp.run(trace=trace)
