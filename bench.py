@@ -286,8 +286,7 @@ def train_step_bench(args):
                              "tflops": round(v["gflop"] / v["ms"], 1) if v["ms"] > 0 else 0.0} for k, v in sorted(fam.items())}}
     print(json.dumps({"metric": "stage-2 training steps/sec @512x512, bs=4, 3 reference frames (non-contract)",
                       "value": round(args.steps / dt, 4), "unit": "it/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-                      "ms_per_step": round(1e3 * dt / args.steps, 3), "ms_per_step_by_rank": [round(1e3 * t / args.steps, 3) for t in timed_steps.by_rank],
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                      "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                       "dtype": "f16", "data": "synthetic",
                       "config": {"workload": "NON-CONTRACT RUN, BASELINE configs[3]: train_StorySalon_stage2.py step, bs=4, fp16 operands / "
                                              "fp32 residual stream and gradients, attn3 gradients only; "
@@ -679,6 +678,22 @@ def main():
         out["mfma_frac_whole_step"] = round(value * executed / (world * PEAK_FP16_TFLOPS), 4)
         out["sample_forwards_per_step"] = {"reference": sampler.executed_sample_forwards()[0],
                                            "main": sampler.executed_sample_forwards()[1], "as_written": 3 * n_ref + 3}
+        if args.fp8_attention:
+            # the e4m3 path is the throughput OPTION BASELINE configs[4] names, not a parity path: state what it costs in accuracy next to
+            # what it buys (since round 5: nothing — the fp16 D = 40 kernel got the softmax-in-MFMA work, the e4m3 kernel did not)
+            n_cmp = 2 * G if G > 1 else 10
+            sampler.prepare(inputs, n_sched, args.stage, 7.5, 3.5)
+            a = sampler.run(max_steps=n_cmp).clone()
+            ref16 = StoryGenSampler(arch, None, dev, N_PER_GPU, hw, hw, n_ref, weights=sampler.weights, ref_ahead=G)
+            ref16.prepare(inputs, n_sched, args.stage, 7.5, 3.5)
+            b = ref16.run(max_steps=n_cmp).clone()
+            torch.cuda.synchronize()
+            out["fp8_attention"] = {"latents_rel_l2_vs_fp16_path": round(float((a.double() - b.double()).norm() / b.double().norm()), 6),
+                                    "after_steps": n_cmp,
+                                    "status": "measured negative: slower than the fp16 attention on the same box since round 5 (compare the "
+                                              "--config5-shape line) and outside the 1e-3 parity bar (3.9e-3 .. 7.6e-3 vs the oracle golden, "
+                                              "tests/test_unet_gpu.py); kept as an opt-in, the product default for config 5 is fp16"}
+            del ref16
         if world == 1 and not args.no_cpu_baseline and not args.config5_shape:
             out["cpu_baseline"] = cpu_baseline(arch, sd, inputs)
         print(json.dumps(out), flush=True)

@@ -93,7 +93,8 @@ typedef struct sg_gemm_desc {
     int32_t        tile_waves;        /* 0, or the tile's wave count: 64x64 per wave = (tile_m/64)*(tile_n/64); round 6: 4 with a 64x64 tile /
                                          8 with a 64x128 tile = the 32x32-per-wave latency kernel (mma_lat_kernel: deep LDS ring, for launches
                                          that are a short dependent chain; linear epilogue only — a GEGLU launch falls back to the heuristic).
-                                         Anything else is rejected.  With 0, 0, 0 the library picks that kernel itself for GEMMs of at most 640
+                                         0, 0, -1 = heuristic tile but never that kernel.  Anything else is rejected.  With 0, 0, 0 the library
+                                         picks it itself for GEMMs of at most 640
                                          64x64 tiles and 8 - 64 K slabs, paired launches excepted (sg_debug_set_option "lat_*"). */
     const void*    res1; int64_t ldr1;   /* fp16, or fp32 with SG_F_RES1_F32 */
     const void*    res2; int64_t ldr2;   /* fp16, or fp32 with SG_F_RES2_F32 */

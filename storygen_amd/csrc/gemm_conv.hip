@@ -1647,7 +1647,8 @@ bool lat_plan(const MmaParams& p, bool pipe, int force_split, int max_ws_split, 
     // development option lat_mask (bisecting): which launch kinds may take the kernel by size — 1 paired launches, 2 LayerNorm-folded
     // consumers, 4 GroupNorm partials, 8 K slices, 16 LayerNorm-partial producers, 32 everything else
     if (hint_waves == 0) {
-        const int kind = g_in_pair ? 1 : p.ln_mode ? 2 : p.stats ? 4 : p.ln_out ? 16 : 32;
+        // (the columns-are-tokens fold, ln_mode 2, only ever occurs as the second problem of a pair: it shares the pairs' bit)
+        const int kind = (g_in_pair || p.ln_mode == 2) ? 1 : p.ln_mode ? 2 : p.stats ? 4 : p.ln_out ? 16 : 32;
         if (!(o.lat_mask & kind)) return false;
     }
     const bool hinted = hint_bm != 0 || hint_bn != 0 || hint_waves != 0;
@@ -1817,6 +1818,7 @@ int check_out_res(const char* who, int flags, const void* C, int64_t ldc, const 
 
 int check_tile_hint(const char* who, int bm, int bn, int waves) {
     if ((bm == 64 && bn == 64 && waves == 4) || (bm == 64 && bn == 128 && waves == 8)) return SG_OK;       // the 32x32-per-wave kernels (mma_lat_kernel)
+    if (bm == 0 && bn == 0 && waves == -1) return SG_OK;                                                   // heuristic tile, never the latency kernel
     if (waves != 0 && waves != (bm / 64) * (bn / 64))
         return sg_set_error(SG_EINVAL, "%s: tile_waves=%d is not available for tile %dx%d (64x64 per wave; 64x64 with 4 waves of 32x32)", who, waves, bm, bn);
     if (bm == 0 && bn == 0) return SG_OK;

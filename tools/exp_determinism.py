@@ -28,6 +28,8 @@ def main():
     print("development options:", ops.apply_env_options())
     if "nomerge" in sys.argv:
         E.FF_PROJ_MERGE = False
+    if "nopairs" in sys.argv:       # every paired projection as two plain launches (engine.PAIR_GEMMS)
+        E.PAIR_GEMMS = False
     reps = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("reps=")), 3)
     only = next((a.split("=")[1] for a in sys.argv if a.startswith("only=")), None)
     dev = torch.device("cuda:0")
@@ -38,7 +40,7 @@ def main():
     outs = {}
     snap0 = None
     for name, kw in (("one graph", dict()), ("split", dict(split_graphs=True)), ("split+priority", dict(split_graphs=True, stream_priority=True)),
-                     ("eager", dict(use_graph=False))):
+                     ("eager", dict(use_graph=False)), ("graph-no-overlap", dict(overlap=False))):
         if only and name.replace(" ", "-") != only:
             continue
         for rep in range(reps):
