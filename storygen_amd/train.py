@@ -131,7 +131,11 @@ class UNetTrainer:
 
     def _batched_ref_engine(self, n_used: int):
         """(engine, context buffers, harvest plan) of the batched reference pass over n_used frames: built on first use, kept (a
-        captured hipGraph holds the buffers' addresses)."""
+        captured hipGraph holds the buffers' addresses).
+        Memory (advisor r5): one engine per DISTINCT n_used the loop draws — train_StorySalon_stage2.py:306-313 draws 1, 2 or 3 — i.e. up
+        to B (1 + 2 + 3) samples of reference-pass activations stay resident (SD-1.5 at a 64x64 latent: ~0.2 GB per sample, 4.8 GB at
+        bs 4; the weights are shared).  That is the price of writing the features in place at every n_used; a caller short of memory
+        can drop the engines (and the graphs captured on them) it no longer needs with release_ref_engines()."""
         st = self._ref_batched.get(n_used)
         if st is None:
             from .arch import feature_shapes
@@ -143,6 +147,16 @@ class UNetTrainer:
             assert plan.is_direct(B * n_used, n_used)
             st = self._ref_batched[n_used] = (eng, ctx, plan)
         return st
+
+    def release_ref_engines(self, keep=()):
+        """Free the batched reference engines of every n_used not in `keep`, together with the captured training-step graphs, which hold
+        their buffers' addresses (they are rebuilt / re-captured on next use)."""
+        for n in [n for n in self._ref_batched if n not in keep]:
+            del self._ref_batched[n]
+        for attr in ("_graphs", "_step_graphs"):
+            g = getattr(self, attr, None)
+            if isinstance(g, dict):
+                g.clear()
 
     # ------------------------------------------------------------------------------------------------ pieces
     def _add_noise(self, x: torch.Tensor, noise: torch.Tensor, t: torch.Tensor) -> torch.Tensor:

@@ -32,16 +32,17 @@ def main():
     guard = torch.zeros(1, dtype=torch.int32, device=dev)
     total_bad = 0
     for tile in [(64, 64, 4), None, (128, 64)]:
-        for M, C in [(192, 1280), (48, 1280), (768, 640), (240, 768)]:
+        for M, C in [(768, 640), (192, 1280), (48, 1280), (240, 768)]:
             x16 = torch.randn(M, C, device=dev).half()
             st = torch.zeros(M, (C // 64 + 1) & ~1, 2, dtype=F32, device=dev)
             st[:, :, 0] = torch.randn(M, (C // 64 + 1) & ~1, device=dev)
             st[:, :, 1] = 64.0 + torch.rand(M, (C // 64 + 1) & ~1, device=dev)
             g, b = torch.rand(C, device=dev) + 0.5, torch.randn(C, device=dev) * 0.1
-            wv = (torch.randn(1280, C, device=dev) / C ** 0.5).half()
+            wv = (torch.randn(C if C in (640, 1280) else 1280, C, device=dev) / C ** 0.5).half()      # V^T = Wv x^T: C rows
             wvf, cv, dv = fold_layernorm(wv, None, g, b)
             for kind in ("ln2 (columns are tokens)", "swapped plain", "ln1 (rows are tokens)"):
-                outs = [torch.full((1280, M) if kind != "ln1 (rows are tokens)" else (M, 1280), float("nan"), dtype=F16, device=dev) for _ in range(reps)]
+                Cr = wv.shape[0]
+                outs = [torch.full((Cr, M) if kind != "ln1 (rows are tokens)" else (M, Cr), float("nan"), dtype=F16, device=dev) for _ in range(reps)]
                 torch.cuda.synchronize()
                 cur = torch.cuda.current_stream()
                 side.wait_stream(cur)

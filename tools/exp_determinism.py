@@ -28,14 +28,28 @@ def main():
     print("development options:", ops.apply_env_options())
     if "nomerge" in sys.argv:
         E.FF_PROJ_MERGE = False
-    if "nopairs" in sys.argv:       # every paired projection as two plain launches (engine.PAIR_GEMMS)
+    vt = next((a.split("=", 1)[1] for a in sys.argv if a.startswith("vt=")), None)
+    if vt is not None:              # vt=ref:down_blocks.1 -> only the V^T projections of the reference engine's transformers whose prefix contains that string
+        which, sub = vt.split(":", 1)
         E.PAIR_GEMMS = False
+        E.VT_LAT_FILTER = lambda prefix, consume: (consume == (which == "main") or which == "both") and sub in prefix
+        if "check" in sys.argv:
+            E.VT_CHECK = torch.zeros((), dtype=torch.int64, device="cuda:0")
+            E.VT_MASK = torch.zeros(640, 768, dtype=torch.int32, device="cuda:0")
+            E.VT_DIFF = torch.zeros(640, 768, dtype=torch.float32, device="cuda:0")
+    if "nopairs" in sys.argv:       # every paired projection as two plain launches (engine.PAIR_GEMMS), free to take the latency kernel
+        E.PAIR_GEMMS = False
+        E.PAIR_FALLBACK_LAT = True
     reps = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("reps=")), 3)
+    hw = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("hw=")), 32)          # hw=64 G=5 R=3: the contract configuration
+    G = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("G=")), 1)
+    R = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("R=")), 2)
+    nsteps = next((int(a.split("=")[1]) for a in sys.argv if a.startswith("steps=")), 5)
     only = next((a.split("=")[1] for a in sys.argv if a.startswith("only=")), None)
     dev = torch.device("cuda:0")
     arch = build_arch(SD15_CONFIG)
     sd = synthetic_state_dict(arch, 0)
-    inputs = synthetic_inputs(1, 2, 32, 32, 21, arch.config["cross_attention_dim"])
+    inputs = synthetic_inputs(1, R, hw, hw, 21, arch.config["cross_attention_dim"])
     wts = EngineWeights(arch, sd, dev)
     outs = {}
     snap0 = None
@@ -44,10 +58,17 @@ def main():
         if only and name.replace(" ", "-") != only:
             continue
         for rep in range(reps):
-            smp = StoryGenSampler(arch, None, dev, 1, 32, 32, 2, weights=wts, **({"use_graph": True} | kw))
+            smp = StoryGenSampler(arch, None, dev, 1, hw, hw, R, weights=wts, **({"use_graph": True, "ref_ahead": G} | kw))
             smp.prepare(inputs, 50, "multi-image-condition", 7.5, 3.5)
-            outs[name, rep] = smp.run(max_steps=5).clone()
+            outs[name, rep] = smp.run(max_steps=nsteps).clone()
             torch.cuda.synchronize()
+            if E.VT_CHECK is not None:
+                print(f"{name} rep {rep}: elements of the hinted V^T launches that differ from the 64x64-per-wave kernel beyond rounding: {int(E.VT_CHECK.item())}", flush=True)
+                E.VT_CHECK.zero_()
+                if E.VT_MASK is not None and int(E.VT_MASK.sum()) > 0:
+                    nz = E.VT_MASK.nonzero()
+                    print("   mismatching (row, col, count, diff):", [(int(r), int(c), int(E.VT_MASK[r, c]), round(float(E.VT_DIFF[r, c]), 4)) for r, c in nz[:64].tolist()], flush=True)
+                    E.VT_MASK.zero_()
             if "buffers" in sys.argv:      # which intermediate buffers differ from the first repeat's?  (reference-pass outputs do not depend on the latents)
                 snap = {}
                 for i, (c, kv) in enumerate(zip(smp.ctx_sets, smp.kv_sets)):
