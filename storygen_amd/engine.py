@@ -76,6 +76,7 @@ LN_EPS = 1e-5         # torch.nn.LayerNorm default, as the reference constructs 
 
 
 PAIR_FALLBACK_LAT = False   # development (tools/exp_determinism.py): let the unpaired form of a paired projection take the latency kernel by size
+VT_LAT_TILE = (64, 64, 4)   # development: the hint VT_LAT_FILTER applies
 VT_CHECK = None             # development: int64 device counter (see VT_LAT_FILTER)
 VT_MASK = VT_DIFF = None    # development: per-element mismatch count / last difference of the checked V^T launches
 VT_LAT_FILTER = None        # development: callable(prefix, consume) -> bool; with PAIR_GEMMS off, the V^T projection (columns-are-tokens fold) of the
@@ -758,7 +759,7 @@ class UNetEngine:
             if fold and VT_LAT_FILTER is not None and not PAIR_GEMMS:      # development: bisecting by transformer
                 ops.gemm(h0r, xf.w_qk1f, qk, ln=(1, L["lnst0"], xf.c_qk1, xf.d_qk1, LN_EPS), guard=gd, tile=(0, 0, -1))
                 sel = VT_LAT_FILTER(xf.spec.prefix, consume)
-                ops.gemm(xf.w_v1f, h0r, vt, ln=(2, L["lnst0"], xf.c_v1, xf.d_v1, LN_EPS), guard=gd, tile=(64, 64, 4) if sel else (0, 0, -1))
+                ops.gemm(xf.w_v1f, h0r, vt, ln=(2, L["lnst0"], xf.c_v1, xf.d_v1, LN_EPS), guard=gd, tile=VT_LAT_TILE if sel else (0, 0, -1))
                 if sel and VT_CHECK is not None:      # the same projection again on the 64x64-per-wave kernel; count elements that differ by more than rounding
                     chk = torch.empty_like(vt)
                     ops.gemm(xf.w_v1f, h0r, chk, ln=(2, L["lnst0"], xf.c_v1, xf.d_v1, LN_EPS), guard=gd, tile=(0, 0, -1))

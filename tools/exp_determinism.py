@@ -33,6 +33,8 @@ def main():
         which, sub = vt.split(":", 1)
         E.PAIR_GEMMS = False
         E.VT_LAT_FILTER = lambda prefix, consume: (consume == (which == "main") or which == "both") and sub in prefix
+        if "wide" in sys.argv:
+            E.VT_LAT_TILE = (64, 128, 8)
         if "check" in sys.argv:
             E.VT_CHECK = torch.zeros((), dtype=torch.int64, device="cuda:0")
             E.VT_MASK = torch.zeros(640, 768, dtype=torch.int32, device="cuda:0")
