@@ -30,6 +30,8 @@ RESOURCES = os.path.join(LIBDIR, "kernel_resources.json")
 # compiler shuttles them through v_accvgpr_read/write around each tile (137 of 281 VALU instructions per tile,
 # profiles/r01d_pmc_kernels.txt); the VGPR form of MFMA (gfx950's register file is unified) removes all of them.
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "attention_f8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               # (round 6) the backward kernel turns S^T / dP^T into P / dS with VALU code between two groups of MFMAs: same reason
+               "attention_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                # the GELU polynomial of the fused feed-forward runs beside MFMAs: packed fp32 VALU (what SLP vectorisation makes of it)
                # is slower there than the scalar forms (MI355X_MICROARCH.md, price of fillers beside MFMAs)
                "ff_fused.hip": ["-fno-slp-vectorize"]}

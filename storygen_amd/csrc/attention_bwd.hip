@@ -83,9 +83,28 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdParams p
     // ---- LDS-DMA issue.  A tile consists of up to five regions (0: X1 rows, 1: X2 rows, 2: X1T, 3: X2T, 4: the (lse2, delta)
     // pairs), each a whole number of 1 KiB segments (= one wave instruction); wave w issues segments w, w + NW, ... of every
     // region, so the region — and with it the base pointer and stride — is a compile-time property of each instruction.
-    const int ntiles = (n_str + 63) / 64;
-    auto issue_region = [&](auto R, const f16* base_ptr, long ld, char* lds_region, int s0, bool full) __attribute__((always_inline)) {
-        constexpr int REGION = decltype(R)::value;
+    // FULL tiles (all 64 streamed rows exist — every tile but possibly the last): the per-lane part of a piece's source address does not
+    // depend on the tile, it is computed ONCE here as a 32-bit element offset; per tile only the wave-uniform base moves (round 6: the
+    // per-tile row / column / clamp arithmetic was ~60 VALU instructions per tile and wave, issued beside the MFMAs where they add).
+    const int ntiles = (n_str + 63) / 64, nfull = n_str / 64;
+    constexpr int TOK_IT = (TOK_SEG + NW - 1) / NW, TR_IT = (TR_SEG + NW - 1) / NW;
+    unsigned tk1[TOK_IT], tk2[TOK_IT], tr1[TR_IT], tr2[TR_IT];
+#pragma unroll
+    for (int j = 0; j < TOK_IT; ++j) {
+        const int s = (j * NW + wave) * 64 + lane, row = s / DC;
+        const int col = ((s - row * DC) ^ kswz<D>(row)) * 8;
+        tk1[j] = (unsigned)(row * (int)ld1 + col);            // < 64 * ld (validated on the host)
+        tk2[j] = (unsigned)(row * (int)ld2_ + col);
+    }
+#pragma unroll
+    for (int j = 0; j < TR_IT; ++j) {
+        const int s = (j * NW + wave) * 64 + lane, row = s >> 3;
+        const int col = ((s & 7) ^ ((row >> 1) & 7)) * 8;
+        tr1[j] = (unsigned)(row * (int)ldt1 + col);           // < D * ldt (validated on the host)
+        tr2[j] = DKV ? (unsigned)(row * (int)ldt2 + col) : 0u;
+    }
+    auto issue_region = [&](auto R, const f16* base_ptr, long ld, char* lds_region, int s0) __attribute__((always_inline)) {
+        constexpr int REGION = decltype(R)::value;             // (partial tile: rows / columns clamped to the last valid one)
         constexpr int NS = REGION < 2 ? TOK_SEG : TR_SEG;
 #pragma unroll
         for (int j = 0; j < (NS + NW - 1) / NW; ++j) {
@@ -96,30 +115,59 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdParams p
                 if constexpr (REGION < 2) {                      // token-major rows [64][D]
                     const int row = s / DC;
                     const int col = ((s - row * DC) ^ kswz<D>(row)) * 8;
-                    src = base_ptr + (long)(full ? s0 + row : min(s0 + row, n_str - 1)) * ld + col;
+                    src = base_ptr + (long)min(s0 + row, n_str - 1) * ld + col;
                 } else {                                         // transposed [D][64]
                     const int row = s >> 3;
                     const int col = ((s & 7) ^ ((row >> 1) & 7)) * 8;
-                    src = base_ptr + (long)row * ld + (full ? s0 + col : min(s0 + col, nstr8 - 8));
+                    src = base_ptr + (long)row * ld + min(s0 + col, nstr8 - 8);
                 }
                 glds16(src, lds_region + gl * 1024);
             }
         }
     };
-    auto issue = [&](int tile, int stage) __attribute__((always_inline)) {
-        char* base = smem + stage * STAGE;
+    auto issue = [&](int tile, auto stage_c, auto full_c) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_c)::value;
+        constexpr bool FULL = decltype(full_c)::value;
+        char* base = smem + ST * STAGE;
         const int s0 = tile * 64;
-        const bool full = s0 + 64 <= n_str;
-        issue_region(std::integral_constant<int, 0>{}, X1, ld1, base, s0, full);
-        issue_region(std::integral_constant<int, 1>{}, X2, ld2_, base + OFF_T2, s0, full);
-        issue_region(std::integral_constant<int, 2>{}, X1T, ldt1, base + OFF_T3, s0, full);
+        if constexpr (FULL) {
+            const f16* b1 = X1 + (long)s0 * ld1;
+            const f16* b2 = X2 + (long)s0 * ld2_;
+#pragma unroll
+            for (int j = 0; j < TOK_IT; ++j) {
+                const int gl = j * NW + wave;
+                if (gl < TOK_SEG) {
+                    glds16(b1 + tk1[j], base + gl * 1024);
+                    glds16(b2 + tk2[j], base + OFF_T2 + gl * 1024);
+                }
+            }
+            const f16* b3 = X1T + s0;
+            const f16* b4 = DKV ? X2T + s0 : nullptr;
+#pragma unroll
+            for (int j = 0; j < TR_IT; ++j) {
+                const int gl = j * NW + wave;
+                if (gl < TR_SEG) {
+                    glds16(b3 + tr1[j], base + OFF_T3 + gl * 1024);
+                    if constexpr (DKV) glds16(b4 + tr2[j], base + OFF_T4 + gl * 1024);
+                }
+            }
+        } else {
+            issue_region(std::integral_constant<int, 0>{}, X1, ld1, base, s0);
+            issue_region(std::integral_constant<int, 1>{}, X2, ld2_, base + OFF_T2, s0);
+            issue_region(std::integral_constant<int, 2>{}, X1T, ldt1, base + OFF_T3, s0);
+            if constexpr (DKV) issue_region(std::integral_constant<int, 3>{}, X2T, ldt2, base + OFF_T4, s0);
+        }
         if constexpr (DKV) {
-            issue_region(std::integral_constant<int, 3>{}, X2T, ldt2, base + OFF_T4, s0, full);
             if (wave == NW - 1) {   // the pairs: 2 floats per streamed row; 16-byte chunks clamped to the last valid one (masked)
                 const int f = min(s0 * 2 + lane * 4, n_str * 2 - 4);
                 glds16(reinterpret_cast<const f16*>(LD + f), base + OFF_LD);
             }
         }
+    };
+    // the tile after `tile` into stage ST (full or partial, whichever it is)
+    auto issue_next = [&](int tile, auto stage_c) __attribute__((always_inline)) {
+        if (tile < nfull) issue(tile, stage_c, std::true_type{});
+        else if (tile < ntiles) issue(tile, stage_c, std::false_type{});
     };
 
     // ---- owned fragments (B operands): lane = (owned row l31, d-chunk 2s + hi); rows beyond n_own clamped (never stored)
@@ -148,16 +196,21 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdParams p
             if constexpr (DO2) acc2[i][r] = 0.f;
         }
 
-    if (S == 2 && ntiles > 0) issue(0, 0);
     const int prow = (l31 & ~12) | ((l31 & 4) << 1) | ((l31 & 8) >> 1);          // pi(l31): swap bits 2 and 3
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    int stage = 0;
-    for (int tile = 0; tile < ntiles; ++tile) {
-        if (S == 1) issue(tile, 0);
+    using C0 = std::integral_constant<int, 0>;
+    using C1 = std::integral_constant<int, 1>;
+    if constexpr (S == 2) issue_next(0, C0{});
+    // One streamed tile.  The ring stage and "all 64 rows exist" are compile-time properties of each copy of the body (round 6): every
+    // LDS address is a loop-invariant per-lane base + an immediate, and the full tiles carry no row masks.
+    auto body = [&](int tile, auto stage_c, auto full_c) __attribute__((always_inline)) {
+        constexpr int ST = decltype(stage_c)::value;
+        constexpr bool FULL = decltype(full_c)::value;
+        if constexpr (S == 1) issue(tile, stage_c, full_c);
         wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (S == 2 && tile + 1 < ntiles) issue(tile + 1, stage ^ 1);
-        const char* T1 = smem + stage * STAGE;
+        if constexpr (S == 2) issue_next(tile + 1, std::integral_constant<int, ST ^ 1>{});
+        const char* T1 = smem + ST * STAGE;
         const char* T2 = T1 + OFF_T2;
         const char* T3 = T1 + OFF_T3;
         const char* T4 = T1 + OFF_T4;
@@ -198,7 +251,7 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdParams p
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int r = 8 * g + j;
-                    const bool valid = tile * 64 + first + j < n_str;
+                    const bool valid = FULL || tile * 64 + first + j < n_str;
                     const float pv = valid ? __builtin_amdgcn_exp2f(fmaf(sT[kb][r], p.scale_log2, -lse[j])) : 0.f;
                     sT[kb][r] = pv;
                     pT[kb][r] = valid ? pv * (pT[kb][r] - dl[j]) : 0.f;
@@ -223,8 +276,21 @@ __global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdParams p
                     acc2[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(T4 + o), pf, acc2[i], 0, 0, 0);
             }
         }
-        if (S == 1) __builtin_amdgcn_s_barrier();   // every wave is done with the only stage before it is refilled
-        else stage ^= 1;
+        if constexpr (S == 1) __builtin_amdgcn_s_barrier();   // every wave is done with the only stage before it is refilled
+    };
+    if constexpr (S == 2) {
+        for (int tile = 0; tile < nfull; tile += 2) {
+            body(tile, C0{}, std::true_type{});
+            if (tile + 1 >= nfull) break;
+            body(tile + 1, C1{}, std::true_type{});
+        }
+        if (nfull < ntiles) {                                  // the partial tile sits in stage nfull & 1
+            if (nfull & 1) body(nfull, C1{}, std::false_type{});
+            else body(nfull, C0{}, std::false_type{});
+        }
+    } else {
+        for (int tile = 0; tile < nfull; ++tile) body(tile, C0{}, std::true_type{});
+        if (nfull < ntiles) body(nfull, C0{}, std::false_type{});
     }
 
     // ---- store (lane holds d = 32i + (r&3) + 8(r>>2) + 4hi of its owned row)
