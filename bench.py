@@ -229,7 +229,9 @@ def train_step_bench(args):
         raise SystemExit("bench.py needs an MI355X")
     from storygen_amd.arch import SD15_CONFIG, build_arch
     from storygen_amd.synth import synthetic_state_dict, synthetic_train_batch
+    from storygen_amd import train as _train
     from storygen_amd.train import UNetTrainer
+    _train.SPLITK_WORKSPACE = not args.train_no_splitk_workspace
     dev = torch.device("cuda", 0)
     arch = build_arch(SD15_CONFIG)
     sd = synthetic_state_dict(arch, 0)
@@ -530,6 +532,8 @@ def main():
                          "the first cross-attention once — the samples share latent and timestep)")
     ap.add_argument("--optimizer", choices=("none", "adamw", "adamw8bit"), default="none",
                     help="with --train-step: include the reference's clip_grad_norm_ + optimizer step (storygen_amd.training.Stage2Trainer)")
+    ap.add_argument("--train-no-splitk-workspace", action="store_true",
+                    help="with --train-step (development A/B): the training classes without split-K scratch, as in rounds 2 - 5")
     ap.add_argument("--train-step", action="store_true",
                     help="NOT the contract workload: BASELINE configs[3] — stage-2 training step, bs=4, 512x512, 3 reference frames "
                          "(forward of 3 reference passes + main pass, backward of the main pass, 80 attn3 gradients); reports it/s")

@@ -559,6 +559,11 @@ int sg_attn_bwd_dkv_f16(const sg_attn_bwd_desc* d, sg_stream_t stream);
 /* dst[c][m] = src[m][c], fp16 out, fp16 / fp32 in (M, C multiples of 8). */
 int sg_transpose_f16(const void* src, int64_t lds, int32_t src_f32, sg_half* dst, int64_t ldd, int32_t M, int32_t C,
                      sg_stream_t stream);
+/* The same for B images in one launch: dst[b][c][m] = src[b][m][c]; bs_src / bs_dst = batch strides in elements (multiples of 8).
+ * The attention operands of a training step (K^T, Q^T, dO^T, V^T per batch row: /root/reference/model/attention.py:171-185 computes
+ * them as strided views) are B such images. */
+int sg_transpose_batched_f16(const void* src, int64_t lds, int64_t bs_src, int32_t src_f32, sg_half* dst, int64_t ldd, int64_t bs_dst,
+                             int32_t B, int32_t M, int32_t C, sg_stream_t stream);
 /* Backward of nearest-2x upsampling: dx[b,y,x,:] (+)= sum of the 2x2 block of du [B, 2H, 2W, C] (fp32). */
 int sg_sum2x2_f32(const float* du, int64_t ldu, float* dx, int64_t ldx, int32_t B, int32_t H, int32_t W, int32_t C,
                   int32_t accumulate, sg_stream_t stream);

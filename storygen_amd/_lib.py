@@ -225,6 +225,8 @@ SIGNATURES = {
     "sg_groupnorm_bwd_nhwc_f16": (C.c_int, [C.POINTER(GroupNormBwdDesc), C.c_void_p]),
     "sg_groupnorm_bwd_workspace_bytes": (C.c_size_t, [C.c_int32, C.c_int32]),
     "sg_transpose_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p]),
+    "sg_transpose_batched_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int64, C.c_int32, C.c_int32,
+                                           C.c_int32, C.c_void_p]),
     "sg_sum2x2_f32": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                 C.c_int32, C.c_void_p]),
     "sg_zero_stuff_f16": (C.c_int, [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32,

@@ -31,7 +31,9 @@ RESOURCES = os.path.join(LIBDIR, "kernel_resources.json")
 # profiles/r01d_pmc_kernels.txt); the VGPR form of MFMA (gfx950's register file is unified) removes all of them.
 EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "attention_f8.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                # (round 6) the backward kernel turns S^T / dP^T into P / dS with VALU code between two groups of MFMAs: same reason
-               "attention_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
+               # ... and no SLP packing: v_pk_add_f32 / v_pk_mul_f32 in the P / dS code beside the MFMAs cost the dK/dV pass 30 %
+               # (417 -> 293 us at B4 Nq 4096 Nk 4096, profiles/r06bc_*; the microarchitecture guide's "packed fp32 VALU is an anti-lever")
+               "attention_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"],
                # the GELU polynomial of the fused feed-forward runs beside MFMAs: packed fp32 VALU (what SLP vectorisation makes of it)
                # is slower there than the scalar forms (MI355X_MICROARCH.md, price of fillers beside MFMAs)
                "ff_fused.hip": ["-fno-slp-vectorize"]}

@@ -45,8 +45,13 @@ struct AttnBwdParams {
 
 // ACC (dKV only): 3 = accumulate dK and dV in one pass; 1 = dK only, 2 = dV only — at D = 160 both accumulators (160
 // registers) plus the owned fragments (80) do not fit, so that head dim runs the pass twice (the 16x16 level is tiny).
+#ifdef SG_BWD_DKV_OCC2          // A/B build (tools/build_variant.py): the D = 40 dK/dV pass held to 256 registers = two waves per SIMD
+#define SG_BWD_WAVES(D, DKV) __attribute__((amdgpu_waves_per_eu((D) == 40 && (DKV) ? 2 : 1, 2)))
+#else
+#define SG_BWD_WAVES(D, DKV)
+#endif
 template <int D, int NW, int S, bool DKV, int ACC = 3>
-__global__ __launch_bounds__(64 * NW) void attn_bwd_kernel(const AttnBwdParams p) {
+__global__ __launch_bounds__(64 * NW) SG_BWD_WAVES(D, DKV) void attn_bwd_kernel(const AttnBwdParams p) {
     constexpr bool DO1 = !DKV || (ACC & 1), DO2 = DKV && (ACC & 2);
     constexpr int DC = D / 8, NDK = (D + 15) / 16, DT = (D + 31) / 32, ROW = D * 2;
     constexpr int TOK_BYTES = 64 * ROW, TR_BYTES = D * 128;

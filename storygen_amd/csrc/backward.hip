@@ -130,10 +130,15 @@ __global__ __launch_bounds__(256) void geglu_bwd_kernel(const f16* proj, long ld
 // ------------------------------------------------------------------------------------------------ transpose
 // dst[c][m] = src[m][c] (fp16 out; fp16 or fp32 in): 64 x 64 tiles through LDS (padded rows), 16-byte global accesses on
 // both sides.  Used for the weight gradients: dW[n, k] = sum_m dy[m, n] x[m, k] is sg_gemm_f16(A = dy^T, W = x^T).
-__global__ __launch_bounds__(256) void transpose_kernel(const void* src, long lds_, int src_f32, f16* dst, long ldd, int M, int C) {
+// blockIdx.z = batch (sg_transpose_batched_f16: the B images of an attention operand in ONE launch; bss / bsd = batch strides in elements)
+__global__ __launch_bounds__(256) void transpose_kernel(const void* src0, long lds_, long bss, int src_f32, f16* dst0, long ldd, long bsd,
+                                                        int M, int C) {
     __shared__ f16 tile[64][72];
     const int t = threadIdx.x;
     const int m0 = blockIdx.x * 64, c0 = blockIdx.y * 64;
+    const void* src = src_f32 ? static_cast<const void*>(static_cast<const float*>(src0) + (long)blockIdx.z * bss)
+                              : static_cast<const void*>(static_cast<const f16*>(src0) + (long)blockIdx.z * bss);
+    f16* dst = dst0 + (long)blockIdx.z * bsd;
     {   // load: 64 rows x 8 chunks of 8 columns; thread -> (row = t / 8 + 32 * i, chunk = t % 8)
         const int ch = t & 7;
 #pragma unroll
@@ -281,9 +286,22 @@ extern "C" int sg_transpose_f16(const void* src, int64_t lds, int32_t src_f32, s
     SG_REQUIRE(M > 0 && C > 0 && M % 8 == 0 && C % 8 == 0, "sg_transpose: M=%d and C=%d must be multiples of 8", M, C);
     SG_REQUIRE(lds % 8 == 0 && ldd % 8 == 0 && lds >= C && ldd >= M, "sg_transpose: bad ld");
     SG_REQUIRE(sg_aligned16(src) && sg_aligned16(dst), "sg_transpose: 16-byte alignment");
-    hipLaunchKernelGGL(transpose_kernel, dim3(sg_cdiv(M, 64), sg_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, src, (long)lds,
-                       src_f32 ? 1 : 0, reinterpret_cast<f16*>(dst), (long)ldd, M, C);
+    hipLaunchKernelGGL(transpose_kernel, dim3(sg_cdiv(M, 64), sg_cdiv(C, 64)), dim3(256), 0, (hipStream_t)stream, src, (long)lds, 0L,
+                       src_f32 ? 1 : 0, reinterpret_cast<f16*>(dst), (long)ldd, 0L, M, C);
     SG_CHECK_LAUNCH("sg_transpose_f16");
+    return SG_OK;
+}
+
+extern "C" int sg_transpose_batched_f16(const void* src, int64_t lds, int64_t bs_src, int32_t src_f32, sg_half* dst, int64_t ldd,
+                                        int64_t bs_dst, int32_t B, int32_t M, int32_t C, sg_stream_t stream) {
+    SG_REQUIRE(src && dst, "sg_transpose_batched: null pointer");
+    SG_REQUIRE(B > 0 && B <= 65535 && M > 0 && C > 0 && M % 8 == 0 && C % 8 == 0,
+               "sg_transpose_batched: B=%d in 1..65535, M=%d and C=%d must be multiples of 8", B, M, C);
+    SG_REQUIRE(lds % 8 == 0 && ldd % 8 == 0 && lds >= C && ldd >= M && bs_src % 8 == 0 && bs_dst % 8 == 0, "sg_transpose_batched: bad ld / batch stride");
+    SG_REQUIRE(sg_aligned16(src) && sg_aligned16(dst), "sg_transpose_batched: 16-byte alignment");
+    hipLaunchKernelGGL(transpose_kernel, dim3(sg_cdiv(M, 64), sg_cdiv(C, 64), B), dim3(256), 0, (hipStream_t)stream, src, (long)lds,
+                       (long)bs_src, src_f32 ? 1 : 0, reinterpret_cast<f16*>(dst), (long)ldd, (long)bs_dst, M, C);
+    SG_CHECK_LAUNCH("sg_transpose_batched_f16");
     return SG_OK;
 }
 

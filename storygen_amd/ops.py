@@ -141,7 +141,32 @@ def new_workspace(nbytes: int, device) -> torch.Tensor:
     return torch.empty((int(nbytes) + 15) & ~15, dtype=torch.uint8, device=device)
 
 
+# Split-K scratch of the gemm / conv3x3 calls that do not pass `workspace=` themselves (round 6).  The library splits K only when the caller
+# owns scratch for the partial tiles; the training classes (train.py, train_blocks.py: ~50 call sites, ONE stream) had none, so their
+# small-M / long-K launches — weight gradients (M = N = 320, K = 12 288 tokens), the 8x8 and 16x16 convolutions at batch 4 — ran 25 - 80
+# workgroups down 180-slab chains (110 us where the sampler's batch-3 twin takes 21).  `with ops.default_workspace(ws):` lends them one
+# buffer for the duration of a step; only for callers whose launches are ordered on one stream.
+DEFAULT_WORKSPACE: Optional[torch.Tensor] = None
+
+
+class default_workspace:
+    def __init__(self, ws: Optional[torch.Tensor]):
+        self.ws, self.prev = ws, None
+
+    def __enter__(self):
+        global DEFAULT_WORKSPACE
+        self.prev, DEFAULT_WORKSPACE = DEFAULT_WORKSPACE, self.ws
+        return self.ws
+
+    def __exit__(self, *exc):
+        global DEFAULT_WORKSPACE
+        DEFAULT_WORKSPACE = self.prev
+        return False
+
+
 def _ws(workspace: Optional[torch.Tensor], d):
+    if workspace is None:
+        workspace = DEFAULT_WORKSPACE
     if workspace is not None:
         d.workspace, d.workspace_bytes = workspace.data_ptr(), workspace.numel() * workspace.element_size()
 
@@ -898,6 +923,18 @@ def transpose(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
         raise ValueError("transpose: dst must be [C, M]")
     check(lib.sg_transpose_f16(src.data_ptr(), _row_stride(src, "src"), int(s32), dst.data_ptr(), _row_stride(dst, "dst"), M, Cc,
                                _stream()), "sg_transpose_f16")
+    return dst
+
+
+def transpose_batched(src: torch.Tensor, dst: torch.Tensor) -> torch.Tensor:
+    """dst [B, C, M] fp16 = src [B, M, C] transposed per batch row, ONE launch (src fp16 or fp32; row- and batch-strided views allowed)."""
+    s32 = _act(src, "src")
+    _f16(dst, "dst")
+    B, M, Cc = src.shape
+    if tuple(dst.shape) != (B, Cc, M) or src.stride(2) != 1 or dst.stride(2) != 1:
+        raise ValueError("transpose_batched: dst must be [B, C, M], last dimensions contiguous")
+    check(lib.sg_transpose_batched_f16(src.data_ptr(), src.stride(1), src.stride(0), int(s32), dst.data_ptr(), dst.stride(1), dst.stride(0),
+                                       B, M, Cc, _stream()), "sg_transpose_batched_f16")
     return dst
 
 

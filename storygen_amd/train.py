@@ -28,6 +28,21 @@ from .scheduler import DDIMSchedule
 from .train_blocks import F16, F32, ResnetBlockTrain, TransformerBlockTrain, _cast16, _e, _t
 
 
+def _nonfinite_flag(tensors: List[torch.Tensor]) -> torch.Tensor:
+    """fp32 [1] on the tensors' device: > 0 iff any entry of any tensor is inf / nan.  One multi-tensor launch (the kernel torch's
+    GradScaler uses, with inverse scale 1: the tensors are left as they are), a few reductions without it."""
+    dev = tensors[0].device
+    fn = getattr(torch, "_amp_foreach_non_finite_check_and_unscale_", None)
+    if fn is not None and dev.type == "cuda" and all(t.dtype == F32 for t in tensors):
+        found = torch.zeros(1, dtype=F32, device=dev)
+        fn(tensors, found, torch.ones(1, dtype=F32, device=dev))
+        return found
+    return torch.stack([(~torch.isfinite(v)).any() for v in tensors]).sum().to(F32).reshape(1)
+
+
+SPLITK_WORKSPACE = True      # development switch (bench.py --train-no-splitk-workspace): the training classes without split-K scratch, as in rounds 2 - 5
+
+
 class Transformer2DTrain:
     """Transformer2DModel (model/attention.py:26-128): GroupNorm(eps 1e-6) -> 1x1 proj_in -> block -> 1x1 proj_out -> + x."""
 
@@ -128,6 +143,9 @@ class UNetTrainer:
         self.scale_growth_interval = 2000
         self._good_steps = 0
         self._alphas_dev = self.schedule.alphas_cumprod.to(self.dev, F32)
+        # split-K scratch shared by every gemm / conv3x3 of the step (one stream: ops.default_workspace).  Largest user: 16 slices of
+        # a [B*H*W/16, 1280] fp32 tile image at the 16x16 level; the engine's reference passes own theirs.
+        self.ws_split = ops.new_workspace(64 << 20, self.dev) if self.dev.type == "cuda" and SPLITK_WORKSPACE else None
 
     def _batched_ref_engine(self, n_used: int):
         """(engine, context buffers, harvest plan) of the batched reference pass over n_used frames: built on first use, kept (a
@@ -241,11 +259,13 @@ class UNetTrainer:
                 ctx16[key] = buf[:, : n_used * n].reshape(B * n_used * n, buf.shape[2]).contiguous()
         text16 = inp["text"].reshape(B * inp["text"].shape[1], -1)
         noisy = self._add_noise(inp["latents"], inp["noise"], t).contiguous()        # :303
-        pred = self.forward_main(noisy, t, text16, ctx16)
-        # ---- loss (:325) and its gradient
-        d_pred, loss = torch.empty_like(pred), _e(1, dev=dev, dtype=F32)
-        ops.mse_grad(pred, inp["noise"], inp["mask"], d_pred, loss)
-        return loss, self.backward_main(d_pred)
+        # (the reference passes above run on the inference engine, which owns its split-K scratch; the training classes below borrow ours)
+        with ops.default_workspace(self.ws_split):
+            pred = self.forward_main(noisy, t, text16, ctx16)
+            # ---- loss (:325) and its gradient
+            d_pred, loss = torch.empty_like(pred), _e(1, dev=dev, dtype=F32)
+            ops.mse_grad(pred, inp["noise"], inp["mask"], d_pred, loss)
+            return loss, self.backward_main(d_pred)
 
     def train_step(self, batch: Dict[str, torch.Tensor], use_refs=(0, 1, 2)) -> Tuple[torch.Tensor, Dict[str, torch.Tensor]]:
         """`batch` as storygen_amd.synth.synthetic_train_batch / oracle.storygen_oracle.train_step.  Returns (loss [1] fp32 on
@@ -281,14 +301,15 @@ class UNetTrainer:
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 loss, grads = self._step_device(static, use_refs)
-            st = self._graphs[use_refs] = dict(graph=g, inputs=static, loss=loss, grads=grads)
+                bad = _nonfinite_flag(list(grads.values()))        # part of the graph (round 6): no per-step eager launches
+            st = self._graphs[use_refs] = dict(graph=g, inputs=static, loss=loss, grads=grads, bad=bad)
         for k, v in staged.items():                  # (capture only records: the capturing call replays like every other)
             st["inputs"][k].copy_(v, non_blocking=True)
         st["graph"].replay()
         if self.check_finite:
-            # ONE host read per step: the number of gradient tensors with a non-finite entry, reduced on the device
-            bad = torch.stack([(~torch.isfinite(v)).any() for v in st["grads"].values()]).sum()
-            if int(bad) > 0:
+            # ONE host read per step: "some gradient has a non-finite entry", computed by the replayed graph itself (rounds 2 - 5 ran
+            # ~400 small eager launches per step here: isfinite / any per gradient tensor, stack, sum)
+            if float(st["bad"]) > 0:
                 # fp16 overflow of the scaled backward: drop the graph and retry with a 16x smaller scale — a BOUNDED number of
                 # times (a NaN that comes from the batch or the weights never goes away: the reference's GradScaler would skip such
                 # a step; here the caller gets an error instead of an endless re-capture)
@@ -406,8 +427,7 @@ class UNetTrainer:
             s /= 16.0
         self.last_grad_scale = s
         if s != 1.0:
-            for g in grads.values():
-                g.mul_(1.0 / s)
+            torch._foreach_mul_(list(grads.values()), 1.0 / s)          # (one multi-tensor launch instead of one per gradient)
         return grads
 
     def _backward_scaled(self, d_pred: torch.Tensor) -> Dict[str, torch.Tensor]:

@@ -53,10 +53,7 @@ def _tr_batched(x: torch.Tensor) -> torch.Tensor:
         xp = torch.zeros(B, Np, C, dtype=x.dtype, device=x.device)
         xp[:, :N] = x
         x = xp
-    out = _e(B, C, Np, dev=x.device)
-    for b in range(B):
-        ops.transpose(x[b], out[b])
-    return out
+    return ops.transpose_batched(x, _e(B, C, Np, dev=x.device))
 
 
 class TransformerBlockTrain:

@@ -208,6 +208,10 @@ def transpose(src, dst):
     return _store(dst, src.t())
 
 
+def transpose_batched(src, dst):
+    return _store(dst, src.transpose(1, 2))
+
+
 def copy_rows(dst, src):
     return _store(dst, src)
 

@@ -138,6 +138,8 @@ def test_backward_entry_points_validate_on_the_host(lib):
     assert b"go together" in lib.sg_last_error()
     assert lib.sg_geglu_bwd_f16(P, 96, P, 48, P, 96, 8, 96, None) == -1                    # N8 % 64
     assert lib.sg_transpose_f16(P, 320, 0, P, 12, 12, 320, None) == -1                     # M % 8
+    assert lib.sg_transpose_batched_f16(P, 320, 320 * 16, 0, P, 16, 320 * 16, 0, 16, 320, None) == -1      # B = 0
+    assert lib.sg_transpose_batched_f16(P, 320, 320 * 16 + 4, 0, P, 16, 320 * 16, 2, 16, 320, None) == -1  # batch stride % 8
     assert lib.sg_sum2x2_f32(P, 6, P, 6, 1, 4, 4, 6, 0, None) == -1                        # C % 4
     assert lib.sg_zero_stuff_f16(P, 320, 0, P, 320, 1, 4, 4, 324, None) == -1
     assert lib.sg_mse_grad_f32(P, P, P, P, P, 0, None) == -1

@@ -85,6 +85,21 @@ def test_transpose(gpu, M, C, f32):
     assert torch.equal(dst, src.half().t())
 
 
+@pytest.mark.parametrize("f32", [False, True])
+def test_transpose_batched_is_the_per_row_transpose_in_one_launch(gpu, f32):
+    """sg_transpose_batched_f16 (round 6: the attention operands K^T, Q^T, dO^T, V^T of a training step, 4 launches -> 1) on
+    row- and batch-strided views, ragged tile edges."""
+    from storygen_amd import ops
+    B, M, C = 3, 200, 72
+    big = rnd((B, M + 8, C + 8), gpu, 1.0, 5, torch.float32 if f32 else torch.float16)
+    src = big[:, :M, :C]                                              # row stride C + 8, batch stride (M + 8)(C + 8)
+    dst_big = torch.zeros(B, C, M + 16, dtype=torch.float16, device=gpu)
+    dst = dst_big[:, :, :M]
+    ops.transpose_batched(src, dst)
+    assert torch.equal(dst, src.half().transpose(1, 2))
+    assert float(dst_big[:, :, M:].abs().max()) == 0.0                # nothing written beyond the M columns
+
+
 def test_weight_gradient_as_a_gemm_on_transposes(gpu):
     """dW[n,k] = sum_m dy[m,n] x[m,k] through the forward GEMM kernel."""
     from storygen_amd import ops
