@@ -59,7 +59,7 @@ __global__ __launch_bounds__(64 * NW) SG_BWD_WAVES(D, DKV) void attn_bwd_kernel(
     constexpr int NTR = DKV ? 2 : 1, LD_SEG = DKV ? 1 : 0;
     constexpr int OFF_T2 = TOK_BYTES, OFF_T3 = 2 * TOK_BYTES, OFF_T4 = OFF_T3 + TR_BYTES, OFF_LD = OFF_T3 + NTR * TR_BYTES;
     constexpr int STAGE = OFF_LD + LD_SEG * 1024;
-    static_assert(S == 1 || S == 2, "1 or 2 stages");
+    static_assert(S >= 1 && S <= 3, "1 .. 3 stages");
     static_assert(S * STAGE + 16 <= 160 * 1024, "ring must fit the LDS");
     __shared__ __attribute__((aligned(16))) char smem[S * STAGE + 16];
 
@@ -205,16 +205,39 @@ __global__ __launch_bounds__(64 * NW) SG_BWD_WAVES(D, DKV) void attn_bwd_kernel(
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     using C0 = std::integral_constant<int, 0>;
     using C1 = std::integral_constant<int, 1>;
-    if constexpr (S == 2) issue_next(0, C0{});
+    using C2 = std::integral_constant<int, 2>;
+    if constexpr (S >= 2) issue_next(0, C0{});
+    if constexpr (S == 3) issue_next(1, C1{});
+    // S = 3 (round 6): tile t + 1 stays in flight while tile t is waited for — a counted wait.  The DMA pieces a wave issues per tile
+    // are the same for every tile but differ between the waves (wave 0 takes the odd segments, the last wave the (lse2, delta) pairs).
+    constexpr int PW_REST = (TOK_SEG / NW) * 2 + (TR_SEG / NW) * NTR;                                   // waves without extras
+    auto wait_landed = [&](int tile) __attribute__((always_inline)) {
+        if constexpr (S == 3) {
+            if (tile + 1 < ntiles) {
+                const int extra = ((wave < TOK_SEG % NW) ? 2 : 0) + ((wave < TR_SEG % NW) ? NTR : 0) + ((DKV && wave == NW - 1) ? 1 : 0);
+                // (at most 2 + NTR + 1 extras: one branch per count, each with its immediate)
+                switch (extra) {
+                    case 0: wait_vmcnt<PW_REST>(); break;
+                    case 1: wait_vmcnt<PW_REST + 1>(); break;
+                    case 2: wait_vmcnt<PW_REST + 2>(); break;
+                    case 3: wait_vmcnt<PW_REST + 3>(); break;
+                    case 4: wait_vmcnt<PW_REST + 4>(); break;
+                    default: wait_vmcnt<PW_REST + 5>(); break;
+                }
+                return;
+            }
+        }
+        wait_vmcnt<0>();
+    };
     // One streamed tile.  The ring stage and "all 64 rows exist" are compile-time properties of each copy of the body (round 6): every
     // LDS address is a loop-invariant per-lane base + an immediate, and the full tiles carry no row masks.
     auto body = [&](int tile, auto stage_c, auto full_c) __attribute__((always_inline)) {
         constexpr int ST = decltype(stage_c)::value;
         constexpr bool FULL = decltype(full_c)::value;
         if constexpr (S == 1) issue(tile, stage_c, full_c);
-        wait_vmcnt<0>();
+        wait_landed(tile);
         __builtin_amdgcn_s_barrier();
-        if constexpr (S == 2) issue_next(tile + 1, std::integral_constant<int, ST ^ 1>{});
+        if constexpr (S >= 2) issue_next(tile + S - 1, std::integral_constant<int, (ST + S - 1) % S>{});
         const char* T1 = smem + ST * STAGE;
         const char* T2 = T1 + OFF_T2;
         const char* T3 = T1 + OFF_T3;
@@ -283,7 +306,21 @@ __global__ __launch_bounds__(64 * NW) SG_BWD_WAVES(D, DKV) void attn_bwd_kernel(
         }
         if constexpr (S == 1) __builtin_amdgcn_s_barrier();   // every wave is done with the only stage before it is refilled
     };
-    if constexpr (S == 2) {
+    if constexpr (S == 3) {
+        for (int tile = 0; tile < nfull; tile += 3) {
+            body(tile, C0{}, std::true_type{});
+            if (tile + 1 >= nfull) break;
+            body(tile + 1, C1{}, std::true_type{});
+            if (tile + 2 >= nfull) break;
+            body(tile + 2, C2{}, std::true_type{});
+        }
+        if (nfull < ntiles) {                                  // the partial tile sits in stage nfull % 3
+            const int st = nfull % 3;
+            if (st == 0) body(nfull, C0{}, std::false_type{});
+            else if (st == 1) body(nfull, C1{}, std::false_type{});
+            else body(nfull, C2{}, std::false_type{});
+        }
+    } else if constexpr (S == 2) {
         for (int tile = 0; tile < nfull; tile += 2) {
             body(tile, C0{}, std::true_type{});
             if (tile + 1 >= nfull) break;
@@ -360,6 +397,10 @@ void launch_bwd(const AttnBwdParams& p0, hipStream_t st) {
 
 using namespace sgattn;
 
+#ifndef SG_BWD_RING
+#define SG_BWD_RING 2          // ring depth of the D = 40 passes and the D = 80 dK/dV pass (A/B builds: tools/build_variant.py ... -DSG_BWD_RING=3)
+#endif
+
 static int check_bwd_desc(const sg_attn_bwd_desc* d, bool dkv, const char* who) {
     SG_REQUIRE(d != nullptr, "%s: null descriptor", who);
     SG_REQUIRE(d->q && d->k && d->v && d->dout && d->ld2, "%s: null q/k/v/dout/ld2", who);
@@ -416,7 +457,7 @@ extern "C" int sg_attn_bwd_dq_f16(const sg_attn_bwd_desc* d, sg_stream_t stream)
     if (rc != SG_OK) return rc;
     const AttnBwdParams p = bwd_params(d);
     hipStream_t st = (hipStream_t)stream;
-    if (d->D == 40) launch_bwd<40, 4, 2, false>(p, st);
+    if (d->D == 40) launch_bwd<40, 4, SG_BWD_RING, false>(p, st);
     else if (d->D == 80) launch_bwd<80, 4, 2, false>(p, st);
     else launch_bwd<160, 4, 1, false>(p, st);
     SG_CHECK_LAUNCH("sg_attn_bwd_dq_f16");
@@ -428,8 +469,8 @@ extern "C" int sg_attn_bwd_dkv_f16(const sg_attn_bwd_desc* d, sg_stream_t stream
     if (rc != SG_OK) return rc;
     const AttnBwdParams p = bwd_params(d);
     hipStream_t st = (hipStream_t)stream;
-    if (d->D == 40) launch_bwd<40, 4, 2, true>(p, st);
-    else if (d->D == 80) launch_bwd<80, 4, 2, true>(p, st);
+    if (d->D == 40) launch_bwd<40, 4, SG_BWD_RING, true>(p, st);
+    else if (d->D == 80) launch_bwd<80, 4, SG_BWD_RING, true>(p, st);
     else {                                            // 83 KB per stage: a single stage; dK and dV in two passes (registers)
         launch_bwd<160, 4, 1, true, 1>(p, st);
         launch_bwd<160, 4, 1, true, 2>(p, st);
