@@ -848,9 +848,22 @@ __global__ __launch_bounds__(256) void mma_kernel(const MmaParams p) {
 // Slab t+2 is issued during slab t (behind its first k-step, or spread over its k-steps: SPREAD / STAGGER in mma_pipe_body), i.e. after the
 // barrier that (a) publishes slab t (every wave waited for its own DMA with a counted vmcnt first) and (b) retires every wave's reads of
 // slab t-1, whose stage it overwrites.
-__device__ __forceinline__ void glds16(const f16* g, char* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                     (__attribute__((address_space(3))) void*)lds_wave_base, 16, 0, 0);
+// One LDS-DMA piece (1 KiB per wave): 16 bytes per lane from `base` (wave-uniform) + `offb` (per-lane BYTE offset, < 2^32: the host
+// validates element offsets < 2^31) to the wave-uniform LDS address `lds_wave_base` (+ lane * 16, the hardware's lane-linear image).
+// SG_GLDS_SADDR (A/B build): the scalar-base form of the instruction, written out — the builtin always materialises a 64-bit per-lane
+// address (one v_lshl_add_u64 per piece beside the MFMAs).  Every piece of a kernel must then go through here (M0 is set by hand).
+struct LdsRef { char* p; unsigned a; };          // one LDS location as a generic pointer and as its LDS byte address
+__device__ __forceinline__ LdsRef operator+(LdsRef r, int d) { return LdsRef{r.p + d, r.a + (unsigned)d}; }
+__device__ __forceinline__ LdsRef lds_ref(char* smem) {
+    return LdsRef{smem, (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned long)((__attribute__((address_space(3))) char*)smem))};
+}
+__device__ __forceinline__ void glds16(const f16* base, unsigned offb, LdsRef dst) {
+#ifdef SG_GLDS_SADDR
+    asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(offb), "s"(base), "s"(dst.a) : "memory");
+#else
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(reinterpret_cast<const char*>(base) + offb),
+                                     (__attribute__((address_space(3))) void*)dst.p, 16, 0, 0);
+#endif
 }
 
 template <int N>
@@ -946,7 +959,7 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     for (int i = 0; i < B_IT; ++i) {
         const int row = srow + 8 * NW * i;
         const int lc = (lane & 7) ^ ((row >> 1) & 7);
-        w_off[i] = (unsigned)((long)min(n0 + row, p.N - 1) * p.ldw + lc * 8);
+        w_off[i] = 2u * (unsigned)((long)min(n0 + row, p.N - 1) * p.ldw + lc * 8);       // bytes
     }
     // `sel` < 0: every piece; otherwise only the pieces whose running index (A pieces first, then W) is sel modulo 4 — the refill of a
     // slab spread over its four k-steps (SG_PIPE_SPREAD builds)
@@ -970,16 +983,17 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
             return (long)kt * BK;
         }
     };
+    const LdsRef lds = lds_ref(smem);
     auto issue_w = [&](long koff, int stage, int sel = -1) __attribute__((always_inline)) {
-        char* sB = smem + stage * STAGE + A_BYTES + wave * 1024;
+        const LdsRef sB = lds + (stage * STAGE + A_BYTES + wave * 1024);
         const f16* Wt = p.W + koff;
 #pragma unroll
         for (int i = 0; i < B_IT; ++i)
-            if (sel < 0 || ((A_IT + i) & 3) == sel) glds16(Wt + w_off[i], sB + i * ISTR);
+            if (sel < 0 || ((A_IT + i) & 3) == sel) glds16(Wt, w_off[i], sB + i * ISTR);
     };
     if (nt > 0) issue_w(w_koff(kt0), 0);
 
-    unsigned a_off[A_IT];                       // offset of the row (GEMM) / of tap (0, 0) (conv)
+    unsigned a_off[A_IT];                       // BYTE offset of the row (GEMM) / of tap (0, 0) (conv)
     unsigned a_par[A_IT];                       // conv with upsampling: parity bits of (oy - 1, ox - 1)
 #pragma unroll
     for (int i = 0; i < A_IT; ++i) {
@@ -993,15 +1007,15 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
             const long img = (long)b * (p.H + 2) * wp;
             // padded input pixel of tap (ky, kx): row ((oy*stride - 1 + ky) >> ups) + 1, column likewise
             if (!p.ups) {
-                a_off[i] = (unsigned)((img + (long)(oy * p.stride) * wp + ox * p.stride) * p.lda + lc * 8);
+                a_off[i] = 2u * (unsigned)((img + (long)(oy * p.stride) * wp + ox * p.stride) * p.lda + lc * 8);
                 a_par[i] = 0;
             } else {
                 // source row of tap ky: ((oy - 1 + ky) >> 1) + 1 = ((oy - 1) >> 1) + 1 + ((ky + ((oy - 1) & 1)) >> 1)
-                a_off[i] = (unsigned)((img + (long)(((oy - 1) >> 1) + 1) * wp + ((ox - 1) >> 1) + 1) * p.lda + lc * 8);
+                a_off[i] = 2u * (unsigned)((img + (long)(((oy - 1) >> 1) + 1) * wp + ((ox - 1) >> 1) + 1) * p.lda + lc * 8);
                 a_par[i] = (unsigned)(((oy - 1) & 1) | (((ox - 1) & 1) << 1));
             }
         } else {
-            a_off[i] = (unsigned)((long)gm * p.lda + lc * 8);
+            a_off[i] = 2u * (unsigned)((long)gm * p.lda + lc * 8);
             a_par[i] = 0;
         }
     }
@@ -1028,25 +1042,25 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
         return r;
     };
     auto a_emit = [&](const ABase& ab, int stage, int sel) __attribute__((always_inline)) {
-        char* sA = smem + stage * STAGE + wave * 1024;
+        const LdsRef sA = lds + (stage * STAGE + wave * 1024);
         if constexpr (CONV) {
             if (!p.ups) {
 #pragma unroll
                 for (int i = 0; i < A_IT; ++i)
-                    if (sel < 0 || (i & 3) == sel) glds16(ab.At + a_off[i], sA + i * ISTR);
+                    if (sel < 0 || (i & 3) == sel) glds16(ab.At, a_off[i], sA + i * ISTR);
             } else {
                 const unsigned rs = (unsigned)(wp * (int)p.lda), cs = (unsigned)p.lda;     // < 2^24 (validated on the host)
 #pragma unroll
                 for (int i = 0; i < A_IT; ++i) {
                     if (!(sel < 0 || (i & 3) == sel)) continue;
                     const unsigned dy = ((unsigned)ab.ky + (a_par[i] & 1u)) >> 1, dx = ((unsigned)ab.kx + (a_par[i] >> 1)) >> 1;
-                    glds16(ab.At + (a_off[i] + __umul24(dy, rs) + __umul24(dx, cs)), sA + i * ISTR);
+                    glds16(ab.At, a_off[i] + 2u * (__umul24(dy, rs) + __umul24(dx, cs)), sA + i * ISTR);
                 }
             }
         } else {
 #pragma unroll
             for (int i = 0; i < A_IT; ++i)
-                if (sel < 0 || (i & 3) == sel) glds16(ab.At + a_off[i], sA + i * ISTR);
+                if (sel < 0 || (i & 3) == sel) glds16(ab.At, a_off[i], sA + i * ISTR);
         }
     };
 #ifdef SG_PIPE_BASE_DIV        // A/B build (tools/ab_lib.py): every slab's base from its index (multiply-shift division + 64-bit products)
