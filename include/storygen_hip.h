@@ -93,7 +93,9 @@ typedef struct sg_gemm_desc {
     int32_t        tile_waves;        /* 0, or the tile's wave count: 64x64 per wave = (tile_m/64)*(tile_n/64); round 6: 4 with a 64x64 tile /
                                          8 with a 64x128 tile = the 32x32-per-wave latency kernel (mma_lat_kernel: deep LDS ring, for launches
                                          that are a short dependent chain; linear epilogue only — a GEGLU launch falls back to the heuristic).
-                                         0, 0, -1 = heuristic tile but never that kernel.  Anything else is rejected.  With 0, 0, 0 the library
+                                         8 with a 512x128 or 256x256 tile = eight waves of 128x64 on a 2-stage ring (mma_fat_kernel: the
+                                         throughput form for the largest launches; linear and GEGLU epilogues, no split-K).
+                                         0, 0, -1 = heuristic tile but never the latency kernel.  Anything else is rejected.  With 0, 0, 0 the library
                                          picks it itself for GEMMs of at most 640
                                          64x64 tiles and 8 - 64 K slabs, paired launches excepted (sg_debug_set_option "lat_*"). */
     const void*    res1; int64_t ldr1;   /* fp16, or fp32 with SG_F_RES1_F32 */
@@ -609,6 +611,8 @@ int sg_debug_ff_anatomy(const sg_ff_desc* d, void* prof, size_t prof_bytes, sg_s
  *   "gn_no_fused", "gn_wide", "gn_fused_max"                                               GroupNorm kernel selection
  *   "lat_tiles" (640; 0 = only on a tile hint), "lat_min_kt" (8), "lat_max_kt" (64), "lat_stages" (4 | 8), "lat_wide" (0 | 1: M <= "lat_wide_m"
  *   takes the 64x128 / 6-stage form), "lat_mask" (62: bit 1 = paired launches, off by default)   when a GEMM runs the 32x32-per-wave kernel
+ *   "fat_m" (0 = off)    convolutions of at least this many output rows take the 128x64-per-wave tiles (512x128 / 256x256, eight waves,
+ *                        2-stage ring) when no tile is hinted; tile hint (512, 128, 8) / (256, 256, 8) selects them per launch
  *   "reset"              every option back to its default */
 int sg_debug_set_option(const char* name, int64_t value);
 

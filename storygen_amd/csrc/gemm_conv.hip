@@ -188,11 +188,12 @@ __device__ __forceinline__ bool epi_prefetches(const MmaParams& p) {
     return p.res1 != nullptr && (p.flags & SG_F_RES1_F32) && p.splits == 1 && p.mode == SG_EPI_LINEAR;
 }
 
-__device__ __forceinline__ void epi_prefetch(const MmaParams& p, int m0, int n0, int wm, int wn, int lane, EPI_PRE_PARAMS) {
+// (wrows = rows per wave: 64, or 128 for the 128x64-per-wave tiles, which fetch the bias only)
+__device__ __forceinline__ void epi_prefetch(const MmaParams& p, int m0, int n0, int wm, int wn, int lane, EPI_PRE_PARAMS, int wrows = 64) {
     if (p.splits > 1 || p.mode != SG_EPI_LINEAR) return;
-    const int rowq = m0 + wm * 64 + (lane >> 4), cq = min(n0 + wn * 64 + 4 * (lane & 15), p.N - 4);
+    const int rowq = m0 + wm * wrows + (lane >> 4), cq = min(n0 + wn * 64 + 4 * (lane & 15), p.N - 4);
     if (p.bias) pbias = *reinterpret_cast<const u32x2*>(p.bias + cq);
-    if (!epi_prefetches(p)) return;
+    if (!epi_prefetches(p) || wrows != 64) return;      // (128 rows per wave: 128 accumulator registers leave no room for 64 more across the last slab)
     const float* r = reinterpret_cast<const float*>(p.res1) + cq;
     const int mlast = p.M - 1;
 #pragma unroll
@@ -250,10 +251,13 @@ __device__ __forceinline__ void store_out4(const MmaParams& p, int gm, int gn, c
 // Everything after the last MFMA.  NW waves as a WGM x WGN grid, this wave at (wm, wn); m0 / n0 = the workgroup's tile origin.
 // One workgroup barrier (the LDS ring is dead once every wave has left the last slab), then each wave works alone; a second
 // barrier only when GroupNorm statistics are requested (to add up the WGM wave rows).
-template <int WGM, int WGN>
-__device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x16 (&acc)[2][2], EPI_PRE_PARAMS,
-                                           int m0, int n0, int z, int wave, int wm, int wn, int lane) {
-    constexpr int BN = 64 * WGN, NW = WGM * WGN, NT = 64 * NW;
+// WTM = 4 (round 6, mma_fat_kernel): a wave owns 128x64 = two 64x64 halves, finished one after the other through the SAME staging region
+// (same-wave LDS traffic is in order); the residual of the second half is read here instead of prefetched, the GroupNorm partial sums of
+// the halves are added in registers before the waves' rows meet in LDS (one partial per 128 WGM rows).
+template <int WGM, int WGN, int WTM = 2>
+__device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x16 (&acc)[WTM][2], EPI_PRE_PARAMS,
+                                           int m0, int n0, int z, int wave, int wm0, int wn, int lane) {
+    constexpr int BN = 64 * WGN, NW = WGM * WGN, NT = 64 * NW, NH = WTM / 2;
     const int lnm = p.ln_mode;
     const int l31 = lane & 31, hi = lane >> 5, lr = lane >> 4, lc = lane & 15;
     float* stg = reinterpret_cast<float*>(smem + wave * EPI_WAVE_BYTES);
@@ -261,6 +265,11 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
     // Raw s_barrier: __syncthreads() would also drain vmcnt, i.e. wait for the prefetched residual before the transpose starts.
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
+    float cs[4] = {0, 0, 0, 0}, cq2[4] = {0, 0, 0, 0};
+    const bool want_stats = p.stats != nullptr;
+#pragma unroll
+    for (int half = 0; half < NH; ++half) {
+    const int wm = wm0 * NH + half;              // this half's 64-row block of the tile
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -268,7 +277,8 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
 #pragma unroll
             for (int g = 0; g < 4; ++g)
                 *reinterpret_cast<float4*>(stg + (i * 32 + l31) * EPI_PITCH + j * 32 + 8 * g + 4 * hi) =
-                    make_float4(acc[i][j][4 * g], acc[i][j][4 * g + 1], acc[i][j][4 * g + 2], acc[i][j][4 * g + 3]);
+                    make_float4(acc[2 * half + i][j][4 * g], acc[2 * half + i][j][4 * g + 1], acc[2 * half + i][j][4 * g + 2],
+                                acc[2 * half + i][j][4 * g + 3]);
     // same-wave LDS write -> read: in-order within the wave, the compiler's lgkmcnt wait covers it
     const int rowq = m0 + wm * 64 + lr, colq = n0 + wn * 64 + 4 * lc;
     float* xtr = stg + EPI_XTR;
@@ -285,7 +295,7 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
         // values, 32..63 the gates of the SAME 32 outputs.  Lane l: row 8 k + (l >> 3), values 4 (l & 7) .. +3.
         const int gr = lane >> 3, gc = (lane & 7) * 4;
         const int gv = n0 + wn * 64 + gc;                         // interleaved column of the 4 values; gates at gv + 32
-        if (gv >= p.N) return;
+        if (gv >= p.N) continue;
         float bv[4] = {0, 0, 0, 0}, bg[4] = {0, 0, 0, 0};
         if (p.bias) {
             H4 a, b;
@@ -316,7 +326,7 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
                 o[e] = (fmaf(mr.y, va[e], bv[e]) - mr.x * cv[e]) * gelu_erf_f(fmaf(mr.y, ga[e], bg[e]) - mr.x * cg[e]);
             store_out4(p, gm, go, o);
         }
-        return;
+        continue;
     }
     const bool col_ok = colq < p.N;
     if (p.splits > 1) {   // raw fp32 partial tile; the epilogue happens in splitk_reduce_kernel
@@ -327,12 +337,11 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
             const float4 v = *reinterpret_cast<const float4*>(stg + row * EPI_PITCH + 4 * lc);
             if (gm < p.M && col_ok) st_stream(wsz + (size_t)gm * p.N, f32x4{v.x, v.y, v.z, v.w});
         }
-        return;
+        continue;
     }
     // ---- fused linear epilogue: bias, temb row-bias, residuals (fp32 res1 prefetched), outputs, optional GroupNorm statistics.
     // Phases, not a per-row loop: all loads of a term are issued together (clamped addresses, no predicate), so the epilogue pays
     // one memory round trip per term instead of one per row quad.
-    const bool want_stats = p.stats != nullptr;
     const bool r1f32 = p.flags & SG_F_RES1_F32, r2f32 = p.flags & SG_F_RES2_F32;
     // (a2 + h) + (a3 + h): the same tensor as both residuals is read once
     const bool res2_same = p.res2 != nullptr && p.res2 == p.res1 && p.ldr2 == p.ldr1 && r1f32 == r2f32;
@@ -377,12 +386,17 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
             }
         }
     }
+    // (loads of a term in batches of KB row quads: all 16 at once, or 8 + 8 where 128 accumulator registers leave less room)
+    constexpr int KB = NH > 1 ? 8 : 16;
     auto add_f32 = [&](const float* base, long ld) __attribute__((always_inline)) {
-        float4 t[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) t[k] = *reinterpret_cast<const float4*>(base + (long)min(rowq + 4 * k, mlast) * ld + cq);
+        for (int kb = 0; kb < 16; kb += KB) {
+            float4 t[KB];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { v[k][0] += t[k].x; v[k][1] += t[k].y; v[k][2] += t[k].z; v[k][3] += t[k].w; }
+            for (int k = 0; k < KB; ++k) t[k] = *reinterpret_cast<const float4*>(base + (long)min(rowq + 4 * (kb + k), mlast) * ld + cq);
+#pragma unroll
+            for (int k = 0; k < KB; ++k) { v[kb + k][0] += t[k].x; v[kb + k][1] += t[k].y; v[kb + k][2] += t[k].z; v[kb + k][3] += t[k].w; }
+        }
     };
     auto add_f16 = [&](const f16* base, long ld) __attribute__((always_inline)) {
         uint2 t[16];
@@ -396,20 +410,38 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
         }
     };
     if (p.rowbias) {
-        float4 t[16];
 #pragma unroll
-        for (int k = 0; k < 16; ++k)
-            t[k] = *reinterpret_cast<const float4*>(p.rowbias + (long)fd_div((unsigned)min(rowq + 4 * k, mlast), p.fd_rpb) * p.rowbias_ld + cq);
+        for (int kb = 0; kb < 16; kb += KB) {
+            float4 t[KB];
 #pragma unroll
-        for (int k = 0; k < 16; ++k) { v[k][0] += t[k].x; v[k][1] += t[k].y; v[k][2] += t[k].z; v[k][3] += t[k].w; }
+            for (int k = 0; k < KB; ++k)
+                t[k] = *reinterpret_cast<const float4*>(p.rowbias + (long)fd_div((unsigned)min(rowq + 4 * (kb + k), mlast), p.fd_rpb) * p.rowbias_ld + cq);
+#pragma unroll
+            for (int k = 0; k < KB; ++k) { v[kb + k][0] += t[k].x; v[kb + k][1] += t[k].y; v[kb + k][2] += t[k].z; v[kb + k][3] += t[k].w; }
+        }
     }
     if (p.res1) {
         if (r1f32) {
             const float w = res2_same ? 2.f : 1.f;       // x + r + r == x + 2 r up to one rounding of the fp32 stream
+            if constexpr (NH > 1) {                       // 128 rows per wave: nothing was prefetched (registers); two batches of 8 row quads
+                const float* r = reinterpret_cast<const float*>(p.res1) + cq;
 #pragma unroll
-            for (int k = 0; k < 16; ++k) {
-                v[k][0] = fmaf(w, pre[k].x, v[k][0]); v[k][1] = fmaf(w, pre[k].y, v[k][1]);
-                v[k][2] = fmaf(w, pre[k].z, v[k][2]); v[k][3] = fmaf(w, pre[k].w, v[k][3]);
+                for (int kb = 0; kb < 16; kb += 8) {
+                    f32x4 t[8];
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) t[k] = ld_stream(r + (long)min(rowq + 4 * (kb + k), mlast) * p.ldr1);
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) {
+                        v[kb + k][0] = fmaf(w, t[k].x, v[kb + k][0]); v[kb + k][1] = fmaf(w, t[k].y, v[kb + k][1]);
+                        v[kb + k][2] = fmaf(w, t[k].z, v[kb + k][2]); v[kb + k][3] = fmaf(w, t[k].w, v[kb + k][3]);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < 16; ++k) {
+                    v[k][0] = fmaf(w, pre[k].x, v[k][0]); v[k][1] = fmaf(w, pre[k].y, v[k][1]);
+                    v[k][2] = fmaf(w, pre[k].z, v[k][2]); v[k][3] = fmaf(w, pre[k].w, v[k][3]);
+                }
             }
         } else {
             add_f16(reinterpret_cast<const f16*>(p.res1), p.ldr1);
@@ -420,7 +452,6 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
         if (r2f32) add_f32(reinterpret_cast<const float*>(p.res2), p.ldr2);
         else add_f16(reinterpret_cast<const f16*>(p.res2), p.ldr2);
     }
-    float cs[4] = {0, 0, 0, 0}, cq2[4] = {0, 0, 0, 0};
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
         const int gm = rowq + 4 * k;
@@ -457,7 +488,9 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
             if (p.ln_guard && !(fabsf(mean) + sqrtf(m2) < 65504.f)) atomicOr(p.ln_guard, SG_LN_GUARD_RANGE);
         }
     }
-    if (want_stats) {
+    }       // halves
+    if (want_stats && p.mode == SG_EPI_LINEAR && p.splits == 1) {
+        float* xtr = stg + EPI_XTR;
         // GroupNorm statistics as an epilogue: per-(row tile, channel) sums of the FINAL fp32 values (bias / temb / residual
         // included, before the fp16 rounding).  A lane holds 16 rows of its 4 columns; the 4 lane groups (l >> 4) are added by two
         // exchanges, the WGM wave rows through LDS in fixed order: deterministic, no atomics.
@@ -483,7 +516,7 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
 #pragma unroll
                 for (int w = 0; w < WGM; ++w)
                     s += reinterpret_cast<const float*>(smem + (w * WGN + (col >> 6)) * EPI_WAVE_BYTES)[EPI_XTR + 128 + (col & 63) * 2 + plane];
-                p.stats[((size_t)(m0 / (64 * WGM)) * 2 + plane) * p.N + gn] = s;
+                p.stats[((size_t)(m0 / (32 * WTM * WGM)) * 2 + plane) * p.N + gn] = s;
             }
         }
     }
@@ -874,9 +907,9 @@ __device__ __forceinline__ void wait_vmcnt() {
 // LDS ring depth S: 3 by default (one slab computing, two in flight).  S = 2 (round 4) halves the bytes in flight but brings the
 // 128x128 and 256x64 tiles down to 74 / 80 KB of LDS, so that TWO workgroups — one of each of the step's two concurrent passes — fit a
 // CU (round 2 measured the forced 128x128 / 2-stage configuration as the fastest whole step; development option pipe_stages).
-template <int WGM, int WGN, int S, int WT = 2>
+template <int WGM, int WGN, int S, int WT = 2, int WTM = WT>
 constexpr int pipe_smem_bytes() {
-    constexpr int ring = S * (32 * WT * WGM + 32 * WT * WGN) * 128;
+    constexpr int ring = S * (32 * WTM * WGM + 32 * WT * WGN) * 128;
     constexpr int epi = WT == 2 ? WGM * WGN * EPI_WAVE_BYTES : (WGM / 2) * (WGN / 2) * EPIQ_GROUP_BYTES;
     return ring > epi ? ring : epi;
 }
@@ -899,7 +932,7 @@ __device__ __forceinline__ void slab_tail(F& slab, int nt) {
     if constexpr (Y > 0) slab_tail<Y - 1, S>(slab, nt);
 }
 
-template <int WGM, int WGN, bool CONV, bool PROF = false, int S = 3, int WT = 2>
+template <int WGM, int WGN, bool CONV, bool PROF = false, int S = 3, int WT = 2, int WTMX = WT>
 __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     // PROF (SG_BUILD_EXPERIMENTS): s_memtime stamps around the phases of every slab, summed per wave (sg_debug_gemm_anatomy /
     // _conv_anatomy): [0] slabs [1] vmcnt wait [2] barrier [3] first fragment reads + k-step 0 [4] k-step 1 up to the DMA issue
@@ -917,7 +950,9 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     // WT = 2: every wave owns 64x64 of the tile (2x2 MFMA accumulators; the throughput shapes).  WT = 1 (round 6, mma_lat_kernel): 32x32 per
     // wave — a 64x64 tile is shared by FOUR waves, so a slab costs each of them 4 MFMAs and 4 LDS-DMA pieces instead of 16 and 16, and the
     // ring is 4 - 8 stages deep: the form for the launches whose time is their dependent chain of slabs, not their FLOPs (below).
-    constexpr int WTM = WT, WTN = WT;
+    // WTMX = 4 with WT = 2 (round 6, mma_fat_kernel): 128x64 per wave — 6 fragment reads and 0.25 LDS-DMA pieces per MFMA instead of 8 and 0.375
+    constexpr int WTM = WTMX, WTN = WT;
+    static_assert(WTM == WT || (WT == 2 && WTM == 4), "wave tiles: 32x32, 64x64 or 128x64");
     constexpr int NW = WGM * WGN, WM = 32 * WTM, WN = 32 * WTN, BM = WM * WGM, BN = WN * WGN;
     constexpr int A_IT = BM / (8 * NW), B_IT = BN / (8 * NW), LPT = A_IT + B_IT;   // LDS-DMA instructions / lane / slab
     constexpr int A_BYTES = BM * 128, B_BYTES = BN * 128, STAGE = A_BYTES + B_BYTES;
@@ -937,7 +972,7 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
     static_assert(WT == 2 || (WGM % 2 == 0 && WGN % 2 == 0), "32x32 waves come in 2x2 groups (epi_finish_q)");
     static_assert((S - 1) * LPT < 64, "vmcnt is a 6-bit counter");
     static_assert(S * STAGE <= 160 * 1024, "the ring must fit the 160 KB of LDS");
-    static_assert(S * STAGE <= pipe_smem_bytes<WGM, WGN, S, WT>(), "the LDS block covers the ring and the epilogue's staging regions");
+    static_assert(S * STAGE <= pipe_smem_bytes<WGM, WGN, S, WT, WTM>(), "the LDS block covers the ring and the epilogue's staging regions");
 
     const int t = threadIdx.x, lane = t & 63;
     const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -1146,7 +1181,7 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     f32x4 pre_f[WT == 2 ? 16 : 4]; u32x2 pre_bias;       // prefetched epilogue operands (epi_prefetch / epi_prefetch_q)
     auto prefetch = [&]() __attribute__((always_inline)) {
-        if constexpr (WT == 2) epi_prefetch(p, m0, n0, wm, wn, lane, pre_f, pre_bias);
+        if constexpr (WT == 2) epi_prefetch(p, m0, n0, wm, wn, lane, pre_f, pre_bias, WM);
         else epi_prefetch_q<WGN>(p, m0, n0, wave, lane, pre_f, pre_bias);
     };
 
@@ -1261,7 +1296,7 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
 #endif
     slab_tail<TAIL - 1, S>(slab, nt);
     if (nt <= 0) prefetch();
-    if constexpr (WT == 2) epi_finish<WGM, WGN>(p, smem, acc, pre_f, pre_bias, m0, n0, z, wave, wm, wn, lane);
+    if constexpr (WT == 2) epi_finish<WGM, WGN, WTM>(p, smem, acc, pre_f, pre_bias, m0, n0, z, wave, wm, wn, lane);
     else epi_finish_q<WGM, WGN>(p, smem, acc[0][0], pre_f, pre_bias, m0, n0, z, wave, lane);
     if constexpr (PROF) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1279,6 +1314,15 @@ template <int WGM, int WGN, bool CONV, int S = 3>
 __global__ __launch_bounds__(64 * WGM * WGN) void mma_pipe_kernel(const MmaParams p) {
     __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN, S>()];
     mma_pipe_body<WGM, WGN, CONV, false, S>(p, smem);
+}
+
+// The "fat wave" form (round 6): WGM x WGN waves of 128x64 on a 2-stage ring — 512x128 (4x2) and 256x256 (2x4) tiles for
+// the batch-20 convolutions of the reference pass.  Per MFMA a wave issues 0.75 fragment reads and 0.25 LDS-DMA pieces (64x64 per wave:
+// 1.0 and 0.375): the non-matrix instructions are what keeps the 256x128 tile at ~41 % matrix-pipe share.
+template <int WGM, int WGN, bool CONV>
+__global__ __launch_bounds__(64 * WGM * WGN) void mma_fat_kernel(const MmaParams p) {
+    __shared__ __attribute__((aligned(16))) char smem[pipe_smem_bytes<WGM, WGN, 2, 2, 4>()];
+    mma_pipe_body<WGM, WGN, CONV, false, 2, 2, 4>(p, smem);
 }
 
 // The latency form (round 6): WGM x WGN waves of 32x32 (a 64x64 tile = 4 waves), S = 4 - 8 ring stages of 16 KB.  The batch-3 main pass
@@ -1553,7 +1597,7 @@ int reduce_stats_rows(const MmaParams& p) {
 }
 
 // ------------------------------------------------------------------------------------------------ host side
-struct Plan { int bm, bn, splits; int lat; };      // lat: 0 = 64x64 per wave; else the 32x32-per-wave kernel (mma_lat_kernel) and its ring depth
+struct Plan { int bm, bn, splits; int lat; int fat = 0; };      // lat: 0 = 64x64 per wave; else the 32x32-per-wave kernel (mma_lat_kernel) and its ring depth
 
 // Development options: storygen_amd/csrc/common.h SgOptions (set through sg_debug_set_option; never from the environment).
 struct TuneView {
@@ -1700,7 +1744,22 @@ int plan_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_w
     pipe = (p.K % BK == 0) && (!CONV || p.padded) && !g_tune.no_pipe;
     const size_t per_split = (size_t)p.M * p.N * 4;
     const int max_ws_split = ws ? (int)(ws_bytes / per_split > 64 ? 64 : ws_bytes / per_split) : 1;
-    if (!lat_plan<CONV>(p, pipe, force_split, max_ws_split, hint_bm, hint_bn, hint_waves, pl)) {
+    const bool ask_fat = hint_waves == 8 && ((hint_bm == 512 && hint_bn == 128) || (hint_bm == 256 && hint_bn == 256));
+    const bool fat_ok = pipe && !p.prof && !g_tune.bm && force_split <= 1 && (p.mode == SG_EPI_LINEAR || p.mode == SG_EPI_GEGLU);
+    // development option fat_m: large convolutions without a hint take 512x128 where an image's rows divide by 512 (GroupNorm partials are
+    // per row tile)
+    int auto_bm = 0, auto_bn = 0;
+    if (CONV && fat_ok && sg_options().fat_m > 0 && p.M >= sg_options().fat_m && hint_bm == 0 && hint_bn == 0 && hint_waves == 0) {
+        // (256x256 lost to 512x128 on every shape measured, profiles/r06bi_*: by hint only)
+        const int rows = p.stats ? p.stats_batch_rows : 512;
+        if (rows % 512 == 0) { auto_bm = 512; auto_bn = 128; }
+    }
+    if (ask_fat && fat_ok) {
+        pl = Plan{hint_bm, hint_bn, 1, 0, 1};
+    } else if (auto_bm) {
+        pl = Plan{auto_bm, auto_bn, 1, 0, 1};
+    } else if (!lat_plan<CONV>(p, pipe, force_split, max_ws_split, ask_fat ? 0 : hint_bm, ask_fat ? 0 : hint_bn, ask_fat ? 0 : hint_waves, pl)) {
+        if (ask_fat) hint_bm = hint_bn = 0;                                                 // asked for, not applicable: the cost model decides
         if ((hint_waves == 4 && hint_bm == 64 && hint_bn == 64) || (hint_waves == 8 && hint_bm == 64 && hint_bn == 128))
             hint_bm = hint_bn = 0;                                                          // asked for, not applicable: the cost model decides
         pl = choose_plan(p.M, p.N, p.KT, force_split, max_ws_split, pipe, hint_bm, hint_bn);
@@ -1790,15 +1849,18 @@ int launch_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint
         g_query_rows = pl.splits;
         if (g_plan_out) {
             g_plan_out[0] = pl.bm; g_plan_out[1] = pl.bn; g_plan_out[2] = pl.splits; g_plan_out[3] = p.tiles_m * p.tiles_n * pl.splits;
-            g_plan_out[4] = pl.lat ? 64 * (pl.bm / 32) * (pl.bn / 32) : pipe ? 64 * (pl.bm / 64) * (pl.bn / 64) : 256;
-            g_plan_out[5] = pl.lat ? 16 + pl.lat : pipe ? 1 : 0;                     // 16 + ring depth: the 32x32-per-wave kernel
+            g_plan_out[4] = pl.fat ? 512 : pl.lat ? 64 * (pl.bm / 32) * (pl.bn / 32) : pipe ? 64 * (pl.bm / 64) * (pl.bn / 64) : 256;
+            g_plan_out[5] = pl.fat ? 2 : pl.lat ? 16 + pl.lat : pipe ? 1 : 0;        // 2: 128x64 per wave; 16 + ring depth: the 32x32-per-wave kernel
         }
         return SG_OK;
     }
     if (p.defer && pl.splits <= 1)
         return sg_set_error(SG_EINVAL, "%s: defer_reduce needs a split-K launch (query sg_conv3x3_planned_splits first)", name);
     dim3 grid(p.tiles_m * p.tiles_n * pl.splits);
-    if (pl.lat) {
+    if (pl.fat) {
+        if (pl.bm == 512) hipLaunchKernelGGL((mma_fat_kernel<4, 2, CONV>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((mma_fat_kernel<2, 4, CONV>), grid, dim3(512), 0, st, p);
+    } else if (pl.lat) {
         if (pl.bn == 128) hipLaunchKernelGGL((mma_lat_kernel<2, 4, CONV, 6>), grid, dim3(512), 0, st, p);
         else if (pl.lat == 8) hipLaunchKernelGGL((mma_lat_kernel<2, 2, CONV, 8>), grid, dim3(256), 0, st, p);
         else hipLaunchKernelGGL((mma_lat_kernel<2, 2, CONV, 4>), grid, dim3(256), 0, st, p);
@@ -1833,6 +1895,7 @@ int check_out_res(const char* who, int flags, const void* C, int64_t ldc, const 
 int check_tile_hint(const char* who, int bm, int bn, int waves) {
     if ((bm == 64 && bn == 64 && waves == 4) || (bm == 64 && bn == 128 && waves == 8)) return SG_OK;       // the 32x32-per-wave kernels (mma_lat_kernel)
     if (bm == 0 && bn == 0 && waves == -1) return SG_OK;                                                   // heuristic tile, never the latency kernel
+    if (waves == 8 && ((bm == 512 && bn == 128) || (bm == 256 && bn == 256))) return SG_OK;                // eight waves of 128x64 (mma_fat_kernel)
     if (waves != 0 && waves != (bm / 64) * (bn / 64))
         return sg_set_error(SG_EINVAL, "%s: tile_waves=%d is not available for tile %dx%d (64x64 per wave; 64x64 with 4 waves of 32x32)", who, waves, bm, bn);
     if (bm == 0 && bn == 0) return SG_OK;

@@ -816,6 +816,123 @@ def test_latency_kernel_every_mode(gpu, stages, lat):
         ops.debug_set_option("reset", 0)
 
 
+@pytest.mark.parametrize("fat", [(512, 128, 8), (256, 256, 8)])
+def test_fat_wave_kernel_every_mode(gpu, fat):
+    """Eight waves of 128x64 on a 2-stage ring (mma_fat_kernel, round 6: tiles 512x128 / 256x256 by tile hint) against fp32 references:
+    every term of the linear epilogue at once on ragged M / N and 1 ... 90 K slabs, GEGLU, GroupNorm partials (one per tile height),
+    the LayerNorm fold on both sides, and the 3x3 convolution gather (stride 1, stride 2, nearest-2x) with the GroupNorm partials of a
+    batch of images — plus the automatic selection for large convolutions (development option fat_m)."""
+    from storygen_amd import ops
+    from storygen_amd.repack import fold_layernorm
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=gpu)
+    bm = fat[0]
+    try:
+        for M, N, K in [(2048, 640, 640), (1000, 328, 128), (5120, 1280, 64), (700, 200, 1280), (4096, 320, 5760)]:
+            a, w = rnd((M, K), gpu, 1.0, 1), rnd((N, K), gpu, K ** -0.5, 2)
+            bias, r1, r2 = rnd((N,), gpu, 1.0, 3), rnd((M, N), gpu, 1.0, 4, torch.float32), rnd((M, N), gpu, 1.0, 5)
+            rpb = max(1, M // 3)
+            rb = rnd((-(-M // rpb), N), gpu, 1.0, 6, torch.float32)
+            ref = a.float() @ w.float().t() + bias.float() + r1 + r2.float() + rb.repeat_interleave(rpb, 0)[:M]
+            o = torch.full((M, N), float("nan"), dtype=torch.float32, device=gpu)
+            o16 = torch.full((M, N), float("nan"), dtype=torch.float16, device=gpu)
+            ops.gemm(a, w, o, bias=bias, res1=r1, res2=r2, rowbias=rb, rows_per_batch=rpb, out2=o16, workspace=ws, tile=fat)
+            check(o, ref, f"fat M{M} N{N} K{K}: fp32 out", l2=2e-6, mx=2e-5)
+            check(o16, ref, "fp16 copy")
+            ops.gemm(a, w, o16, bias=bias, res1=r2, tile=fat)
+            check(o16, a.float() @ w.float().t() + bias.float() + r2.float(), "fp16 out + fp16 residual")
+            ops.gemm(a, w, o, bias=bias, res1=r1, res2=r1, tile=fat)
+            check(o, a.float() @ w.float().t() + bias.float() + 2.0 * r1, "res1 == res2", l2=2e-6, mx=2e-5)
+        # the launch really is the 128x64-per-wave kernel
+        d, _, _ = ops._gemm_desc(a, w, o, tile=fat)
+        assert ops._plan_of(ops.lib.sg_gemm_launch_plan, d)[:2] == [fat[0], fat[1]] and ops._plan_of(ops.lib.sg_gemm_launch_plan, d)[5] == 2
+        # GEGLU (interleaved weight rows) against the heuristic tile: the same products, the same epilogue arithmetic
+        M, C = 2048, 320
+        a, w = rnd((M, C), gpu, 1.0, 21), rnd((8 * C, C), gpu, C ** -0.5, 22)
+        bias = rnd((8 * C,), gpu, 1.0, 23)
+        g1, g2 = torch.empty(M, 4 * C, dtype=torch.float16, device=gpu), torch.empty(M, 4 * C, dtype=torch.float16, device=gpu)
+        ops.gemm(a, w, g1, bias=bias, epilogue=ops.EPI_GEGLU, tile=fat)
+        ops.gemm(a, w, g2, bias=bias, epilogue=ops.EPI_GEGLU, use_table=False)
+        check(g1, g2.float(), "GEGLU on the fat tile vs the heuristic tile", l2=1e-3, mx=2e-2)
+        # LayerNorm fold: producer partials and both consumer orientations
+        M, C = 2048, 640
+        a0, w0 = rnd((M, C), gpu, 1.0, 1), rnd((C, C), gpu, C ** -0.5, 2)
+        res = rnd((M, C), gpu, 1.0, 3, torch.float32) + 3.0
+        x, x16 = torch.empty(M, C, dtype=torch.float32, device=gpu), torch.empty(M, C, dtype=torch.float16, device=gpu)
+        st = torch.zeros(M, (C // 64 + 1) & ~1, 2, dtype=torch.float32, device=gpu)
+        guard = torch.zeros(1, dtype=torch.int32, device=gpu)
+        ops.gemm(a0, w0, x, res1=res, out2=x16, ln_out=st, guard=guard, tile=fat)
+        xr = a0.float() @ w0.float().t() + res
+        check(x, xr, "producer stream", l2=2e-6, mx=2e-5)
+        blk = xr.view(M, C // 64, 64).double()
+        got = st[:, : C // 64].double()
+        assert rel_l2(got[..., 0].cpu(), blk.sum(-1).cpu()) < 1e-5
+        assert rel_l2(got[..., 1].cpu(), ((blk - blk.mean(-1, keepdim=True)) ** 2).sum(-1).cpu()) < 1e-4
+        g, b = rnd((C,), gpu, 0.2, 7, torch.float32) + 1.0, rnd((C,), gpu, 0.1, 8, torch.float32)
+        wq = rnd((2 * C, C), gpu, C ** -0.5, 9)
+        wf, cq, dq = fold_layernorm(wq, None, g, b)
+        y = torch.empty(M, 2 * C, dtype=torch.float16, device=gpu)
+        ops.gemm(x16, wf, y, ln=(1, st, cq, dq, 1e-5), guard=guard, tile=fat)
+        lnx = F.layer_norm(xr, (C,), g, b, 1e-5)
+        check(y, lnx @ wq.float().t(), "folded consumer, rows are tokens", l2=1.5e-3, mx=2e-2)
+        wv = rnd((C, C), gpu, C ** -0.5, 10)
+        wvf, cv, dv = fold_layernorm(wv, None, g, b)
+        yt = torch.empty(C, M, dtype=torch.float16, device=gpu)
+        ops.gemm(wvf, x16, yt, ln=(2, st, cv, dv, 1e-5), guard=guard, tile=fat)
+        check(yt, wv.float() @ lnx.t(), "folded consumer, columns are tokens", l2=1.5e-3, mx=2e-2)
+        assert int(guard.item()) == 0
+        # GroupNorm partials from the epilogue: one per tile height
+        a, w = rnd((4096, 1280), gpu, 1.0, 11), rnd((640, 1280), gpu, 1280 ** -0.5, 12)
+        o = torch.empty(4096, 640, dtype=torch.float32, device=gpu)
+        stt = torch.zeros(4096 // bm * 2 * 640, dtype=torch.float32, device=gpu)
+        rows = ops.gemm_stats_rows(a, w, o, stats=(stt, 1024), tile=fat)
+        assert rows == bm
+        ops.gemm(a, w, o, stats=(stt, 1024), tile=fat)
+        t = o.view(4096 // rows, rows, 640).double()
+        got = stt.view(4096 // rows, 2, 640).double()
+        assert rel_l2(got[:, 0].cpu(), t.sum(1).cpu()) < 1e-6 and rel_l2(got[:, 1].cpu(), (t * t).sum(1).cpu()) < 1e-6
+        # 3x3 convolution: bias + temb row + fp32 residual + GroupNorm partials; stride 2; nearest-2x
+        for B, H, W, Ci, Co, stride, ups in [(4, 32, 32, 128, 320, 1, False), (2, 64, 64, 64, 128, 2, False), (2, 16, 16, 128, 256, 1, True),
+                                             (3, 32, 16, 192, 200, 1, False)]:
+            xx = rnd((B, Ci, H, W), gpu, 1.0, 8)
+            xp = torch.zeros(B, H + 2, W + 2, Ci, dtype=torch.float16, device=gpu)
+            xp[:, 1:-1, 1:-1] = xx.permute(0, 2, 3, 1)
+            wk = rnd((Co, Ci, 3, 3), gpu, (9 * Ci) ** -0.5, 9)
+            bias, rb = rnd((Co,), gpu, 1.0, 10), rnd((B, Co), gpu, 1.0, 11, torch.float32)
+            xin = F.interpolate(xx.float(), scale_factor=2.0, mode="nearest") if ups else xx.float()
+            ref = F.conv2d(xin, wk.float(), bias.float(), stride=stride, padding=1) + rb[:, :, None, None]
+            Ho, Wo = ref.shape[2], ref.shape[3]
+            res = rnd((B, Ho, Wo, Co), gpu, 1.0, 12, torch.float32)
+            ref = ref.permute(0, 2, 3, 1) + res
+            oc = torch.full((B, Ho, Wo, Co), float("nan"), dtype=torch.float32, device=gpu)
+            kw = dict(stride=stride, upsample2x=ups, bias=bias, rowbias=rb, res1=res, x_padded=True, tile=fat)
+            wkr = wk.permute(0, 2, 3, 1).contiguous()
+            hw = Ho * Wo
+            if hw % bm == 0 and Co % 64 == 0:
+                stc = torch.zeros(B * hw // bm * 2 * Co, dtype=torch.float32, device=gpu)
+                assert ops.conv3x3_stats_rows(xp, wkr, oc, stats=stc, **kw) == bm
+                ops.conv3x3(xp, wkr, oc, stats=stc, **kw)
+                t = oc.view(B * hw // bm, bm, Co).double()
+                got = stc.view(B * hw // bm, 2, Co).double()
+                assert rel_l2(got[:, 0].cpu(), t.sum(1).cpu()) < 1e-6 and rel_l2(got[:, 1].cpu(), (t * t).sum(1).cpu()) < 1e-6
+            else:
+                ops.conv3x3(xp, wkr, oc, **kw)
+            check(oc, ref, f"fat conv {B}x{H}x{W} {Ci}->{Co} stride {stride} ups {ups}", l2=2e-6, mx=2e-5)
+        # automatic selection (development option fat_m): the same values as the heuristic tile up to summation order
+        xx = rnd((8, 64, 32, 32), gpu, 1.0, 31)
+        xp = torch.zeros(8, 34, 34, 64, dtype=torch.float16, device=gpu)
+        xp[:, 1:-1, 1:-1] = xx.permute(0, 2, 3, 1)
+        wkr = rnd((640, 3, 3, 64), gpu, (9 * 64) ** -0.5, 32)
+        o1, o2 = (torch.empty(8, 32, 32, 640, dtype=torch.float32, device=gpu) for _ in range(2))
+        ops.conv3x3(xp, wkr, o1, x_padded=True)
+        ops.debug_set_option("fat_m", 4096)
+        d, _, _ = ops._conv_desc(xp, wkr, o2, x_padded=True)
+        assert ops._plan_of(ops.lib.sg_conv3x3_launch_plan, d)[5] == 2
+        ops.conv3x3(xp, wkr, o2, x_padded=True)
+        check(o2, o1, "automatically selected fat tile vs heuristic tile", l2=1e-6, mx=1e-5)
+    finally:
+        ops.debug_set_option("reset", 0)
+
+
 PATCH_CASES = [
     # B, H, W, Cin, Cout, split, tile
     (3, 64, 64, 320, 320, 0, None), (3, 64, 64, 320, 320, 1, (256, 128)), (2, 64, 64, 128, 64, 1, (128, 64)), (1, 64, 64, 64, 72, 1, (64, 64)),

@@ -17,7 +17,7 @@ import json
 import os
 import sys
 
-GROUPS = {"mma_pipe_body (gemm + conv3x3: mma_pipe_kernel / mma_lat_kernel)": ("mma_pipe_kernel", "mma_pipe_pair_kernel", "mma_lat_kernel", "mma_lat_pair_kernel", "mma_kernel", "splitk_reduce_kernel"),
+GROUPS = {"mma_pipe_body (gemm + conv3x3: mma_pipe_kernel / mma_lat_kernel)": ("mma_pipe_kernel", "mma_pipe_pair_kernel", "mma_lat_kernel", "mma_lat_pair_kernel", "mma_fat_kernel", "mma_kernel", "splitk_reduce_kernel"),
           "attn_fwd_kernel": ("attn_fwd_kernel",), "ff_fused_kernel": ("ff_fused_kernel",),
           "groupnorm": ("gn_stats", "gn_apply", "gn_fused"), "layernorm": ("layernorm_kernel",)}
 
