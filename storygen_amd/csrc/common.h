@@ -45,6 +45,7 @@ struct SgOptions {
     int lat_mask = 62;                 // launch kinds that may take it by size: 1 paired launches (OFF: with pairs on it the one-graph loop differed run to run
                                        // in 6 - 12 of 30 repeats, profiles/r06h_*; every other kind 30 / 30 bit-identical), 2 LN-folded consumers, 4 GroupNorm
                                        // partials, 8 K slices, 16 LN-partial producers, 32 others
+    int big_m = 0, big_bm = 0, big_bn = 0; // big_m > 0: launches of M >= big_m rows without a tile hint take the (big_bm, big_bn) tile — the batched reference pass on smaller workgroups (A/B: how long a CU is held matters to the co-running main pass)
     int fat_m = 0;                         // > 0: convolutions of M >= fat_m rows take the 128x64-per-wave tiles (mma_fat_kernel: 512x128 / 256x256) when no tile is hinted
     int lat_wide = 0, lat_wide_m = 256;   // 1: M <= lat_wide_m (the 8x8 level) takes the 64x128-tile / 6-stage weight-streaming form (measured neutral: default off; tile hint (64, 128, 8) selects it per launch)
     int attn_sub2 = 0, attn_prio = 0, attn_d80 = 1, attn_d160 = 4 /* 4: key-split workgroups at Nq <= 256 */, attn_lean = 0;

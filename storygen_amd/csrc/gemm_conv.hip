@@ -1744,6 +1744,9 @@ int plan_mma(MmaParams& p, int force_split, int hint_bm, int hint_bn, int hint_w
     pipe = (p.K % BK == 0) && (!CONV || p.padded) && !g_tune.no_pipe;
     const size_t per_split = (size_t)p.M * p.N * 4;
     const int max_ws_split = ws ? (int)(ws_bytes / per_split > 64 ? 64 : ws_bytes / per_split) : 1;
+    if (sg_options().big_m > 0 && p.M >= sg_options().big_m && hint_bm == 0 && hint_bn == 0 && hint_waves == 0 && pipe) {
+        hint_bm = sg_options().big_bm; hint_bn = sg_options().big_bn;       // development option: see common.h
+    }
     const bool ask_fat = hint_waves == 8 && ((hint_bm == 512 && hint_bn == 128) || (hint_bm == 256 && hint_bn == 256));
     const bool fat_ok = pipe && !p.prof && !g_tune.bm && force_split <= 1 && (p.mode == SG_EPI_LINEAR || p.mode == SG_EPI_GEGLU);
     // development option fat_m: large convolutions without a hint take 512x128 where an image's rows divide by 512 (GroupNorm partials are

@@ -21,7 +21,7 @@ extern "C" int sg_debug_set_option(const char* name, int64_t value) {
                            {"gn_wide", &o.gn_wide}, {"attn_lean", &o.attn_lean}, {"attn_d40_general", &o.attn_d40_general},
                            {"gn_fused_nt", &o.gn_fused_nt}, {"pipe_stages", &o.pipe_stages}, {"ff_variant", &o.ff_variant},
                            {"gn_chunks", &o.gn_chunks}, {"lat_tiles", &o.lat_tiles}, {"lat_min_kt", &o.lat_min_kt},
-                           {"lat_max_kt", &o.lat_max_kt}, {"lat_stages", &o.lat_stages}, {"lat_wide", &o.lat_wide}, {"lat_mask", &o.lat_mask}, {"lat_wide_m", &o.lat_wide_m}, {"fat_m", &o.fat_m}};
+                           {"lat_max_kt", &o.lat_max_kt}, {"lat_stages", &o.lat_stages}, {"lat_wide", &o.lat_wide}, {"lat_mask", &o.lat_mask}, {"lat_wide_m", &o.lat_wide_m}, {"fat_m", &o.fat_m}, {"big_m", &o.big_m}, {"big_bm", &o.big_bm}, {"big_bn", &o.big_bn}};
     for (const Entry& e : table)
         if (strcmp(e.n, name) == 0) {
             *e.p = (int)value;

@@ -1080,7 +1080,7 @@ def debug_set_option(name: str, value: int) -> None:
 _ENV_OPTIONS = {"SG_NO_NMAJOR": "no_nmajor", "SG_NO_PIPE": "no_pipe", "SG_NO_SPLIT": "no_split",
                 "SG_ATTN_SUB2": "attn_sub2", "SG_ATTN_PRIO": "attn_prio", "SG_ATTN_D80": "attn_d80", "SG_ATTN_D160": "attn_d160",
                 "SG_FF_VARIANT": "ff_variant", "SG_PIPE_STAGES": "pipe_stages", "SG_GN_FUSED_NT": "gn_fused_nt", "SG_GN_CHUNKS": "gn_chunks", "SG_ATTN_LEAN": "attn_lean", "SG_ATTN_D40_GENERAL": "attn_d40_general", "SG_NO_GN_FUSED": "gn_no_fused", "SG_GN_WIDE": "gn_wide", "SG_GN_FUSED_MAX": "gn_fused_max",
-                "SG_LAT_TILES": "lat_tiles", "SG_LAT_MIN_KT": "lat_min_kt", "SG_LAT_MAX_KT": "lat_max_kt", "SG_LAT_STAGES": "lat_stages", "SG_LAT_WIDE": "lat_wide", "SG_LAT_MASK": "lat_mask", "SG_LAT_WIDE_M": "lat_wide_m", "SG_FAT_M": "fat_m"}
+                "SG_LAT_TILES": "lat_tiles", "SG_LAT_MIN_KT": "lat_min_kt", "SG_LAT_MAX_KT": "lat_max_kt", "SG_LAT_STAGES": "lat_stages", "SG_LAT_WIDE": "lat_wide", "SG_LAT_MASK": "lat_mask", "SG_LAT_WIDE_M": "lat_wide_m", "SG_FAT_M": "fat_m", "SG_BIG_M": "big_m", "SG_BIG_BM": "big_bm", "SG_BIG_BN": "big_bn"}
 
 
 def apply_env_options() -> dict:

@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 6, call 38: closing measurements on the final kernel sources (backward attention / batched transpose changed the source hash): smoke, whole GPU
+# round 6, call 38 (run twice: r6bz, then r6cz after the epilogue was generalised for the 128x64-per-wave prototype): closing measurements on the final kernel sources (backward attention / batched transpose changed the source hash): smoke, whole GPU
 # suite, contract line (cpu_baseline, loop_50_steps_ms, algorithmic bytes), kernel stats of the same command, the two PMC traffic passes, training lines
-O=$GRAFT_REPO_ROOT/gpurun_out/r6bz; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r6cz; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -n 1 | tee $O/smoke.txt
 timeout 1800 python -m pytest tests -q -m gpu --no-header -p no:cacheprovider --maxfail=20 > $O/gpu_tests.log 2>&1; grep -E "passed|failed" $O/gpu_tests.log
