@@ -715,3 +715,44 @@ def test_layernorm_fold_is_the_same_linear_map():
         e_cur = float((cur - ref).norm() / ref.norm())
         e_fold = float((fold - ref).norm() / ref.norm())
         assert e_fold < 1e-3 * (1.0 + offset) and e_fold < 2.0 * (1.0 + offset) * e_cur, (offset, e_cur, e_fold)
+
+
+def test_default_workspace_is_lent_and_returned():
+    """ops.default_workspace (round 6): gemm / conv3x3 calls that pass no `workspace=` borrow the current default — the training classes'
+    split-K scratch — and an explicit argument still wins; nested scopes restore the outer buffer; nothing is left set afterwards."""
+    from storygen_amd import ops
+    from storygen_amd._lib import GemmDesc
+    a, b = torch.empty(1024, dtype=torch.uint8), torch.empty(4096, dtype=torch.uint8)
+
+    def ws_of(explicit):
+        d = GemmDesc()
+        ops._ws(explicit, d)
+        return d.workspace or 0, d.workspace_bytes
+
+    assert ops.DEFAULT_WORKSPACE is None and ws_of(None) == (0, 0)
+    with ops.default_workspace(a):
+        assert ws_of(None) == (a.data_ptr(), 1024)
+        assert ws_of(b) == (b.data_ptr(), 4096)
+        with ops.default_workspace(b):
+            assert ws_of(None) == (b.data_ptr(), 4096)
+        assert ws_of(None) == (a.data_ptr(), 1024)
+        with ops.default_workspace(None):                      # a caller that must not borrow (e.g. concurrent streams)
+            assert ws_of(None) == (0, 0)
+    assert ops.DEFAULT_WORKSPACE is None and ws_of(None) == (0, 0)
+
+
+def test_nonfinite_flag_of_a_gradient_list():
+    """train._nonfinite_flag (round 6: the per-step finiteness check is part of the captured training graph): > 0 iff any entry of any
+    tensor is inf / nan; the tensors are left as they are."""
+    from storygen_amd.train import _nonfinite_flag
+    g = [torch.randn(7, 5), torch.randn(3), torch.zeros(2, 2)]
+    keep = [t.clone() for t in g]
+    assert float(_nonfinite_flag(g)) == 0.0
+    g[1][2] = float("inf")
+    assert float(_nonfinite_flag(g)) > 0.0
+    g[1][2] = 0.5
+    g[2][1, 1] = float("nan")
+    assert float(_nonfinite_flag(g)) > 0.0
+    g[2][1, 1] = 0.0
+    keep[1][2] = 0.5
+    assert all(torch.equal(x, y) for x, y in zip(g, keep))
