@@ -23,7 +23,16 @@ LIBDIR = os.path.join(PKG, "lib")
 LIB = os.path.join(LIBDIR, "libstorygen_hip.so")
 LIB_EXP = os.path.join(LIBDIR, "libstorygen_hip_exp.so")      # --experiments: a SEPARATE library that only tools/anatomy.py loads
 SOURCES = ["gemm_conv.hip", "attention.hip", "attention_f8.hip", "norm.hip", "misc.hip", "backward.hip", "attention_bwd.hip", "encoders.hip", "optim.hip", "ff_fused.hip"]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function",
+# -fno-slp-vectorize for EVERY kernel (round 6): no packed fp32 VALU (v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32 with op_sel).
+#  * correctness: the one run-to-run difference this project ever saw — the columns-are-tokens LayerNorm fold on the 4-stage latency
+#    kernel under the two-branch graph — was ONE half of a `v_pk_add_f32 ..., v[c:d] op_sel:[0,1]` in the epilogue losing its d term
+#    for lanes 48 - 63 (the output was exactly `right - d_row` on 16 columns of a row; inputs bit-identical; profiles/r06bm_*).  With
+#    the same source built without SLP packing: 40 / 40 and 40 / 40 repeats bit-identical where the packed build gave 34 / 40 and
+#    1 / 40 (profiles/r06bn_*).  Two workgroups of that kernel share a CU; whatever the hardware condition is, the compiler's hazard
+#    recogniser does not know it, so nothing in this library issues packed fp32 arithmetic.
+#  * speed: neutral on the sampler's step (gemm_conv.hip / attention.hip: 12.39 / 12.37 vs 12.41 / 12.43 ms), -30 % on the backward
+#    attention's dK/dV pass, which ran such instructions beside MFMAs (the microarchitecture guide's anti-lever).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-fno-slp-vectorize",
          "-Rpass-analysis=kernel-resource-usage"]          # remarks only: parsed into lib/kernel_resources.json
 RESOURCES = os.path.join(LIBDIR, "kernel_resources.json")
 # attention keeps its O^T accumulators live across the softmax VALU code of every tile: with MFMA results in AGPRs the
@@ -33,10 +42,10 @@ EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"], "attenti
                # (round 6) the backward kernel turns S^T / dP^T into P / dS with VALU code between two groups of MFMAs: same reason
                # ... and no SLP packing: v_pk_add_f32 / v_pk_mul_f32 in the P / dS code beside the MFMAs cost the dK/dV pass 30 %
                # (417 -> 293 us at B4 Nq 4096 Nk 4096, profiles/r06bc_*; the microarchitecture guide's "packed fp32 VALU is an anti-lever")
-               "attention_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1", "-fno-slp-vectorize"],
+               "attention_bwd.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"],
                # the GELU polynomial of the fused feed-forward runs beside MFMAs: packed fp32 VALU (what SLP vectorisation makes of it)
                # is slower there than the scalar forms (MI355X_MICROARCH.md, price of fillers beside MFMAs)
-               "ff_fused.hip": ["-fno-slp-vectorize"]}
+               "ff_fused.hip": []}
 
 
 def _hipcc() -> str:
@@ -130,9 +139,9 @@ def build(force: bool = False, verbose: bool = True, experiments: bool = False) 
     # a kernel with a private segment either spills or keeps an array in memory: both are order-of-magnitude cliffs on this
     # hardware (the D = 160 attention instantiation once ran 6x slower that way) — refuse to ship one silently
     # (mma_fat_kernel — eight waves of 128x64, a measured negative reachable by tile hint only — has 256 registers per wave for 128
-    # accumulators and spills ~30 dwords in its EPILOGUE, none in the mainloop: tolerated, listed, checked to stay small)
+    # accumulators and spills 30 - 60 dwords in its EPILOGUE, none in the mainloop: tolerated, listed, checked to stay small)
     bad = {k: v["scratch_bytes_per_lane"] for k, v in resources.items()
-           if v["scratch_bytes_per_lane"] and not ("mma_fat_kernel" in k and v["scratch_bytes_per_lane"] <= 192)}
+           if v["scratch_bytes_per_lane"] and not ("mma_fat_kernel" in k and v["scratch_bytes_per_lane"] <= 256)}
     if bad and os.environ.get("SG_ALLOW_SCRATCH") != "1":
         raise RuntimeError(f"kernels using scratch memory (set SG_ALLOW_SCRATCH=1 to build anyway): {bad}")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", out_lib]

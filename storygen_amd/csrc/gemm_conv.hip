@@ -189,7 +189,7 @@ __device__ __forceinline__ bool epi_prefetches(const MmaParams& p) {
 }
 
 // (wrows = rows per wave: 64, or 128 for the 128x64-per-wave tiles, which fetch the bias only)
-__device__ __forceinline__ void epi_prefetch(const MmaParams& p, int m0, int n0, int wm, int wn, int lane, EPI_PRE_PARAMS, int wrows = 64) {
+__device__ __forceinline__ void epi_prefetch(const MmaParams& p, int m0, int n0, int wm, int wn, int lane, EPI_PRE_PARAMS, int wrows = 64, int npre = 16) {
     if (p.splits > 1 || p.mode != SG_EPI_LINEAR) return;
     const int rowq = m0 + wm * wrows + (lane >> 4), cq = min(n0 + wn * 64 + 4 * (lane & 15), p.N - 4);
     if (p.bias) pbias = *reinterpret_cast<const u32x2*>(p.bias + cq);
@@ -197,8 +197,14 @@ __device__ __forceinline__ void epi_prefetch(const MmaParams& p, int m0, int n0,
     const float* r = reinterpret_cast<const float*>(p.res1) + cq;
     const int mlast = p.M - 1;
 #pragma unroll
-    for (int k = 0; k < 16; ++k) pre[k] = ld_stream(r + (long)min(rowq + 4 * k, mlast) * p.ldr1);
+    for (int k = 0; k < 16; ++k)
+        if (k < npre) pre[k] = ld_stream(r + (long)min(rowq + 4 * k, mlast) * p.ldr1);     // (npre < 16: the rest is read in the epilogue)
 }
+
+// Row quads of the fp32 residual prefetched across the last slab: all 16, or 8 where eight waves share a CU's registers (256 per wave:
+// without packed fp32 arithmetic the 256x128 tile's last slab had spilled three of them)
+template <int NW>
+constexpr int epi_npre() { return NW >= 8 ? 8 : 16; }
 
 // LayerNorm fold (consumer side).  The GEMM ran on the RAW fp16 activations x with W' = gamma (.) W, so
 //   LN(x) W^T + b = rstd (x W'^T - mean c) + d,   c_n = sum_k W'_nk,  d_n = sum_k beta_k W_nk + b_n
@@ -386,8 +392,8 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
             }
         }
     }
-    // (loads of a term in batches of KB row quads: all 16 at once, or 8 + 8 where 128 accumulator registers leave less room)
-    constexpr int KB = NH > 1 ? 8 : 16;
+    // (loads of a term in batches of KB row quads: all 16 at once, or 8 + 8 where the register budget is 256 per wave)
+    constexpr int KB = (NH > 1 || NW >= 8) ? 8 : 16;      // (eight waves per workgroup: 256 registers per wave)
     auto add_f32 = [&](const float* base, long ld) __attribute__((always_inline)) {
 #pragma unroll
         for (int kb = 0; kb < 16; kb += KB) {
@@ -437,6 +443,11 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
                     }
                 }
             } else {
+                if constexpr (epi_npre<NW>() < 16) {
+                    const float* r = reinterpret_cast<const float*>(p.res1) + cq;
+#pragma unroll
+                    for (int k = epi_npre<NW>(); k < 16; ++k) pre[k] = ld_stream(r + (long)min(rowq + 4 * k, mlast) * p.ldr1);
+                }
 #pragma unroll
                 for (int k = 0; k < 16; ++k) {
                     v[k][0] = fmaf(w, pre[k].x, v[k][0]); v[k][1] = fmaf(w, pre[k].y, v[k][1]);
@@ -1181,7 +1192,7 @@ __device__ __forceinline__ void mma_pipe_body(const MmaParams& p, char* smem) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
     f32x4 pre_f[WT == 2 ? 16 : 4]; u32x2 pre_bias;       // prefetched epilogue operands (epi_prefetch / epi_prefetch_q)
     auto prefetch = [&]() __attribute__((always_inline)) {
-        if constexpr (WT == 2) epi_prefetch(p, m0, n0, wm, wn, lane, pre_f, pre_bias, WM);
+        if constexpr (WT == 2) epi_prefetch(p, m0, n0, wm, wn, lane, pre_f, pre_bias, WM, epi_npre<NW>());
         else epi_prefetch_q<WGN>(p, m0, n0, wave, lane, pre_f, pre_bias);
     };
 

@@ -79,6 +79,7 @@ PAIR_FALLBACK_LAT = False   # development (tools/exp_determinism.py): let the un
 VT_LAT_TILE = (64, 64, 4)   # development: the hint VT_LAT_FILTER applies
 VT_CHECK = None             # development: int64 device counter (see VT_LAT_FILTER)
 VT_MASK = VT_DIFF = None    # development: per-element mismatch count / last difference of the checked V^T launches
+VT_HASH = None              # development: dict(buf=[K, 4] int64, ctr=[1] int64): per hinted V^T launch the integer sums of its inputs (raw copy, LayerNorm partials) and outputs (q|k, V^T), in launch order
 VT_LAT_FILTER = None        # development: callable(prefix, consume) -> bool; with PAIR_GEMMS off, the V^T projection (columns-are-tokens fold) of the
                             # transformers it selects is HINTED onto the latency kernel, every other unpaired projection is kept off it
 
@@ -760,6 +761,17 @@ class UNetEngine:
                 ops.gemm(h0r, xf.w_qk1f, qk, ln=(1, L["lnst0"], xf.c_qk1, xf.d_qk1, LN_EPS), guard=gd, tile=(0, 0, -1))
                 sel = VT_LAT_FILTER(xf.spec.prefix, consume)
                 ops.gemm(xf.w_v1f, h0r, vt, ln=(2, L["lnst0"], xf.c_v1, xf.d_v1, LN_EPS), guard=gd, tile=VT_LAT_TILE if sel else (0, 0, -1))
+                if sel and VT_HASH is not None:       # order-independent integer sums: are the INPUTS of a differing launch the same in both runs?
+                    HS = VT_HASH[bool(consume)]          # (one record per engine: the two branches of the graph run concurrently)
+                    isum = lambda t, dt: t.contiguous().view(dt).sum(dtype=torch.int64)      # noqa: E731
+                    row = torch.stack([isum(h0r, torch.int16), isum(L["lnst0"], torch.int32), isum(qk, torch.int16), isum(vt, torch.int16),
+                                       torch.full((), vt.shape[1], dtype=torch.int64, device=vt.device)])
+                    HS["buf"].index_copy_(0, HS["ctr"], row.unsqueeze(0))
+                    if "vts" in HS:                      # ... and the V^T images themselves (flattened, zero-padded to the row length), + the inputs
+                        for key, t in (("vts", vt), ("xs", h0r), ("sts", L["lnst0"])):
+                            flat = t.contiguous().reshape(1, -1)
+                            HS[key].index_copy_(0, HS["ctr"], torch.nn.functional.pad(flat, (0, HS[key].shape[1] - flat.shape[1])))
+                    HS["ctr"].add_(1)
                 if sel and VT_CHECK is not None:      # the same projection again on the 64x64-per-wave kernel; count elements that differ by more than rounding
                     chk = torch.empty_like(vt)
                     ops.gemm(xf.w_v1f, h0r, chk, ln=(2, L["lnst0"], xf.c_v1, xf.d_v1, LN_EPS), guard=gd, tile=(0, 0, -1))
