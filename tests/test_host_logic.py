@@ -756,3 +756,11 @@ def test_nonfinite_flag_of_a_gradient_list():
     g[2][1, 1] = 0.0
     keep[1][2] = 0.5
     assert all(torch.equal(x, y) for x, y in zip(g, keep))
+
+
+def test_library_is_built_without_packed_fp32_arithmetic():
+    """the one run-to-run difference this project saw was one half of a `v_pk_add_f32 ... op_sel` losing a term; the kernels are
+    built with -fno-slp-vectorize (for every translation unit, not per file)."""
+    from storygen_amd import build
+    assert "-fno-slp-vectorize" in build.FLAGS
+    assert all("-fslp-vectorize" not in f for flags in build.EXTRA_FLAGS.values() for f in flags)

@@ -51,7 +51,9 @@ def test_adamw_f32_is_torch_adamw(gpu, clip):
         opt.zero_grad()
         assert all(v._version > old for v, old in zip(mine.values(), versions))
         for v, p in zip(mine.values(), ref):
-            assert float((v - p.detach()).abs().max()) <= 2e-6
+            # (two implementations of the same fp32 recurrence: 2e-6 until the kernels lost their packed fp32 arithmetic — DESIGN §6 —,
+            #  2.4e-6 = 10 ulp of a parameter in [2, 4) after it)
+            assert float((v - p.detach()).abs().max()) <= 4e-6
     sd = opt.state_dict()
     assert sd["step"] == 6 and set(sd["state"]) == set(mine)
     assert rel_l2(sd["state"]["p0"]["exp_avg"], topt.state[ref[0]]["exp_avg"].flatten().cpu()) < 1e-5

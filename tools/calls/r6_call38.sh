@@ -1,7 +1,7 @@
 #!/bin/bash
-# round 6, call 38 (run twice: r6bz, then r6cz after the epilogue was generalised for the 128x64-per-wave prototype): closing measurements on the final kernel sources (backward attention / batched transpose changed the source hash): smoke, whole GPU
+# round 6, call 38 (run three times: r6bz; r6cz after the epilogue was generalised for the 128x64-per-wave prototype; r6dz on the library built without SLP vectorisation): closing measurements on the final kernel sources (backward attention / batched transpose changed the source hash): smoke, whole GPU
 # suite, contract line (cpu_baseline, loop_50_steps_ms, algorithmic bytes), kernel stats of the same command, the two PMC traffic passes, training lines
-O=$GRAFT_REPO_ROOT/gpurun_out/r6cz; mkdir -p $O
+O=$GRAFT_REPO_ROOT/gpurun_out/r6dz; mkdir -p $O
 cd $GRAFT_REPO_ROOT
 timeout 300 python __graft_entry__.py smoke 2>&1 | tail -n 1 | tee $O/smoke.txt
 timeout 1800 python -m pytest tests -q -m gpu --no-header -p no:cacheprovider --maxfail=20 > $O/gpu_tests.log 2>&1; grep -E "passed|failed" $O/gpu_tests.log
@@ -14,7 +14,7 @@ timeout 400 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/
 timeout 400 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/w -o p -- $CMD > $O/w.log 2>&1
 cd $GRAFT_REPO_ROOT
 F=$(find $O/f -name "*counter_collection.csv" | head -1); W=$(find $O/w -name "*counter_collection.csv" | head -1)
-python tools/traffic_from_pmc.py $F $W "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-loop (ref_ahead 5); algorithmic bytes: bench.py --dump-algorithmic of the same build; MI355X; round 6, FINAL sources (as r06z + the backward-attention / batched-transpose changes of the training step: the sampler's kernels are unchanged); $(date -u +%F)" $O/algorithmic.json > $O/traffic.json; head -c 300 $O/traffic.json; echo
+python tools/traffic_from_pmc.py $F $W "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) --kernel-trace -- python bench.py --steps 5 --warmup 5 --no-cpu-baseline --no-loop (ref_ahead 5); algorithmic bytes: bench.py --dump-algorithmic of the same build; MI355X; round 6, FINAL sources and build flags (no SLP vectorisation); $(date -u +%F)" $O/algorithmic.json > $O/traffic.json; head -c 300 $O/traffic.json; echo
 find $O -name "*kernel_trace.csv" -delete; find $O -name "*counter_collection.csv" -delete; find $O -name "*.db" -delete; rm -rf $O/ks $O/f $O/w
 cp $O/traffic.json profiles/traffic.json
 timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2>$O/err.txt; cut -c1-200 $O/bench.json
