@@ -479,18 +479,39 @@ __device__ __forceinline__ void epi_finish(const MmaParams& p, char* smem, f32x1
 #pragma unroll
         for (int k = 0; k < 16; ++k)
             *reinterpret_cast<float4*>(stg + (4 * k + lr) * EPI_PITCH + 4 * lc) = make_float4(v[k][0], v[k][1], v[k][2], v[k][3]);
-        float4 rv[16];
+        float sum = 0.f, m2 = 0.f, mean = 0.f;
+        if constexpr (NH > 1) {      // 128 rows per wave: the row is read twice, eight quads at a time (registers)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) rv[q] = *reinterpret_cast<const float4*>(stg + lane * EPI_PITCH + 4 * q);
-        float sum = 0.f;
+            for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) sum += (rv[q].x + rv[q].y) + (rv[q].z + rv[q].w);
-        const float mean = sum * (1.f / 64.f);
-        float m2 = 0.f;
+                for (int qb = 0; qb < 16; qb += 8) {
+                    float4 rv[8];
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-            const float a = rv[q].x - mean, b = rv[q].y - mean, c = rv[q].z - mean, d = rv[q].w - mean;
-            m2 = fmaf(a, a, m2); m2 = fmaf(b, b, m2); m2 = fmaf(c, c, m2); m2 = fmaf(d, d, m2);
+                    for (int q = 0; q < 8; ++q) rv[q] = *reinterpret_cast<const float4*>(stg + lane * EPI_PITCH + 4 * (qb + q));
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) {
+                        if (pass == 0) {
+                            sum += (rv[q].x + rv[q].y) + (rv[q].z + rv[q].w);
+                        } else {
+                            const float a = rv[q].x - mean, b = rv[q].y - mean, c = rv[q].z - mean, d = rv[q].w - mean;
+                            m2 = fmaf(a, a, m2); m2 = fmaf(b, b, m2); m2 = fmaf(c, c, m2); m2 = fmaf(d, d, m2);
+                        }
+                    }
+                }
+                if (pass == 0) mean = sum * (1.f / 64.f);
+            }
+        } else {
+            float4 rv[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) rv[q] = *reinterpret_cast<const float4*>(stg + lane * EPI_PITCH + 4 * q);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) sum += (rv[q].x + rv[q].y) + (rv[q].z + rv[q].w);
+            mean = sum * (1.f / 64.f);
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const float a = rv[q].x - mean, b = rv[q].y - mean, c = rv[q].z - mean, d = rv[q].w - mean;
+                m2 = fmaf(a, a, m2); m2 = fmaf(b, b, m2); m2 = fmaf(c, c, m2); m2 = fmaf(d, d, m2);
+            }
         }
         const int gm = m0 + wm * 64 + lane;
         if (gm < p.M && n0 + wn * 64 < p.N) {
